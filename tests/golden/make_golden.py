@@ -1,0 +1,343 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ by IMPORTING THE REFERENCE (read-only, /root/reference)
+in the build container.  The fixtures are data only: inputs (seeded / closed-form / the reference tests'
+own literal arrays re-captured as arrays) and the outputs the reference's numpy code produced for them.
+No reference source text is stored.  Run:   python tests/golden/make_golden.py
+
+Outputs
+  ref_test_literals.npz   literal arrays held by the reference's own tests (known answers), by name
+  ref_leaf.npz            leaf functions of SURVEY section 8a run by the reference on seeded inputs
+  ref_hierarchical.npz    HierarchicalOptimizer2d runs (per-iteration warp fields)
+  ref_slavcheva.npz       SlavchevaOptimizer2d runs (per-iteration live / warp / gradient / energies)
+"""
+import ast
+import contextlib
+import io
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refstubs  # noqa: E402
+
+_refstubs.install()
+REF = _refstubs.REFERENCE_ROOT
+
+import utils.sampling as sampling  # noqa: E402
+from nonrigid_opt import field_warping as fw  # noqa: E402
+from nonrigid_opt.hierarchical import hierarchical_optimizer2d as ho  # noqa: E402
+from nonrigid_opt.hierarchical import hierarchical_optimization_visualizer as hov  # noqa: E402
+from nonrigid_opt.hierarchical.pyramid import ScalarFieldPyramid2d  # noqa: E402
+from nonrigid_opt.slavcheva import data_term as dt, smoothing_term as st  # noqa: E402
+from nonrigid_opt.slavcheva import slavcheva_optimizer2d as so  # noqa: E402
+from nonrigid_opt.slavcheva import slavcheva_visualizer as sviz  # noqa: E402
+from nonrigid_opt.slavcheva.level_set_term import level_set_term_at_location  # noqa: E402
+from nonrigid_opt.slavcheva.sobolev_filter import generate_1d_sobolev_kernel  # noqa: E402
+import math_utils.convolution as mc  # noqa: E402
+import math_utils.resampling as mr  # noqa: E402
+import tsdf.generation as tsdf_gen  # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------------
+def extract_test_literals(rel_path, out, prefix):
+    """Evaluate every `name = np.array(<literal>...)`-style assignment inside the test methods of a
+    reference test file and store the resulting ARRAY under '<prefix>.<test name>.<variable>[#k]'."""
+    with open(os.path.join(REF, rel_path)) as f:
+        tree = ast.parse(f.read())
+    for cls in [n for n in tree.body if isinstance(n, ast.ClassDef)]:
+        for fn in [n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name.startswith("test_")]:
+            seen = {}
+            for node in ast.walk(fn):
+                if not (isinstance(node, ast.Assign) and len(node.targets) == 1
+                        and isinstance(node.targets[0], ast.Name)):
+                    continue
+                names = {n.id for n in ast.walk(node.value) if isinstance(n, ast.Name)}
+                if not names <= {"np"} or "np" not in names:
+                    continue
+                try:
+                    val = eval(compile(ast.Expression(node.value), "<lit>", "eval"), {"np": np})
+                except Exception:
+                    continue
+                if not isinstance(val, np.ndarray):
+                    continue
+                var = node.targets[0].id
+                k = seen.get(var, 0)
+                seen[var] = k + 1
+                key = "%s.%s.%s%s" % (prefix, fn.name, var, "" if k == 0 else "#%d" % k)
+                out[key] = val
+
+
+def literals():
+    out = {}
+    for rel, prefix in (("tests/test_field_warping.py", "field_warping"),
+                        ("tests/test_convolution.py", "convolution"),
+                        ("tests/test_data_term.py", "data_term"),
+                        ("tests/test_smoothing_term.py", "smoothing_term"),
+                        ("tests/test_slavcheva_optimizer.py", "slavcheva"),
+                        ("tests/test_field_pyramid.py", "pyramid"),
+                        ("tests/test_math.py", "math")):
+        extract_test_literals(rel, out, prefix)
+    import tests.test_data.hierarchical_optimizer_test_data as hd
+    import tests.test_data.test_data_convolution as cd
+    for mod, prefix in ((hd, "hierarchical_data"), (cd, "convolution_data")):
+        for name in dir(mod):
+            v = getattr(mod, name)
+            if isinstance(v, np.ndarray):
+                out["%s.%s" % (prefix, name)] = v
+    # scalar known answers of tests/test_slavcheva_optimizer.py:141-145 (convergence report), as numbers
+    out["slavcheva.report.warp_stats"] = np.array([0.272727, 0.0, 0.0684823, 0.0364445, 0.0167321, 1, 2])
+    out["slavcheva.report.tsdf_stats"] = np.array([0, 0.246834, 0.111843, 0.0812234, 3, 3])
+    np.savez_compressed(os.path.join(HERE, "ref_test_literals.npz"), **out)
+    print("ref_test_literals.npz:", len(out), "arrays")
+
+
+# ------------------------------------------------------------------------------------------------------
+def smooth_random_field(rng, n, scale):
+    """smooth-ish TSDF-like test field in [-1, 1] with exact +-1 plateaus"""
+    yy, xx = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    f = 0.08 * (yy - n / 2) + 0.3 * np.sin(xx * 0.35) + scale * rng.standard_normal((n, n))
+    return np.clip(f, -1.0, 1.0).astype(np.float32)
+
+
+def leaf():
+    rng = np.random.default_rng(20240607)
+    out = {}
+    n = 12
+    field = smooth_random_field(rng, n, 0.05)
+    canon = smooth_random_field(rng, n, 0.05)
+    warp = (1.7 * rng.standard_normal((n, n, 2))).astype(np.float32)
+    warp[0, 0] = (-3.2, 0.4)
+    warp[n - 1, n - 1] = (2.6, 5.1)
+    warp[3, 4] = (0.0, 0.0)
+    warp[5, 5] = (1.0, -2.0)  # integer displacement
+    out["warp.field"], out["warp.canonical"], out["warp.warp"] = field, canon, warp
+    out["warp.warp_field"] = fw.warp_field(field, warp)
+    out["warp.warp_field_replacement0"] = fw.warp_field_replacement(field, warp, 0.0)
+    out["warp.warp_field_replacement_m05"] = fw.warp_field_replacement(field, warp, -0.5)
+    small = (0.4 * rng.standard_normal((n, n, 2))).astype(np.float32)
+    out["warp.small_warp"] = small
+    for tag, flags in (("000", (False, False, False)), ("100", (True, False, False)),
+                       ("010", (False, True, False)), ("001", (False, False, True)),
+                       ("111", (True, True, True))):
+        w = small.copy()
+        g = (w * 10).astype(np.float32)
+        with contextlib.redirect_stdout(io.StringIO()):
+            new_live = fw.warp_field_advanced(canon, field.copy(), w, g, *flags)
+        out["warp.advanced_%s.live" % tag] = new_live
+        out["warp.advanced_%s.warp" % tag] = w
+        out["warp.advanced_%s.gradient" % tag] = g
+
+    # np.gradient + pyramid
+    f32 = smooth_random_field(rng, 32, 0.1)
+    gy, gx = np.gradient(f32)
+    out["grad.field"], out["grad.gx"], out["grad.gy"] = f32, gx, gy
+    for chunk in (4, 8):
+        for i, lvl in enumerate(ScalarFieldPyramid2d(f32, chunk).levels):
+            out["pyramid.chunk%d.level%d" % (chunk, i)] = lvl.astype(np.float32)
+
+    # convolution, 2-D and 3-D, float64 7-tap (hard-coded) and float32 generated kernels
+    vf2 = rng.standard_normal((16, 16, 2)).astype(np.float32)
+    vf2[np.abs(vf2) < 0.3] = 0.0
+    vf3 = rng.standard_normal((8, 9, 7, 3)).astype(np.float32)
+    k7 = generate_1d_sobolev_kernel(size=7, strength=0.1)
+    k3 = generate_1d_sobolev_kernel(size=3, strength=0.1)
+    k9 = generate_1d_sobolev_kernel(size=9, strength=0.15)
+    out["sobolev.k3"], out["sobolev.k7"], out["sobolev.k9"] = k3, k7, k9
+    out["sobolev.hardcoded7"] = mc.sobolev_kernel_1d
+    out["conv.vf2"], out["conv.vf3"] = vf2, vf3
+    out["conv.vf2_k7f64"] = mc.convolve_with_kernel(vf2.copy(), mc.sobolev_kernel_1d)
+    out["conv.vf2_k7f32"] = mc.convolve_with_kernel(vf2.copy(), k7)
+    out["conv.vf2_asym"] = mc.convolve_with_kernel(vf2.copy(), np.array([0.5, 0.2, -0.1, 0.05, 0.3]))
+    out["conv.vf3_k7f64"] = mc.convolve_with_kernel(vf3.copy(), mc.sobolev_kernel_1d)
+    out["conv.vf3_asym"] = mc.convolve_with_kernel(vf3.copy(), np.array([0.5, 0.2, -0.1]))
+    out["conv.vf2_pz_k3"] = mc.convolve_with_kernel_preserve_zeros(vf2.copy(), k3)
+    out["conv.vf2_pz_k7"] = mc.convolve_with_kernel_preserve_zeros(vf2.copy(), mc.sobolev_kernel_1d)
+
+    # Slavcheva leaf terms on a 12x12 case
+    live = field.copy()
+    live[2, 3] = 1.0
+    live[2, 4] = 1.0
+    live[7, 7] = -1.0
+    canon2 = canon.copy()
+    canon2[2, 3] = 1.0
+    canon2[7, 7] = 1.0
+    lgy, lgx = np.gradient(live)
+    out["terms.live"], out["terms.canonical"], out["terms.warp"] = live, canon2, small
+    out["terms.data_vectorized"] = dt.compute_data_term_gradient_vectorized(live, canon2, lgx, lgy)
+    out["terms.data_energy"] = np.array(dt.compute_data_term_energy_contribution(live, canon2))
+    out["terms.tikhonov_vectorized"] = st.compute_smoothing_term_gradient_vectorized(small)
+    out["terms.smoothing_energy_vectorized"] = np.array(st.compute_smoothing_term_energy(small, live, canon2))
+    steep = np.clip(live * 6.0, -1, 1).astype(np.float32)
+    sgy, sgx = np.gradient(steep)
+    out["terms.steep_live"] = steep
+    data_fdm = np.zeros((n, n, 2), np.float32)
+    data_basic = np.zeros((n, n, 2), np.float32)
+    tik = np.zeros((n, n, 2), np.float32)
+    tik_e = np.zeros((n, n))
+    kil = np.zeros((n, n, 2), np.float32)
+    kil_e = np.zeros((n, n))
+    ls = np.zeros((n, n, 2), np.float32)
+    ls_e = np.zeros((n, n))
+    sampling.set_focus_coordinates(-5, -5)
+    for y in range(n):
+        for x in range(n):
+            data_fdm[y, x] = dt.compute_local_data_term_gradient_thresholded_fdm(steep, canon2, x, y, sgx, sgy)[0]
+            data_basic[y, x] = dt.compute_local_data_term_gradient_basic(live, canon2, x, y, lgx, lgy)[0]
+            tik[y, x], tik_e[y, x] = st.compute_local_smoothing_term_gradient_tikhonov(small, x, y,
+                                                                                     copy_if_zero=False)
+            kil[y, x], kil_e[y, x] = st.compute_local_smoothing_term_gradient_killing(
+                small, x, y, copy_if_zero=False, isomorphic_enforcement_factor=0.1)
+            g, e = level_set_term_at_location(live, x, y)
+            ls[y, x], ls_e[y, x] = g, e
+    out["terms.data_fdm"], out["terms.data_basic"] = data_fdm, data_basic
+    out["terms.tikhonov_direct"], out["terms.tikhonov_direct_energy"] = tik, tik_e
+    out["terms.killing"], out["terms.killing_energy"] = kil, kil_e
+    out["terms.level_set"], out["terms.level_set_energy"] = ls, ls_e
+
+    # 3-D linear resampling prototype (math_utils/resampling.py)
+    vol = rng.standard_normal((4, 6, 4))
+    out["resampling.vol"] = vol
+    out["resampling.up"] = mr.upsample2x_linear(vol)
+    out["resampling.down"] = mr.downsample2x_linear(vol)
+    np.savez_compressed(os.path.join(HERE, "ref_leaf.npz"), **out)
+    print("ref_leaf.npz:", len(out), "arrays")
+
+
+# ------------------------------------------------------------------------------------------------------
+def circle_pair(n):
+    """2-D analogue of the SURVEY 8(d) 'sphere-pair' generator (closed form)"""
+    yy, xx = np.meshgrid(np.arange(n, dtype=np.float64), np.arange(n, dtype=np.float64), indexing="ij")
+    c, r, h = n / 2.0, 0.3 * n, 10.0
+
+    def tsdf(sx, sy, ax, ay):
+        d = np.sqrt(((xx - (c + sx)) / ax) ** 2 + ((yy - (c + sy)) / ay) ** 2) - r
+        return np.clip(d / h, -1.0, 1.0).astype(np.float32)
+
+    return tsdf(0.0, 0.0, 1.0, 1.0), tsdf(1.5, -1.0, 1.05, 0.95)
+
+
+def hierarchical():
+    import tests.test_data.hierarchical_optimizer_test_data as hd
+    out = {}
+    cases = {"g16": (hd.canonical_field, hd.live_field)}
+    c64, l64 = circle_pair(64)
+    cases["c64"] = (c64, l64)
+    out["c64.canonical"], out["c64.live"] = c64, l64
+    k7 = generate_1d_sobolev_kernel(size=7, strength=0.1)
+    out["kernel7"] = k7
+    captured = []
+
+    def hook(self, level, it, canonical_lvl, resampled_live, warp_field, data_gradient=None,
+             inverse_tikhonov_gradient=None):
+        captured.append((level, it, warp_field.copy()))
+
+    hov.HierarchicalOptimizer2dVisualizer.generate_per_iteration_visualizations = hook
+    for case, (canon, live) in cases.items():
+        for tik in (False, True):
+            for ker in (False, True):
+                for chunk in (4, 8):
+                    n_it = 4
+                    opt = ho.HierarchicalOptimizer2d(tikhonov_term_enabled=tik, gradient_kernel_enabled=ker,
+                                                     maximum_chunk_size=chunk, rate=0.2,
+                                                     maximum_iteration_count=n_it,
+                                                     maximum_warp_update_threshold=0.0, data_term_amplifier=1.0,
+                                                     tikhonov_strength=0.2, kernel=k7 if ker else None)
+                    del captured[:]
+                    try:
+                        warp = opt.optimize(canon, live)
+                    except ValueError:
+                        # the reference cannot convolve a pyramid level narrower than the kernel
+                        # (np.convolve 'same' returns max(M, N) samples) -- no golden for that combination
+                        continue
+                    tag = "%s.tik%d.ker%d.chunk%d" % (case, tik, ker, chunk)
+                    out[tag + ".final_warp"] = warp
+                    if case == "g16" or chunk == 8:
+                        for level, it, w in captured:
+                            out["%s.L%d.it%d.warp" % (tag, level, it)] = w
+    # threshold-terminated run (iteration counts are part of the contract)
+    opt = ho.HierarchicalOptimizer2d(tikhonov_term_enabled=True, gradient_kernel_enabled=False,
+                                     maximum_chunk_size=8, rate=0.1, maximum_iteration_count=40,
+                                     maximum_warp_update_threshold=0.01, tikhonov_strength=0.2)
+    del captured[:]
+    out["c64.threshold_run.final_warp"] = opt.optimize(c64, l64)
+    counts = {}
+    for level, it, _ in captured:
+        counts[level] = max(counts.get(level, 0), it + 1)
+    out["c64.threshold_run.iteration_counts"] = np.array([counts[k] for k in sorted(counts)])
+    np.savez_compressed(os.path.join(HERE, "ref_hierarchical.npz"), **out)
+    print("ref_hierarchical.npz:", len(out), "arrays")
+
+
+def slavcheva():
+    out = {}
+    sampling.set_focus_coordinates(0, 0)
+    live_full, canon_full = tsdf_gen.generate_initial_orthographic_2d_tsdf_fields(field_size=128)
+    live32 = live_full[46:78, 40:72].copy()
+    canon32 = canon_full[46:78, 40:72].copy()
+    live64 = live_full[30:94, 30:94].copy()
+    canon64 = canon_full[30:94, 30:94].copy()
+    out["ortho32.live"], out["ortho32.canonical"] = live32, canon32
+    out["ortho64.live"], out["ortho64.canonical"] = live64, canon64
+    k7 = generate_1d_sobolev_kernel(size=7, strength=0.1)
+    k3 = generate_1d_sobolev_kernel(size=3, strength=0.1)
+    out["kernel7"], out["kernel3"] = k7, k3
+    configs = {
+        # SobolevFusion: VECTORIZED, Tikhonov + Sobolev
+        "sobolev_vec": dict(compute_method=so.ComputeMethod.VECTORIZED, sobolev_smoothing_enabled=True,
+                            sobolev_kernel=k7),
+        # the reference's own test configuration, DIRECT
+        "sobolev_direct": dict(compute_method=so.ComputeMethod.DIRECT, sobolev_smoothing_enabled=True,
+                               sobolev_kernel=k3),
+        # KillingFusion: DIRECT, Killing + level set, no Sobolev
+        "killing": dict(compute_method=so.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                        smoothing_term_method=st.SmoothingTermMethod.KILLING),
+        "tikhonov_direct": dict(compute_method=so.ComputeMethod.DIRECT),
+        "fdm_direct": dict(compute_method=so.ComputeMethod.DIRECT,
+                           data_term_method=dt.DataTermMethod.THRESHOLDED_FDM),
+    }
+    captured = []
+
+    def hook(self, iteration_number, warp_field, gradient_field, live_field, canonical_field):
+        captured.append((iteration_number, warp_field.copy(), gradient_field.copy(), live_field.copy()))
+
+    sviz.SlavchevaVisualizer.write_all_iteration_visualizations = hook
+    tmp = tempfile.mkdtemp()
+    for size_tag, live0, canon, n_it, per_it in (("ortho32", live32, canon32, 4, True),
+                                                 ("ortho64", live64, canon64, 3, False)):
+        for name, kw in configs.items():
+            opt = so.SlavchevaOptimizer2d(out_path=tmp, field_size=live0.shape[0],
+                                          maximum_warp_length_lower_threshold=0.0, max_iterations=n_it,
+                                          min_iterations=n_it, enable_convergence_status_logging=True, **kw)
+            live = live0.copy()
+            del captured[:]
+            with contextlib.redirect_stdout(io.StringIO()):
+                opt.optimize(live, canon)
+            tag = "%s.%s" % (size_tag, name)
+            out[tag + ".final_live"] = live
+            out[tag + ".final_gradient"] = opt.gradient_field.copy()
+            out[tag + ".max_warps"] = np.array(opt.log.max_warps, dtype=np.float64)
+            out[tag + ".data_energies"] = np.array(opt.log.data_energies, dtype=np.float64)
+            out[tag + ".smoothing_energies"] = np.array(opt.log.smoothing_energies, dtype=np.float64)
+            out[tag + ".level_set_energies"] = np.array(opt.log.level_set_energies, dtype=np.float64)
+            out[tag + ".final_warp"] = captured[-1][1]
+            if per_it:
+                for it, w, g, l in captured:
+                    out["%s.it%d.warp" % (tag, it)] = w
+                    out["%s.it%d.gradient" % (tag, it)] = g
+                    out["%s.it%d.live" % (tag, it)] = l
+    np.savez_compressed(os.path.join(HERE, "ref_slavcheva.npz"), **out)
+    print("ref_slavcheva.npz:", len(out), "arrays")
+
+
+if __name__ == "__main__":
+    os.chdir(tempfile.mkdtemp())
+    literals()
+    leaf()
+    hierarchical()
+    slavcheva()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print("%8d  %s" % (os.path.getsize(os.path.join(HERE, f)), f))
