@@ -1,0 +1,213 @@
+/*
+ * lsf_hip.h -- C ABI of liblsf_hip.so: hand-written HIP (gfx950 / MI355X) kernels for the per-voxel
+ * warp-field gradient-descent path of KillingFusion / SobolevFusion-style non-rigid TSDF alignment.
+ *
+ * This is the drop-in boundary under the Python classes SlavchevaOptimizer2d / HierarchicalOptimizer2d/3d.
+ * The reference (Algomorph/LevelSetFusion-Python) crosses its only language boundary through a boost-python
+ * module `level_set_fusion_optimization` (un-vendored C++); the entry points below are what a binding for
+ * THIS path binds instead.  Each one names the reference interface it replaces (path:line under the
+ * reference checkout).
+ *
+ * Rules of the ABI
+ *   - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns 0 on success or a
+ *     hipError_t value; nothing throws.  LSF_ERR_* (negative) flag argument errors detected on the host.
+ *   - The library owns no memory and keeps no global state.  All pointers are DEVICE pointers supplied by
+ *     the caller (e.g. torch.Tensor.data_ptr()), all launches are asynchronous on `stream` (a hipStream_t
+ *     passed as void*; NULL = the default stream).  Re-entrant across streams and devices.
+ *   - Layouts (MI355X-first):
+ *       scalar fields      float32 [z][y][x]            (nz = 1 for 2-D)
+ *       vector fields      float32 PLANAR [c][z][y][x]  c = 0:x(u) 1:y(v) 2:z(w); `dims` planes
+ *       packed live field  float4  [z][y][x] = (live, d/dx live, d/dy live, d/dz live)   (gather operand)
+ *       interleaved        float32 [z][y][x][c]         only at the API edge (lsf_interleave/deinterleave)
+ *   - Slab support: a launch processes slices z in [z_begin, z_end) of an array that holds nz slices
+ *     (owned slab + halo).  z_global_offset is added to z when a voxel index is reported (arg-max).
+ *   - Arithmetic: float32, multiply and add rounded separately (-ffp-contract=off), in the operation order
+ *     of oracle/lsf_oracle.py, so results are bit-identical to the oracle except for sum reductions.
+ */
+#ifndef LSF_HIP_H
+#define LSF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSF_ABI_VERSION 1
+#define LSF_MAX_KERNEL_TAPS 31
+
+#define LSF_ERR_BAD_ARGUMENT (-1)
+#define LSF_ERR_BAD_DIMS (-2)
+#define LSF_ERR_KERNEL_TOO_LONG (-3)
+
+/* extents of one field as stored on this device */
+typedef struct lsf_grid {
+    int32_t dims;            /* 2 or 3 */
+    int32_t nz, ny, nx;      /* allocated extents, nz = 1 when dims == 2 */
+    int32_t z_begin, z_end;  /* slices processed by the launch, 0 <= z_begin <= z_end <= nz */
+    int32_t z_global_offset; /* global z of local slice 0 (for reported voxel indices) */
+    int32_t reserved;
+} lsf_grid;
+
+/* per-iteration reduction record written by the iteration kernels (one record per iteration slot).
+ * max_packed = (float bits of the maximum vector length << 32) | ~(linear voxel index): the largest value
+ * with the smallest index wins an unsigned 64-bit max, which reproduces numpy's first-arg-max tie break
+ * (hierarchical_optimizer2d.py:223-225, slavcheva_optimizer2d.py:213-215).  0 = slot not executed. */
+typedef struct lsf_iteration_record {
+    uint64_t max_packed;
+    double data_energy;      /* Slavcheva: sum over band of 0.5*diff^2 ; hierarchical: sum diff^2 */
+    double smoothing_energy; /* un-weighted */
+    double level_set_energy; /* un-weighted */
+} lsf_iteration_record;
+
+/* Device-side convergence gate.  The reference tests its stop condition on the host after every iteration
+ * (hierarchical_optimizer2d.py:169-171, slavcheva_optimizer2d.py:360-362); here every kernel of iteration i
+ * looks at the record of iteration i-1 and turns itself into a no-op when that iteration already met the
+ * stop condition (or was itself a no-op), so the host may enqueue iterations in batches without a sync and
+ * still get exactly the reference's iteration count.  prev_record == NULL: always run.
+ *   mode LSF_GATE_HIERARCHICAL: run iff NOT (max < a)            (a = maximum_warp_update_threshold)
+ *   mode LSF_GATE_SLAVCHEVA:    run iff  a < max  AND  max < b   (a, b = lower / upper warp thresholds) */
+#define LSF_GATE_HIERARCHICAL 0
+#define LSF_GATE_SLAVCHEVA 1
+typedef struct lsf_gate {
+    const lsf_iteration_record *prev_record; /* DEVICE pointer or NULL */
+    int32_t mode;
+    float a;
+    float b;
+} lsf_gate;
+
+/* ---------------------------------------------------------------------------------------------------- */
+int lsf_abi_version(void);
+/* name of the code object's target, e.g. "gfx950" */
+const char *lsf_target_arch(void);
+
+/* ---- layout helpers (API edge only) ---------------------------------------------------------------- */
+/* [z][y][x][c] -> [c][z][y][x] and back; n_voxels = nz*ny*nx, channels = dims */
+int lsf_deinterleave(const float *interleaved, float *planar, int64_t n_voxels, int32_t channels, void *stream);
+int lsf_interleave(const float *planar, float *interleaved, int64_t n_voxels, int32_t channels, void *stream);
+
+/* ---- a1/a2: resample a scalar field under a warp ---------------------------------------------------
+ * replaces nonrigid_opt/field_warping.py:67-85 (warp_field, oob_value = 1) and :88-109
+ * (warp_field_replacement, oob_value = replacement) with utils/sampling.py:139-175,222-263. */
+int lsf_warp_field(const float *field, const float *warp_planar, float *out, const lsf_grid *grid,
+                   float oob_value, void *stream);
+
+/* ---- a3: truncation-aware re-warp -------------------------------------------------------------------
+ * replaces nonrigid_opt/field_warping.py:112-151 and the C++ twin cpp.warp_field_advanced called at
+ * nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:227-228.  warp (and gradient, may be NULL) are zeroed in
+ * place where the new value snaps to +-1.  flags: bit0 band_union_only, bit1 known_values_only,
+ * bit2 substitute_original. */
+int lsf_warp_field_advanced(const float *canonical, const float *live, float *warp_planar,
+                            float *gradient_planar, float *new_live, const lsf_grid *grid, int32_t flags,
+                            void *stream);
+
+/* ---- a4 + packing: np.gradient of the live field, packed with it as float4 ------------------------
+ * replaces np.gradient at hierarchical_optimizer2d.py:126 (+ the four pyramids' level-0 inputs :128-131) */
+int lsf_pack_live_gradient(const float *live, float *packed4, const lsf_grid *grid, void *stream);
+
+/* ---- a5/a6: pyramid restrict (2^D block mean, per channel) and prolong (repeat, no rescale) -------
+ * replaces nonrigid_opt/hierarchical/pyramid.py:45-56 and hierarchical_optimizer2d.py:155-156.
+ * `fine` describes the fine grid; the coarse grid has every extent halved (nz stays 1 in 2-D).
+ * restrict: interleaved channels (1 = scalar, 4 = packed live field).  prolong: planar vector field. */
+int lsf_restrict_mean(const float *fine, float *coarse, const lsf_grid *fine_grid, int32_t channels,
+                      void *stream);
+int lsf_prolong_repeat(const float *coarse_planar, float *fine_planar, const lsf_grid *fine_grid, void *stream);
+
+/* ---- a9/a10: one pass of the separable convolution along one axis (0 = x, 1 = y, 2 = z) ------------
+ * replaces math_utils/convolution.py:70-111 (convolve_with_kernel) and :114-132 (…_preserve_zeros) pass by
+ * pass: out[i] = sum_j k[j]*in[i + n/2 - j], zero padded, accumulated in float64 in tap order, stored
+ * float32.  zero_mask_source (may be NULL): where |zero_mask_source| < 1e-6 the output is forced to 0
+ * (convolution.py:118,123,127).  Operates on `planes` planes of a planar vector field. */
+int lsf_convolve_axis(const float *in_planar, float *out_planar, const float *zero_mask_source,
+                      const lsf_grid *grid, int32_t planes, int32_t axis, const double *taps_host,
+                      int32_t n_taps, const lsf_gate *gate, void *stream);
+
+/* ---- hierarchical optimizer iteration ---------------------------------------------------------------
+ * replaces one pass of the loop body nonrigid_opt/hierarchical/hierarchical_optimizer2d.py:184-225:
+ *   resample live and its gradients under `warp` (a1,a2), data term (a7), Tikhonov = Laplacian of the
+ *   previous gradient (a8), and -- when apply_update != 0 (no gradient kernel) -- warp -= rate*g and the
+ *   max-update reduction (a11).  With a gradient kernel the caller runs lsf_convolve_axis passes on
+ *   g_out and then lsf_hier_update.
+ * gate (may be NULL): see lsf_gate.  g_prev_planar may be NULL when Tikhonov is off; g_out_planar may be NULL
+ * when apply_update is set and the gradient is not wanted. */
+typedef struct lsf_hier_params {
+    float data_term_amplifier;
+    float tikhonov_strength;   /* used when tikhonov_enabled */
+    float rate;
+    int32_t tikhonov_enabled;
+    int32_t apply_update;
+    int32_t compute_energy;    /* accumulate sum(diff^2) into record->data_energy */
+    int32_t reserved[2];
+} lsf_hier_params;
+
+int lsf_hier_iteration(const float *packed_live4, const float *canonical, float *warp_planar,
+                       const float *g_prev_planar, float *g_out_planar, const lsf_grid *grid,
+                       const lsf_hier_params *params, const lsf_gate *gate, lsf_iteration_record *record,
+                       void *stream);
+
+/* warp -= rate*g ; record->max_packed = max |g|   (hierarchical_optimizer2d.py:220-225) */
+int lsf_hier_update(const float *g_planar, float *warp_planar, const lsf_grid *grid, float rate,
+                    const lsf_gate *gate, lsf_iteration_record *record, void *stream);
+
+/* ---- Slavcheva (KillingFusion / SobolevFusion) optimizer iteration ----------------------------------
+ * replaces nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:163-236 (VECTORIZED) and :238-330 (DIRECT)
+ * with data_term.py:169-227,334-358, smoothing_term.py:50-177, level_set_term.py:28-64.
+ *
+ * lsf_slavcheva_iteration, stage = LSF_STAGE_FUSED: one kernel does gradient, warp = -g*rate, max-warp
+ *   reduction, energies and the truncation-aware re-warp of the live field (a12-a18 + a3): the "fused
+ *   per-voxel warp-update kernel".  Used when no Sobolev filter sits between gradient and update.
+ * stage = LSF_STAGE_GRADIENT: gradient + energies only (g_out), for the Sobolev path; then
+ *   lsf_convolve_axis passes (zero-preserving) and lsf_slavcheva_update_rewarp. */
+#define LSF_STAGE_FUSED 0
+#define LSF_STAGE_GRADIENT 1
+
+#define LSF_SMOOTHING_TIKHONOV 0
+#define LSF_SMOOTHING_KILLING 1
+#define LSF_DATA_BASIC 0
+#define LSF_DATA_THRESHOLDED_FDM 2
+#define LSF_ENERGY_NONE 0
+#define LSF_ENERGY_DIRECT 1     /* per-voxel energies of DIRECT mode */
+#define LSF_ENERGY_VECTORIZED 2 /* np.gradient-based smoothing energy of VECTORIZED mode */
+
+typedef struct lsf_slavcheva_params {
+    double isomorphic_enforcement_factor_f64; /* lambda as given (energies are accumulated in double) */
+    float rate;
+    float data_term_weight;
+    float smoothing_term_weight;
+    float level_set_term_weight;
+    float isomorphic_enforcement_factor; /* float32(lambda) */
+    float killing_c1;                    /* float32(-2*(1+lambda)), evaluated in double on the host */
+    int32_t smoothing_method;
+    int32_t data_method;
+    int32_t level_set_enabled;
+    int32_t energy_mode;
+    int32_t zero_gradient_on_snap; /* DIRECT: 1 (field_warping.py:141) ; VECTORIZED: 0 */
+    int32_t reserved;
+} lsf_slavcheva_params;
+
+int lsf_slavcheva_iteration(int32_t stage, const float *live, const float *canonical,
+                            const float *warp_prev_planar, float *warp_out_planar, float *live_out,
+                            float *g_out_planar /* may be NULL in FUSED */, const lsf_grid *grid,
+                            const lsf_slavcheva_params *params, const lsf_gate *gate,
+                            lsf_iteration_record *record, void *stream);
+
+int lsf_slavcheva_update_rewarp(const float *live, const float *canonical, float *g_planar /* inout */,
+                                float *warp_out_planar, float *live_out, const lsf_grid *grid,
+                                const lsf_slavcheva_params *params, const lsf_gate *gate,
+                                lsf_iteration_record *record, void *stream);
+
+/* ---- a20: convergence statistics ---------------------------------------------------------------------
+ * replaces cpp.build_warp_delta_statistics_2d / build_tsdf_difference_statistics_2d
+ * (slavcheva_optimizer2d.py:394-398; known answer tests/test_slavcheva_optimizer.py:141-145).
+ * out (device, 8 doubles each):
+ *   warp:  [count_band, count_above_lo, max_len, sum_len, sum_len^2, argmax_linear_index, 0, scratch]
+ *   tsdf:  [count, min, max, sum, sum^2, argmax_linear_index, 0, scratch]    of |canonical - live|   */
+int lsf_warp_statistics(const float *warp_planar, const float *canonical, const float *live,
+                        const lsf_grid *grid, float lower_threshold, double *out8, void *stream);
+int lsf_tsdf_difference_statistics(const float *canonical, const float *live, const lsf_grid *grid,
+                                   double *out8, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSF_HIP_H */

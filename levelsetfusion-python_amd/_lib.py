@@ -1,0 +1,118 @@
+"""ctypes binding of liblsf_hip.so (C ABI: include/lsf_hip.h).
+
+There is NO fallback: if the HIP library is missing, importing this module raises.  The numpy oracle under
+oracle/ is test infrastructure and is never imported from the package.
+"""
+import ctypes
+import os
+
+from ._build import LIB_PATH
+
+c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+MAX_KERNEL_TAPS = 31
+ABI_VERSION = 1
+
+ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG"}
+
+STAGE_FUSED, STAGE_GRADIENT = 0, 1
+SMOOTHING_TIKHONOV, SMOOTHING_KILLING = 0, 1
+DATA_BASIC, DATA_THRESHOLDED_FDM = 0, 2
+ENERGY_NONE, ENERGY_DIRECT, ENERGY_VECTORIZED = 0, 1, 2
+GATE_HIERARCHICAL, GATE_SLAVCHEVA = 0, 1
+
+
+class Grid(ctypes.Structure):
+    _fields_ = [("dims", ctypes.c_int32), ("nz", ctypes.c_int32), ("ny", ctypes.c_int32), ("nx", ctypes.c_int32),
+                ("z_begin", ctypes.c_int32), ("z_end", ctypes.c_int32), ("z_global_offset", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+class IterationRecord(ctypes.Structure):
+    _fields_ = [("max_packed", ctypes.c_uint64), ("data_energy", ctypes.c_double),
+                ("smoothing_energy", ctypes.c_double), ("level_set_energy", ctypes.c_double)]
+
+
+RECORD_BYTES = ctypes.sizeof(IterationRecord)  # 32
+
+
+class Gate(ctypes.Structure):
+    _fields_ = [("prev_record", ctypes.c_void_p), ("mode", ctypes.c_int32), ("a", ctypes.c_float),
+                ("b", ctypes.c_float)]
+
+
+class HierParams(ctypes.Structure):
+    _fields_ = [("data_term_amplifier", ctypes.c_float), ("tikhonov_strength", ctypes.c_float),
+                ("rate", ctypes.c_float), ("tikhonov_enabled", ctypes.c_int32), ("apply_update", ctypes.c_int32),
+                ("compute_energy", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
+
+
+class SlavchevaParams(ctypes.Structure):
+    _fields_ = [("isomorphic_enforcement_factor_f64", ctypes.c_double), ("rate", ctypes.c_float),
+                ("data_term_weight", ctypes.c_float), ("smoothing_term_weight", ctypes.c_float),
+                ("level_set_term_weight", ctypes.c_float), ("isomorphic_enforcement_factor", ctypes.c_float),
+                ("killing_c1", ctypes.c_float), ("smoothing_method", ctypes.c_int32),
+                ("data_method", ctypes.c_int32), ("level_set_enabled", ctypes.c_int32),
+                ("energy_mode", ctypes.c_int32), ("zero_gradient_on_snap", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+_P = ctypes.POINTER
+_vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+# name -> (restype, argtypes); every symbol include/lsf_hip.h declares
+PROTOTYPES = {
+    "lsf_abi_version": (ctypes.c_int, []),
+    "lsf_target_arch": (ctypes.c_char_p, []),
+    "lsf_deinterleave": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "lsf_interleave": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "lsf_warp_field": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp]),
+    "lsf_warp_field_advanced": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _i32, _vp]),
+    "lsf_pack_live_gradient": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp]),
+    "lsf_restrict_mean": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp]),
+    "lsf_prolong_repeat": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp]),
+    "lsf_convolve_axis": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _i32, _i32, _P(ctypes.c_double), _i32,
+                                         _P(Gate), _vp]),
+    "lsf_hier_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(HierParams), _P(Gate), _vp, _vp]),
+    "lsf_hier_update": (ctypes.c_int, [_vp, _vp, _P(Grid), _f32, _P(Gate), _vp, _vp]),
+    "lsf_slavcheva_iteration": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _P(Grid),
+                                               _P(SlavchevaParams), _P(Gate), _vp, _vp]),
+    "lsf_slavcheva_update_rewarp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),
+                                                   _P(Gate), _vp, _vp]),
+    "lsf_warp_statistics": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp, _vp]),
+    "lsf_tsdf_difference_statistics": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp, _vp]),
+}
+
+
+class LsfHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "liblsf_hip.so is missing (%s).  This package has no CPU fallback: build the HIP library first with\n"
+            "    python -c 'import __graft_entry__ as g; g.build()'      (needs hipcc, cross-compiles gfx950)"
+            % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in PROTOTYPES.items():
+        if argtypes is None:
+            continue
+        fn = getattr(lib, name)  # AttributeError here = the .so is stale against the header
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.lsf_abi_version() != ABI_VERSION:
+        raise ImportError("liblsf_hip.so ABI version %d != binding version %d: rebuild" %
+                          (lib.lsf_abi_version(), ABI_VERSION))
+    return lib
+
+
+lib = _load()
+
+
+def check(status, what):
+    if status == 0:
+        return
+    if status in ERRORS:
+        raise LsfHipError("%s: %s" % (what, ERRORS[status]))
+    raise LsfHipError("%s: HIP error %d" % (what, status))

@@ -1,0 +1,251 @@
+// Device-side helpers shared by the kernels of liblsf_hip.so (gfx950 / CDNA4 only; wave = 64 lanes).
+// All float arithmetic here is written so that, compiled with -ffp-contract=off, it follows the
+// operation order of oracle/lsf_oracle.py bit for bit.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lsf_hip.h"
+
+namespace lsf {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
+
+struct Grid {
+    int nz, ny, nx;
+    int z_begin, z_end;
+    int z_global_offset;
+    long long plane;  // nz*ny*nx: stride between the planes of a planar vector field
+};
+
+__host__ inline Grid make_grid(const lsf_grid* g) {
+    Grid r;
+    r.nz = g->nz; r.ny = g->ny; r.nx = g->nx;
+    r.z_begin = g->z_begin; r.z_end = g->z_end;
+    r.z_global_offset = g->z_global_offset;
+    r.plane = (long long)g->nz * g->ny * g->nx;
+    return r;
+}
+
+__host__ inline int check_grid(const lsf_grid* g) {
+    if (!g) return LSF_ERR_BAD_ARGUMENT;
+    if (g->dims != 2 && g->dims != 3) return LSF_ERR_BAD_DIMS;
+    if (g->nx <= 0 || g->ny <= 0 || g->nz <= 0) return LSF_ERR_BAD_ARGUMENT;
+    if (g->dims == 2 && g->nz != 1) return LSF_ERR_BAD_DIMS;
+    if (g->z_begin < 0 || g->z_end > g->nz || g->z_begin > g->z_end) return LSF_ERR_BAD_ARGUMENT;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// launch geometry: one thread per voxel, x fastest.  Blocks are (64 x 4) tiles in (x, y) of one z slice, so a
+// wave reads 256 contiguous bytes per field row.  The grid is 1-D over tiles; consecutive block ids walk x
+// tiles, then y tiles, then z -- neighbouring blocks (which share halo rows) therefore land on different XCDs
+// under round-robin dispatch, so remap block ids so that each XCD owns a contiguous chunk of z-slices (T1).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kTileX = 64;
+constexpr int kTileY = 4;
+
+struct Tiling {
+    int tiles_x, tiles_y, tiles_z;
+    unsigned total;
+};
+
+__host__ __device__ inline Tiling make_tiling(const Grid& g) {
+    Tiling t;
+    t.tiles_x = (g.nx + kTileX - 1) / kTileX;
+    t.tiles_y = (g.ny + kTileY - 1) / kTileY;
+    t.tiles_z = g.z_end - g.z_begin;
+    t.total = (unsigned)t.tiles_x * t.tiles_y * t.tiles_z;
+    return t;
+}
+
+// bijective XCD-aware remap of a 1-D block id (8 XCDs, round-robin dispatch): blocks b, b+8, b+16 ... share
+// an XCD, so give XCD k the k-th contiguous chunk of the tile sequence.
+__device__ inline unsigned xcd_remap(unsigned bid, unsigned total) {
+    const unsigned nx = 8;
+    unsigned q = total / nx, r = total % nx;
+    unsigned xcd = bid % nx, i = bid / nx;
+    unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + i;
+}
+
+// voxel of this thread; returns false when outside the grid
+__device__ inline bool thread_voxel(const Grid& g, int& x, int& y, int& z) {
+    Tiling t = make_tiling(g);
+    unsigned bid = xcd_remap(blockIdx.x, t.total);
+    int tx = bid % t.tiles_x;
+    unsigned rest = bid / t.tiles_x;
+    int ty = rest % t.tiles_y;
+    int tz = rest / t.tiles_y;
+    x = tx * kTileX + (threadIdx.x & (kTileX - 1));
+    y = ty * kTileY + (threadIdx.x / kTileX);
+    z = g.z_begin + tz;
+    return x < g.nx && y < g.ny;
+}
+
+__device__ inline long long vidx(const Grid& g, int x, int y, int z) {
+    return ((long long)z * g.ny + y) * g.nx + x;
+}
+
+__device__ inline bool inside(const Grid& g, int x, int y, int z) {
+    return (unsigned)x < (unsigned)g.nx && (unsigned)y < (unsigned)g.ny && (unsigned)z < (unsigned)g.nz;
+}
+
+// scalar read with a constant for out-of-bounds taps (utils/sampling.py:35-55)
+__device__ inline float read_oob(const float* __restrict__ f, const Grid& g, int x, int y, int z, float oob) {
+    return inside(g, x, y, z) ? f[vidx(g, x, y, z)] : oob;
+}
+
+// clamp-to-edge read (edge replication)
+__device__ inline float read_clamp(const float* __restrict__ f, const Grid& g, int x, int y, int z) {
+    x = min(max(x, 0), g.nx - 1);
+    y = min(max(y, 0), g.ny - 1);
+    z = min(max(z, 0), g.nz - 1);
+    return f[vidx(g, x, y, z)];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// D-linear interpolation of a scalar field (oracle.sample_linear): per-tap OOB constant, lerp z, then y, then x
+// ------------------------------------------------------------------------------------------------------
+template <int D>
+__device__ inline float sample_linear(const float* __restrict__ f, const Grid& g, float px, float py, float pz,
+                                      float oob) {
+    float fx = floorf(px), fy = floorf(py);
+    float rx = px - fx, ry = py - fy;
+    float ix = 1.0f - rx, iy = 1.0f - ry;
+    // clamp the base so the int conversion is defined for wild warps; anything beyond is OOB anyway
+    int bx = (int)fminf(fmaxf(fx, -2.0f), (float)g.nx + 1.0f);
+    int by = (int)fminf(fmaxf(fy, -2.0f), (float)g.ny + 1.0f);
+    if (D == 2) {
+        float v00 = read_oob(f, g, bx, by, 0, oob);
+        float v01 = read_oob(f, g, bx, by + 1, 0, oob);
+        float v10 = read_oob(f, g, bx + 1, by, 0, oob);
+        float v11 = read_oob(f, g, bx + 1, by + 1, 0, oob);
+        float i0 = v00 * iy + v01 * ry;
+        float i1 = v10 * iy + v11 * ry;
+        return i0 * ix + i1 * rx;
+    } else {
+        float fz = floorf(pz);
+        float rz = pz - fz, iz = 1.0f - rz;
+        int bz = (int)fminf(fmaxf(fz, -2.0f), (float)g.nz + 1.0f);
+        float c[2][2];  // [x offset][y offset] after the z lerp
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+            for (int oy = 0; oy < 2; ++oy) {
+                float a = read_oob(f, g, bx + ox, by + oy, bz, oob);
+                float b = read_oob(f, g, bx + ox, by + oy, bz + 1, oob);
+                c[ox][oy] = a * iz + b * rz;
+            }
+        float i0 = c[0][0] * iy + c[0][1] * ry;
+        float i1 = c[1][0] * iy + c[1][1] * ry;
+        return i0 * ix + i1 * rx;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// block reductions: 64-lane shuffles -> LDS across the 4 waves -> one atomic per block
+// ------------------------------------------------------------------------------------------------------
+__device__ inline unsigned long long shfl_down_u64(unsigned long long v, int delta) {
+    unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    lo = __shfl_down(lo, delta, kWave);
+    hi = __shfl_down(hi, delta, kWave);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ inline double shfl_down_f64(double v, int delta) {
+    return __longlong_as_double((long long)shfl_down_u64((unsigned long long)__double_as_longlong(v), delta));
+}
+
+__device__ inline unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        unsigned long long o = shfl_down_u64(v, d);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__device__ inline double wave_sum_f64(double v) {
+#pragma unroll
+    for (int d = kWave / 2; d > 0; d >>= 1) v += shfl_down_f64(v, d);
+    return v;
+}
+
+__device__ inline unsigned long long pack_max(float length, unsigned linear_index) {
+    return ((unsigned long long)__float_as_uint(length) << 32) | (unsigned long long)(~linear_index);
+}
+
+__device__ inline float unpack_max_value(unsigned long long packed) { return __uint_as_float((unsigned)(packed >> 32)); }
+
+// Block-wide: max of `packed` -> atomicMax(dst_max); sums of up to NS doubles -> atomicAdd(dst_sum[i]).
+// Must be called by every thread of the block.
+template <int NS>
+__device__ inline void block_reduce_commit(unsigned long long packed, const double (&sums)[NS > 0 ? NS : 1],
+                                           unsigned long long* dst_max, double* const (&dst_sum)[NS > 0 ? NS : 1]) {
+    __shared__ unsigned long long s_max[kBlock / kWave];
+    __shared__ double s_sum[(NS > 0 ? NS : 1)][kBlock / kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    unsigned long long m = wave_max_u64(packed);
+    double s[NS > 0 ? NS : 1];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) s[i] = wave_sum_f64(sums[i]);
+    if (lane == 0) {
+        s_max[wave] = m;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) s_sum[i][wave] = s[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long mm = s_max[0];
+#pragma unroll
+        for (int w = 1; w < kBlock / kWave; ++w) mm = s_max[w] > mm ? s_max[w] : mm;
+        if (dst_max && mm != 0ull) atomicMax(dst_max, mm);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < kBlock / kWave; ++w) t += s_sum[i][w];
+            if (dst_sum[i] && t != 0.0) atomicAdd(dst_sum[i], t);
+        }
+    }
+}
+
+// vector length as np.linalg.norm(axis=-1) evaluates it in float32: sqrt((a^2 + b^2) [+ c^2])
+template <int D>
+__device__ inline float vec_length(const float (&v)[3]) {
+    float s = v[0] * v[0] + v[1] * v[1];
+    if (D == 3) s = s + v[2] * v[2];
+    return sqrtf(s);
+}
+
+// scipy.ndimage.laplace on one axis: float32( -2*a0 + (ap + am) ) evaluated in double
+__device__ inline float second_difference_f64(float am, float a0, float ap) {
+    return (float)(-2.0 * (double)a0 + ((double)ap + (double)am));
+}
+
+// device-side convergence gate (see lsf_gate in include/lsf_hip.h) ------------------------------------------
+__device__ inline bool gate_closed(const lsf_gate& gate) {
+    if (!gate.prev_record) return false;
+    unsigned long long p = gate.prev_record->max_packed;
+    if (p == 0ull) return true;  // previous iteration was itself a no-op
+    float m = unpack_max_value(p);
+    if (gate.mode == LSF_GATE_HIERARCHICAL) return m < gate.a;
+    return !(gate.a < m && m < gate.b);
+}
+
+__device__ inline unsigned long long* record_max(lsf_iteration_record* r) {
+    return reinterpret_cast<unsigned long long*>(&r->max_packed);
+}
+
+__host__ inline lsf_gate gate_or_open(const lsf_gate* gate) {
+    return gate ? *gate : lsf_gate{nullptr, 0, 0.0f, 0.0f};
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int launch_status() { return (int)hipGetLastError(); }
+
+}  // namespace lsf

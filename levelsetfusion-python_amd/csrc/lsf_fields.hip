@@ -1,0 +1,427 @@
+// Field utilities of liblsf_hip.so: layout conversion, resampling under a warp (a1-a3), np.gradient packing
+// (a4), pyramid restrict / prolong (a5, a6), separable convolution passes (a9, a10), convergence statistics
+// (a20).  Reference citations are in include/lsf_hip.h next to each entry point.
+#include "lsf_device.h"
+
+using namespace lsf;
+
+// =====================================================================================================
+//  layout helpers
+// =====================================================================================================
+__global__ __launch_bounds__(kBlock) void deinterleave_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              long long n, int channels) {
+    long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < channels; ++c) out[(long long)c * n + i] = in[i * channels + c];
+}
+
+__global__ __launch_bounds__(kBlock) void interleave_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            long long n, int channels) {
+    long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    for (int c = 0; c < channels; ++c) out[i * channels + c] = in[(long long)c * n + i];
+}
+
+extern "C" int lsf_deinterleave(const float* interleaved, float* planar, int64_t n_voxels, int32_t channels,
+                                void* stream) {
+    if (!interleaved || !planar || n_voxels < 0 || channels < 1 || channels > 4) return LSF_ERR_BAD_ARGUMENT;
+    if (n_voxels == 0) return 0;
+    unsigned blocks = (unsigned)((n_voxels + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(deinterleave_kernel, dim3(blocks), dim3(kBlock), 0, as_stream(stream), interleaved, planar,
+                       (long long)n_voxels, channels);
+    return launch_status();
+}
+
+extern "C" int lsf_interleave(const float* planar, float* interleaved, int64_t n_voxels, int32_t channels,
+                              void* stream) {
+    if (!interleaved || !planar || n_voxels < 0 || channels < 1 || channels > 4) return LSF_ERR_BAD_ARGUMENT;
+    if (n_voxels == 0) return 0;
+    unsigned blocks = (unsigned)((n_voxels + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(interleave_kernel, dim3(blocks), dim3(kBlock), 0, as_stream(stream), planar, interleaved,
+                       (long long)n_voxels, channels);
+    return launch_status();
+}
+
+// =====================================================================================================
+//  a1/a2  warp_field / warp_field_replacement
+// =====================================================================================================
+template <int D>
+__global__ __launch_bounds__(kBlock) void warp_field_kernel(const float* __restrict__ field,
+                                                            const float* __restrict__ warp, float* __restrict__ out,
+                                                            Grid g, float oob) {
+    int x, y, z;
+    if (!thread_voxel(g, x, y, z)) return;
+    long long i = vidx(g, x, y, z);
+    float px = (float)x + warp[i];
+    float py = (float)y + warp[g.plane + i];
+    float pz = D == 3 ? (float)z + warp[2 * g.plane + i] : 0.0f;
+    out[i] = sample_linear<D>(field, g, px, py, pz, oob);
+}
+
+extern "C" int lsf_warp_field(const float* field, const float* warp_planar, float* out, const lsf_grid* grid,
+                              float oob_value, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!field || !warp_planar || !out) return LSF_ERR_BAD_ARGUMENT;
+    Grid g = make_grid(grid);
+    Tiling t = make_tiling(g);
+    if (t.total == 0) return 0;
+    if (grid->dims == 2)
+        hipLaunchKernelGGL(warp_field_kernel<2>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), field,
+                           warp_planar, out, g, oob_value);
+    else
+        hipLaunchKernelGGL(warp_field_kernel<3>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), field,
+                           warp_planar, out, g, oob_value);
+    return launch_status();
+}
+
+// =====================================================================================================
+//  a3  warp_field_advanced
+// =====================================================================================================
+template <int D>
+__global__ __launch_bounds__(kBlock) void warp_field_advanced_kernel(const float* __restrict__ canonical,
+                                                                     const float* __restrict__ live,
+                                                                     float* __restrict__ warp,
+                                                                     float* __restrict__ gradient,
+                                                                     float* __restrict__ new_live, Grid g, int flags) {
+    int x, y, z;
+    if (!thread_voxel(g, x, y, z)) return;
+    long long i = vidx(g, x, y, z);
+    float original = live[i];
+    bool skip = false;
+    if (flags & 1) skip = skip || (fabsf(original) == 1.0f && fabsf(canonical[i]) == 1.0f);
+    if (flags & 2) skip = skip || (original == 1.0f);
+    if (skip) {
+        new_live[i] = original;
+        return;
+    }
+    float px = (float)x + warp[i];
+    float py = (float)y + warp[g.plane + i];
+    float pz = D == 3 ? (float)z + warp[2 * g.plane + i] : 0.0f;
+    float v = sample_linear<D>(live, g, px, py, pz, (flags & 4) ? original : 1.0f);
+    if (1.0f - fabsf(v) < 1e-6f) {
+        v = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : v);
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            warp[c * g.plane + i] = 0.0f;
+            if (gradient) gradient[c * g.plane + i] = 0.0f;
+        }
+    }
+    new_live[i] = v;
+}
+
+extern "C" int lsf_warp_field_advanced(const float* canonical, const float* live, float* warp_planar,
+                                       float* gradient_planar, float* new_live, const lsf_grid* grid,
+                                       int32_t flags, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!canonical || !live || !warp_planar || !new_live || live == new_live) return LSF_ERR_BAD_ARGUMENT;
+    Grid g = make_grid(grid);
+    Tiling t = make_tiling(g);
+    if (t.total == 0) return 0;
+    if (grid->dims == 2)
+        hipLaunchKernelGGL(warp_field_advanced_kernel<2>, dim3(t.total), dim3(kBlock), 0, as_stream(stream),
+                           canonical, live, warp_planar, gradient_planar, new_live, g, flags);
+    else
+        hipLaunchKernelGGL(warp_field_advanced_kernel<3>, dim3(t.total), dim3(kBlock), 0, as_stream(stream),
+                           canonical, live, warp_planar, gradient_planar, new_live, g, flags);
+    return launch_status();
+}
+
+// =====================================================================================================
+//  a4  np.gradient of live, packed as float4 (live, gx, gy, gz)
+// =====================================================================================================
+__device__ inline float np_gradient_axis(const float* __restrict__ f, long long i, int coord, int n, long long stride) {
+    if (n == 1) return 0.0f;
+    if (coord == 0) return f[i + stride] - f[i];
+    if (coord == n - 1) return f[i] - f[i - stride];
+    return (f[i + stride] - f[i - stride]) * 0.5f;
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void pack_live_gradient_kernel(const float* __restrict__ live,
+                                                                    float4* __restrict__ packed, Grid g) {
+    int x, y, z;
+    if (!thread_voxel(g, x, y, z)) return;
+    long long i = vidx(g, x, y, z);
+    float4 r;
+    r.x = live[i];
+    r.y = np_gradient_axis(live, i, x, g.nx, 1);
+    r.z = np_gradient_axis(live, i, y, g.ny, g.nx);
+    r.w = D == 3 ? np_gradient_axis(live, i, z, g.nz, (long long)g.ny * g.nx) : 0.0f;
+    packed[i] = r;
+}
+
+extern "C" int lsf_pack_live_gradient(const float* live, float* packed4, const lsf_grid* grid, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!live || !packed4) return LSF_ERR_BAD_ARGUMENT;
+    Grid g = make_grid(grid);
+    Tiling t = make_tiling(g);
+    if (t.total == 0) return 0;
+    if (grid->dims == 2)
+        hipLaunchKernelGGL(pack_live_gradient_kernel<2>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), live,
+                           reinterpret_cast<float4*>(packed4), g);
+    else
+        hipLaunchKernelGGL(pack_live_gradient_kernel<3>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), live,
+                           reinterpret_cast<float4*>(packed4), g);
+    return launch_status();
+}
+
+// =====================================================================================================
+//  a5  restrict (2^D block mean per channel)     a6  prolong (repeat)
+// =====================================================================================================
+// sum order: 2-D ((a00 + a01) + a10) + a11 (numpy's float32 reduction of the reshaped 4-vector);
+// 3-D (s(z0) + s(z1)) * 0.125 with s the 2-D block sums (oracle.restrict_mean).
+template <int D, int C>
+__global__ __launch_bounds__(kBlock) void restrict_mean_kernel(const float* __restrict__ fine,
+                                                               float* __restrict__ coarse, Grid gc, int fnx, int fny) {
+    int x, y, z;
+    if (!thread_voxel(gc, x, y, z)) return;
+    long long o = vidx(gc, x, y, z);
+    const long long row = fnx, slice = (long long)fnx * fny;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        long long b = (((long long)(D == 3 ? 2 * z : 0) * fny + 2 * y) * fnx + 2 * x);
+        auto at = [&](long long j) { return fine[j * C + c]; };
+        float s0 = ((at(b) + at(b + 1)) + at(b + row)) + at(b + row + 1);
+        float r;
+        if (D == 2) {
+            r = s0 * 0.25f;
+        } else {
+            long long b1 = b + slice;
+            float s1 = ((at(b1) + at(b1 + 1)) + at(b1 + row)) + at(b1 + row + 1);
+            r = (s0 + s1) * 0.125f;
+        }
+        coarse[o * C + c] = r;
+    }
+}
+
+extern "C" int lsf_restrict_mean(const float* fine, float* coarse, const lsf_grid* fine_grid, int32_t channels,
+                                 void* stream) {
+    if (int e = check_grid(fine_grid)) return e;
+    if (!fine || !coarse || (channels != 1 && channels != 4)) return LSF_ERR_BAD_ARGUMENT;
+    if ((fine_grid->nx & 1) || (fine_grid->ny & 1) || (fine_grid->dims == 3 && (fine_grid->nz & 1)))
+        return LSF_ERR_BAD_DIMS;
+    lsf_grid cg = *fine_grid;
+    cg.nx /= 2;
+    cg.ny /= 2;
+    if (cg.dims == 3) cg.nz /= 2;
+    cg.z_begin = 0;
+    cg.z_end = cg.nz;
+    Grid gc = make_grid(&cg);
+    Tiling t = make_tiling(gc);
+    if (t.total == 0) return 0;
+    hipStream_t s = as_stream(stream);
+#define LSF_LAUNCH_RESTRICT(D, C)                                                                             \
+    hipLaunchKernelGGL((restrict_mean_kernel<D, C>), dim3(t.total), dim3(kBlock), 0, s, fine, coarse, gc, \
+                       fine_grid->nx, fine_grid->ny)
+    if (fine_grid->dims == 2) {
+        if (channels == 1) LSF_LAUNCH_RESTRICT(2, 1); else LSF_LAUNCH_RESTRICT(2, 4);
+    } else {
+        if (channels == 1) LSF_LAUNCH_RESTRICT(3, 1); else LSF_LAUNCH_RESTRICT(3, 4);
+    }
+#undef LSF_LAUNCH_RESTRICT
+    return launch_status();
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void prolong_repeat_kernel(const float* __restrict__ coarse,
+                                                                float* __restrict__ fine, Grid gf) {
+    int x, y, z;
+    if (!thread_voxel(gf, x, y, z)) return;
+    const int cnx = gf.nx / 2, cny = gf.ny / 2, cnz = D == 3 ? gf.nz / 2 : 1;
+    const long long cplane = (long long)cnx * cny * cnz;
+    long long ci = ((long long)(D == 3 ? z / 2 : 0) * cny + y / 2) * cnx + x / 2;
+    long long fi = vidx(gf, x, y, z);
+#pragma unroll
+    for (int c = 0; c < D; ++c) fine[c * gf.plane + fi] = coarse[c * cplane + ci];
+}
+
+extern "C" int lsf_prolong_repeat(const float* coarse_planar, float* fine_planar, const lsf_grid* fine_grid,
+                                  void* stream) {
+    if (int e = check_grid(fine_grid)) return e;
+    if (!coarse_planar || !fine_planar) return LSF_ERR_BAD_ARGUMENT;
+    if ((fine_grid->nx & 1) || (fine_grid->ny & 1) || (fine_grid->dims == 3 && (fine_grid->nz & 1)))
+        return LSF_ERR_BAD_DIMS;
+    Grid g = make_grid(fine_grid);
+    Tiling t = make_tiling(g);
+    if (t.total == 0) return 0;
+    if (fine_grid->dims == 2)
+        hipLaunchKernelGGL(prolong_repeat_kernel<2>, dim3(t.total), dim3(kBlock), 0, as_stream(stream),
+                           coarse_planar, fine_planar, g);
+    else
+        hipLaunchKernelGGL(prolong_repeat_kernel<3>, dim3(t.total), dim3(kBlock), 0, as_stream(stream),
+                           coarse_planar, fine_planar, g);
+    return launch_status();
+}
+
+// =====================================================================================================
+//  a9/a10  one separable-convolution pass
+// =====================================================================================================
+struct Taps {
+    double k[LSF_MAX_KERNEL_TAPS];
+    int n;
+};
+
+__global__ __launch_bounds__(kBlock) void convolve_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               const float* __restrict__ mask_src, Grid g, int axis,
+                                                               Taps taps, lsf_gate gate) {
+    if (gate_closed(gate)) return;
+    int x, y, z;
+    if (!thread_voxel(g, x, y, z)) return;
+    const long long base = (long long)blockIdx.y * g.plane;
+    const long long i = vidx(g, x, y, z);
+    const int coord = axis == 0 ? x : (axis == 1 ? y : z);
+    const int len = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz);
+    const long long stride = axis == 0 ? 1 : (axis == 1 ? g.nx : (long long)g.nx * g.ny);
+    const int c = taps.n / 2;
+    double acc = 0.0;
+    for (int j = 0; j < taps.n; ++j) {
+        int s = c - j;
+        int q = coord + s;
+        if (q >= 0 && q < len) acc = acc + taps.k[j] * (double)in[base + i + s * stride];
+    }
+    float r = (float)acc;
+    if (mask_src && fabsf(mask_src[base + i]) < 1e-6f) r = 0.0f;
+    out[base + i] = r;
+}
+
+extern "C" int lsf_convolve_axis(const float* in_planar, float* out_planar, const float* zero_mask_source,
+                                 const lsf_grid* grid, int32_t planes, int32_t axis, const double* taps_host,
+                                 int32_t n_taps, const lsf_gate* gate, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!in_planar || !out_planar || in_planar == out_planar || !taps_host) return LSF_ERR_BAD_ARGUMENT;
+    if (n_taps < 1 || n_taps > LSF_MAX_KERNEL_TAPS) return LSF_ERR_KERNEL_TOO_LONG;
+    if (axis < 0 || axis >= grid->dims || planes < 1 || planes > 4) return LSF_ERR_BAD_ARGUMENT;
+    Grid g = make_grid(grid);
+    Tiling t = make_tiling(g);
+    if (t.total == 0) return 0;
+    Taps taps;
+    taps.n = n_taps;
+    for (int j = 0; j < LSF_MAX_KERNEL_TAPS; ++j) taps.k[j] = j < n_taps ? taps_host[j] : 0.0;
+    lsf_gate gt = gate ? *gate : lsf_gate{nullptr, 0, 0.0f, 0.0f};
+    hipLaunchKernelGGL(convolve_axis_kernel, dim3(t.total, planes), dim3(kBlock), 0, as_stream(stream), in_planar,
+                       out_planar, zero_mask_source, g, axis, taps, gt);
+    return launch_status();
+}
+
+// =====================================================================================================
+//  a20  convergence statistics
+// =====================================================================================================
+__global__ void stats_init_kernel(double* out8, int is_tsdf) {
+    if (threadIdx.x < 8) out8[threadIdx.x] = 0.0;
+    if (threadIdx.x == 0 && is_tsdf) out8[1] = __longlong_as_double(0x7ff0000000000000ll);  // +inf (min)
+}
+
+__device__ inline void atomic_min_f64_nonneg(double* addr, double v) {
+    // non-negative doubles order like their bit patterns
+    atomicMin(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+__device__ inline void atomic_max_f64_nonneg(double* addr, double v) {
+    atomicMax(reinterpret_cast<unsigned long long*>(addr), (unsigned long long)__double_as_longlong(v));
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void warp_statistics_kernel(const float* __restrict__ warp,
+                                                                 const float* __restrict__ canonical,
+                                                                 const float* __restrict__ live, Grid g, float lo,
+                                                                 double* out8, unsigned long long* packed_out) {
+    int x, y, z;
+    bool active = thread_voxel(g, x, y, z);
+    unsigned long long packed = 0ull;
+    double sums[4] = {0.0, 0.0, 0.0, 0.0};
+    if (active) {
+        long long i = vidx(g, x, y, z);
+        bool band = !(fabsf(live[i]) == 1.0f && fabsf(canonical[i]) == 1.0f);
+        if (band) {
+            float v[3] = {warp[i], warp[g.plane + i], D == 3 ? warp[2 * g.plane + i] : 0.0f};
+            float len = vec_length<D>(v);
+            unsigned lin = (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);
+            packed = pack_max(len, lin);
+            sums[0] = 1.0;
+            sums[1] = len > lo ? 1.0 : 0.0;
+            sums[2] = (double)len;
+            sums[3] = (double)len * (double)len;
+        }
+    }
+    double* dst[4] = {out8 + 0, out8 + 1, out8 + 3, out8 + 4};
+    block_reduce_commit<4>(packed, sums, packed_out, dst);
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void tsdf_statistics_kernel(const float* __restrict__ canonical,
+                                                                 const float* __restrict__ live, Grid g, double* out8,
+                                                                 unsigned long long* packed_out) {
+    int x, y, z;
+    bool active = thread_voxel(g, x, y, z);
+    unsigned long long packed = 0ull;
+    double sums[3] = {0.0, 0.0, 0.0};
+    double mn = __longlong_as_double(0x7ff0000000000000ll);
+    if (active) {
+        long long i = vidx(g, x, y, z);
+        double d = fabs((double)canonical[i] - (double)live[i]);
+        unsigned lin = (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);
+        packed = pack_max((float)d, lin);
+        sums[0] = 1.0;
+        sums[1] = d;
+        sums[2] = d * d;
+        mn = d;
+    }
+    // min over the wave, one atomic per wave (tiny kernel, run once per optimize call)
+    for (int dl = kWave / 2; dl > 0; dl >>= 1) mn = fmin(mn, shfl_down_f64(mn, dl));
+    if ((threadIdx.x & (kWave - 1)) == 0) atomic_min_f64_nonneg(out8 + 1, mn);
+    double* dst[3] = {out8 + 0, out8 + 3, out8 + 4};
+    block_reduce_commit<3>(packed, sums, packed_out, dst);
+}
+
+__global__ void stats_finish_kernel(double* out8, const unsigned long long* packed, int is_tsdf) {
+    if (threadIdx.x != 0) return;
+    unsigned long long p = *packed;
+    out8[2] = p ? (double)unpack_max_value(p) : 0.0;
+    out8[5] = p ? (double)(~(unsigned)p) : -1.0;
+    (void)is_tsdf;
+}
+
+extern "C" int lsf_warp_statistics(const float* warp_planar, const float* canonical, const float* live,
+                                   const lsf_grid* grid, float lower_threshold, double* out8, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!warp_planar || !canonical || !live || !out8) return LSF_ERR_BAD_ARGUMENT;
+    Grid g = make_grid(grid);
+    Tiling t = make_tiling(g);
+    hipStream_t s = as_stream(stream);
+    unsigned long long* packed = reinterpret_cast<unsigned long long*>(out8 + 7);
+    hipLaunchKernelGGL(stats_init_kernel, dim3(1), dim3(64), 0, s, out8, 0);
+    if (t.total) {
+        if (grid->dims == 2)
+            hipLaunchKernelGGL(warp_statistics_kernel<2>, dim3(t.total), dim3(kBlock), 0, s, warp_planar, canonical,
+                               live, g, lower_threshold, out8, packed);
+        else
+            hipLaunchKernelGGL(warp_statistics_kernel<3>, dim3(t.total), dim3(kBlock), 0, s, warp_planar, canonical,
+                               live, g, lower_threshold, out8, packed);
+    }
+    hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(64), 0, s, out8, packed, 0);
+    return launch_status();
+}
+
+extern "C" int lsf_tsdf_difference_statistics(const float* canonical, const float* live, const lsf_grid* grid,
+                                              double* out8, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!canonical || !live || !out8) return LSF_ERR_BAD_ARGUMENT;
+    Grid g = make_grid(grid);
+    Tiling t = make_tiling(g);
+    hipStream_t s = as_stream(stream);
+    unsigned long long* packed = reinterpret_cast<unsigned long long*>(out8 + 7);
+    hipLaunchKernelGGL(stats_init_kernel, dim3(1), dim3(64), 0, s, out8, 1);
+    if (t.total) {
+        if (grid->dims == 2)
+            hipLaunchKernelGGL(tsdf_statistics_kernel<2>, dim3(t.total), dim3(kBlock), 0, s, canonical, live, g, out8,
+                               packed);
+        else
+            hipLaunchKernelGGL(tsdf_statistics_kernel<3>, dim3(t.total), dim3(kBlock), 0, s, canonical, live, g, out8,
+                               packed);
+    }
+    hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(64), 0, s, out8, packed, 1);
+    return launch_status();
+}
+
+extern "C" int lsf_abi_version(void) { return LSF_ABI_VERSION; }
+extern "C" const char* lsf_target_arch(void) { return "gfx950"; }

@@ -1,0 +1,230 @@
+// Hierarchical optimizer iteration kernels.
+// One launch = one pass of the loop body of nonrigid_opt/hierarchical/hierarchical_optimizer2d.py:184-225
+// over one pyramid level, dimension-generic (D = 2, 3).
+//
+// Data layout: the live field and its D np.gradient components are STATIC per optimize()
+// call and are only ever read through the data-dependent D-linear gather, so they are packed as one float4 per
+// voxel (live, gx, gy, gz): one 16-byte load per tap instead of four scattered dwords.  warp / gradient are
+// planar ([c][z][y][x]) so that the pointwise and 7-point-stencil accesses are unit-stride dword streams.
+#include "lsf_device.h"
+
+using namespace lsf;
+
+namespace {
+
+struct Packed {
+    float l, gx, gy, gz;
+};
+
+__device__ inline Packed read_packed(const float4* __restrict__ s, const Grid& g, int x, int y, int z) {
+    Packed p;
+    if (inside(g, x, y, z)) {
+        float4 v = s[vidx(g, x, y, z)];
+        p.l = v.x; p.gx = v.y; p.gy = v.z; p.gz = v.w;
+    } else {  // OOB taps: live reads 1 (field_warping.py:67-85), gradients read 0 (:88-109 with replacement 0)
+        p.l = 1.0f; p.gx = 0.0f; p.gy = 0.0f; p.gz = 0.0f;
+    }
+    return p;
+}
+
+__device__ inline Packed lerp(const Packed& a, const Packed& b, float inv, float ratio) {
+    Packed r;
+    r.l = a.l * inv + b.l * ratio;
+    r.gx = a.gx * inv + b.gx * ratio;
+    r.gy = a.gy * inv + b.gy * ratio;
+    r.gz = a.gz * inv + b.gz * ratio;
+    return r;
+}
+
+// D-linear gather of the packed field: lerp along z, then y, then x (oracle.sample_linear)
+template <int D>
+__device__ inline Packed gather_packed(const float4* __restrict__ s, const Grid& g, float px, float py, float pz) {
+    float fx = floorf(px), fy = floorf(py);
+    float rx = px - fx, ry = py - fy;
+    float ix = 1.0f - rx, iy = 1.0f - ry;
+    int bx = (int)fminf(fmaxf(fx, -2.0f), (float)g.nx + 1.0f);
+    int by = (int)fminf(fmaxf(fy, -2.0f), (float)g.ny + 1.0f);
+    Packed c[2][2];
+    if (D == 2) {
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+            for (int oy = 0; oy < 2; ++oy) c[ox][oy] = read_packed(s, g, bx + ox, by + oy, 0);
+    } else {
+        float fz = floorf(pz);
+        float rz = pz - fz, iz = 1.0f - rz;
+        int bz = (int)fminf(fmaxf(fz, -2.0f), (float)g.nz + 1.0f);
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+            for (int oy = 0; oy < 2; ++oy) {
+                Packed a = read_packed(s, g, bx + ox, by + oy, bz);
+                Packed b = read_packed(s, g, bx + ox, by + oy, bz + 1);
+                c[ox][oy] = lerp(a, b, iz, rz);
+            }
+    }
+    Packed i0 = lerp(c[0][0], c[0][1], iy, ry);
+    Packed i1 = lerp(c[1][0], c[1][1], iy, ry);
+    return lerp(i0, i1, ix, rx);
+}
+
+// scipy.ndimage.laplace(mode='nearest') of one plane at (x,y,z): per-axis second differences evaluated in
+// double and stored float32, summed in float32, slowest axis first (oracle.laplace_replicate)
+template <int D>
+__device__ inline float laplace_replicate(const float* __restrict__ a, const Grid& g, int x, int y, int z) {
+    const long long i = vidx(g, x, y, z);
+    const float a0 = a[i];
+    const long long sy = g.nx, sz = (long long)g.nx * g.ny;
+    float out;
+    float d2y = second_difference_f64(y > 0 ? a[i - sy] : a0, a0, y < g.ny - 1 ? a[i + sy] : a0);
+    float d2x = second_difference_f64(x > 0 ? a[i - 1] : a0, a0, x < g.nx - 1 ? a[i + 1] : a0);
+    if (D == 3) {
+        float d2z = second_difference_f64(z > 0 ? a[i - sz] : a0, a0, z < g.nz - 1 ? a[i + sz] : a0);
+        out = d2z + d2y;
+    } else {
+        out = d2y;
+    }
+    return out + d2x;
+}
+
+template <int D, bool TIK, bool UPDATE, bool ENERGY>
+__global__ __launch_bounds__(kBlock) void hier_iteration_kernel(const float4* __restrict__ packed,
+                                                                const float* __restrict__ canonical,
+                                                                float* __restrict__ warp,
+                                                                const float* __restrict__ g_prev,
+                                                                float* __restrict__ g_out, Grid g, float amp,
+                                                                float strength, float rate, lsf_gate gate,
+                                                                lsf_iteration_record* record) {
+    if (gate_closed(gate)) return;
+    int x, y, z;
+    const bool active = thread_voxel(g, x, y, z);
+    unsigned long long best = 0ull;
+    double sums[1] = {0.0};
+    if (active) {
+        const long long i = vidx(g, x, y, z);
+        float w[3];
+        w[0] = warp[i];
+        w[1] = warp[g.plane + i];
+        w[2] = D == 3 ? warp[2 * g.plane + i] : 0.0f;
+        const float px = (float)x + w[0], py = (float)y + w[1], pz = D == 3 ? (float)z + w[2] : 0.0f;
+        const Packed s = gather_packed<D>(packed, g, px, py, pz);
+        const float diff = s.l - canonical[i];
+        const float live_grad[3] = {s.gx, s.gy, s.gz};
+        float gv[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            float gd = diff * live_grad[c];
+            if (TIK) {
+                float lap = laplace_replicate<D>(g_prev + c * g.plane, g, x, y, z);
+                gv[c] = amp * gd - strength * lap;
+            } else {
+                gv[c] = amp * gd;
+            }
+            if (g_out) g_out[c * g.plane + i] = gv[c];
+        }
+        if (UPDATE) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) warp[c * g.plane + i] = w[c] - rate * gv[c];
+            unsigned lin = (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);
+            best = pack_max(vec_length<D>(gv), lin);
+        }
+        if (ENERGY) sums[0] = (double)diff * (double)diff;
+    }
+    if (UPDATE || ENERGY) {
+        double* dst[1] = {ENERGY ? &record->data_energy : nullptr};
+        block_reduce_commit<1>(best, sums, UPDATE ? record_max(record) : nullptr, dst);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void hier_update_kernel(const float* __restrict__ gfield,
+                                                             float* __restrict__ warp, Grid g, float rate,
+                                                             lsf_gate gate, lsf_iteration_record* record) {
+    if (gate_closed(gate)) return;
+    int x, y, z;
+    const bool active = thread_voxel(g, x, y, z);
+    unsigned long long best = 0ull;
+    if (active) {
+        const long long i = vidx(g, x, y, z);
+        float gv[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            gv[c] = gfield[c * g.plane + i];
+            warp[c * g.plane + i] = warp[c * g.plane + i] - rate * gv[c];
+        }
+        unsigned lin = (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);
+        best = pack_max(vec_length<D>(gv), lin);
+    }
+    const double sums[1] = {0.0};
+    double* dst[1] = {nullptr};
+    block_reduce_commit<0>(best, sums, record_max(record), dst);
+}
+
+template <int D, bool TIK, bool UPDATE>
+void launch_hier(bool energy, unsigned blocks, hipStream_t s, const float4* packed, const float* canonical,
+                 float* warp, const float* g_prev, float* g_out, const Grid& g, const lsf_hier_params* p,
+                 const lsf_gate& gate, lsf_iteration_record* record) {
+    if (energy)
+        hipLaunchKernelGGL((hier_iteration_kernel<D, TIK, UPDATE, true>), dim3(blocks), dim3(kBlock), 0, s, packed,
+                           canonical, warp, g_prev, g_out, g, p->data_term_amplifier, p->tikhonov_strength, p->rate,
+                           gate, record);
+    else
+        hipLaunchKernelGGL((hier_iteration_kernel<D, TIK, UPDATE, false>), dim3(blocks), dim3(kBlock), 0, s, packed,
+                           canonical, warp, g_prev, g_out, g, p->data_term_amplifier, p->tikhonov_strength, p->rate,
+                           gate, record);
+}
+
+template <int D>
+void dispatch_hier(unsigned blocks, hipStream_t s, const float4* packed, const float* canonical, float* warp,
+                   const float* g_prev, float* g_out, const Grid& g, const lsf_hier_params* p, const lsf_gate& gate,
+                   lsf_iteration_record* record) {
+    const bool e = p->compute_energy != 0;
+    if (p->tikhonov_enabled) {
+        if (p->apply_update) launch_hier<D, true, true>(e, blocks, s, packed, canonical, warp, g_prev, g_out, g, p, gate, record);
+        else launch_hier<D, true, false>(e, blocks, s, packed, canonical, warp, g_prev, g_out, g, p, gate, record);
+    } else {
+        if (p->apply_update) launch_hier<D, false, true>(e, blocks, s, packed, canonical, warp, g_prev, g_out, g, p, gate, record);
+        else launch_hier<D, false, false>(e, blocks, s, packed, canonical, warp, g_prev, g_out, g, p, gate, record);
+    }
+}
+
+}  // namespace
+
+extern "C" int lsf_hier_iteration(const float* packed_live4, const float* canonical, float* warp_planar,
+                                  const float* g_prev_planar, float* g_out_planar, const lsf_grid* grid,
+                                  const lsf_hier_params* params, const lsf_gate* gate, lsf_iteration_record* record,
+                                  void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!packed_live4 || !canonical || !warp_planar || !params || !record) return LSF_ERR_BAD_ARGUMENT;
+    if (params->tikhonov_enabled && (!g_prev_planar || g_prev_planar == g_out_planar)) return LSF_ERR_BAD_ARGUMENT;
+    if (!params->apply_update && !g_out_planar) return LSF_ERR_BAD_ARGUMENT;
+    Grid g = make_grid(grid);
+    Tiling t = make_tiling(g);
+    if (t.total == 0) return 0;
+    const float4* packed = reinterpret_cast<const float4*>(packed_live4);
+    lsf_gate gt = gate_or_open(gate);
+    if (grid->dims == 2)
+        dispatch_hier<2>(t.total, as_stream(stream), packed, canonical, warp_planar, g_prev_planar, g_out_planar, g,
+                         params, gt, record);
+    else
+        dispatch_hier<3>(t.total, as_stream(stream), packed, canonical, warp_planar, g_prev_planar, g_out_planar, g,
+                         params, gt, record);
+    return launch_status();
+}
+
+extern "C" int lsf_hier_update(const float* g_planar, float* warp_planar, const lsf_grid* grid, float rate,
+                               const lsf_gate* gate, lsf_iteration_record* record, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!g_planar || !warp_planar || !record) return LSF_ERR_BAD_ARGUMENT;
+    Grid g = make_grid(grid);
+    Tiling t = make_tiling(g);
+    if (t.total == 0) return 0;
+    lsf_gate gt = gate_or_open(gate);
+    if (grid->dims == 2)
+        hipLaunchKernelGGL(hier_update_kernel<2>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), g_planar,
+                           warp_planar, g, rate, gt, record);
+    else
+        hipLaunchKernelGGL(hier_update_kernel<3>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), g_planar,
+                           warp_planar, g, rate, gt, record);
+    return launch_status();
+}

@@ -1,0 +1,250 @@
+"""Torch-facing wrappers around the C ABI of liblsf_hip.so.
+
+torch is plumbing here: it owns device memory and the HIP stream.  Every wrapper validates dtype, device,
+contiguity and element counts on the host BEFORE the launch (a hand-written kernel that reads past a buffer can
+take the whole GPU down), then passes raw device pointers + the current HIP stream to the library.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Gate, Grid, HierParams, SlavchevaParams, check, lib
+
+RECORD_WORDS = _lib.RECORD_BYTES // 8  # an iteration record is 4 x 8 bytes
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("levelsetfusion-python_amd needs an AMD GPU (ROCm): torch.cuda.is_available() is False. "
+                           "There is no CPU execution path in this package.")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_grid(shape, z_begin=0, z_end=None, z_global_offset=0):
+    """shape: spatial extents (ny, nx) or (nz, ny, nx)"""
+    shape = tuple(int(s) for s in shape)
+    if len(shape) == 2:
+        nz, (ny, nx), dims = 1, shape, 2
+    elif len(shape) == 3:
+        (nz, ny, nx), dims = shape, 3
+    else:
+        raise ValueError("fields must be 2-D or 3-D, got shape %r" % (shape,))
+    z_end = nz if z_end is None else z_end
+    if not (0 <= z_begin <= z_end <= nz):
+        raise ValueError("bad z range [%d, %d) for nz = %d" % (z_begin, z_end, nz))
+    return Grid(dims, nz, ny, nx, z_begin, z_end, z_global_offset, 0)
+
+
+def n_voxels(grid):
+    return grid.nz * grid.ny * grid.nx
+
+
+def _ptr(t, numel, name, dtype=torch.float32, allow_none=False):
+    if t is None:
+        if allow_none:
+            return ctypes.c_void_p(0)
+        raise ValueError("%s: tensor required" % name)
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise ValueError("%s: expected a CUDA/ROCm tensor" % name)
+    if t.dtype != dtype:
+        raise ValueError("%s: expected dtype %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s: tensor must be contiguous" % name)
+    if t.numel() != numel:
+        raise ValueError("%s: expected %d elements, got %d" % (name, numel, t.numel()))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _record_ptr(records, index, name="records"):
+    """records: int64 tensor [n, 4] (raw 32-byte records); returns pointer to record `index`"""
+    if records.dtype != torch.int64 or not records.is_cuda or not records.is_contiguous() or records.dim() != 2 \
+            or records.shape[1] != RECORD_WORDS:
+        raise ValueError("%s: expected a contiguous CUDA int64 tensor of shape [n, %d]" % (name, RECORD_WORDS))
+    if not (0 <= index < records.shape[0]):
+        raise IndexError("%s: record index %d out of range [0, %d)" % (name, index, records.shape[0]))
+    return ctypes.c_void_p(records.data_ptr() + index * _lib.RECORD_BYTES)
+
+
+def new_records(n, device):
+    return torch.zeros((n, RECORD_WORDS), dtype=torch.int64, device=device)
+
+
+def make_gate(records, prev_index, mode, a, b=0.0):
+    """gate on record `prev_index` (None / negative: always run)"""
+    if records is None or prev_index is None or prev_index < 0:
+        return None
+    return Gate(_record_ptr(records, prev_index).value, int(mode), float(a), float(b))
+
+
+def _gate_ref(gate):
+    return ctypes.byref(gate) if gate is not None else None
+
+
+def decode_records(records_host):
+    """records_host: numpy int64 [n,4] -> dict of arrays (max value, linear arg-max index, energies, executed)"""
+    raw = np.ascontiguousarray(records_host)
+    packed = raw[:, 0].view(np.uint64)
+    executed = packed != 0
+    max_value = (packed >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    index = (~packed.astype(np.uint32)).astype(np.int64) & 0xFFFFFFFF
+    return dict(executed=executed, max_value=max_value, argmax=index,
+                data_energy=raw[:, 1].view(np.float64), smoothing_energy=raw[:, 2].view(np.float64),
+                level_set_energy=raw[:, 3].view(np.float64))
+
+
+# ---------------------------------------------------------------------------------------------- layout
+def deinterleave(interleaved, channels):
+    n = interleaved.numel() // channels
+    out = torch.empty((channels,) + tuple(interleaved.shape[:-1]), dtype=torch.float32, device=interleaved.device)
+    check(lib.lsf_deinterleave(_ptr(interleaved, n * channels, "interleaved"), _ptr(out, n * channels, "planar"),
+                               n, channels, stream_ptr()), "lsf_deinterleave")
+    return out
+
+
+def interleave(planar):
+    channels = planar.shape[0]
+    n = planar.numel() // channels
+    out = torch.empty(tuple(planar.shape[1:]) + (channels,), dtype=torch.float32, device=planar.device)
+    check(lib.lsf_interleave(_ptr(planar, n * channels, "planar"), _ptr(out, n * channels, "interleaved"), n,
+                             channels, stream_ptr()), "lsf_interleave")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- a1-a3
+def warp_field(field, warp_planar, oob_value, grid=None, out=None):
+    grid = grid or make_grid(field.shape)
+    n = n_voxels(grid)
+    out = torch.empty_like(field) if out is None else out
+    check(lib.lsf_warp_field(_ptr(field, n, "field"), _ptr(warp_planar, n * grid.dims, "warp"),
+                             _ptr(out, n, "out"), ctypes.byref(grid), float(oob_value), stream_ptr()),
+          "lsf_warp_field")
+    return out
+
+
+def warp_field_advanced(canonical, live, warp_planar, gradient_planar, flags, grid=None, out=None):
+    grid = grid or make_grid(live.shape)
+    n = n_voxels(grid)
+    out = torch.empty_like(live) if out is None else out
+    check(lib.lsf_warp_field_advanced(_ptr(canonical, n, "canonical"), _ptr(live, n, "live"),
+                                      _ptr(warp_planar, n * grid.dims, "warp"),
+                                      _ptr(gradient_planar, n * grid.dims, "gradient", allow_none=True),
+                                      _ptr(out, n, "new_live"), ctypes.byref(grid), int(flags), stream_ptr()),
+          "lsf_warp_field_advanced")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- a4-a6
+def pack_live_gradient(live, grid=None):
+    grid = grid or make_grid(live.shape)
+    n = n_voxels(grid)
+    out = torch.empty(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device)
+    check(lib.lsf_pack_live_gradient(_ptr(live, n, "live"), _ptr(out, 4 * n, "packed"), ctypes.byref(grid),
+                                     stream_ptr()), "lsf_pack_live_gradient")
+    return out
+
+
+def restrict_mean(fine, channels):
+    """fine: [z,]y,x (channels == 1) or [z,]y,x,4"""
+    spatial = tuple(fine.shape) if channels == 1 else tuple(fine.shape[:-1])
+    grid = make_grid(spatial)
+    coarse_spatial = tuple(s // 2 for s in spatial)
+    out = torch.empty(coarse_spatial + (() if channels == 1 else (channels,)), dtype=torch.float32,
+                      device=fine.device)
+    check(lib.lsf_restrict_mean(_ptr(fine, n_voxels(grid) * channels, "fine"),
+                                _ptr(out, out.numel(), "coarse"), ctypes.byref(grid), channels, stream_ptr()),
+          "lsf_restrict_mean")
+    return out
+
+
+def prolong_repeat(coarse_planar):
+    dims = coarse_planar.shape[0]
+    fine_spatial = tuple(2 * s for s in coarse_planar.shape[1:])
+    grid = make_grid(fine_spatial)
+    out = torch.empty((dims,) + fine_spatial, dtype=torch.float32, device=coarse_planar.device)
+    check(lib.lsf_prolong_repeat(_ptr(coarse_planar, coarse_planar.numel(), "coarse"),
+                                 _ptr(out, n_voxels(grid) * dims, "fine"), ctypes.byref(grid), stream_ptr()),
+          "lsf_prolong_repeat")
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- a9/a10
+def convolve_axis(src, dst, zero_mask_source, grid, axis, taps, gate=None):
+    taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float64))
+    if taps.ndim != 1 or not (1 <= taps.size <= _lib.MAX_KERNEL_TAPS):
+        raise ValueError("kernel must be 1-D with 1..%d taps" % _lib.MAX_KERNEL_TAPS)
+    length = (grid.nx, grid.ny, grid.nz)[axis]
+    if length < taps.size:
+        # the reference cannot do this either: np.convolve(..., 'same') returns max(M, N) samples
+        raise ValueError("cannot convolve a field of extent %d with a %d-tap kernel" % (length, taps.size))
+    planes = src.shape[0]
+    n = n_voxels(grid) * planes
+    check(lib.lsf_convolve_axis(_ptr(src, n, "conv src"), _ptr(dst, n, "conv dst"),
+                                _ptr(zero_mask_source, n, "zero mask", allow_none=True), ctypes.byref(grid),
+                                planes, axis, taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), taps.size,
+                                _gate_ref(gate), stream_ptr()), "lsf_convolve_axis")
+
+
+# ------------------------------------------------------------------------------------- optimizer kernels
+def hier_iteration(packed, canonical, warp, g_prev, g_out, grid, params, gate, records, index):
+    n = n_voxels(grid)
+    check(lib.lsf_hier_iteration(_ptr(packed, 4 * n, "packed live"), _ptr(canonical, n, "canonical"),
+                                 _ptr(warp, n * grid.dims, "warp"),
+                                 _ptr(g_prev, n * grid.dims, "g_prev", allow_none=True),
+                                 _ptr(g_out, n * grid.dims, "g_out", allow_none=True), ctypes.byref(grid),
+                                 ctypes.byref(params), _gate_ref(gate), _record_ptr(records, index), stream_ptr()),
+          "lsf_hier_iteration")
+
+
+def hier_update(g, warp, grid, rate, gate, records, index):
+    n = n_voxels(grid) * grid.dims
+    check(lib.lsf_hier_update(_ptr(g, n, "g"), _ptr(warp, n, "warp"), ctypes.byref(grid), float(rate),
+                              _gate_ref(gate), _record_ptr(records, index), stream_ptr()), "lsf_hier_update")
+
+
+def slavcheva_iteration(stage, live, canonical, warp_prev, warp_out, live_out, g_out, grid, params, gate, records,
+                        index):
+    n = n_voxels(grid)
+    nd = n * grid.dims
+    check(lib.lsf_slavcheva_iteration(int(stage), _ptr(live, n, "live"), _ptr(canonical, n, "canonical"),
+                                      _ptr(warp_prev, nd, "warp_prev"),
+                                      _ptr(warp_out, nd, "warp_out", allow_none=True),
+                                      _ptr(live_out, n, "live_out", allow_none=True),
+                                      _ptr(g_out, nd, "g_out", allow_none=True), ctypes.byref(grid),
+                                      ctypes.byref(params), _gate_ref(gate), _record_ptr(records, index),
+                                      stream_ptr()), "lsf_slavcheva_iteration")
+
+
+def slavcheva_update_rewarp(live, canonical, g, warp_out, live_out, grid, params, gate, records, index):
+    n = n_voxels(grid)
+    nd = n * grid.dims
+    check(lib.lsf_slavcheva_update_rewarp(_ptr(live, n, "live"), _ptr(canonical, n, "canonical"), _ptr(g, nd, "g"),
+                                          _ptr(warp_out, nd, "warp_out"), _ptr(live_out, n, "live_out"),
+                                          ctypes.byref(grid), ctypes.byref(params), _gate_ref(gate),
+                                          _record_ptr(records, index), stream_ptr()),
+          "lsf_slavcheva_update_rewarp")
+
+
+# ---------------------------------------------------------------------------------------------- a20
+def warp_statistics(warp_planar, canonical, live, lower_threshold, grid=None):
+    grid = grid or make_grid(live.shape)
+    n = n_voxels(grid)
+    out = torch.empty(8, dtype=torch.float64, device=live.device)
+    check(lib.lsf_warp_statistics(_ptr(warp_planar, n * grid.dims, "warp"), _ptr(canonical, n, "canonical"),
+                                  _ptr(live, n, "live"), ctypes.byref(grid), float(lower_threshold),
+                                  _ptr(out, 8, "out8", dtype=torch.float64), stream_ptr()), "lsf_warp_statistics")
+    return out
+
+
+def tsdf_difference_statistics(canonical, live, grid=None):
+    grid = grid or make_grid(live.shape)
+    n = n_voxels(grid)
+    out = torch.empty(8, dtype=torch.float64, device=live.device)
+    check(lib.lsf_tsdf_difference_statistics(_ptr(canonical, n, "canonical"), _ptr(live, n, "live"),
+                                             ctypes.byref(grid), _ptr(out, 8, "out8", dtype=torch.float64),
+                                             stream_ptr()), "lsf_tsdf_difference_statistics")
+    return out

@@ -1,0 +1,329 @@
+"""Device-resident optimizer engines (dimension-generic, slab-aware).  The drop-in classes under
+nonrigid_opt/ are thin shells around these.
+
+All state lives in torch ROCm tensors; every per-voxel operation is a hand-written HIP kernel reached through
+the C ABI (device.py -> liblsf_hip.so).  The host loop only enqueues launches and, every `check_interval`
+iterations, reads back the tiny iteration records to learn whether the device-side convergence gate has closed.
+"""
+import numpy as np
+import torch
+
+from . import _lib, device as dev
+from .slab import SlabComm, SlabLayout
+
+
+def as_device_field(x, device=None):
+    """numpy array or torch tensor -> contiguous float32 ROCm tensor (no copy when already one)"""
+    dev.require_gpu()
+    if isinstance(x, torch.Tensor):
+        t = x
+        if not t.is_cuda:
+            t = t.to(device or "cuda")
+        return t.to(torch.float32).contiguous()
+    a = np.ascontiguousarray(np.asarray(x, dtype=np.float32))
+    return torch.from_numpy(a).to(device or "cuda")
+
+
+def _is_power_of_two(n):
+    return n > 0 and (n & (n - 1)) == 0
+
+
+def pyramid_level_count(shape, maximum_chunk_size):
+    """level-count rule and error behaviour of nonrigid_opt/hierarchical/pyramid.py:31-45"""
+    if not all(_is_power_of_two(int(s)) for s in shape):
+        raise ValueError("The argument 'field' must be an array where each dimension is a power of two.")
+    if not _is_power_of_two(int(maximum_chunk_size)):
+        raise ValueError("The argument 'maximum_chunk_size' must be an integer power of 2, i.e. 4, 8, 16, etc.")
+    p = int(maximum_chunk_size).bit_length() - 1
+    if min(int(s).bit_length() - 1 for s in shape) <= p:
+        raise ValueError("maximum chunk size {:d} is too large for a field of size {:s}"
+                         .format(int(maximum_chunk_size), str(tuple(int(s) for s in shape))))
+    return p + 1
+
+
+def _conv_axis_order(dims):
+    # kernel axis ids: 0 = x, 1 = y, 2 = z.  2-D: y then x (math_utils/convolution.py:77-83);
+    # 3-D: x, y, z (math_utils/convolution.py:94-105)
+    return [1, 0] if dims == 2 else [0, 1, 2]
+
+
+class LevelResult:
+    def __init__(self, iteration_count, max_updates, argmax, data_energies, voxel_count=0):
+        self.voxel_count = voxel_count
+        self.iteration_count = iteration_count
+        self.max_updates = max_updates
+        self.argmax = argmax
+        self.data_energies = data_energies
+        self.iteration_limit_reached = False
+
+
+class HierarchicalEngine:
+    """coarse-to-fine gradient descent on a cumulative warp field
+    (nonrigid_opt/hierarchical/hierarchical_optimizer2d.py:123-246), D = 2 or 3."""
+
+    def __init__(self, tikhonov_term_enabled, gradient_kernel_enabled, maximum_chunk_size, rate,
+                 maximum_iteration_count, maximum_warp_update_threshold, data_term_amplifier, tikhonov_strength,
+                 kernel, compute_energy=False, check_interval=8):
+        self.maximum_chunk_size = maximum_chunk_size
+        self.rate = rate
+        self.data_term_amplifier = data_term_amplifier
+        # enable-flag folding of hierarchical_optimizer2d.py:96-107
+        if tikhonov_term_enabled:
+            self.tikhonov_strength = tikhonov_strength
+            self.tikhonov_term_enabled = tikhonov_strength != 0.0
+        else:
+            self.tikhonov_strength = 0.0
+            self.tikhonov_term_enabled = False
+        if gradient_kernel_enabled:
+            self.gradient_kernel = kernel
+            self.gradient_kernel_enabled = kernel is not None
+        else:
+            self.gradient_kernel = None
+            self.gradient_kernel_enabled = False
+        self.maximum_warp_update_threshold = maximum_warp_update_threshold
+        self.maximum_iteration_count = int(maximum_iteration_count)
+        self.compute_energy = compute_energy
+        self.check_interval = max(1, int(check_interval))
+        self.level_results = []
+        self.last_gradient = None  # planar gradient of the finest level after the last iteration
+
+    # ------------------------------------------------------------------------------------------------
+    def build_pyramids(self, canonical, live):
+        """canonical / live pyramids, coarsest first; live is packed with its full-resolution np.gradient
+        BEFORE restriction (gradients are averaged, not recomputed: hierarchical_optimizer2d.py:126-131)"""
+        n_levels = pyramid_level_count(live.shape, self.maximum_chunk_size)
+        canon_levels = [canonical]
+        packed_levels = [dev.pack_live_gradient(live)]
+        for _ in range(1, n_levels):
+            canon_levels.append(dev.restrict_mean(canon_levels[-1], 1))
+            packed_levels.append(dev.restrict_mean(packed_levels[-1], 4))
+        canon_levels.reverse()
+        packed_levels.reverse()
+        return canon_levels, packed_levels
+
+    def optimize(self, canonical, live):
+        """canonical, live: float32 device tensors [z,]y,x.  Returns the warp field, PLANAR [c][z][y][x]."""
+        if canonical.shape != live.shape:
+            raise ValueError("canonical and live fields must have the same shape")
+        dims = live.dim()
+        canon_levels, packed_levels = self.build_pyramids(canonical, live)
+        self.level_results = []
+        warp = None
+        for level, (canon_l, packed_l) in enumerate(zip(canon_levels, packed_levels)):
+            if level == 0:
+                warp = torch.zeros((dims,) + tuple(canon_l.shape), dtype=torch.float32, device=live.device)
+            self.optimize_level(canon_l, packed_l, warp)
+            if level != len(canon_levels) - 1:
+                warp = dev.prolong_repeat(warp)
+        return warp
+
+    def optimize_level(self, canonical, packed, warp):
+        dims = canonical.dim()
+        grid = dev.make_grid(canonical.shape)
+        max_it = self.maximum_iteration_count
+        thr = float(self.maximum_warp_update_threshold)
+        records = dev.new_records(max(max_it, 1), canonical.device)
+        tik, ker = self.tikhonov_term_enabled, self.gradient_kernel_enabled
+        params = _lib.HierParams(float(self.data_term_amplifier), float(self.tikhonov_strength), float(self.rate),
+                                 int(tik), int(not ker), int(self.compute_energy))
+        n_buf = 3 if ker else (2 if tik else 0)
+        bufs = [torch.zeros_like(warp) for _ in range(n_buf)]
+        final = 0  # buffer that holds the previous iteration's final gradient (zeros at level start, :179)
+        finals = []
+        it = 0
+        n_exec = 0
+        dec = None
+        while it < max_it:
+            batch = min(self.check_interval, max_it - it)
+            for i in range(it, it + batch):
+                gate = dev.make_gate(records, i - 1, _lib.GATE_HIERARCHICAL, thr) if i > 0 else None
+                if ker:
+                    a, b = [k for k in range(3) if k != final]
+                    dev.hier_iteration(packed, canonical, warp, bufs[final] if tik else None, bufs[a], grid, params,
+                                       gate, records, i)
+                    src, dst = a, b
+                    for axis in _conv_axis_order(dims):
+                        dev.convolve_axis(bufs[src], bufs[dst], None, grid, axis, self.gradient_kernel, gate)
+                        src, dst = dst, src
+                    final = src
+                    dev.hier_update(bufs[final], warp, grid, self.rate, gate, records, i)
+                elif tik:
+                    out = 1 - final
+                    dev.hier_iteration(packed, canonical, warp, bufs[final], bufs[out], grid, params, gate, records,
+                                       i)
+                    final = out
+                else:
+                    dev.hier_iteration(packed, canonical, warp, None, None, grid, params, gate, records, i)
+                finals.append(final)
+            it += batch
+            dec = dev.decode_records(records[:it].cpu().numpy())  # the only host sync of the batch
+            n_exec = int(dec["executed"].sum())
+            if n_exec < it or dec["max_value"][n_exec - 1] < np.float32(thr):
+                break
+        if dec is None:  # maximum_iteration_count == 0: the reference's loop body never runs
+            dec = dev.decode_records(records[:1].cpu().numpy())
+        res = LevelResult(n_exec, [float(v) for v in dec["max_value"][:n_exec]],
+                          [int(v) for v in dec["argmax"][:n_exec]],
+                          [float(v) for v in dec["data_energy"][:n_exec]], dev.n_voxels(grid))
+        res.iteration_limit_reached = n_exec >= max_it
+        self.level_results.append(res)
+        self.last_gradient = bufs[finals[n_exec - 1]] if (n_buf and n_exec) else None
+        return warp
+
+
+class SlavchevaEngine:
+    """per-iteration-update optimizer with in-place re-warping of the live field
+    (nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:332-408), D = 2 or 3, optionally on a z-slab."""
+
+    def __init__(self, direct, level_set_term_enabled, sobolev_smoothing_enabled, data_term_method,
+                 smoothing_term_method, gradient_descent_rate, data_term_weight, smoothing_term_weight,
+                 isomorphic_enforcement_factor, level_set_term_weight, lower_threshold, upper_threshold,
+                 max_iterations, min_iterations, sobolev_kernel, compute_energies=True, check_interval=8,
+                 comm=None):
+        self.direct = bool(direct)
+        self.sobolev = bool(sobolev_smoothing_enabled)
+        self.sobolev_kernel = sobolev_kernel
+        if self.sobolev and sobolev_kernel is None:
+            raise ValueError("sobolev_smoothing_enabled requires a sobolev_kernel")
+        lam = float(isomorphic_enforcement_factor)
+        # VECTORIZED ignores the Killing / level-set / thresholded options (slavcheva_optimizer2d.py:163-190)
+        smoothing = smoothing_term_method if self.direct else _lib.SMOOTHING_TIKHONOV
+        data = data_term_method if self.direct else _lib.DATA_BASIC
+        level_set = bool(level_set_term_enabled) and self.direct
+        energy = _lib.ENERGY_NONE if not compute_energies else \
+            (_lib.ENERGY_DIRECT if self.direct else _lib.ENERGY_VECTORIZED)
+        self.params = _lib.SlavchevaParams(lam, float(gradient_descent_rate), float(data_term_weight),
+                                           float(smoothing_term_weight), float(level_set_term_weight), lam,
+                                           float(np.float32(-2.0 * (1.0 + lam))), int(smoothing), int(data),
+                                           int(level_set), int(energy), int(self.direct), 0)
+        self.weights = (float(data_term_weight), float(smoothing_term_weight), float(level_set_term_weight))
+        self.lo, self.hi = float(lower_threshold), float(upper_threshold)
+        self.max_iterations, self.min_iterations = int(max_iterations), int(min_iterations)
+        self.check_interval = max(1, int(check_interval))
+        self.comm = comm
+        self.iteration_count = 0
+        self.log = None
+        self._gradient_state = None
+
+    def _grid(self, live):
+        if self.comm is not None and self.comm.active:
+            L = self.comm.layout
+            if live.dim() != 3 or live.shape[0] != L.nz_local:
+                raise ValueError("slab runs need a 3-D local field with %d slices, got %r"
+                                 % (L.nz_local, tuple(live.shape)))
+            return dev.make_grid(live.shape, L.z_begin, L.z_end, L.z_global_offset)
+        return dev.make_grid(live.shape)
+
+    def _enqueue_iteration(self, i, live_in, live_out, warp_in, warp_out, canonical, grid, records, gbufs):
+        # iteration i runs iff i < min_iterations or (i < max_iterations and lo < max_warp[i-1] < hi)
+        # (slavcheva_optimizer2d.py:360-362)
+        gate = None if i < self.min_iterations else dev.make_gate(records, i - 1, _lib.GATE_SLAVCHEVA, self.lo,
+                                                                  self.hi)
+        if not self.sobolev:
+            dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None, grid,
+                                    self.params, gate, records, i)
+        else:
+            g0, t1, t2 = gbufs
+            dev.slavcheva_iteration(_lib.STAGE_GRADIENT, live_in, canonical, warp_in, None, None, g0, grid,
+                                    self.params, gate, records, i)
+            in_plane_grid = grid
+            if self.comm is not None and self.comm.active:
+                # the z pass of the filter reads len(kernel)//2 slices of the (x,y)-filtered field on either
+                # side: exchange the raw gradient's halo once and run the x and y passes on the halo slices too
+                self.comm.exchange_halos([g0])
+                in_plane_grid = dev.make_grid(live_in.shape, 0, grid.nz, grid.z_global_offset)
+            src, dst = g0, t1
+            for axis in _conv_axis_order(grid.dims):
+                dev.convolve_axis(src, dst, g0, grid if axis == 2 else in_plane_grid, axis, self.sobolev_kernel,
+                                  gate)
+                src, dst = dst, (t2 if dst is t1 else t1)
+            dev.slavcheva_update_rewarp(live_in, canonical, src, warp_out, live_out, grid, self.params, gate,
+                                        records, i)
+            self._last_g = src
+        if self.comm is not None and self.comm.active:
+            self.comm.exchange_halos([live_out, warp_out])
+            self.comm.reduce_records(records, i, i + 1)
+
+    def optimize(self, live, canonical):
+        """live, canonical: float32 device tensors.  Returns (final live tensor, final warp PLANAR).  The
+        caller's `live` tensor is not modified; the drop-in class copies the result back in place."""
+        if live.shape != canonical.shape:
+            raise ValueError("live and canonical fields must have the same shape")
+        grid = self._grid(live)
+        dims = grid.dims
+        n_rec = max(self.max_iterations, self.min_iterations, 1)
+        slab = self.comm is not None and self.comm.active
+        if slab:
+            need = 1 if not self.sobolev else max(1, len(self.sobolev_kernel) // 2)
+            if self.comm.layout.halo < need:
+                raise ValueError("slab halo of %d slices is too narrow: this configuration needs >= %d"
+                                 % (self.comm.layout.halo, need))
+        records = dev.new_records(n_rec, live.device)
+        lives = [live.clone(), torch.empty_like(live)]
+        warps = [torch.zeros((dims,) + tuple(live.shape), dtype=torch.float32, device=live.device) for _ in range(2)]
+        if self.comm is not None and self.comm.active:
+            lives[1].copy_(live)  # halo slices of both buffers start out valid
+        gbufs = [torch.zeros_like(warps[0]) for _ in range(3)] if self.sobolev else None
+        self._last_g = None
+        # with min_iterations == 0 the reference never enters its loop (max_warp starts at +inf, :354,:360-362)
+        limit = 0 if self.min_iterations == 0 else max(self.max_iterations, self.min_iterations)
+        it, n_exec = 0, 0
+        dec = None
+        while it < limit:
+            batch = min(self.check_interval, limit - it)
+            for i in range(it, it + batch):
+                self._enqueue_iteration(i, lives[i % 2], lives[(i + 1) % 2], warps[i % 2], warps[(i + 1) % 2],
+                                        canonical, grid, records, gbufs)
+            it += batch
+            dec = dev.decode_records(records[:it].cpu().numpy())
+            n_exec = int(dec["executed"].sum())
+            if n_exec < it:
+                break
+            m = dec["max_value"][n_exec - 1]
+            if slab and not (m < self.comm.layout.halo):
+                raise RuntimeError("warp update of %.3f voxels reaches past the %d-slice slab halo; re-run with a "
+                                   "wider halo" % (float(m), self.comm.layout.halo))
+            if n_exec >= self.min_iterations and not (np.float32(self.lo) < m < np.float32(self.hi)):
+                break
+        self.iteration_count = n_exec
+        wd, ws, wl = self.weights
+        if dec is None:
+            dec = dev.decode_records(records[:1].cpu().numpy())
+        self.log = dict(max_warps=[float(v) for v in dec["max_value"][:n_exec]],
+                        max_warp_indices=[int(v) for v in dec["argmax"][:n_exec]],
+                        data_energies=[wd * float(v) for v in dec["data_energy"][:n_exec]],
+                        smoothing_energies=[ws * float(v) for v in dec["smoothing_energy"][:n_exec]],
+                        level_set_energies=[wl * float(v) for v in dec["level_set_energy"][:n_exec]])
+        final_live, final_warp = lives[n_exec % 2], warps[n_exec % 2]
+        # what is needed to (re)produce gradient_field of the last executed iteration on demand
+        if n_exec == 0:
+            self._gradient_state = ("zeros", torch.zeros_like(warps[0]))
+        elif self.sobolev:
+            # g buffers rotate identically every iteration, so the last executed iteration's filtered gradient
+            # is in the buffer the (gated, skipped) later launches would have used too
+            self._gradient_state = ("ready", self._last_g)
+        else:
+            self._gradient_state = ("recompute", lives[(n_exec - 1) % 2], warps[(n_exec - 1) % 2], canonical, grid)
+        return final_live, final_warp
+
+    def gradient_field(self):
+        """planar gradient of the last executed iteration (zeroed where the live field snapped, DIRECT only).
+        The fused kernel does not store it (12 B/voxel/iteration saved); it is recomputed here from the inputs
+        of the last iteration, which the ping-pong buffers still hold, by the unfused kernels -- same code path,
+        same bits."""
+        st = self._gradient_state
+        if st is None:
+            return None
+        if st[0] in ("zeros", "ready"):
+            return st[1]
+        _, live_in, warp_in, canonical, grid = st
+        g = torch.empty_like(warp_in)
+        scratch_records = dev.new_records(1, live_in.device)
+        params = _lib.SlavchevaParams.from_buffer_copy(self.params)
+        params.energy_mode = _lib.ENERGY_NONE
+        dev.slavcheva_iteration(_lib.STAGE_GRADIENT, live_in, canonical, warp_in, None, None, g, grid, params, None,
+                                scratch_records, 0)
+        dev.slavcheva_update_rewarp(live_in, canonical, g, torch.empty_like(warp_in), torch.empty_like(live_in), grid,
+                                    params, None, scratch_records, 0)
+        self._gradient_state = ("ready", g)
+        return g

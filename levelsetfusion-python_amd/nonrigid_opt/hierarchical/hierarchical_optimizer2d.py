@@ -1,0 +1,128 @@
+"""HierarchicalOptimizer2d -- drop-in for nonrigid_opt/hierarchical/hierarchical_optimizer2d.py:62-167 of the
+reference: same constructor keywords, same optimize(canonical_field, live_field) -> warp_field (H, W, 2) float32
+convention (inputs untouched), same ValueErrors for fields a pyramid cannot be built from.  The work is done by
+HIP kernels on the GPU (engine.HierarchicalEngine)."""
+import numpy as np
+import torch
+
+from ... import device as dev
+from ...engine import HierarchicalEngine, as_device_field
+from ...convergence_report import (ConvergenceReport, build_tsdf_difference_statistics,
+                                   build_warp_delta_statistics)
+
+
+class _HierarchicalOptimizerBase:
+    DIMS = 2
+
+    class VerbosityParameters:
+        """stdout verbosity switches (hierarchical_optimizer2d.py:41-60; the 3-D/C++ variant adds the
+        mean/std TSDF-difference flags, build_helper.py:127-154)"""
+
+        def __init__(self, print_max_warp_update=False, print_iteration_mean_tsdf_difference=False,
+                     print_iteration_std_tsdf_difference=False, print_iteration_data_energy=False,
+                     print_iteration_tikhonov_energy=False):
+            self.print_max_warp_update = print_max_warp_update
+            self.print_iteration_mean_tsdf_difference = print_iteration_mean_tsdf_difference
+            self.print_iteration_std_tsdf_difference = print_iteration_std_tsdf_difference
+            self.print_iteration_data_energy = print_iteration_data_energy
+            self.print_iteration_tikhonov_energy = print_iteration_tikhonov_energy
+            self.per_iteration_flags = [print_max_warp_update, print_iteration_data_energy,
+                                        print_iteration_tikhonov_energy]
+            self.print_per_iteration_info = any(self.per_iteration_flags)
+            self.print_per_level_info = self.print_per_iteration_info or False
+
+    class LoggingParameters:
+        def __init__(self, collect_per_level_convergence_reports=False, collect_per_level_iteration_data=False):
+            self.collect_per_level_convergence_reports = collect_per_level_convergence_reports
+            self.collect_per_level_iteration_data = collect_per_level_iteration_data
+
+    def __init__(self, tikhonov_term_enabled=True, gradient_kernel_enabled=True, maximum_chunk_size=8, rate=0.1,
+                 maximum_iteration_count=100, maximum_warp_update_threshold=0.001, data_term_amplifier=1.0,
+                 tikhonov_strength=0.2, kernel=None, verbosity_parameters=None, visualization_parameters=None,
+                 logging_parameters=None, check_interval=8):
+        self.verbosity_parameters = verbosity_parameters or self.VerbosityParameters()
+        self.visualization_parameters = visualization_parameters  # accepted, unused: no video writers here
+        self.logging_parameters = logging_parameters or self.LoggingParameters()
+        self._engine = HierarchicalEngine(
+            tikhonov_term_enabled, gradient_kernel_enabled, maximum_chunk_size, rate, maximum_iteration_count,
+            maximum_warp_update_threshold, data_term_amplifier, tikhonov_strength,
+            None if kernel is None else np.asarray(kernel, dtype=np.float64),
+            compute_energy=bool(getattr(self.verbosity_parameters, "print_iteration_data_energy", False)),
+            check_interval=check_interval)
+        e = self._engine
+        self.maximum_chunk_size = e.maximum_chunk_size
+        self.rate = e.rate
+        self.data_term_amplifier = e.data_term_amplifier
+        self.tikhonov_strength = e.tikhonov_strength
+        self.tikhonov_term_enabled = e.tikhonov_term_enabled
+        self.gradient_kernel = e.gradient_kernel
+        self.gradient_kernel_enabled = e.gradient_kernel_enabled
+        self.maximum_warp_update_threshold = e.maximum_warp_update_threshold
+        self.maximum_iteration_count = e.maximum_iteration_count
+        self.hierarchy_level = 0
+        self._reports = []
+
+    def optimize(self, canonical_field, live_field):
+        """returns the cumulative warp field, interleaved [.., D] float32: a numpy array for numpy inputs, a
+        device tensor when both inputs are ROCm tensors (nothing crosses PCIe then)"""
+        on_device = isinstance(canonical_field, torch.Tensor) and isinstance(live_field, torch.Tensor) \
+            and canonical_field.is_cuda
+        if len(canonical_field.shape) != self.DIMS or len(live_field.shape) != self.DIMS:
+            raise ValueError("%s expects %d-D fields" % (type(self).__name__, self.DIMS))
+        canonical = as_device_field(canonical_field)
+        live = as_device_field(live_field)
+        warp_planar = self._engine.optimize(canonical, live)
+        self.hierarchy_level = len(self._engine.level_results)
+        self._print_levels()
+        self._reports = []
+        if self.logging_parameters.collect_per_level_convergence_reports:
+            self._reports = self._build_reports(canonical, live, warp_planar)
+        warp = dev.interleave(warp_planar)
+        return warp if on_device else warp.cpu().numpy()
+
+    # ------------------------------------------------------------------------------------------------
+    def get_per_level_iteration_counts(self):
+        return [r.iteration_count for r in self._engine.level_results]
+
+    def get_per_level_maximum_updates(self):
+        return [list(r.max_updates) for r in self._engine.level_results]
+
+    def get_per_level_convergence_reports(self):
+        """one ConvergenceReport per pyramid level (run_hierarchical_optimizer3d.py:104); needs
+        LoggingParameters(collect_per_level_convergence_reports=True)"""
+        return list(self._reports)
+
+    def _build_reports(self, canonical, live, warp_planar):
+        # statistics of the finest level are exact; coarser levels report iteration counts only (their fields
+        # are gone by the time optimize() returns; collect them with check_interval=1 hooks if needed)
+        reports = []
+        n = len(self._engine.level_results)
+        for k, r in enumerate(self._engine.level_results):
+            if k == n - 1:
+                resampled = dev.warp_field(live, warp_planar, 1.0)
+                ws = build_warp_delta_statistics(self._engine.last_gradient if self._engine.last_gradient is not None
+                                                 else warp_planar, canonical, resampled,
+                                                 self.maximum_warp_update_threshold, float("inf"))
+                ds = build_tsdf_difference_statistics(canonical, resampled)
+                reports.append(ConvergenceReport(r.iteration_count, r.iteration_limit_reached, ws, ds))
+            else:
+                reports.append(ConvergenceReport(r.iteration_count, r.iteration_limit_reached))
+        return reports
+
+    def _print_levels(self):
+        vp = self.verbosity_parameters
+        if not vp.print_per_iteration_info:
+            return
+        for level, r in enumerate(self._engine.level_results):
+            for it in range(r.iteration_count):
+                line = "[ITERATION %d COMPLETED]" % it
+                if vp.print_max_warp_update:
+                    line += " max upd. l.: %f" % r.max_updates[it]
+                if vp.print_iteration_data_energy:
+                    line += " norm. data energy: %f" % (1000000.0 * r.data_energies[it] / max(r.voxel_count, 1))
+                print(line)
+            print("[LEVEL %d COMPLETED]" % level)
+
+
+class HierarchicalOptimizer2d(_HierarchicalOptimizerBase):
+    DIMS = 2

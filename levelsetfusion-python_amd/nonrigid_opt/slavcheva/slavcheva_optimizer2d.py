@@ -1,0 +1,157 @@
+"""SlavchevaOptimizer2d -- drop-in for nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:74-411 of the reference
+(KillingFusion / SobolevFusion style optimizer): same constructor keywords and enums, same
+optimize(live_field, canonical_field) convention (argument order REVERSED with respect to the hierarchical
+optimizer; live_field is warped IN PLACE and returned), same .log / .get_convergence_report() / .gradient_field
+surface.  Differences, all deliberate: no video/plot writers are opened and nothing is printed unless
+verbose=True (the reference prints every iteration); both compute methods run the same HIP kernels and differ
+only where the reference's two code paths differ arithmetically."""
+import os
+from enum import Enum
+
+import numpy as np
+import torch
+
+from ... import _lib, device as dev
+from ...convergence_report import (ConvergenceReport, build_tsdf_difference_statistics,
+                                   build_warp_delta_statistics)
+from ...engine import SlavchevaEngine, as_device_field
+from .data_term import DataTermMethod
+from .smoothing_term import SmoothingTermMethod
+
+
+class AdaptiveLearningRateMethod(Enum):
+    NONE = 0
+    RMS_PROP = 1   # the reference only allocates an unused buffer for it (slavcheva_optimizer2d.py:348-350)
+
+
+class ComputeMethod(Enum):
+    DIRECT = 0
+    VECTORIZED = 1
+
+
+class OptimizationLog:
+    def __init__(self):
+        self.data_energies = []
+        self.smoothing_energies = []
+        self.level_set_energies = []
+        self.max_warps = []
+        self.convergence_report = ConvergenceReport()
+
+
+class _SlavchevaOptimizerBase:
+    DIMS = 2
+
+    def __init__(self, out_path="out2D", field_size=128, default_value=1.0, compute_method=ComputeMethod.DIRECT,
+                 level_set_term_enabled=False, sobolev_smoothing_enabled=False,
+                 data_term_method=DataTermMethod.BASIC, smoothing_term_method=SmoothingTermMethod.TIKHONOV,
+                 adaptive_learning_rate_method=AdaptiveLearningRateMethod.NONE, gradient_descent_rate=0.1,
+                 data_term_weight=1.0, smoothing_term_weight=0.2, isomorphic_enforcement_factor=0.1,
+                 level_set_term_weight=0.2, maximum_warp_length_lower_threshold=0.1,
+                 maximum_warp_length_upper_threshold=10000, max_iterations=100, min_iterations=1,
+                 sobolev_kernel=None, visualization_settings=None, enable_convergence_status_logging=True,
+                 verbose=False, check_interval=8, comm=None):
+        self.visualization_settings = visualization_settings  # accepted, unused
+        self.field_size = field_size
+        self.out_path = out_path
+        if out_path and not os.path.exists(out_path):  # slavcheva_optimizer2d.py:112-113
+            os.makedirs(out_path, exist_ok=True)
+        self.total_data_energy = 0.
+        self.total_smoothing_energy = 0.
+        self.total_level_set_energy = 0.
+        self.compute_method = compute_method
+        self.level_set_term_enabled = level_set_term_enabled
+        self.sobolev_smoothing_enabled = sobolev_smoothing_enabled
+        self.gradient_descent_rate = gradient_descent_rate
+        self.data_term_weight = data_term_weight
+        self.smoothing_term_weight = smoothing_term_weight
+        self.isomorphic_enforcement_factor = isomorphic_enforcement_factor
+        self.level_set_term_weight = level_set_term_weight
+        self.maximum_warp_length_lower_threshold = maximum_warp_length_lower_threshold
+        self.maximum_warp_length_upper_threshold = maximum_warp_length_upper_threshold
+        self.max_iterations = max_iterations
+        self.min_iterations = min_iterations
+        self.sobolev_kernel = sobolev_kernel
+        self.data_term_method = data_term_method
+        self.smoothing_term_method = smoothing_term_method
+        self.adaptive_learning_rate_method = adaptive_learning_rate_method
+        self.default_value = default_value
+        self.enable_convergence_status_logging = enable_convergence_status_logging
+        self.verbose = verbose
+        self.log = None
+        self.warp_field = None
+        self._engine = SlavchevaEngine(
+            direct=compute_method == ComputeMethod.DIRECT, level_set_term_enabled=level_set_term_enabled,
+            sobolev_smoothing_enabled=sobolev_smoothing_enabled,
+            data_term_method=_lib.DATA_THRESHOLDED_FDM if data_term_method == DataTermMethod.THRESHOLDED_FDM
+            else _lib.DATA_BASIC,
+            smoothing_term_method=_lib.SMOOTHING_KILLING if smoothing_term_method == SmoothingTermMethod.KILLING
+            else _lib.SMOOTHING_TIKHONOV,
+            gradient_descent_rate=gradient_descent_rate, data_term_weight=data_term_weight,
+            smoothing_term_weight=smoothing_term_weight, isomorphic_enforcement_factor=isomorphic_enforcement_factor,
+            level_set_term_weight=level_set_term_weight, lower_threshold=maximum_warp_length_lower_threshold,
+            upper_threshold=maximum_warp_length_upper_threshold, max_iterations=max_iterations,
+            min_iterations=min_iterations,
+            sobolev_kernel=None if sobolev_kernel is None else np.asarray(sobolev_kernel, dtype=np.float64),
+            check_interval=check_interval, comm=comm)
+
+    def _run_checks(self, live_field, canonical_field):
+        # slavcheva_optimizer2d.py:157-161,339: equal shapes, square/cubic, side == field_size
+        shape = tuple(live_field.shape)
+        if shape != tuple(canonical_field.shape) or len(shape) != self.DIMS \
+                or any(s != self.field_size for s in shape):
+            raise ValueError("warp field, warped live field, and canonical field all need to be arrays of the same "
+                             "size (field_size = %d on every side)." % self.field_size)
+
+    @property
+    def gradient_field(self):
+        """gradient of the last iteration, interleaved numpy array (reference attribute of the same name)"""
+        g = self._engine.gradient_field()
+        return None if g is None else dev.interleave(g).cpu().numpy()
+
+    def optimize(self, live_field, canonical_field):
+        on_device = isinstance(live_field, torch.Tensor) and live_field.is_cuda
+        if self._engine.comm is None or not self._engine.comm.active:
+            self._run_checks(live_field, canonical_field)
+        live = as_device_field(live_field)
+        canonical = as_device_field(canonical_field)
+        final_live, final_warp = self._engine.optimize(live, canonical)
+        eng_log = self._engine.log
+        self.log = OptimizationLog()
+        self.log.max_warps = eng_log["max_warps"]
+        self.log.data_energies = eng_log["data_energies"]
+        self.log.smoothing_energies = eng_log["smoothing_energies"]
+        self.log.level_set_energies = eng_log["level_set_energies"]
+        self.log.max_warp_locations = [tuple(int(i) for i in np.unravel_index(k, tuple(live.shape))[::-1])
+                                       for k in eng_log["max_warp_indices"]] \
+            if (self._engine.comm is None or not self._engine.comm.active) else eng_log["max_warp_indices"]
+        if self.log.max_warps:
+            self.total_data_energy = self.log.data_energies[-1]
+            self.total_smoothing_energy = self.log.smoothing_energies[-1]
+            self.total_level_set_energy = self.log.level_set_energies[-1]
+        self._final_warp_planar = final_warp
+        n = self._engine.iteration_count
+        if self.verbose:
+            for i in range(n):
+                print("[Iteration %d done], data energy: %f; smoothing energy: %f; level set energy: %f; max warp: %f"
+                      % (i, self.log.data_energies[i], self.log.smoothing_energies[i],
+                         self.log.level_set_energies[i], self.log.max_warps[i]))
+        if self.enable_convergence_status_logging and (self._engine.comm is None or not self._engine.comm.active):
+            ws = build_warp_delta_statistics(final_warp, canonical, final_live,
+                                             self.maximum_warp_length_lower_threshold,
+                                             self.maximum_warp_length_upper_threshold)
+            ds = build_tsdf_difference_statistics(canonical, final_live)
+            self.log.convergence_report = ConvergenceReport(n, n >= self.max_iterations, ws, ds)
+        if on_device:
+            live_field.copy_(final_live)
+            self.warp_field = dev.interleave(final_warp)
+        else:
+            np.copyto(live_field, final_live.cpu().numpy())  # in place, like np.copyto at :230,:328
+            self.warp_field = dev.interleave(final_warp).cpu().numpy()
+        return live_field
+
+    def get_convergence_report(self):
+        return self.log.convergence_report
+
+
+class SlavchevaOptimizer2d(_SlavchevaOptimizerBase):
+    DIMS = 2

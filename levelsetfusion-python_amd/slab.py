@@ -1,0 +1,95 @@
+"""z-slab domain decomposition for multi-GPU runs (one process per GPU, torch.distributed; backend "nccl" is
+RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+A volume [z][y][x] of nz_global slices is cut into `world` contiguous slabs along z (the slowest axis, so every
+slab face is one contiguous run of ny*nx floats).  Each rank stores its slab plus `halo` slices of its
+neighbours on the interior sides; the two ends of the volume carry no halo, so the array edge of an end rank IS
+the domain boundary and the kernels' boundary rules (OOB constants, edge replication, one-sided differences)
+apply unchanged.  After every iteration the dynamic fields' boundary slices are exchanged point-to-point with
+the (at most two) neighbours, and the iteration record (max update, energies) is all-reduced.
+
+The reference has no distributed code at all; this module is new design, see DESIGN.md section 6.
+"""
+import torch
+import torch.distributed as dist
+
+
+class SlabLayout:
+    def __init__(self, nz_global, rank=0, world=1, halo=0):
+        if nz_global % world != 0:
+            raise ValueError("nz_global=%d is not divisible by the number of slabs %d" % (nz_global, world))
+        per = nz_global // world
+        if world > 1 and halo > per:
+            raise ValueError("halo %d wider than a slab of %d slices" % (halo, per))
+        self.nz_global, self.rank, self.world, self.halo = nz_global, rank, world, halo
+        self.z0, self.z1 = rank * per, (rank + 1) * per
+        self.halo_lo = halo if rank > 0 else 0
+        self.halo_hi = halo if rank < world - 1 else 0
+        self.nz_local = per + self.halo_lo + self.halo_hi
+        self.z_begin, self.z_end = self.halo_lo, self.halo_lo + per
+        self.z_global_offset = self.z0 - self.halo_lo
+
+    def local_slice(self):
+        """slice of the GLOBAL z axis held locally (owned slab + halos)"""
+        return slice(self.z0 - self.halo_lo, self.z1 + self.halo_hi)
+
+    def owned_local(self):
+        return slice(self.z_begin, self.z_end)
+
+
+class SlabComm:
+    """halo exchange + record reduction for one slab layout.  `group` = a torch.distributed process group
+    (None = default group).  With world == 1 every method is a no-op."""
+
+    def __init__(self, layout, group=None):
+        self.layout = layout
+        self.group = group
+
+    @property
+    def active(self):
+        return self.layout.world > 1
+
+    def _z_view(self, t, a, b):
+        # scalar field [z,y,x] or planar vector field [c,z,y,x]
+        return t[a:b] if t.dim() == 3 else t[:, a:b]
+
+    def exchange_halos(self, tensors, width=None):
+        """fill the halo slices of every tensor from the neighbours' owned boundary slices"""
+        L = self.layout
+        if not self.active:
+            return
+        h = L.halo if width is None else width
+        if h == 0:
+            return
+        if h > L.halo:
+            raise ValueError("requested halo width %d exceeds the layout's halo %d" % (h, L.halo))
+        ops, copies = [], []
+        for t in tensors:
+            if L.rank > 0:  # lower neighbour: send my first h owned slices, receive into my lower halo
+                send = self._z_view(t, L.z_begin, L.z_begin + h).contiguous()
+                recv = torch.empty_like(send)
+                ops.append(dist.P2POp(dist.isend, send, L.rank - 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, recv, L.rank - 1, self.group))
+                copies.append((self._z_view(t, L.z_begin - h, L.z_begin), recv))
+            if L.rank < L.world - 1:  # upper neighbour
+                send = self._z_view(t, L.z_end - h, L.z_end).contiguous()
+                recv = torch.empty_like(send)
+                ops.append(dist.P2POp(dist.isend, send, L.rank + 1, self.group))
+                ops.append(dist.P2POp(dist.irecv, recv, L.rank + 1, self.group))
+                copies.append((self._z_view(t, L.z_end, L.z_end + h), recv))
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        for dst, src in copies:
+            dst.copy_(src)
+
+    def reduce_records(self, records, first, last):
+        """all-reduce records [first, last): column 0 (packed max, non-negative as int64) with MAX, the three
+        energy columns (float64 bit patterns) with SUM"""
+        if not self.active or last <= first:
+            return
+        mx = records[first:last, 0].contiguous()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        records[first:last, 0] = mx
+        en = records[first:last, 1:4].contiguous().view(torch.float64)
+        dist.all_reduce(en, op=dist.ReduceOp.SUM, group=self.group)
+        records[first:last, 1:4] = en.view(torch.int64)

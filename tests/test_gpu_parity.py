@@ -1,0 +1,487 @@
+"""Parity of the HIP path (through the C ABI of liblsf_hip.so) against the CPU oracle and the committed golden
+fixtures.  Everything here needs a real MI355X: run with  pytest -m gpu.
+
+Tolerances (absolute, float32 fields in [-1, 1], warps of a few voxels):
+  * EXACT  = 0.0   -- the kernels follow the oracle's operation order with -ffp-contract=off, so everything that is
+                      not a sum reduction is expected to be bit-identical; this is what the tests demand wherever
+                      the oracle itself is the comparison target.
+  * ATOL   = 1e-5  -- the north-star bound, used against the REFERENCE's goldens (numpy's own dot/convolve may
+                      round differently from the oracle in the last place).
+  * energies (sum reductions, float64 atomics): relative 1e-9.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lsf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+EXACT = 0.0
+ATOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def lsf():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import levelsetfusion_python_amd as pkg
+    return pkg
+
+
+def maxdiff(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+def rand_field(rng, shape, noise=0.05):
+    grids = np.meshgrid(*[np.arange(s) for s in shape], indexing="ij")
+    f = 0.06 * (grids[-2] - shape[-2] / 2) + 0.3 * np.sin(grids[-1] * 0.35) + noise * rng.standard_normal(shape)
+    if len(shape) == 3:
+        f = f + 0.2 * np.cos(grids[0] * 0.4)
+    return np.clip(f, -1.0, 1.0).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------------ leaf kernels
+@pytest.mark.parametrize("shape", [(12, 12), (33, 70), (9, 20, 67)])
+def test_warp_field_kernels(lsf, shape):
+    from levelsetfusion_python_amd.nonrigid_opt import field_warping as fw
+    rng = np.random.default_rng(1)
+    d = len(shape)
+    field = rand_field(rng, shape)
+    warp = (1.9 * rng.standard_normal(shape + (d,))).astype(np.float32)
+    warp[(0,) * d] = -3.3
+    warp[tuple(s - 1 for s in shape)] = 4.2
+    assert maxdiff(fw.warp_field(field, warp), O.warp_field(field, warp)) == EXACT
+    assert maxdiff(fw.warp_field_replacement(field, warp, 0.0), O.warp_field_replacement(field, warp, 0.0)) == EXACT
+    assert maxdiff(fw.warp_field_replacement(field, warp, -0.5), O.warp_field_replacement(field, warp, -0.5)) == EXACT
+
+
+@pytest.mark.parametrize("shape", [(12, 12), (10, 18, 66)])
+@pytest.mark.parametrize("flags", [(False, False, False), (True, False, False), (False, True, False),
+                                   (False, False, True), (True, True, True)])
+def test_warp_field_advanced_kernel(lsf, shape, flags):
+    from levelsetfusion_python_amd.nonrigid_opt import field_warping as fw
+    rng = np.random.default_rng(2)
+    d = len(shape)
+    live = rand_field(rng, shape)
+    canon = rand_field(rng, shape)
+    warp = (0.6 * rng.standard_normal(shape + (d,))).astype(np.float32)
+    wa, wb = warp.copy(), warp.copy()
+    ga, gb = (wa * 10).astype(np.float32), (wb * 10).astype(np.float32)
+    a = fw.warp_field_advanced(canon, live.copy(), wa, ga, *flags)
+    b = O.warp_field_advanced(canon, live.copy(), wb, gb, *flags)
+    assert maxdiff(a, b) == EXACT and maxdiff(wa, wb) == EXACT and maxdiff(ga, gb) == EXACT
+    assert (np.abs(b) == 1).any()  # the snap branch is exercised
+
+
+def test_reference_field_warping_known_answers(lsf, ref_literals):
+    from levelsetfusion_python_amd.nonrigid_opt import field_warping as fw
+    T = ref_literals
+    assert maxdiff(fw.warp_field(T["hierarchical_data.field_A_16x16"], T["hierarchical_data.warp_field_A_16x16"]),
+                   T["hierarchical_data.fA_resampled_with_wfA"]) <= ATOL
+    assert maxdiff(fw.warp_field_replacement(T["hierarchical_data.field_B_16x16"],
+                                             T["hierarchical_data.warp_field_B_16x16"], 0.0),
+                   T["hierarchical_data.fB_resampled_with_wfB_replacement"]) <= ATOL
+    flags = {"01": (False, False, False), "02": (True, False, True), "03": (False, False, False),
+             "04": (False, False, False), "05": (False, False, False)}
+    for case, fl in flags.items():
+        p = "field_warping.test_warp_field_advanced%s." % case
+        warp = np.stack((T[p + "u_vectors"], T[p + "v_vectors"]), axis=2)
+        grad = (warp * 10).astype(np.float32)
+        new_live = fw.warp_field_advanced(T[p + "canonical_field"], T[p + "warped_live_template"].copy(), warp, grad,
+                                          *fl)
+        assert np.allclose(new_live, T[p + "expected_new_warped_live_field"], atol=ATOL), case
+        if p + "expected_u_vectors" in T.files:
+            assert np.allclose(warp[..., 0], T[p + "expected_u_vectors"], atol=ATOL), case
+            assert np.allclose(warp[..., 1], T[p + "expected_v_vectors"], atol=ATOL), case
+
+
+@pytest.mark.parametrize("shape", [(16, 64), (8, 16, 32)])
+def test_pyramid_pack_restrict_prolong(lsf, shape):
+    from levelsetfusion_python_amd import device as dev
+    from levelsetfusion_python_amd.engine import as_device_field
+    from levelsetfusion_python_amd.nonrigid_opt.hierarchical import pyramid
+    rng = np.random.default_rng(3)
+    d = len(shape)
+    f = rand_field(rng, shape, 0.2)
+    packed = dev.pack_live_gradient(as_device_field(f)).cpu().numpy()
+    grads = O.gradient(f)
+    assert maxdiff(packed[..., 0], f) == EXACT
+    for c in range(d):
+        assert maxdiff(packed[..., 1 + c], grads[c]) == EXACT
+    cls = pyramid.ScalarFieldPyramid2d if d == 2 else pyramid.ScalarFieldPyramid3d
+    levels = cls(f, 4).levels
+    ref = O.pyramid(f, 4)
+    assert len(levels) == len(ref) == 3
+    for a, b in zip(levels, ref):
+        assert a.shape == b.shape and maxdiff(a, b) == EXACT
+    r4 = dev.restrict_mean(as_device_field(packed), 4).cpu().numpy()
+    for c in range(4):
+        assert maxdiff(r4[..., c], O.restrict_mean(np.ascontiguousarray(packed[..., c]))) == EXACT
+    w = rng.standard_normal(shape + (d,)).astype(np.float32)
+    up = dev.interleave(dev.prolong_repeat(dev.deinterleave(as_device_field(w), d))).cpu().numpy()
+    assert maxdiff(up, O.prolong_repeat(w)) == EXACT
+    with pytest.raises(ValueError):
+        cls(np.zeros(tuple(s + 1 for s in shape), np.float32), 4)
+    with pytest.raises(ValueError):
+        cls(f, 3)
+
+
+def test_reference_pyramid_known_answer(lsf):
+    from levelsetfusion_python_amd.nonrigid_opt.hierarchical.pyramid import ScalarFieldPyramid2d
+    tile = np.array([[1, 2, 5, 6, -1, -2, -5, -6], [3, 4, 7, 8, -3, -4, -7, -8],
+                     [-1, -2, -5, -6, 1, 2, 5, 6], [-3, -4, -7, -8, 3, 4, 7, 8],
+                     [1, 2, 5, 6, 5, 5, 5, 5], [3, 4, 7, 8, 5, 5, 5, 5],
+                     [-1, -2, -5, -6, 5, 5, 5, 5], [-3, -4, -7, -8, 5, 5, 5, 5]], dtype=np.float32)
+    levels = ScalarFieldPyramid2d(np.tile(tile, (16, 16))).levels  # tests/test_field_pyramid.py:24-73
+    assert [l.shape for l in levels] == [(16, 16), (32, 32), (64, 64), (128, 128)]
+    assert levels[2][0, 0] == tile[0:2, 0:2].mean() and levels[2][1, 1] == tile[2:4, 2:4].mean()
+    assert levels[1][1, 1] == 5.0 and levels[0][0, 0] == 5.0 / 4
+
+
+def test_convolution_kernels(lsf, ref_leaf, ref_literals):
+    from levelsetfusion_python_amd.math_utils import convolution as mc
+    L, T = ref_leaf, ref_literals
+    vf2, vf3 = L["conv.vf2"], L["conv.vf3"]
+    k7 = L["sobolev.hardcoded7"]
+    for vf, kern in ((vf2, k7), (vf3, k7), (vf2, L["sobolev.k7"]), (vf2, np.array([0.5, 0.2, -0.1, 0.05, 0.3])),
+                     (vf3, np.array([0.5, 0.2, -0.1]))):
+        assert maxdiff(mc.convolve_with_kernel(vf.copy(), kern), O.convolve_with_kernel(vf.copy(), kern)) == EXACT
+    assert maxdiff(mc.convolve_with_kernel_preserve_zeros(vf2.copy(), L["sobolev.k3"]),
+                   O.convolve_with_kernel_preserve_zeros(vf2.copy(), L["sobolev.k3"])) == EXACT
+    # against the reference's own outputs / known answers
+    assert maxdiff(mc.convolve_with_kernel(vf2.copy(), k7), L["conv.vf2_k7f64"]) <= ATOL
+    assert maxdiff(mc.convolve_with_kernel(vf3.copy(), k7), L["conv.vf3_k7f64"]) <= ATOL
+    assert maxdiff(mc.convolve_with_kernel_preserve_zeros(vf2.copy(), k7), L["conv.vf2_pz_k7"]) <= ATOL
+    v = np.arange(1.0, 241.0).reshape(5, 4, 4, 3).astype(np.float32)  # tests/test_convolution.py:215-219
+    mc.convolve_with_kernel(v, np.array([3.0, 2.0, 1.0]))
+    assert np.allclose(v, T["convolution_data.convolved_3d_vector_field"])
+    v = np.arange(1.0, 241.0).reshape(5, 4, 4, 3).astype(np.float32)
+    mc.convolve_with_kernel_x(v, np.array([3.0, 2.0, 1.0]))
+    assert np.allclose(v, T["convolution_data.convolved_x_3d_vector_field"])
+    p = "convolution.test_convolve_with_kernel_preserve_zeros02."
+    v = T[p + "vector_field"].copy()
+    mc.convolve_with_kernel_preserve_zeros(v, np.flip(T[p + "kernel"]))
+    assert np.allclose(v, T[p + "expected_output"], rtol=0.0, atol=1e-6)
+    with pytest.raises(ValueError):  # narrower than the kernel: the reference fails too
+        mc.convolve_with_kernel(np.zeros((4, 16, 2), np.float32), k7)
+    with pytest.raises(ValueError):
+        mc.convolve_with_kernel(np.zeros((4, 16, 3), np.float32), k7)
+
+
+def test_sobolev_kernel_generation(lsf, ref_leaf):
+    for s, lam, k in ((3, 0.1, "k3"), (7, 0.1, "k7"), (9, 0.15, "k9")):
+        assert maxdiff(lsf.generate_1d_sobolev_kernel(s, lam), ref_leaf["sobolev." + k]) <= 1e-7
+
+
+# ------------------------------------------------------------------------------- hierarchical optimizer
+def test_hierarchical_reference_golden_16x16(lsf, ref_literals):
+    """tests/test_hierarchical_optimizer2d.py:39-54 of the reference"""
+    T = ref_literals
+    from levelsetfusion_python_amd.nonrigid_opt import field_warping as fw
+    canon, live = T["hierarchical_data.canonical_field"], T["hierarchical_data.live_field"]
+    canon0, live0 = canon.copy(), live.copy()
+    opt = lsf.HierarchicalOptimizer2d(rate=0.2, data_term_amplifier=1.0, maximum_warp_update_threshold=0.001,
+                                      maximum_iteration_count=100, tikhonov_term_enabled=False, kernel=None)
+    warp = opt.optimize(canon, live)
+    assert warp.shape == (16, 16, 2) and warp.dtype == np.float32
+    assert np.array_equal(canon, canon0) and np.array_equal(live, live0)  # inputs untouched
+    assert opt.get_per_level_iteration_counts() == [1, 100, 100, 100]
+    assert maxdiff(warp, T["hierarchical_data.warp_field"]) <= ATOL
+    assert maxdiff(fw.warp_field(live, warp), T["hierarchical_data.final_live_field"]) <= ATOL
+    o = O.HierarchicalOracle(rate=0.2, maximum_warp_update_threshold=0.001, maximum_iteration_count=100,
+                             tikhonov_term_enabled=False, kernel=None)
+    assert maxdiff(warp, o.optimize(canon, live)) == EXACT
+
+
+def test_hierarchical_runs_match_reference_and_oracle(lsf, ref_hierarchical, ref_literals):
+    H, T = ref_hierarchical, ref_literals
+    cases = {"g16": (T["hierarchical_data.canonical_field"], T["hierarchical_data.live_field"]),
+             "c64": (H["c64.canonical"], H["c64.live"])}
+    n = 0
+    for key in H.files:
+        if not key.endswith(".final_warp") or "threshold" in key:
+            continue
+        case, tik, ker, chunk, _ = key.split(".")
+        kw = dict(tikhonov_term_enabled=tik == "tik1", gradient_kernel_enabled=ker == "ker1",
+                  maximum_chunk_size=int(chunk[5:]), rate=0.2, maximum_iteration_count=4,
+                  maximum_warp_update_threshold=0.0, tikhonov_strength=0.2,
+                  kernel=H["kernel7"] if ker == "ker1" else None)
+        warp = lsf.HierarchicalOptimizer2d(**kw).optimize(*cases[case])
+        assert maxdiff(warp, H[key]) <= ATOL, key
+        assert maxdiff(warp, O.HierarchicalOracle(**kw).optimize(*cases[case])) == EXACT, key
+        n += 1
+    assert n >= 10
+    # threshold-terminated: the device-side gate must reproduce the reference's iteration counts for every
+    # check interval (1 = sync every iteration ... 16 = sync once per 16)
+    for ci in (1, 3, 16):
+        opt = lsf.HierarchicalOptimizer2d(tikhonov_term_enabled=True, gradient_kernel_enabled=False,
+                                          maximum_chunk_size=8, rate=0.1, maximum_iteration_count=40,
+                                          maximum_warp_update_threshold=0.01, check_interval=ci)
+        warp = opt.optimize(*cases["c64"])
+        assert opt.get_per_level_iteration_counts() == list(H["c64.threshold_run.iteration_counts"])
+        assert maxdiff(warp, H["c64.threshold_run.final_warp"]) <= ATOL
+
+
+@pytest.mark.parametrize("tik,ker", [(False, False), (True, False), (False, True), (True, True)])
+def test_hierarchical_threshold_gate_counts(lsf, tik, ker):
+    """convergence gating with all kernel combinations: iteration counts and results equal the oracle's"""
+    c, l = O.sphere_pair(64, d=2)
+    # tikhonov_strength 0.05: the reference's Tikhonov recurrence g <- d - s*Laplace(g_prev) amplifies the highest
+    # frequency by 4*D*s per iteration, i.e. it diverges for s >= 1/8 in 2-D (the default 0.2 does, after a few
+    # dozen iterations); parity in a diverging run is meaningless, so the long runs use a stable strength
+    kw = dict(tikhonov_term_enabled=tik, gradient_kernel_enabled=ker, maximum_chunk_size=4, rate=0.1,
+              maximum_iteration_count=60, maximum_warp_update_threshold=0.0295 if ker else 0.0245,
+              tikhonov_strength=0.05, kernel=O.generate_1d_sobolev_kernel(7, 0.1) if ker else None)
+    o = O.HierarchicalOracle(**kw)
+    ref = o.optimize(c, l)
+    assert 1 < o.per_level_iteration_counts[0] < 60  # the threshold, not the limit, ends level 0
+    for ci in (1, 7):
+        opt = lsf.HierarchicalOptimizer2d(check_interval=ci, **kw)
+        warp = opt.optimize(c, l)
+        assert opt.get_per_level_iteration_counts() == o.per_level_iteration_counts
+        assert maxdiff(warp, ref) == EXACT
+        for a, b in zip(opt.get_per_level_maximum_updates(), o.per_level_max_updates):
+            assert np.array_equal(np.float32(a), np.float32(b))
+
+
+@pytest.mark.parametrize("tik,ker", [(False, False), (True, False), (True, True)])
+def test_hierarchical_3d_matches_oracle(lsf, tik, ker):
+    c, l = O.sphere_pair(32, d=3)
+    kw = dict(tikhonov_term_enabled=tik, gradient_kernel_enabled=ker, maximum_chunk_size=4, rate=0.2,
+              maximum_iteration_count=3, maximum_warp_update_threshold=0.0, tikhonov_strength=0.2,
+              kernel=O.generate_1d_sobolev_kernel(7, 0.1) if ker else None)
+    warp = lsf.HierarchicalOptimizer3d(**kw).optimize(c, l)
+    assert warp.shape == (32, 32, 32, 3)
+    assert maxdiff(warp, O.HierarchicalOracle(**kw).optimize(c, l)) == EXACT
+
+
+def test_hierarchical_errors(lsf):
+    opt = lsf.HierarchicalOptimizer2d()
+    with pytest.raises(ValueError):
+        opt.optimize(np.zeros((12, 16), np.float32), np.zeros((12, 16), np.float32))
+    with pytest.raises(ValueError):
+        opt.optimize(np.zeros((8, 8), np.float32), np.zeros((8, 8), np.float32))  # chunk 8 too large
+    with pytest.raises(ValueError):
+        opt.optimize(np.zeros((16, 16), np.float32), np.zeros((32, 32), np.float32))
+    # enable-flag folding (hierarchical_optimizer2d.py:96-107)
+    o = lsf.HierarchicalOptimizer2d(tikhonov_term_enabled=True, tikhonov_strength=0.0, gradient_kernel_enabled=True,
+                                    kernel=None)
+    assert not o.tikhonov_term_enabled and not o.gradient_kernel_enabled
+
+
+# ---------------------------------------------------------------------------------- Slavcheva optimizer
+def _slavcheva_kwargs(lsf, name, S):
+    CM, SM, DM = lsf.ComputeMethod, lsf.SmoothingTermMethod, lsf.DataTermMethod
+    return {
+        "sobolev_vec": (dict(compute_method=CM.VECTORIZED, sobolev_smoothing_enabled=True, sobolev_kernel=S["kernel7"]),
+                        dict(compute_method=O.VECTORIZED, sobolev_smoothing_enabled=True, sobolev_kernel=S["kernel7"])),
+        "sobolev_direct": (dict(compute_method=CM.DIRECT, sobolev_smoothing_enabled=True, sobolev_kernel=S["kernel3"]),
+                           dict(compute_method=O.DIRECT, sobolev_smoothing_enabled=True, sobolev_kernel=S["kernel3"])),
+        "killing": (dict(compute_method=CM.DIRECT, level_set_term_enabled=True, smoothing_term_method=SM.KILLING),
+                    dict(compute_method=O.DIRECT, level_set_term_enabled=True, smoothing_term_method=O.KILLING)),
+        "tikhonov_direct": (dict(compute_method=CM.DIRECT), dict(compute_method=O.DIRECT)),
+        "fdm_direct": (dict(compute_method=CM.DIRECT, data_term_method=DM.THRESHOLDED_FDM),
+                       dict(compute_method=O.DIRECT, data_term_method=O.THRESHOLDED_FDM)),
+    }[name]
+
+
+@pytest.mark.parametrize("size_tag,n_it", [("ortho32", 4), ("ortho64", 3)])
+@pytest.mark.parametrize("name", ["sobolev_vec", "sobolev_direct", "killing", "tikhonov_direct", "fdm_direct"])
+def test_slavcheva_2d_matches_reference_and_oracle(lsf, ref_slavcheva, tmp_path, size_tag, n_it, name):
+    S = ref_slavcheva
+    kw_gpu, kw_cpu = _slavcheva_kwargs(lsf, name, S)
+    live0, canon = S[size_tag + ".live"], S[size_tag + ".canonical"]
+    common = dict(maximum_warp_length_lower_threshold=0.0, max_iterations=n_it, min_iterations=n_it)
+    opt = lsf.SlavchevaOptimizer2d(out_path=str(tmp_path), field_size=live0.shape[0], **common, **kw_gpu)
+    live = live0.copy()
+    assert opt.optimize(live, canon) is live  # warped in place and returned
+    tag = size_tag + "." + name
+    # against the reference's own run
+    assert maxdiff(live, S[tag + ".final_live"]) <= ATOL
+    assert maxdiff(opt.warp_field, S[tag + ".final_warp"]) <= ATOL
+    assert maxdiff(opt.gradient_field, S[tag + ".final_gradient"]) <= ATOL
+    assert maxdiff(opt.log.max_warps, S[tag + ".max_warps"]) <= ATOL
+    for mine, theirs in ((opt.log.data_energies, S[tag + ".data_energies"]),
+                         (opt.log.smoothing_energies, S[tag + ".smoothing_energies"]),
+                         (opt.log.level_set_energies, S[tag + ".level_set_energies"])):
+        assert np.allclose(mine, theirs, rtol=1e-5, atol=1e-7)
+    # against the oracle: bit for bit
+    o = O.SlavchevaOracle(**common, **kw_cpu)
+    live_ref = live0.copy()
+    o.optimize(live_ref, canon)
+    assert maxdiff(live, live_ref) == EXACT
+    assert maxdiff(opt.warp_field, o.warp_field) == EXACT
+    assert maxdiff(opt.gradient_field, o.gradient_field) == EXACT
+    assert np.array_equal(np.float32(opt.log.max_warps), np.float32(o.log["max_warps"]))
+    assert opt.log.max_warp_locations == [tuple(int(i) for i in at[::-1]) for at in o.log["max_warp_locations"]]
+    for mine, theirs in ((opt.log.data_energies, o.log["data_energies"]),
+                         (opt.log.smoothing_energies, o.log["smoothing_energies"]),
+                         (opt.log.level_set_energies, o.log["level_set_energies"])):
+        assert np.allclose(mine, theirs, rtol=1e-9, atol=1e-12)
+
+
+def test_slavcheva_reference_golden_4x4_and_report(lsf, ref_literals, ref_slavcheva, tmp_path):
+    """tests/test_slavcheva_optimizer.py:64-149 of the reference (live-field goldens + convergence report)"""
+    from levelsetfusion_python_amd.convergence_report import (ConvergenceReport, TsdfDifferenceStatistics,
+                                                              WarpDeltaStatistics)
+    T = ref_literals
+    live0 = T["slavcheva.test_nonrigid_optimization01.live_field_template"]
+    canon = T["slavcheva.test_nonrigid_optimization01.canonical_field"]
+    reports = []
+    for method in (lsf.ComputeMethod.VECTORIZED, lsf.ComputeMethod.DIRECT):
+        for n_it, key in ((1, "slavcheva.test_nonrigid_optimization01.expected_live_field_out"),
+                          (2, "slavcheva.test_nonrigid_optimization02.expected_live_field_out")):
+            opt = lsf.SlavchevaOptimizer2d(out_path=str(tmp_path), field_size=4, compute_method=method,
+                                           sobolev_smoothing_enabled=True, maximum_warp_length_lower_threshold=0.05,
+                                           max_iterations=n_it, sobolev_kernel=ref_slavcheva["kernel3"])
+            live = live0.copy()
+            opt.optimize(live, canon)
+            assert np.allclose(live, T[key], atol=ATOL)
+        reports.append(opt.get_convergence_report())
+    assert reports[0] == reports[1]
+    ws, ts = T["slavcheva.report.warp_stats"], T["slavcheva.report.tsdf_stats"]
+    expected = ConvergenceReport(2, True,
+                                 WarpDeltaStatistics(ws[0], ws[1], ws[2], ws[3], ws[4], (int(ws[5]), int(ws[6])),
+                                                     False, False),
+                                 TsdfDifferenceStatistics(ts[0], ts[1], ts[2], ts[3], (int(ts[4]), int(ts[5]))))
+    assert reports[1] == expected
+
+
+@pytest.mark.parametrize("ci", [1, 4, 32])
+def test_slavcheva_threshold_termination(lsf, ref_slavcheva, tmp_path, ci):
+    """loop condition of slavcheva_optimizer2d.py:360-362 on the device-side gate, any check interval"""
+    S = ref_slavcheva
+    live0, canon = S["ortho32.live"], S["ortho32.canonical"]
+    kw = dict(maximum_warp_length_lower_threshold=0.1, max_iterations=25, min_iterations=2)
+    o = O.SlavchevaOracle(compute_method=O.DIRECT, **kw)
+    live_ref = live0.copy()
+    o.optimize(live_ref, canon)
+    assert 2 < o.iteration_count < 25  # the threshold, not a limit, ends this run
+    opt = lsf.SlavchevaOptimizer2d(out_path=str(tmp_path), field_size=32, compute_method=lsf.ComputeMethod.DIRECT,
+                                   check_interval=ci, **kw)
+    live = live0.copy()
+    opt.optimize(live, canon)
+    assert len(opt.log.max_warps) == o.iteration_count
+    assert maxdiff(live, live_ref) == EXACT and maxdiff(opt.warp_field, o.warp_field) == EXACT
+    assert opt.get_convergence_report().iteration_count == o.iteration_count
+
+
+def test_slavcheva_errors(lsf, tmp_path):
+    opt = lsf.SlavchevaOptimizer2d(out_path=str(tmp_path / "made"), field_size=8)
+    assert (tmp_path / "made").exists()
+    with pytest.raises(ValueError):
+        opt.optimize(np.zeros((8, 8), np.float32), np.zeros((8, 4), np.float32))
+    with pytest.raises(ValueError):
+        opt.optimize(np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32))  # field_size mismatch
+
+
+@pytest.mark.parametrize("name", ["killing", "sobolev_direct", "sobolev_vec", "fdm_direct"])
+def test_slavcheva_3d_matches_oracle(lsf, ref_slavcheva, name):
+    kw_gpu, kw_cpu = _slavcheva_kwargs(lsf, name, ref_slavcheva)
+    n = 32
+    canon, live0 = O.sphere_pair(n, d=3)
+    common = dict(maximum_warp_length_lower_threshold=0.0, max_iterations=3, min_iterations=3)
+    opt = lsf.SlavchevaOptimizer3d(field_size=n, **common, **kw_gpu)
+    live = live0.copy()
+    opt.optimize(live, canon)
+    o = O.SlavchevaOracle(**common, **kw_cpu)
+    live_ref = live0.copy()
+    o.optimize(live_ref, canon)
+    assert maxdiff(live, live_ref) == EXACT
+    assert maxdiff(opt.warp_field, o.warp_field) == EXACT
+    assert maxdiff(opt.gradient_field, o.gradient_field) == EXACT
+    for mine, theirs in ((opt.log.data_energies, o.log["data_energies"]),
+                         (opt.log.smoothing_energies, o.log["smoothing_energies"]),
+                         (opt.log.level_set_energies, o.log["level_set_energies"])):
+        assert np.allclose(mine, theirs, rtol=1e-9, atol=1e-12)
+
+
+def test_slavcheva_3d_random_fields_match_oracle(lsf):
+    """non-smooth inputs with truncated plateaus, OOB gathers and snapping"""
+    rng = np.random.default_rng(11)
+    shape = (24, 24, 24)
+    live0 = rand_field(rng, shape, 0.15)
+    canon = rand_field(rng, shape, 0.15)
+    live0[:, :5] = 1.0
+    canon[:, :4] = 1.0
+    live0[3:6, 10:14, 10:14] = -1.0
+    common = dict(maximum_warp_length_lower_threshold=0.0, max_iterations=3, min_iterations=3,
+                  gradient_descent_rate=0.1)
+    opt = lsf.SlavchevaOptimizer3d(field_size=24, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING, **common)
+    live = live0.copy()
+    opt.optimize(live, canon)
+    o = O.SlavchevaOracle(compute_method=O.DIRECT, level_set_term_enabled=True, smoothing_term_method=O.KILLING,
+                          **common)
+    live_ref = live0.copy()
+    o.optimize(live_ref, canon)
+    assert maxdiff(live, live_ref) == EXACT and maxdiff(opt.warp_field, o.warp_field) == EXACT
+
+
+# ------------------------------------------------------------ full-size, size-independent properties
+def test_full_size_2d_embedding_256(lsf):
+    """BASELINE size 256^3: a z-constant volume must reproduce the 2-D result (computed by the ORACLE at 256^2)
+    on interior slices, bit for bit, with w == 0 -- KillingFusion-style and hierarchical."""
+    n = 256
+    c2, l2 = O.sphere_pair(n, d=2)
+    c3 = torch.from_numpy(c2).cuda()[None].repeat(n, 1, 1).contiguous()
+    l3 = torch.from_numpy(l2).cuda()[None].repeat(n, 1, 1).contiguous()
+    common = dict(maximum_warp_length_lower_threshold=0.0, max_iterations=3, min_iterations=3)
+    opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING, **common)
+    live = l3.clone()
+    opt.optimize(live, c3)
+    o = O.SlavchevaOracle(compute_method=O.DIRECT, level_set_term_enabled=True, smoothing_term_method=O.KILLING,
+                          **common)
+    live_ref = l2.copy()
+    o.optimize(live_ref, c2)
+    for z in (8, n // 2, n - 9):
+        assert maxdiff(live[z].cpu().numpy(), live_ref) == EXACT
+        assert maxdiff(opt.warp_field[z][..., :2].cpu().numpy(), o.warp_field) == EXACT
+        assert float(opt.warp_field[z][..., 2].abs().max()) == 0.0
+    kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=4, rate=0.2,
+              maximum_iteration_count=3, maximum_warp_update_threshold=0.0)
+    warp3 = lsf.HierarchicalOptimizer3d(**kw).optimize(c3, l3)
+    warp2 = O.HierarchicalOracle(**kw).optimize(c2, l2)
+    assert maxdiff(warp3[n // 2][..., :2].cpu().numpy(), warp2) == EXACT
+    assert float(warp3[n // 2][..., 2].abs().max()) == 0.0
+
+
+def test_full_size_fixed_point_and_slab_invariance_256(lsf):
+    """(i) live == canonical is a fixed point: zero warp, live unchanged, the loop stops after min_iterations;
+    (ii) processing the 256^3 volume as two z-slabs with a 2-slice halo (kernel z-range arguments) gives exactly
+    the result of the single launch."""
+    from levelsetfusion_python_amd import _lib, device as dev
+    n = 256
+    c, l = O.sphere_pair(n, d=3)
+    ct, lt = torch.from_numpy(c).cuda(), torch.from_numpy(l).cuda()
+    opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=False,
+                                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
+                                   maximum_warp_length_lower_threshold=0.0, max_iterations=10)
+    live = ct.clone()
+    opt.optimize(live, ct)
+    assert len(opt.log.max_warps) == 1 and opt.log.max_warps[0] == 0.0
+    assert torch.equal(live, ct) and float(opt.warp_field.abs().max()) == 0.0
+    # (ii) one fused iteration, full volume vs two slabs
+    eng = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING)._engine
+    warp_prev = (0.3 * torch.randn((3, n, n, n), device="cuda", generator=torch.Generator("cuda").manual_seed(3)))
+    rec = dev.new_records(3, "cuda")
+    full_w, full_l = torch.empty_like(warp_prev), torch.empty_like(lt)
+    dev.slavcheva_iteration(_lib.STAGE_FUSED, lt, ct, warp_prev, full_w, full_l, None, dev.make_grid(lt.shape),
+                            eng.params, None, rec, 0)
+    h, half = 2, n // 2
+    pieces = []
+    for k, (a, b, zb, ze) in enumerate(((0, half + h, 0, half), (half - h, n, h, h + half))):
+        ls, cs, ws = lt[a:b].contiguous(), ct[a:b].contiguous(), warp_prev[:, a:b].contiguous()
+        ow, ol = torch.zeros_like(ws), torch.zeros_like(ls)
+        dev.slavcheva_iteration(_lib.STAGE_FUSED, ls, cs, ws, ow, ol, None, dev.make_grid(ls.shape, zb, ze, a),
+                                eng.params, None, rec, 1 + k)
+        pieces.append((ow[:, zb:ze], ol[zb:ze]))
+    assert torch.equal(torch.cat([p[1] for p in pieces], 0), full_l)
+    assert torch.equal(torch.cat([p[0] for p in pieces], 1), full_w)
+    d = dev.decode_records(rec.cpu().numpy())
+    assert d["max_value"][0] == max(d["max_value"][1], d["max_value"][2])
+    assert d["argmax"][0] == (d["argmax"][1] if d["max_value"][1] >= d["max_value"][2] else d["argmax"][2])
+    assert np.isclose(d["data_energy"][0], d["data_energy"][1] + d["data_energy"][2], rtol=1e-10)
