@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py -- voxel-warp-updates/s and HBM-roofline fraction of the fused per-voxel warp-update path.
+
+Workload (BASELINE.json config 4, the configuration the metric is quoted on): 3-D 256^3 KillingFusion-style
+optimizer -- SlavchevaOptimizer3d, DIRECT, Killing regulariser (lambda 0.1, weight 0.2) + level-set term
+(weight 0.2), no Sobolev filter, rate 0.1, FIXED 50 iterations -- on the synthetic "sphere pair" of SURVEY.md
+section 8(d), fp32.  One *step* = one optimize(live, canonical) call = 50 launches of the fused warp-update kernel
+over one 256^3 pair (+ the convergence-statistics reductions the reference also runs per call).
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns a 256^3 z-slab of a
+256 x 256 x (256 N) volume, exchanges a 2-slice halo of the live field and the warp with its z-neighbours after
+every iteration (RCCL point-to-point over xGMI) and all-reduces the 32-byte iteration record.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_ALG = {"killing": 52, "sobolev": 76}  # algorithmic bytes per voxel-update, fp32, 3-D
+HBM_PEAK_GBS = 8000.0                    # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=256, help="edge of the per-GPU volume (256 = BASELINE config 4)")
+    ap.add_argument("--iterations", type=int, default=50)
+    ap.add_argument("--halo", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-size", type=int, default=96)
+    ap.add_argument("--cpu-sample-iterations", type=int, default=16)
+    return ap.parse_args()
+
+
+def cpu_baseline(size, iterations):
+    """the numpy oracle (vectorised restatement of the reference, 1 thread) on a bounded sample of the SAME
+    workload: a size^3 sphere pair, same optimizer configuration, `iterations` fixed iterations"""
+    from oracle import lsf_oracle as O
+    canonical, live = O.sphere_pair(size, d=3)
+    opt = O.SlavchevaOracle(compute_method=O.DIRECT, level_set_term_enabled=True, smoothing_term_method=O.KILLING,
+                            maximum_warp_length_lower_threshold=0.0, max_iterations=iterations,
+                            min_iterations=iterations)
+    t0 = time.perf_counter()
+    opt.optimize(live, canonical)
+    dt = time.perf_counter() - t0
+    return dict(value=size ** 3 * iterations / dt, unit="voxel-warp-updates/s", cores=1, kind="port",
+                sample="%d^3 sphere pair, %d fixed iterations of the same Killing+level-set configuration, "
+                       "oracle/lsf_oracle.py (numpy, 1 thread), %.1f s" % (size, iterations, dt),
+                host_cpus=os.cpu_count(), host_affinity=len(os.sched_getaffinity(0)))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd import _lib, device as dev
+    from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+
+    n, iters = args.size, args.iterations
+    layout = SlabLayout(n * world, rank, world, args.halo if world > 1 else 0)
+    comm = SlabComm(layout) if world > 1 else None
+    sl = layout.local_slice()
+    canonical, live0 = sphere_pair(n, 3, device, (sl.start, sl.stop))
+    opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT,
+                                   level_set_term_enabled=True,
+                                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
+                                   gradient_descent_rate=0.1, data_term_weight=1.0, smoothing_term_weight=0.2,
+                                   isomorphic_enforcement_factor=0.1, level_set_term_weight=0.2,
+                                   maximum_warp_length_lower_threshold=0.0, max_iterations=iters,
+                                   min_iterations=iters, check_interval=iters, comm=comm)
+    live = torch.empty_like(live0)
+
+    def step():
+        live.copy_(live0)  # a fresh pair every step (optimize() warps live in place)
+        opt.optimize(live, canonical)
+        return len(opt.log.max_warps)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    executed = 0
+    for _ in range(args.warmup):
+        executed = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        executed = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert executed == iters, "expected %d fixed iterations, the gate closed after %d" % (iters, executed)
+    voxels_per_rank = n ** 3
+    updates = voxels_per_rank * world * iters * args.steps
+    value = updates / elapsed
+
+    # ---- roofline of the dominant kernel: the fused warp-update kernel alone, HIP events on its stream
+    eng = opt._engine
+    grid = eng._grid(live0)
+    rec = dev.new_records(2, device)
+    lives = [live0.clone(), torch.empty_like(live0)]
+    warps = [torch.zeros((3,) + tuple(live0.shape), dtype=torch.float32, device=device) for _ in range(2)]
+    n_launch = 40
+    for i in range(4):
+        dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], canonical, warps[i % 2], warps[(i + 1) % 2],
+                                lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for i in range(n_launch):
+        dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], canonical, warps[i % 2], warps[(i + 1) % 2],
+                                lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0)
+    e1.record()
+    torch.cuda.synchronize()
+    kernel_ms = e0.elapsed_time(e1) / n_launch
+    alg_bytes = B_ALG["killing"] * voxels_per_rank
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                    traffic=None, kernel="slavcheva_iteration_kernel<3,KILLING,LEVELSET,BASIC,DIRECT,FUSED>",
+                    kernel_ms=kernel_ms, algorithmic_bytes_per_launch=alg_bytes,
+                    compulsory_bytes_per_launch=36 * voxels_per_rank)
+
+    out = dict(metric="voxel-warp-updates/sec", value=value, unit="voxel-warp-updates/s", n_gpus=world,
+               steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload="3D %d^3 KillingFusion (Killing + level-set) SlavchevaOptimizer3d, %d fixed "
+                                    "iterations per step, sphere-pair TSDF" % (n, iters),
+                           voxels_per_gpu=voxels_per_rank, iterations_per_step=iters,
+                           parallelism="z-slab x%d, halo %d" % (world, args.halo) if world > 1 else "single GPU"),
+               roofline=roofline)
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_size, args.cpu_sample_iterations)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,11 @@ oracle/ is test infrastructure and is never imported from the package.
 import ctypes
 import os
 
+# torch FIRST: the PyTorch-ROCm wheel ships its own libamdhip64.so; liblsf_hip.so must bind to that already-loaded
+# HIP runtime (same soname), otherwise the process ends up with two runtimes and launches on torch's streams fail
+# with hipErrorNoDevice.
+import torch  # noqa: F401
+
 from ._build import LIB_PATH
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())

@@ -30,6 +30,9 @@ __host__ inline Grid make_grid(const lsf_grid* g) {
 }
 
 __host__ inline int check_grid(const lsf_grid* g) {
+    // every entry point validates its grid first: also drop any stale (non-sticky) error an earlier, unrelated
+    // runtime call of this thread left behind, so that launch_status() reports THIS launch only
+    (void)hipGetLastError();
     if (!g) return LSF_ERR_BAD_ARGUMENT;
     if (g->dims != 2 && g->dims != 3) return LSF_ERR_BAD_DIMS;
     if (g->nx <= 0 || g->ny <= 0 || g->nz <= 0) return LSF_ERR_BAD_ARGUMENT;
@@ -61,28 +64,58 @@ __host__ __device__ inline Tiling make_tiling(const Grid& g) {
     return t;
 }
 
-// bijective XCD-aware remap of a 1-D block id (8 XCDs, round-robin dispatch): blocks b, b+8, b+16 ... share
-// an XCD, so give XCD k the k-th contiguous chunk of the tile sequence.
-__device__ inline unsigned xcd_remap(unsigned bid, unsigned total) {
-    const unsigned nx = 8;
-    unsigned q = total / nx, r = total % nx;
-    unsigned xcd = bid % nx, i = bid / nx;
-    unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + i;
+// Persistent blocks: a launch uses at most kMaxBlocks workgroups (8 per CU); each walks its share of the tile
+// sequence.  One reduction + one atomic per block and address instead of one per tile: 65536 same-address atomics
+// (256^3 / 256-voxel tiles) serialise at ~12 ns each, which alone cost 0.8 ms per launch.
+// XCD-aware order (T1): blocks b, b+8, b+16 ... share an XCD under round-robin dispatch, so XCD k owns the k-th
+// contiguous chunk of the tile sequence (a contiguous z-range) and its blocks walk that chunk side by side;
+// neighbouring tiles -- which share halo rows -- then hit the same L2.  Speed only, never correctness.
+constexpr unsigned kMaxBlocks = 2048;
+constexpr unsigned kXcds = 8;
+
+__host__ inline unsigned launch_blocks(unsigned total_tiles) {
+    unsigned b = total_tiles < kMaxBlocks ? total_tiles : kMaxBlocks;
+    if (b > kXcds) b -= b % kXcds;
+    return b;
 }
 
-// voxel of this thread; returns false when outside the grid
-__device__ inline bool thread_voxel(const Grid& g, int& x, int& y, int& z) {
-    Tiling t = make_tiling(g);
-    unsigned bid = xcd_remap(blockIdx.x, t.total);
-    int tx = bid % t.tiles_x;
-    unsigned rest = bid / t.tiles_x;
-    int ty = rest % t.tiles_y;
-    int tz = rest / t.tiles_y;
-    x = tx * kTileX + (threadIdx.x & (kTileX - 1));
-    y = ty * kTileY + (threadIdx.x / kTileX);
-    z = g.z_begin + tz;
-    return x < g.nx && y < g.ny;
+struct TileRange {
+    unsigned first, end, step;
+};
+
+__device__ inline TileRange tile_range(unsigned total) {
+    TileRange r;
+    const unsigned nb = gridDim.x, bid = blockIdx.x;
+    if (nb % kXcds != 0) {  // tiny grids: plain grid-stride
+        r.first = bid; r.end = total; r.step = nb;
+        return r;
+    }
+    const unsigned xcd = bid % kXcds, j = bid / kXcds, per_xcd = nb / kXcds;
+    const unsigned q = total / kXcds, rem = total % kXcds;
+    const unsigned start = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    const unsigned count = q + (xcd < rem ? 1u : 0u);
+    r.first = start + j; r.end = start + count; r.step = per_xcd;
+    return r;
+}
+
+// calls f(x, y, z) for every voxel this thread owns (z in [z_begin, z_end))
+template <class F>
+__device__ inline void for_each_voxel(const Grid& g, F&& f) {
+    const Tiling t = make_tiling(g);
+    const TileRange r = tile_range(t.total);
+    const int lx = threadIdx.x & (kTileX - 1), ly = threadIdx.x / kTileX;
+    for (unsigned tile = r.first; tile < r.end; tile += r.step) {
+        const int tx = tile % t.tiles_x;
+        const unsigned rest = tile / t.tiles_x;
+        const int ty = rest % t.tiles_y;
+        const int tz = rest / t.tiles_y;
+        const int x = tx * kTileX + lx, y = ty * kTileY + ly, z = g.z_begin + tz;
+        if (x < g.nx && y < g.ny) f(x, y, z);
+    }
+}
+
+__device__ inline unsigned linear_index(const Grid& g, int x, int y, int z) {
+    return (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);
 }
 
 __device__ inline long long vidx(const Grid& g, int x, int y, int z) {
@@ -107,7 +140,9 @@ __device__ inline float read_clamp(const float* __restrict__ f, const Grid& g, i
 }
 
 // ------------------------------------------------------------------------------------------------------
-// D-linear interpolation of a scalar field (oracle.sample_linear): per-tap OOB constant, lerp z, then y, then x
+// D-linear interpolation of a scalar field (oracle.sample_linear): per-tap OOB constant, lerp z, then y, then x.
+// pz is the GLOBAL z position (z + z_global_offset + w): float32 rounding of "coordinate + displacement" depends
+// on the coordinate's magnitude, so a slab must form it from the global coordinate to match the whole volume.
 // ------------------------------------------------------------------------------------------------------
 template <int D>
 __device__ inline float sample_linear(const float* __restrict__ f, const Grid& g, float px, float py, float pz,
@@ -129,7 +164,7 @@ __device__ inline float sample_linear(const float* __restrict__ f, const Grid& g
     } else {
         float fz = floorf(pz);
         float rz = pz - fz, iz = 1.0f - rz;
-        int bz = (int)fminf(fmaxf(fz, -2.0f), (float)g.nz + 1.0f);
+        int bz = (int)fminf(fmaxf(fz - (float)g.z_global_offset, -2.0f), (float)g.nz + 1.0f);
         float c[2][2];  // [x offset][y offset] after the z lerp
 #pragma unroll
         for (int ox = 0; ox < 2; ++ox)

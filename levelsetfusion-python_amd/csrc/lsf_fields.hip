@@ -24,6 +24,7 @@ __global__ __launch_bounds__(kBlock) void interleave_kernel(const float* __restr
 
 extern "C" int lsf_deinterleave(const float* interleaved, float* planar, int64_t n_voxels, int32_t channels,
                                 void* stream) {
+    (void)hipGetLastError();
     if (!interleaved || !planar || n_voxels < 0 || channels < 1 || channels > 4) return LSF_ERR_BAD_ARGUMENT;
     if (n_voxels == 0) return 0;
     unsigned blocks = (unsigned)((n_voxels + kBlock - 1) / kBlock);
@@ -34,6 +35,7 @@ extern "C" int lsf_deinterleave(const float* interleaved, float* planar, int64_t
 
 extern "C" int lsf_interleave(const float* planar, float* interleaved, int64_t n_voxels, int32_t channels,
                               void* stream) {
+    (void)hipGetLastError();
     if (!interleaved || !planar || n_voxels < 0 || channels < 1 || channels > 4) return LSF_ERR_BAD_ARGUMENT;
     if (n_voxels == 0) return 0;
     unsigned blocks = (unsigned)((n_voxels + kBlock - 1) / kBlock);
@@ -49,13 +51,13 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void warp_field_kernel(const float* __restrict__ field,
                                                             const float* __restrict__ warp, float* __restrict__ out,
                                                             Grid g, float oob) {
-    int x, y, z;
-    if (!thread_voxel(g, x, y, z)) return;
+    for_each_voxel(g, [&](int x, int y, int z) {
     long long i = vidx(g, x, y, z);
     float px = (float)x + warp[i];
     float py = (float)y + warp[g.plane + i];
-    float pz = D == 3 ? (float)z + warp[2 * g.plane + i] : 0.0f;
+    float pz = D == 3 ? (float)(z + g.z_global_offset) + warp[2 * g.plane + i] : 0.0f;
     out[i] = sample_linear<D>(field, g, px, py, pz, oob);
+    });
 }
 
 extern "C" int lsf_warp_field(const float* field, const float* warp_planar, float* out, const lsf_grid* grid,
@@ -66,10 +68,10 @@ extern "C" int lsf_warp_field(const float* field, const float* warp_planar, floa
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
     if (grid->dims == 2)
-        hipLaunchKernelGGL(warp_field_kernel<2>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), field,
+        hipLaunchKernelGGL(warp_field_kernel<2>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream), field,
                            warp_planar, out, g, oob_value);
     else
-        hipLaunchKernelGGL(warp_field_kernel<3>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), field,
+        hipLaunchKernelGGL(warp_field_kernel<3>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream), field,
                            warp_planar, out, g, oob_value);
     return launch_status();
 }
@@ -83,8 +85,7 @@ __global__ __launch_bounds__(kBlock) void warp_field_advanced_kernel(const float
                                                                      float* __restrict__ warp,
                                                                      float* __restrict__ gradient,
                                                                      float* __restrict__ new_live, Grid g, int flags) {
-    int x, y, z;
-    if (!thread_voxel(g, x, y, z)) return;
+    for_each_voxel(g, [&](int x, int y, int z) {
     long long i = vidx(g, x, y, z);
     float original = live[i];
     bool skip = false;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(kBlock) void warp_field_advanced_kernel(const float
     }
     float px = (float)x + warp[i];
     float py = (float)y + warp[g.plane + i];
-    float pz = D == 3 ? (float)z + warp[2 * g.plane + i] : 0.0f;
+    float pz = D == 3 ? (float)(z + g.z_global_offset) + warp[2 * g.plane + i] : 0.0f;
     float v = sample_linear<D>(live, g, px, py, pz, (flags & 4) ? original : 1.0f);
     if (1.0f - fabsf(v) < 1e-6f) {
         v = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : v);
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(kBlock) void warp_field_advanced_kernel(const float
         }
     }
     new_live[i] = v;
+    });
 }
 
 extern "C" int lsf_warp_field_advanced(const float* canonical, const float* live, float* warp_planar,
@@ -118,10 +120,10 @@ extern "C" int lsf_warp_field_advanced(const float* canonical, const float* live
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
     if (grid->dims == 2)
-        hipLaunchKernelGGL(warp_field_advanced_kernel<2>, dim3(t.total), dim3(kBlock), 0, as_stream(stream),
+        hipLaunchKernelGGL(warp_field_advanced_kernel<2>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream),
                            canonical, live, warp_planar, gradient_planar, new_live, g, flags);
     else
-        hipLaunchKernelGGL(warp_field_advanced_kernel<3>, dim3(t.total), dim3(kBlock), 0, as_stream(stream),
+        hipLaunchKernelGGL(warp_field_advanced_kernel<3>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream),
                            canonical, live, warp_planar, gradient_planar, new_live, g, flags);
     return launch_status();
 }
@@ -139,8 +141,7 @@ __device__ inline float np_gradient_axis(const float* __restrict__ f, long long 
 template <int D>
 __global__ __launch_bounds__(kBlock) void pack_live_gradient_kernel(const float* __restrict__ live,
                                                                     float4* __restrict__ packed, Grid g) {
-    int x, y, z;
-    if (!thread_voxel(g, x, y, z)) return;
+    for_each_voxel(g, [&](int x, int y, int z) {
     long long i = vidx(g, x, y, z);
     float4 r;
     r.x = live[i];
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(kBlock) void pack_live_gradient_kernel(const float*
     r.z = np_gradient_axis(live, i, y, g.ny, g.nx);
     r.w = D == 3 ? np_gradient_axis(live, i, z, g.nz, (long long)g.ny * g.nx) : 0.0f;
     packed[i] = r;
+    });
 }
 
 extern "C" int lsf_pack_live_gradient(const float* live, float* packed4, const lsf_grid* grid, void* stream) {
@@ -157,10 +159,10 @@ extern "C" int lsf_pack_live_gradient(const float* live, float* packed4, const l
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
     if (grid->dims == 2)
-        hipLaunchKernelGGL(pack_live_gradient_kernel<2>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), live,
+        hipLaunchKernelGGL(pack_live_gradient_kernel<2>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream), live,
                            reinterpret_cast<float4*>(packed4), g);
     else
-        hipLaunchKernelGGL(pack_live_gradient_kernel<3>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), live,
+        hipLaunchKernelGGL(pack_live_gradient_kernel<3>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream), live,
                            reinterpret_cast<float4*>(packed4), g);
     return launch_status();
 }
@@ -173,8 +175,7 @@ extern "C" int lsf_pack_live_gradient(const float* live, float* packed4, const l
 template <int D, int C>
 __global__ __launch_bounds__(kBlock) void restrict_mean_kernel(const float* __restrict__ fine,
                                                                float* __restrict__ coarse, Grid gc, int fnx, int fny) {
-    int x, y, z;
-    if (!thread_voxel(gc, x, y, z)) return;
+    for_each_voxel(gc, [&](int x, int y, int z) {
     long long o = vidx(gc, x, y, z);
     const long long row = fnx, slice = (long long)fnx * fny;
 #pragma unroll
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(kBlock) void restrict_mean_kernel(const float* __re
         }
         coarse[o * C + c] = r;
     }
+    });
 }
 
 extern "C" int lsf_restrict_mean(const float* fine, float* coarse, const lsf_grid* fine_grid, int32_t channels,
@@ -211,7 +213,7 @@ extern "C" int lsf_restrict_mean(const float* fine, float* coarse, const lsf_gri
     if (t.total == 0) return 0;
     hipStream_t s = as_stream(stream);
 #define LSF_LAUNCH_RESTRICT(D, C)                                                                             \
-    hipLaunchKernelGGL((restrict_mean_kernel<D, C>), dim3(t.total), dim3(kBlock), 0, s, fine, coarse, gc, \
+    hipLaunchKernelGGL((restrict_mean_kernel<D, C>), dim3(launch_blocks(t.total)), dim3(kBlock), 0, s, fine, coarse, gc, \
                        fine_grid->nx, fine_grid->ny)
     if (fine_grid->dims == 2) {
         if (channels == 1) LSF_LAUNCH_RESTRICT(2, 1); else LSF_LAUNCH_RESTRICT(2, 4);
@@ -225,14 +227,14 @@ extern "C" int lsf_restrict_mean(const float* fine, float* coarse, const lsf_gri
 template <int D>
 __global__ __launch_bounds__(kBlock) void prolong_repeat_kernel(const float* __restrict__ coarse,
                                                                 float* __restrict__ fine, Grid gf) {
-    int x, y, z;
-    if (!thread_voxel(gf, x, y, z)) return;
+    for_each_voxel(gf, [&](int x, int y, int z) {
     const int cnx = gf.nx / 2, cny = gf.ny / 2, cnz = D == 3 ? gf.nz / 2 : 1;
     const long long cplane = (long long)cnx * cny * cnz;
     long long ci = ((long long)(D == 3 ? z / 2 : 0) * cny + y / 2) * cnx + x / 2;
     long long fi = vidx(gf, x, y, z);
 #pragma unroll
     for (int c = 0; c < D; ++c) fine[c * gf.plane + fi] = coarse[c * cplane + ci];
+    });
 }
 
 extern "C" int lsf_prolong_repeat(const float* coarse_planar, float* fine_planar, const lsf_grid* fine_grid,
@@ -245,10 +247,10 @@ extern "C" int lsf_prolong_repeat(const float* coarse_planar, float* fine_planar
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
     if (fine_grid->dims == 2)
-        hipLaunchKernelGGL(prolong_repeat_kernel<2>, dim3(t.total), dim3(kBlock), 0, as_stream(stream),
+        hipLaunchKernelGGL(prolong_repeat_kernel<2>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream),
                            coarse_planar, fine_planar, g);
     else
-        hipLaunchKernelGGL(prolong_repeat_kernel<3>, dim3(t.total), dim3(kBlock), 0, as_stream(stream),
+        hipLaunchKernelGGL(prolong_repeat_kernel<3>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream),
                            coarse_planar, fine_planar, g);
     return launch_status();
 }
@@ -265,8 +267,7 @@ __global__ __launch_bounds__(kBlock) void convolve_axis_kernel(const float* __re
                                                                const float* __restrict__ mask_src, Grid g, int axis,
                                                                Taps taps, lsf_gate gate) {
     if (gate_closed(gate)) return;
-    int x, y, z;
-    if (!thread_voxel(g, x, y, z)) return;
+    for_each_voxel(g, [&](int x, int y, int z) {
     const long long base = (long long)blockIdx.y * g.plane;
     const long long i = vidx(g, x, y, z);
     const int coord = axis == 0 ? x : (axis == 1 ? y : z);
@@ -282,6 +283,7 @@ __global__ __launch_bounds__(kBlock) void convolve_axis_kernel(const float* __re
     float r = (float)acc;
     if (mask_src && fabsf(mask_src[base + i]) < 1e-6f) r = 0.0f;
     out[base + i] = r;
+    });
 }
 
 extern "C" int lsf_convolve_axis(const float* in_planar, float* out_planar, const float* zero_mask_source,
@@ -298,7 +300,7 @@ extern "C" int lsf_convolve_axis(const float* in_planar, float* out_planar, cons
     taps.n = n_taps;
     for (int j = 0; j < LSF_MAX_KERNEL_TAPS; ++j) taps.k[j] = j < n_taps ? taps_host[j] : 0.0;
     lsf_gate gt = gate ? *gate : lsf_gate{nullptr, 0, 0.0f, 0.0f};
-    hipLaunchKernelGGL(convolve_axis_kernel, dim3(t.total, planes), dim3(kBlock), 0, as_stream(stream), in_planar,
+    hipLaunchKernelGGL(convolve_axis_kernel, dim3(launch_blocks(t.total), planes), dim3(kBlock), 0, as_stream(stream), in_planar,
                        out_planar, zero_mask_source, g, axis, taps, gt);
     return launch_status();
 }
@@ -325,24 +327,22 @@ __global__ __launch_bounds__(kBlock) void warp_statistics_kernel(const float* __
                                                                  const float* __restrict__ canonical,
                                                                  const float* __restrict__ live, Grid g, float lo,
                                                                  double* out8, unsigned long long* packed_out) {
-    int x, y, z;
-    bool active = thread_voxel(g, x, y, z);
     unsigned long long packed = 0ull;
     double sums[4] = {0.0, 0.0, 0.0, 0.0};
-    if (active) {
+    for_each_voxel(g, [&](int x, int y, int z) {
         long long i = vidx(g, x, y, z);
         bool band = !(fabsf(live[i]) == 1.0f && fabsf(canonical[i]) == 1.0f);
         if (band) {
             float v[3] = {warp[i], warp[g.plane + i], D == 3 ? warp[2 * g.plane + i] : 0.0f};
             float len = vec_length<D>(v);
-            unsigned lin = (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);
-            packed = pack_max(len, lin);
-            sums[0] = 1.0;
-            sums[1] = len > lo ? 1.0 : 0.0;
-            sums[2] = (double)len;
-            sums[3] = (double)len * (double)len;
+            unsigned long long p = pack_max(len, linear_index(g, x, y, z));
+            packed = p > packed ? p : packed;
+            sums[0] += 1.0;
+            sums[1] += len > lo ? 1.0 : 0.0;
+            sums[2] += (double)len;
+            sums[3] += (double)len * (double)len;
         }
-    }
+    });
     double* dst[4] = {out8 + 0, out8 + 1, out8 + 3, out8 + 4};
     block_reduce_commit<4>(packed, sums, packed_out, dst);
 }
@@ -351,22 +351,20 @@ template <int D>
 __global__ __launch_bounds__(kBlock) void tsdf_statistics_kernel(const float* __restrict__ canonical,
                                                                  const float* __restrict__ live, Grid g, double* out8,
                                                                  unsigned long long* packed_out) {
-    int x, y, z;
-    bool active = thread_voxel(g, x, y, z);
     unsigned long long packed = 0ull;
     double sums[3] = {0.0, 0.0, 0.0};
     double mn = __longlong_as_double(0x7ff0000000000000ll);
-    if (active) {
+    for_each_voxel(g, [&](int x, int y, int z) {
         long long i = vidx(g, x, y, z);
         double d = fabs((double)canonical[i] - (double)live[i]);
-        unsigned lin = (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);
-        packed = pack_max((float)d, lin);
-        sums[0] = 1.0;
-        sums[1] = d;
-        sums[2] = d * d;
-        mn = d;
-    }
-    // min over the wave, one atomic per wave (tiny kernel, run once per optimize call)
+        unsigned long long p = pack_max((float)d, linear_index(g, x, y, z));
+        packed = p > packed ? p : packed;
+        sums[0] += 1.0;
+        sums[1] += d;
+        sums[2] += d * d;
+        mn = fmin(mn, d);
+    });
+    // min: wave shuffle, one atomic per wave (at most 4 * kMaxBlocks atomics per launch)
     for (int dl = kWave / 2; dl > 0; dl >>= 1) mn = fmin(mn, shfl_down_f64(mn, dl));
     if ((threadIdx.x & (kWave - 1)) == 0) atomic_min_f64_nonneg(out8 + 1, mn);
     double* dst[3] = {out8 + 0, out8 + 3, out8 + 4};
@@ -392,10 +390,10 @@ extern "C" int lsf_warp_statistics(const float* warp_planar, const float* canoni
     hipLaunchKernelGGL(stats_init_kernel, dim3(1), dim3(64), 0, s, out8, 0);
     if (t.total) {
         if (grid->dims == 2)
-            hipLaunchKernelGGL(warp_statistics_kernel<2>, dim3(t.total), dim3(kBlock), 0, s, warp_planar, canonical,
+            hipLaunchKernelGGL(warp_statistics_kernel<2>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, s, warp_planar, canonical,
                                live, g, lower_threshold, out8, packed);
         else
-            hipLaunchKernelGGL(warp_statistics_kernel<3>, dim3(t.total), dim3(kBlock), 0, s, warp_planar, canonical,
+            hipLaunchKernelGGL(warp_statistics_kernel<3>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, s, warp_planar, canonical,
                                live, g, lower_threshold, out8, packed);
     }
     hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(64), 0, s, out8, packed, 0);
@@ -413,10 +411,10 @@ extern "C" int lsf_tsdf_difference_statistics(const float* canonical, const floa
     hipLaunchKernelGGL(stats_init_kernel, dim3(1), dim3(64), 0, s, out8, 1);
     if (t.total) {
         if (grid->dims == 2)
-            hipLaunchKernelGGL(tsdf_statistics_kernel<2>, dim3(t.total), dim3(kBlock), 0, s, canonical, live, g, out8,
+            hipLaunchKernelGGL(tsdf_statistics_kernel<2>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, s, canonical, live, g, out8,
                                packed);
         else
-            hipLaunchKernelGGL(tsdf_statistics_kernel<3>, dim3(t.total), dim3(kBlock), 0, s, canonical, live, g, out8,
+            hipLaunchKernelGGL(tsdf_statistics_kernel<3>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, s, canonical, live, g, out8,
                                packed);
     }
     hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(64), 0, s, out8, packed, 1);

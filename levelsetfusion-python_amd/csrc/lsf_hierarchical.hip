@@ -53,7 +53,7 @@ __device__ inline Packed gather_packed(const float4* __restrict__ s, const Grid&
     } else {
         float fz = floorf(pz);
         float rz = pz - fz, iz = 1.0f - rz;
-        int bz = (int)fminf(fmaxf(fz, -2.0f), (float)g.nz + 1.0f);
+        int bz = (int)fminf(fmaxf(fz - (float)g.z_global_offset, -2.0f), (float)g.nz + 1.0f);
 #pragma unroll
         for (int ox = 0; ox < 2; ++ox)
 #pragma unroll
@@ -96,17 +96,16 @@ __global__ __launch_bounds__(kBlock) void hier_iteration_kernel(const float4* __
                                                                 float strength, float rate, lsf_gate gate,
                                                                 lsf_iteration_record* record) {
     if (gate_closed(gate)) return;
-    int x, y, z;
-    const bool active = thread_voxel(g, x, y, z);
     unsigned long long best = 0ull;
     double sums[1] = {0.0};
-    if (active) {
+    for_each_voxel(g, [&](int x, int y, int z) {
         const long long i = vidx(g, x, y, z);
         float w[3];
         w[0] = warp[i];
         w[1] = warp[g.plane + i];
         w[2] = D == 3 ? warp[2 * g.plane + i] : 0.0f;
-        const float px = (float)x + w[0], py = (float)y + w[1], pz = D == 3 ? (float)z + w[2] : 0.0f;
+        const float px = (float)x + w[0], py = (float)y + w[1];
+        const float pz = D == 3 ? (float)(z + g.z_global_offset) + w[2] : 0.0f;
         const Packed s = gather_packed<D>(packed, g, px, py, pz);
         const float diff = s.l - canonical[i];
         const float live_grad[3] = {s.gx, s.gy, s.gz};
@@ -125,11 +124,11 @@ __global__ __launch_bounds__(kBlock) void hier_iteration_kernel(const float4* __
         if (UPDATE) {
 #pragma unroll
             for (int c = 0; c < D; ++c) warp[c * g.plane + i] = w[c] - rate * gv[c];
-            unsigned lin = (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);
-            best = pack_max(vec_length<D>(gv), lin);
+            unsigned long long p = pack_max(vec_length<D>(gv), linear_index(g, x, y, z));
+            best = p > best ? p : best;
         }
-        if (ENERGY) sums[0] = (double)diff * (double)diff;
-    }
+        if (ENERGY) sums[0] += (double)diff * (double)diff;
+    });
     if (UPDATE || ENERGY) {
         double* dst[1] = {ENERGY ? &record->data_energy : nullptr};
         block_reduce_commit<1>(best, sums, UPDATE ? record_max(record) : nullptr, dst);
@@ -141,10 +140,8 @@ __global__ __launch_bounds__(kBlock) void hier_update_kernel(const float* __rest
                                                              float* __restrict__ warp, Grid g, float rate,
                                                              lsf_gate gate, lsf_iteration_record* record) {
     if (gate_closed(gate)) return;
-    int x, y, z;
-    const bool active = thread_voxel(g, x, y, z);
     unsigned long long best = 0ull;
-    if (active) {
+    for_each_voxel(g, [&](int x, int y, int z) {
         const long long i = vidx(g, x, y, z);
         float gv[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -152,9 +149,9 @@ __global__ __launch_bounds__(kBlock) void hier_update_kernel(const float* __rest
             gv[c] = gfield[c * g.plane + i];
             warp[c * g.plane + i] = warp[c * g.plane + i] - rate * gv[c];
         }
-        unsigned lin = (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);
-        best = pack_max(vec_length<D>(gv), lin);
-    }
+        unsigned long long p = pack_max(vec_length<D>(gv), linear_index(g, x, y, z));
+        best = p > best ? p : best;
+    });
     const double sums[1] = {0.0};
     double* dst[1] = {nullptr};
     block_reduce_commit<0>(best, sums, record_max(record), dst);
@@ -204,10 +201,10 @@ extern "C" int lsf_hier_iteration(const float* packed_live4, const float* canoni
     const float4* packed = reinterpret_cast<const float4*>(packed_live4);
     lsf_gate gt = gate_or_open(gate);
     if (grid->dims == 2)
-        dispatch_hier<2>(t.total, as_stream(stream), packed, canonical, warp_planar, g_prev_planar, g_out_planar, g,
+        dispatch_hier<2>(launch_blocks(t.total), as_stream(stream), packed, canonical, warp_planar, g_prev_planar, g_out_planar, g,
                          params, gt, record);
     else
-        dispatch_hier<3>(t.total, as_stream(stream), packed, canonical, warp_planar, g_prev_planar, g_out_planar, g,
+        dispatch_hier<3>(launch_blocks(t.total), as_stream(stream), packed, canonical, warp_planar, g_prev_planar, g_out_planar, g,
                          params, gt, record);
     return launch_status();
 }
@@ -221,10 +218,10 @@ extern "C" int lsf_hier_update(const float* g_planar, float* warp_planar, const 
     if (t.total == 0) return 0;
     lsf_gate gt = gate_or_open(gate);
     if (grid->dims == 2)
-        hipLaunchKernelGGL(hier_update_kernel<2>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), g_planar,
+        hipLaunchKernelGGL(hier_update_kernel<2>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream), g_planar,
                            warp_planar, g, rate, gt, record);
     else
-        hipLaunchKernelGGL(hier_update_kernel<3>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), g_planar,
+        hipLaunchKernelGGL(hier_update_kernel<3>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream), g_planar,
                            warp_planar, g, rate, gt, record);
     return launch_status();
 }

@@ -273,8 +273,9 @@ __device__ inline unsigned long long update_and_rewarp(const float* __restrict__
 #pragma unroll
     for (int c = 0; c < D; ++c) wv[c] = (-gv[c]) * p.rate;
     const float len = vec_length<D>(wv);
-    const unsigned lin = (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);
-    const float px = (float)x + wv[0], py = (float)y + wv[1], pz = D == 3 ? (float)z + wv[2] : 0.0f;
+    const unsigned lin = linear_index(g, x, y, z);
+    const float px = (float)x + wv[0], py = (float)y + wv[1];
+    const float pz = D == 3 ? (float)(z + g.z_global_offset) + wv[2] : 0.0f;
     float v = sample_linear<D>(live, g, px, py, pz, 1.0f);
     if (1.0f - fabsf(v) < 1e-6f) {  // field_warping.py:138-141
         v = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : v);
@@ -296,21 +297,24 @@ __global__ __launch_bounds__(kBlock) void slavcheva_iteration_kernel(
     float* __restrict__ warp_out, float* __restrict__ live_out, float* __restrict__ g_out, Grid g, Params p,
     lsf_gate gate, lsf_iteration_record* record) {
     if (gate_closed(gate)) return;
-    int x, y, z;
-    const bool active = thread_voxel(g, x, y, z);
     unsigned long long best = 0ull;
     double en[3] = {0.0, 0.0, 0.0};
-    if (active) {
+    for_each_voxel(g, [&](int x, int y, int z) {
         const long long i = vidx(g, x, y, z);
         float gv[3];
-        voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(live, canonical, warp_prev, g, p, x, y, z, i, gv, en);
+        double e[3] = {0.0, 0.0, 0.0};
+        voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(live, canonical, warp_prev, g, p, x, y, z, i, gv, e);
+        en[0] += e[0];
+        en[1] += e[1];
+        en[2] += e[2];
         if (FUSED) {
-            best = update_and_rewarp<D>(live, g, p, x, y, z, i, gv, warp_out, live_out, g_out);
+            unsigned long long q = update_and_rewarp<D>(live, g, p, x, y, z, i, gv, warp_out, live_out, g_out);
+            best = q > best ? q : best;
         } else {
 #pragma unroll
             for (int c = 0; c < D; ++c) g_out[c * g.plane + i] = gv[c];
         }
-    }
+    });
     if (FUSED || ENERGY != LSF_ENERGY_NONE) {
         double* dst[3] = {ENERGY != LSF_ENERGY_NONE ? &record->data_energy : nullptr,
                           ENERGY != LSF_ENERGY_NONE ? &record->smoothing_energy : nullptr,
@@ -327,15 +331,14 @@ __global__ __launch_bounds__(kBlock) void slavcheva_update_rewarp_kernel(const f
                                                                          Params p, lsf_gate gate,
                                                                          lsf_iteration_record* record) {
     if (gate_closed(gate)) return;
-    int x, y, z;
-    const bool active = thread_voxel(g, x, y, z);
     unsigned long long best = 0ull;
-    if (active) {
+    for_each_voxel(g, [&](int x, int y, int z) {
         const long long i = vidx(g, x, y, z);
         float gv[3] = {gfield[i], gfield[g.plane + i], D == 3 ? gfield[2 * g.plane + i] : 0.0f};
-        best = update_and_rewarp<D>(live, g, p, x, y, z, i, gv, warp_out, live_out,
-                                    p.zero_gradient_on_snap ? gfield : nullptr);
-    }
+        unsigned long long q = update_and_rewarp<D>(live, g, p, x, y, z, i, gv, warp_out, live_out,
+                                                    p.zero_gradient_on_snap ? gfield : nullptr);
+        best = q > best ? q : best;
+    });
     const double sums[1] = {0.0};
     double* dst[1] = {nullptr};
     block_reduce_commit<0>(best, sums, record_max(record), dst);
@@ -417,7 +420,7 @@ extern "C" int lsf_slavcheva_iteration(int32_t stage, const float* live, const f
     Grid g = make_grid(grid);
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
-    LaunchArgs a{t.total, as_stream(stream), live, canonical, warp_prev_planar, warp_out_planar, live_out,
+    LaunchArgs a{launch_blocks(t.total), as_stream(stream), live, canonical, warp_prev_planar, warp_out_planar, live_out,
                  g_out_planar, g, make_params(params), gate_or_open(gate), record};
     if (grid->dims == 2) {
         if (stage == LSF_STAGE_FUSED) pick_terms<2, true>(params, a); else pick_terms<2, false>(params, a);
@@ -441,10 +444,10 @@ extern "C" int lsf_slavcheva_update_rewarp(const float* live, const float* canon
     Params p = make_params(params);
     lsf_gate gt = gate_or_open(gate);
     if (grid->dims == 2)
-        hipLaunchKernelGGL(slavcheva_update_rewarp_kernel<2>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), live,
+        hipLaunchKernelGGL(slavcheva_update_rewarp_kernel<2>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream), live,
                            g_planar, warp_out_planar, live_out, g, p, gt, record);
     else
-        hipLaunchKernelGGL(slavcheva_update_rewarp_kernel<3>, dim3(t.total), dim3(kBlock), 0, as_stream(stream), live,
+        hipLaunchKernelGGL(slavcheva_update_rewarp_kernel<3>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream), live,
                            g_planar, warp_out_planar, live_out, g, p, gt, record);
     return launch_status();
 }

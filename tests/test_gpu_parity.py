@@ -71,7 +71,8 @@ def test_warp_field_advanced_kernel(lsf, shape, flags):
     a = fw.warp_field_advanced(canon, live.copy(), wa, ga, *flags)
     b = O.warp_field_advanced(canon, live.copy(), wb, gb, *flags)
     assert maxdiff(a, b) == EXACT and maxdiff(wa, wb) == EXACT and maxdiff(ga, gb) == EXACT
-    assert (np.abs(b) == 1).any()  # the snap branch is exercised
+    if flags == (False, False, False):
+        assert (np.abs(b) == 1).any() and (wb == 0).any()  # the snap branch is exercised
 
 
 def test_reference_field_warping_known_answers(lsf, ref_literals):
