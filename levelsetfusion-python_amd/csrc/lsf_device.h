@@ -38,6 +38,7 @@ __host__ inline int check_grid(const lsf_grid* g) {
     if (g->nx <= 0 || g->ny <= 0 || g->nz <= 0) return LSF_ERR_BAD_ARGUMENT;
     if (g->dims == 2 && g->nz != 1) return LSF_ERR_BAD_DIMS;
     if (g->z_begin < 0 || g->z_end > g->nz || g->z_begin > g->z_end) return LSF_ERR_BAD_ARGUMENT;
+    if ((long long)g->nz * g->ny * g->nx > 0x7fffffffll) return LSF_ERR_BAD_DIMS;  // 32-bit voxel indices
     return 0;
 }
 
@@ -118,8 +119,10 @@ __device__ inline unsigned linear_index(const Grid& g, int x, int y, int z) {
     return (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);
 }
 
-__device__ inline long long vidx(const Grid& g, int x, int y, int z) {
-    return ((long long)z * g.ny + y) * g.nx + x;
+// voxel index inside one plane: 32-bit on purpose (check_grid caps a plane at 2^31-1 voxels) so that loads take the
+// "scalar base + 32-bit offset" form instead of 64-bit VALU address arithmetic
+__device__ inline int vidx(const Grid& g, int x, int y, int z) {
+    return (z * g.ny + y) * g.nx + x;
 }
 
 __device__ inline bool inside(const Grid& g, int x, int y, int z) {
@@ -144,39 +147,61 @@ __device__ inline float read_clamp(const float* __restrict__ f, const Grid& g, i
 // pz is the GLOBAL z position (z + z_global_offset + w): float32 rounding of "coordinate + displacement" depends
 // on the coordinate's magnitude, so a slab must form it from the global coordinate to match the whole volume.
 // ------------------------------------------------------------------------------------------------------
+// per-axis tap addressing for the D-linear gathers: both taps of an axis are read from CLAMPED (always valid)
+// coordinates and an out-of-bounds tap is replaced by select afterwards -- no exec-mask branches around loads
+struct AxisTaps {
+    int c0, c1;    // clamped coordinates of the two taps
+    bool v0, v1;   // tap inside the array?
+    float r, i;    // ratio and 1 - ratio
+};
+
+__device__ inline AxisTaps axis_taps(float p, int n, int global_offset) {
+    AxisTaps t;
+    const float f = floorf(p);
+    t.r = p - f;
+    t.i = 1.0f - t.r;
+    // clamp the base so the int conversion is defined for wild warps; anything beyond is OOB anyway
+    const int b = (int)fminf(fmaxf(f - (float)global_offset, -2.0f), (float)n + 1.0f);
+    t.v0 = (unsigned)b < (unsigned)n;
+    t.v1 = (unsigned)(b + 1) < (unsigned)n;
+    t.c0 = min(max(b, 0), n - 1);
+    t.c1 = min(max(b + 1, 0), n - 1);
+    return t;
+}
+
 template <int D>
 __device__ inline float sample_linear(const float* __restrict__ f, const Grid& g, float px, float py, float pz,
                                       float oob) {
-    float fx = floorf(px), fy = floorf(py);
-    float rx = px - fx, ry = py - fy;
-    float ix = 1.0f - rx, iy = 1.0f - ry;
-    // clamp the base so the int conversion is defined for wild warps; anything beyond is OOB anyway
-    int bx = (int)fminf(fmaxf(fx, -2.0f), (float)g.nx + 1.0f);
-    int by = (int)fminf(fmaxf(fy, -2.0f), (float)g.ny + 1.0f);
+    const AxisTaps ax = axis_taps(px, g.nx, 0), ay = axis_taps(py, g.ny, 0);
+    const int row0 = ay.c0 * g.nx, row1 = ay.c1 * g.nx;
     if (D == 2) {
-        float v00 = read_oob(f, g, bx, by, 0, oob);
-        float v01 = read_oob(f, g, bx, by + 1, 0, oob);
-        float v10 = read_oob(f, g, bx + 1, by, 0, oob);
-        float v11 = read_oob(f, g, bx + 1, by + 1, 0, oob);
-        float i0 = v00 * iy + v01 * ry;
-        float i1 = v10 * iy + v11 * ry;
-        return i0 * ix + i1 * rx;
+        float v00 = f[row0 + ax.c0], v01 = f[row1 + ax.c0], v10 = f[row0 + ax.c1], v11 = f[row1 + ax.c1];
+        v00 = (ax.v0 && ay.v0) ? v00 : oob;
+        v01 = (ax.v0 && ay.v1) ? v01 : oob;
+        v10 = (ax.v1 && ay.v0) ? v10 : oob;
+        v11 = (ax.v1 && ay.v1) ? v11 : oob;
+        const float i0 = v00 * ay.i + v01 * ay.r;
+        const float i1 = v10 * ay.i + v11 * ay.r;
+        return i0 * ax.i + i1 * ax.r;
     } else {
-        float fz = floorf(pz);
-        float rz = pz - fz, iz = 1.0f - rz;
-        int bz = (int)fminf(fmaxf(fz - (float)g.z_global_offset, -2.0f), (float)g.nz + 1.0f);
+        const AxisTaps az = axis_taps(pz, g.nz, g.z_global_offset);
+        const int slice = g.nx * g.ny;
+        const int s0 = az.c0 * slice, s1 = az.c1 * slice;
         float c[2][2];  // [x offset][y offset] after the z lerp
 #pragma unroll
         for (int ox = 0; ox < 2; ++ox)
 #pragma unroll
             for (int oy = 0; oy < 2; ++oy) {
-                float a = read_oob(f, g, bx + ox, by + oy, bz, oob);
-                float b = read_oob(f, g, bx + ox, by + oy, bz + 1, oob);
-                c[ox][oy] = a * iz + b * rz;
+                const int xy = (oy ? row1 : row0) + (ox ? ax.c1 : ax.c0);
+                const bool vxy = (ox ? ax.v1 : ax.v0) && (oy ? ay.v1 : ay.v0);
+                float a = f[s0 + xy], b = f[s1 + xy];
+                a = (vxy && az.v0) ? a : oob;
+                b = (vxy && az.v1) ? b : oob;
+                c[ox][oy] = a * az.i + b * az.r;
             }
-        float i0 = c[0][0] * iy + c[0][1] * ry;
-        float i1 = c[1][0] * iy + c[1][1] * ry;
-        return i0 * ix + i1 * rx;
+        const float i0 = c[0][0] * ay.i + c[0][1] * ay.r;
+        const float i1 = c[1][0] * ay.i + c[1][1] * ay.r;
+        return i0 * ax.i + i1 * ax.r;
     }
 }
 

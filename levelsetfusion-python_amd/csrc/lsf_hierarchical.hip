@@ -16,14 +16,13 @@ struct Packed {
     float l, gx, gy, gz;
 };
 
-__device__ inline Packed read_packed(const float4* __restrict__ s, const Grid& g, int x, int y, int z) {
+__device__ inline Packed select_packed(const float4& v, bool valid) {
+    // OOB taps: live reads 1 (field_warping.py:67-85), gradients read 0 (:88-109 with replacement 0)
     Packed p;
-    if (inside(g, x, y, z)) {
-        float4 v = s[vidx(g, x, y, z)];
-        p.l = v.x; p.gx = v.y; p.gy = v.z; p.gz = v.w;
-    } else {  // OOB taps: live reads 1 (field_warping.py:67-85), gradients read 0 (:88-109 with replacement 0)
-        p.l = 1.0f; p.gx = 0.0f; p.gy = 0.0f; p.gz = 0.0f;
-    }
+    p.l = valid ? v.x : 1.0f;
+    p.gx = valid ? v.y : 0.0f;
+    p.gy = valid ? v.z : 0.0f;
+    p.gz = valid ? v.w : 0.0f;
     return p;
 }
 
@@ -36,45 +35,48 @@ __device__ inline Packed lerp(const Packed& a, const Packed& b, float inv, float
     return r;
 }
 
-// D-linear gather of the packed field: lerp along z, then y, then x (oracle.sample_linear)
+// D-linear gather of the packed field: lerp along z, then y, then x (oracle.sample_linear); taps are read from
+// clamped coordinates and replaced by select when out of bounds (no branches around the 16-byte loads)
 template <int D>
 __device__ inline Packed gather_packed(const float4* __restrict__ s, const Grid& g, float px, float py, float pz) {
-    float fx = floorf(px), fy = floorf(py);
-    float rx = px - fx, ry = py - fy;
-    float ix = 1.0f - rx, iy = 1.0f - ry;
-    int bx = (int)fminf(fmaxf(fx, -2.0f), (float)g.nx + 1.0f);
-    int by = (int)fminf(fmaxf(fy, -2.0f), (float)g.ny + 1.0f);
+    const AxisTaps ax = axis_taps(px, g.nx, 0), ay = axis_taps(py, g.ny, 0);
+    const int row0 = ay.c0 * g.nx, row1 = ay.c1 * g.nx;
     Packed c[2][2];
     if (D == 2) {
 #pragma unroll
         for (int ox = 0; ox < 2; ++ox)
 #pragma unroll
-            for (int oy = 0; oy < 2; ++oy) c[ox][oy] = read_packed(s, g, bx + ox, by + oy, 0);
+            for (int oy = 0; oy < 2; ++oy) {
+                const int xy = (oy ? row1 : row0) + (ox ? ax.c1 : ax.c0);
+                c[ox][oy] = select_packed(s[xy], (ox ? ax.v1 : ax.v0) && (oy ? ay.v1 : ay.v0));
+            }
     } else {
-        float fz = floorf(pz);
-        float rz = pz - fz, iz = 1.0f - rz;
-        int bz = (int)fminf(fmaxf(fz - (float)g.z_global_offset, -2.0f), (float)g.nz + 1.0f);
+        const AxisTaps az = axis_taps(pz, g.nz, g.z_global_offset);
+        const int slice = g.nx * g.ny;
+        const int s0 = az.c0 * slice, s1 = az.c1 * slice;
 #pragma unroll
         for (int ox = 0; ox < 2; ++ox)
 #pragma unroll
             for (int oy = 0; oy < 2; ++oy) {
-                Packed a = read_packed(s, g, bx + ox, by + oy, bz);
-                Packed b = read_packed(s, g, bx + ox, by + oy, bz + 1);
-                c[ox][oy] = lerp(a, b, iz, rz);
+                const int xy = (oy ? row1 : row0) + (ox ? ax.c1 : ax.c0);
+                const bool vxy = (ox ? ax.v1 : ax.v0) && (oy ? ay.v1 : ay.v0);
+                const Packed a = select_packed(s[s0 + xy], vxy && az.v0);
+                const Packed b = select_packed(s[s1 + xy], vxy && az.v1);
+                c[ox][oy] = lerp(a, b, az.i, az.r);
             }
     }
-    Packed i0 = lerp(c[0][0], c[0][1], iy, ry);
-    Packed i1 = lerp(c[1][0], c[1][1], iy, ry);
-    return lerp(i0, i1, ix, rx);
+    const Packed i0 = lerp(c[0][0], c[0][1], ay.i, ay.r);
+    const Packed i1 = lerp(c[1][0], c[1][1], ay.i, ay.r);
+    return lerp(i0, i1, ax.i, ax.r);
 }
 
 // scipy.ndimage.laplace(mode='nearest') of one plane at (x,y,z): per-axis second differences evaluated in
 // double and stored float32, summed in float32, slowest axis first (oracle.laplace_replicate)
 template <int D>
 __device__ inline float laplace_replicate(const float* __restrict__ a, const Grid& g, int x, int y, int z) {
-    const long long i = vidx(g, x, y, z);
+    const int i = vidx(g, x, y, z);
     const float a0 = a[i];
-    const long long sy = g.nx, sz = (long long)g.nx * g.ny;
+    const int sy = g.nx, sz = g.nx * g.ny;
     float out;
     float d2y = second_difference_f64(y > 0 ? a[i - sy] : a0, a0, y < g.ny - 1 ? a[i + sy] : a0);
     float d2x = second_difference_f64(x > 0 ? a[i - 1] : a0, a0, x < g.nx - 1 ? a[i + 1] : a0);
@@ -99,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void hier_iteration_kernel(const float4* __
     unsigned long long best = 0ull;
     double sums[1] = {0.0};
     for_each_voxel(g, [&](int x, int y, int z) {
-        const long long i = vidx(g, x, y, z);
+        const int i = vidx(g, x, y, z);
         float w[3];
         w[0] = warp[i];
         w[1] = warp[g.plane + i];
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void hier_update_kernel(const float* __rest
     if (gate_closed(gate)) return;
     unsigned long long best = 0ull;
     for_each_voxel(g, [&](int x, int y, int z) {
-        const long long i = vidx(g, x, y, z);
+        const int i = vidx(g, x, y, z);
         float gv[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int c = 0; c < D; ++c) {
