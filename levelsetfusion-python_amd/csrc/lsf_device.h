@@ -17,7 +17,8 @@ struct Grid {
     int nz, ny, nx;
     int z_begin, z_end;
     int z_global_offset;
-    long long plane;  // nz*ny*nx: stride between the planes of a planar vector field
+    unsigned chunk_tiles;  // tiles per scheduling chunk (see tile_range)
+    long long plane;       // nz*ny*nx: stride between the planes of a planar vector field
 };
 
 __host__ inline Grid make_grid(const lsf_grid* g) {
@@ -26,6 +27,19 @@ __host__ inline Grid make_grid(const lsf_grid* g) {
     r.z_begin = g->z_begin; r.z_end = g->z_end;
     r.z_global_offset = g->z_global_offset;
     r.plane = (long long)g->nz * g->ny * g->nx;
+    // scheduling chunk: a few consecutive z-slices of tiles (3-D) or a few tile rows (2-D), so that the volume is
+    // cut into >= ~32 chunks dealt round-robin to the 8 XCDs (load balance when the narrow band is localised)
+    // while a chunk is still thick enough that most stencil / halo re-reads stay inside one XCD's L2
+    const unsigned tiles_x = (unsigned)(g->nx + 63) / 64, tiles_y = (unsigned)(g->ny + 3) / 4;
+    const unsigned slices = (unsigned)(g->z_end - g->z_begin);
+    if (g->dims == 3) {
+        unsigned s = slices / 32;
+        s = s < 1 ? 1 : (s > 8 ? 8 : s);
+        r.chunk_tiles = tiles_x * tiles_y * s;
+    } else {
+        unsigned rows = tiles_y / 32;
+        r.chunk_tiles = tiles_x * (rows < 1 ? 1 : rows);
+    }
     return r;
 }
 
@@ -80,32 +94,48 @@ __host__ inline unsigned launch_blocks(unsigned total_tiles) {
     return b;
 }
 
-struct TileRange {
-    unsigned first, end, step;
+// Tiles are numbered x fastest, then y, then z.  The sequence is cut into chunks of g.chunk_tiles tiles; chunk c
+// belongs to XCD (c mod 8) (blocks b, b+8, ... share an XCD under round-robin dispatch: MI355X_MICROARCH.md), and
+// the blocks of one XCD walk that XCD's chunks side by side.
+struct TileWalk {
+    unsigned q, count, step, xcd, chunk;  // XCD-local sequence position / length / stride
+    bool plain;                            // tiny grids: plain grid-stride over [0, count)
 };
 
-__device__ inline TileRange tile_range(unsigned total) {
-    TileRange r;
+__device__ inline TileWalk tile_walk(unsigned total, unsigned chunk) {
+    TileWalk w;
     const unsigned nb = gridDim.x, bid = blockIdx.x;
-    if (nb % kXcds != 0) {  // tiny grids: plain grid-stride
-        r.first = bid; r.end = total; r.step = nb;
-        return r;
+    w.chunk = chunk;
+    if (nb % kXcds != 0) {
+        w.plain = true; w.q = bid; w.count = total; w.step = nb; w.xcd = 0;
+        return w;
     }
-    const unsigned xcd = bid % kXcds, j = bid / kXcds, per_xcd = nb / kXcds;
-    const unsigned q = total / kXcds, rem = total % kXcds;
-    const unsigned start = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
-    const unsigned count = q + (xcd < rem ? 1u : 0u);
-    r.first = start + j; r.end = start + count; r.step = per_xcd;
-    return r;
+    w.plain = false;
+    w.xcd = bid % kXcds;
+    w.q = bid / kXcds;
+    w.step = nb / kXcds;
+    const unsigned cycle = kXcds * chunk;
+    const unsigned rem = total % cycle;
+    const unsigned lo = w.xcd * chunk;
+    const unsigned extra = rem > lo ? (rem - lo < chunk ? rem - lo : chunk) : 0u;
+    w.count = (total / cycle) * chunk + extra;
+    return w;
+}
+
+__device__ inline unsigned tile_of(const TileWalk& w, unsigned q) {
+    if (w.plain) return q;
+    const unsigned m = q / w.chunk, within = q % w.chunk;
+    return (w.xcd + kXcds * m) * w.chunk + within;
 }
 
 // calls f(x, y, z) for every voxel this thread owns (z in [z_begin, z_end))
 template <class F>
 __device__ inline void for_each_voxel(const Grid& g, F&& f) {
     const Tiling t = make_tiling(g);
-    const TileRange r = tile_range(t.total);
+    const TileWalk w = tile_walk(t.total, g.chunk_tiles);
     const int lx = threadIdx.x & (kTileX - 1), ly = threadIdx.x / kTileX;
-    for (unsigned tile = r.first; tile < r.end; tile += r.step) {
+    for (unsigned q = w.q; q < w.count; q += w.step) {
+        const unsigned tile = tile_of(w, q);
         const int tx = tile % t.tiles_x;
         const unsigned rest = tile / t.tiles_x;
         const int ty = rest % t.tiles_y;
