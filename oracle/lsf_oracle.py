@@ -579,6 +579,7 @@ class SlavchevaOracle:
         self.gradient_field = None
         self.log = None
         self.iteration_hook = None  # f(it, live, warp, gradient, energies(dict), max_warp, location)
+        self.max_region = None      # optional slice along axis 0: restrict the max-warp search (slab tests)
 
     def iteration(self, live, canonical, warp):
         """slavcheva_optimizer2d.py:163-236 (VECTORIZED) / :238-330 (DIRECT).  live, warp updated in place.
@@ -611,7 +612,11 @@ class SlavchevaOracle:
             convolve_with_kernel_preserve_zeros(g, self.sobolev_kernel)
         np.copyto(warp, ((-g).astype(F32) * F32(self.gradient_descent_rate)).astype(F32))
         lengths = vector_norm(warp)
-        _, at = first_argmax(lengths)
+        if self.max_region is not None:
+            _, at = first_argmax(lengths[self.max_region])
+            at = (at[0] + (self.max_region.start or 0),) + tuple(at[1:])
+        else:
+            _, at = first_argmax(lengths)
         max_warp = float(lengths[at])
         # DIRECT passes gradient_field to warp_field_advanced (zeroed where snapped, :324-327);
         # VECTORIZED hands only u,v to the C++ twin (:224-234), so its gradient_field is left alone.

@@ -1,0 +1,169 @@
+"""CPU-side checks (no GPU needed): the C-ABI library builds for gfx950, loads, and exports every symbol that
+include/lsf_hip.h declares; ctypes structures match the header's layouts; host-side logic (pyramid rules, slab
+layout, record decoding, Sobolev filter generation); and the product refuses to run without a GPU instead of
+falling back to a CPU path."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "lsf_hip.h")
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_lsf_build_t", os.path.join(ROOT, "levelsetfusion-python_amd",
+                                                                              "_build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    b.build(force=False, verbose=False)  # hipcc cross-compiles gfx950 without a GPU
+    import levelsetfusion_python_amd as lsf
+    return lsf
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lsf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    names = declared_functions()
+    assert len(names) >= 16
+    lib = ctypes.CDLL(pkg._lib.LIB_PATH)
+    for name in names:
+        assert hasattr(lib, name), "liblsf_hip.so does not export %s" % name
+        assert name in pkg._lib.PROTOTYPES, "no ctypes prototype for %s" % name
+    assert sorted(pkg._lib.PROTOTYPES) == names
+    assert pkg._lib.lib.lsf_abi_version() == 1
+    assert pkg._lib.lib.lsf_target_arch() == b"gfx950"
+
+
+def test_code_object_targets_gfx950_only(pkg):
+    data = open(pkg._lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in data
+    for other in (b"gfx90a", b"gfx942", b"sm_80", b"sm_90"):
+        assert other not in data
+
+
+def test_ctypes_structs_match_header_layout(pkg):
+    L = pkg._lib
+    assert ctypes.sizeof(L.Grid) == 32
+    assert ctypes.sizeof(L.IterationRecord) == 32 == L.RECORD_BYTES
+    assert ctypes.sizeof(L.Gate) == 24 and L.Gate.mode.offset == 8 and L.Gate.a.offset == 12
+    assert ctypes.sizeof(L.HierParams) == 32
+    assert ctypes.sizeof(L.SlavchevaParams) == 56 and L.SlavchevaParams.rate.offset == 8
+    text = open(HEADER).read()
+    for macro, value in (("LSF_ABI_VERSION", 1), ("LSF_MAX_KERNEL_TAPS", L.MAX_KERNEL_TAPS),
+                         ("LSF_STAGE_GRADIENT", L.STAGE_GRADIENT), ("LSF_SMOOTHING_KILLING", L.SMOOTHING_KILLING),
+                         ("LSF_DATA_THRESHOLDED_FDM", L.DATA_THRESHOLDED_FDM),
+                         ("LSF_ENERGY_VECTORIZED", L.ENERGY_VECTORIZED), ("LSF_GATE_SLAVCHEVA", L.GATE_SLAVCHEVA)):
+        assert re.search(r"#define\s+%s\s+%d\b" % (macro, value), text), macro
+
+
+def test_argument_errors_are_reported_not_launched(pkg):
+    """host-side validation returns LSF_ERR_* before anything touches a device"""
+    L = pkg._lib
+    bad = L.Grid(4, 1, 8, 8, 0, 1, 0, 0)
+    assert L.lib.lsf_warp_field(1, 1, 1, ctypes.byref(bad), 1.0, None) == -2          # dims
+    g2 = L.Grid(2, 3, 8, 8, 0, 1, 0, 0)
+    assert L.lib.lsf_warp_field(1, 1, 1, ctypes.byref(g2), 1.0, None) == -2           # 2-D needs nz == 1
+    g3 = L.Grid(3, 4, 8, 8, 2, 9, 0, 0)
+    assert L.lib.lsf_warp_field(1, 1, 1, ctypes.byref(g3), 1.0, None) == -1           # z range
+    ok = L.Grid(3, 4, 8, 8, 0, 4, 0, 0)
+    assert L.lib.lsf_warp_field(None, 1, 1, ctypes.byref(ok), 1.0, None) == -1        # null pointer
+    taps = (ctypes.c_double * 40)()
+    assert L.lib.lsf_convolve_axis(1, 2, None, ctypes.byref(ok), 3, 0, taps, 33, None, None) == -3
+    assert L.lib.lsf_convolve_axis(1, 1, None, ctypes.byref(ok), 3, 0, taps, 7, None, None) == -1  # in place
+    with pytest.raises(pkg._lib.LsfHipError):
+        pkg._lib.check(-2, "x")
+
+
+def test_no_cpu_fallback(pkg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    c = np.zeros((16, 16), np.float32)
+    with pytest.raises(RuntimeError, match="no CPU execution path"):
+        pkg.HierarchicalOptimizer2d(maximum_chunk_size=4).optimize(c, c)
+    with pytest.raises(RuntimeError, match="no CPU execution path"):
+        pkg.SlavchevaOptimizer2d(out_path=None, field_size=16).optimize(c.copy(), c)
+    # nothing under the package imports the oracle
+    pkg_dir = os.path.dirname(pkg._lib.__file__)
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "lsf_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_pyramid_rules(pkg):
+    from levelsetfusion_python_amd.engine import _conv_axis_order, pyramid_level_count
+    assert pyramid_level_count((128, 128), 8) == 4 and pyramid_level_count((16, 16), 4) == 3
+    assert pyramid_level_count((64, 64, 64), 8) == 4
+    for shape, chunk in (((12, 16), 4), ((16, 16), 3), ((8, 8), 8), ((16, 4), 4)):
+        with pytest.raises(ValueError):
+            pyramid_level_count(shape, chunk)
+    assert _conv_axis_order(2) == [1, 0] and _conv_axis_order(3) == [0, 1, 2]
+
+
+def test_flag_folding_and_attributes(pkg):
+    o = pkg.HierarchicalOptimizer2d(tikhonov_term_enabled=True, tikhonov_strength=0.0, gradient_kernel_enabled=True,
+                                    kernel=None)
+    assert not o.tikhonov_term_enabled and not o.gradient_kernel_enabled
+    o = pkg.HierarchicalOptimizer2d(tikhonov_term_enabled=False, tikhonov_strength=0.3,
+                                    kernel=np.ones(3), gradient_kernel_enabled=False)
+    assert o.tikhonov_strength == 0.0 and o.gradient_kernel is None
+    o = pkg.HierarchicalOptimizer2d(kernel=np.array([0.1, 0.8, 0.1]))
+    assert o.tikhonov_term_enabled and o.gradient_kernel_enabled and o.rate == 0.1
+    assert o.maximum_iteration_count == 100 and o.maximum_warp_update_threshold == 0.001
+    vp = pkg.HierarchicalOptimizer2d.VerbosityParameters(print_max_warp_update=True)
+    assert vp.print_per_iteration_info and vp.print_per_level_info
+    assert pkg.ComputeMethod.DIRECT.value == 0 and pkg.ComputeMethod.VECTORIZED.value == 1
+    assert [m.name for m in pkg.DataTermMethod] == ["BASIC", "BASIC_CPP", "THRESHOLDED_FDM"]
+    assert [m.name for m in pkg.SmoothingTermMethod] == ["TIKHONOV", "KILLING"]
+    with pytest.raises(ValueError):
+        pkg.SlavchevaOptimizer2d(out_path=None, sobolev_smoothing_enabled=True, sobolev_kernel=None)
+
+
+def test_sobolev_filter_host_code(pkg, ref_leaf):
+    for s, lam, k in ((3, 0.1, "k3"), (7, 0.1, "k7"), (9, 0.15, "k9")):
+        got = pkg.generate_1d_sobolev_kernel(s, lam)
+        assert got.dtype == np.float32 and np.abs(got - ref_leaf["sobolev." + k]).max() <= 1e-7
+    from levelsetfusion_python_amd.math_utils.convolution import sobolev_kernel_1d
+    assert np.abs(sobolev_kernel_1d - ref_leaf["sobolev.hardcoded7"]).max() == 0.0
+
+
+def test_record_decoding(pkg):
+    from levelsetfusion_python_amd import device as dev
+    raw = np.zeros((3, 4), np.int64)
+    val, idx = np.float32(0.125), 77
+    packed = (np.uint64(val.view(np.uint32)) << np.uint64(32)) | np.uint64((~np.uint32(idx)) & 0xFFFFFFFF)
+    raw[0, 0] = np.array([packed], np.uint64).view(np.int64)[0]
+    raw[0, 1:] = np.array([1.5, 2.5, 3.5]).view(np.int64)
+    d = dev.decode_records(raw)
+    assert list(d["executed"]) == [True, False, False]
+    assert d["max_value"][0] == val and d["argmax"][0] == idx
+    assert (d["data_energy"][0], d["smoothing_energy"][0], d["level_set_energy"][0]) == (1.5, 2.5, 3.5)
+
+
+def test_slab_layout(pkg):
+    from levelsetfusion_python_amd.slab import SlabLayout
+    a, b, c = (SlabLayout(24, r, 3, 2) for r in range(3))
+    assert (a.z0, a.z1, a.halo_lo, a.halo_hi, a.nz_local, a.z_begin, a.z_end, a.z_global_offset) == \
+        (0, 8, 0, 2, 10, 0, 8, 0)
+    assert (b.z0, b.z1, b.halo_lo, b.halo_hi, b.nz_local, b.z_begin, b.z_end, b.z_global_offset) == \
+        (8, 16, 2, 2, 12, 2, 10, 6)
+    assert (c.nz_local, c.z_begin, c.z_end, c.z_global_offset) == (10, 2, 10, 14)
+    assert b.local_slice() == slice(6, 18) and c.owned_local() == slice(2, 10)
+    one = SlabLayout(16)
+    assert one.nz_local == 16 and one.halo_lo == one.halo_hi == 0
+    with pytest.raises(ValueError):
+        SlabLayout(10, 0, 3, 1)
+    with pytest.raises(ValueError):
+        SlabLayout(8, 0, 4, 3)

@@ -1,0 +1,96 @@
+"""Multi-rank path on CPU: world_size 2, gloo backend.  The product's z-slab communicator (SlabComm: halo exchange
++ iteration-record reduction, the same code that runs over RCCL/xGMI on the GPUs) drives the ORACLE's per-iteration
+step on each rank's slab (+ halo); the stitched result must equal the oracle run on the whole volume.
+
+Tolerance 2e-6 rather than 0: the oracle forms gather positions z + w from the slab-LOCAL z, and the float32
+rounding of that sum depends on z's magnitude (the HIP kernels use the global z for exactly this reason and are
+bit-identical -- tests/test_gpu_parity.py::test_full_size_fixed_point_and_slab_invariance_256)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, nz, halo, iterations, sobolev, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
+    from oracle import lsf_oracle as O
+    canonical, live = O.sphere_pair(n, d=3, nz=nz)
+    layout = SlabLayout(nz, rank, world, halo)
+    comm = SlabComm(layout)
+    sl = layout.local_slice()
+    live_l = torch.from_numpy(live[sl].copy())
+    canon_l = canonical[sl].copy()
+    warp_l = torch.zeros(live_l.shape + (3,), dtype=torch.float32)
+    kernel = O.generate_1d_sobolev_kernel(3, 0.1) if sobolev else None
+    opt = O.SlavchevaOracle(compute_method=O.DIRECT, level_set_term_enabled=not sobolev,
+                            smoothing_term_method=O.TIKHONOV if sobolev else O.KILLING,
+                            sobolev_smoothing_enabled=sobolev, sobolev_kernel=kernel)
+    records = torch.zeros((iterations, 4), dtype=torch.int64)
+    own = layout.owned_local()
+    opt.max_region = own
+    for it in range(iterations):
+        lv, wp = live_l.numpy(), warp_l.numpy()
+        # the local step: everything the oracle computes within `halo` of a fake (interior) array edge is wrong and
+        # is overwritten by the exchange below; owned voxels only read up to one slice into the halo (+ the gather)
+        max_warp, at, en = opt.iteration(lv, canon_l, wp)
+        m = np.float32(max_warp)
+        flat = int(np.ravel_multi_index((at[0] - layout.z_begin + layout.z0, at[1], at[2]), (nz, n, n)))
+        packed = (np.uint64(m.view(np.uint32)) << np.uint64(32)) | np.uint64((~np.uint32(flat)) & 0xFFFFFFFF)
+        records[it, 0] = int(np.array([packed], np.uint64).view(np.int64)[0])
+        band = ~(O.is_truncated(lv) & O.is_truncated(canon_l))
+        records[it, 1] = int(np.array([float(band[own].sum())]).view(np.int64)[0])  # any per-rank partial sum
+        warp_planar = warp_l.permute(3, 0, 1, 2).contiguous()
+        comm.exchange_halos([live_l, warp_planar])
+        warp_l.copy_(warp_planar.permute(1, 2, 3, 0))
+        comm.reduce_records(records, it, it + 1)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), live=live_l.numpy()[own], warp=warp_l.numpy()[own],
+             records=records.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("sobolev", [False])
+def test_two_rank_slab_run_matches_whole_volume(tmp_path, sobolev):
+    from oracle import lsf_oracle as O
+    n, nz, halo, iterations, world = 24, 16, 3, 3, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n, nz, halo, iterations, sobolev, str(tmp_path)), nprocs=world, join=True)
+    canonical, live = O.sphere_pair(n, d=3, nz=nz)
+    opt = O.SlavchevaOracle(compute_method=O.DIRECT, level_set_term_enabled=True, smoothing_term_method=O.KILLING,
+                            maximum_warp_length_lower_threshold=0.0, max_iterations=iterations,
+                            min_iterations=iterations)
+    opt.optimize(live, canonical)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    live_cat = np.concatenate([p["live"] for p in parts], axis=0)
+    warp_cat = np.concatenate([p["warp"] for p in parts], axis=0)
+    assert live_cat.shape == live.shape
+    assert np.abs(live_cat - live).max() <= 2e-6
+    assert np.abs(warp_cat - opt.warp_field).max() <= 2e-6
+    # reduced records are identical on both ranks and carry the global max / arg-max and the summed partials
+    assert np.array_equal(parts[0]["records"], parts[1]["records"])
+    rec = parts[0]["records"]
+    packed = rec[:, 0].view(np.uint64)
+    got_max = (packed >> np.uint64(32)).astype(np.uint32).view(np.float32)
+    assert np.allclose(got_max, np.float32(opt.log["max_warps"]), atol=2e-6)
+    got_idx = (~packed.astype(np.uint32)).astype(np.int64)
+    want_idx = [np.ravel_multi_index(at, live.shape) for at in opt.log["max_warp_locations"]]
+    assert list(got_idx) == [int(i) for i in want_idx]
+    assert np.all(rec[:, 1].view(np.float64) > 0)
