@@ -37,6 +37,11 @@ def parse():
     ap.add_argument("--size", type=int, default=256, help="edge of the per-GPU volume (256 = BASELINE config 4)")
     ap.add_argument("--iterations", type=int, default=50)
     ap.add_argument("--halo", type=int, default=2)
+    ap.add_argument("--workload", default="killing",
+                    choices=["killing", "sobolev", "hier-tik", "hier-full"],
+                    help="killing = BASELINE config 4 (default, the metric's configuration); the others are extra "
+                         "single-GPU measurements: SobolevFusion-style Slavcheva, hierarchical Tikhonov-only, "
+                         "hierarchical Tikhonov + 7-tap kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-size", type=int, default=96)
     ap.add_argument("--cpu-sample-iterations", type=int, default=16)
@@ -60,6 +65,61 @@ def cpu_baseline(size, iterations):
                 host_cpus=os.cpu_count(), host_affinity=len(os.sched_getaffinity(0)))
 
 
+def extra_workload(args, device):
+    """single-GPU measurements of the other iteration kernels at the same volume size (not the headline line)"""
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    n, iters = args.size, args.iterations
+    canonical, live0 = sphere_pair(n, 3, device)
+    k7 = lsf.generate_1d_sobolev_kernel(7, 0.1)
+    if args.workload == "sobolev":
+        opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT,
+                                       sobolev_smoothing_enabled=True, sobolev_kernel=k7,
+                                       maximum_warp_length_lower_threshold=0.0, max_iterations=iters,
+                                       min_iterations=iters, check_interval=iters)
+        live = torch.empty_like(live0)
+
+        def step():
+            live.copy_(live0)
+            opt.optimize(live, canonical)
+            return iters * n ** 3
+        b_alg, name = 76, "3D %d^3 SobolevFusion-style SlavchevaOptimizer3d (Tikhonov + 7-tap Sobolev), %d iterations"
+    else:
+        full = args.workload == "hier-full"
+        # tikhonov_strength 0.05: the reference's recurrence diverges for strength >= 1/12 in 3-D (DESIGN.md section 2)
+        opt = lsf.HierarchicalOptimizer3d(tikhonov_term_enabled=True, gradient_kernel_enabled=full,
+                                          maximum_chunk_size=8, rate=0.1, maximum_iteration_count=iters,
+                                          maximum_warp_update_threshold=0.0, tikhonov_strength=0.05,
+                                          kernel=k7 if full else None, check_interval=iters)
+        levels = [(n >> k) ** 3 for k in range(4)]
+
+        def step():
+            opt.optimize(canonical, live0)
+            return iters * sum(levels)
+        b_alg = 104 if full else 68
+        name = "3D %d^3 HierarchicalOptimizer3d, 4 levels, Tikhonov" + (" + 7-tap kernel" if full else "") + \
+            ", %d iterations per level"
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    updates = 0
+    for _ in range(args.steps):
+        updates += step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    value = updates / elapsed
+    achieved = value * b_alg / 1e9
+    print(json.dumps(dict(metric="voxel-warp-updates/sec", value=value, unit="voxel-warp-updates/s", n_gpus=1,
+                          steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
+                          higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                          config=dict(workload=name % (n, iters)),
+                          roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                                        frac=achieved / HBM_PEAK_GBS, traffic=None,
+                                        note="whole-step rate x B_alg (%d B/voxel-update), all kernels of the "
+                                             "iteration together" % b_alg))), flush=True)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -74,6 +134,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device)
+
+    if args.workload != "killing":
+        if world > 1:
+            raise SystemExit("--workload %s is a single-GPU measurement" % args.workload)
+        return extra_workload(args, device)
 
     import levelsetfusion_python_amd as lsf
     from levelsetfusion_python_amd import _lib, device as dev
@@ -144,8 +209,16 @@ def main():
     kernel_ms = e0.elapsed_time(e1) / n_launch
     alg_bytes = B_ALG["killing"] * voxels_per_rank
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md), default size only
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        if t.get("size") == n and t.get("workload") == "killing":
+            traffic = t["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
     roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=None, kernel="slavcheva_iteration_kernel<3,KILLING,LEVELSET,BASIC,DIRECT,FUSED>",
+                    traffic=traffic, kernel="slavcheva_iteration_kernel<3,KILLING,LEVELSET,BASIC,DIRECT,FUSED>",
                     kernel_ms=kernel_ms, algorithmic_bytes_per_launch=alg_bytes,
                     compulsory_bytes_per_launch=36 * voxels_per_rank)
 

@@ -263,27 +263,82 @@ struct Taps {
     int n;
 };
 
-__global__ __launch_bounds__(kBlock) void convolve_axis_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                               const float* __restrict__ mask_src, Grid g, int axis,
-                                                               Taps taps, lsf_gate gate) {
+// One pass = one launch.  Every block stages its tile PLUS the taps' reach along the filter axis in LDS (zero outside
+// the array = np.convolve's zero padding), so each input is fetched from global memory once per block instead of once
+// per tap; the taps are then read from LDS.  Accumulation in float64 in tap order, one rounding to float32 per pass,
+// exactly as the oracle / the reference's float64-kernel path.
+constexpr int kConvRun = 32;  // outputs along the filter axis per block (strided axes)
+
+// filter along y (AXIS 1) or z (AXIS 2): tile = 64 x-lanes x kConvRun positions along the axis, fixed other coordinate
+template <int AXIS>
+__global__ __launch_bounds__(kBlock) void convolve_strided_kernel(const float* __restrict__ in,
+                                                                  float* __restrict__ out,
+                                                                  const float* __restrict__ mask_src, Grid g,
+                                                                  Taps taps, lsf_gate gate) {
     if (gate_closed(gate)) return;
-    for_each_voxel(g, [&](int x, int y, int z) {
-    const long long base = (long long)blockIdx.y * g.plane;
-    const long long i = vidx(g, x, y, z);
-    const int coord = axis == 0 ? x : (axis == 1 ? y : z);
-    const int len = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz);
-    const long long stride = axis == 0 ? 1 : (axis == 1 ? g.nx : (long long)g.nx * g.ny);
-    const int c = taps.n / 2;
-    double acc = 0.0;
-    for (int j = 0; j < taps.n; ++j) {
-        int s = c - j;
-        int q = coord + s;
-        if (q >= 0 && q < len) acc = acc + taps.k[j] * (double)in[base + i + s * stride];
+    __shared__ float tile[kConvRun + LSF_MAX_KERNEL_TAPS - 1][kTileX];
+    const int lx = threadIdx.x & (kTileX - 1), lr = threadIdx.x / kTileX;  // lr in 0..3
+    const int x = blockIdx.x * kTileX + lx;
+    const int len = AXIS == 1 ? g.ny : g.nz;
+    const int stride = AXIS == 1 ? g.nx : g.nx * g.ny;
+    // blockIdx.y enumerates (run along the axis, other coordinate); blockIdx.z = plane
+    const int runs = AXIS == 1 ? (g.ny + kConvRun - 1) / kConvRun : (g.z_end - g.z_begin + kConvRun - 1) / kConvRun;
+    const int run = blockIdx.y % runs, other = blockIdx.y / runs;
+    const int a0 = (AXIS == 1 ? 0 : g.z_begin) + run * kConvRun;
+    const int a_end = AXIS == 1 ? g.ny : g.z_end;
+    const int count = min(kConvRun, a_end - a0);
+    const int y_or_z = AXIS == 1 ? g.z_begin + other : other;  // AXIS 1: other = z ; AXIS 2: other = y
+    const long long base = (long long)blockIdx.z * g.plane;
+    const int fixed = AXIS == 1 ? y_or_z * g.nx * g.ny : y_or_z * g.nx;
+    const int c = taps.n / 2, lo = taps.n - 1 - c;
+    const int rows = count + taps.n - 1;
+    if (x < g.nx) {
+        for (int r = lr; r < rows; r += kBlock / kTileX) {
+            const int a = a0 - lo + r;
+            tile[r][lx] = (a >= 0 && a < len) ? in[base + fixed + a * stride + x] : 0.0f;
+        }
     }
+    __syncthreads();
+    if (x >= g.nx) return;
+    for (int m = lr; m < count; m += kBlock / kTileX) {
+        double acc = 0.0;
+        for (int j = 0; j < taps.n; ++j) acc = acc + taps.k[j] * (double)tile[m + taps.n - 1 - j][lx];
+        float r = (float)acc;
+        const long long o = base + fixed + (a0 + m) * stride + x;
+        if (mask_src && fabsf(mask_src[o]) < 1e-6f) r = 0.0f;
+        out[o] = r;
+    }
+}
+
+// filter along x: tile = (64 + reach) x 4 rows of one z-slice
+__global__ __launch_bounds__(kBlock) void convolve_x_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            const float* __restrict__ mask_src, Grid g, Taps taps,
+                                                            lsf_gate gate) {
+    if (gate_closed(gate)) return;
+    __shared__ float tile[kTileY][kTileX + LSF_MAX_KERNEL_TAPS - 1];
+    const int lx = threadIdx.x & (kTileX - 1), ly = threadIdx.x / kTileX;
+    const int tiles_y = (g.ny + kTileY - 1) / kTileY;
+    const int x0 = blockIdx.x * kTileX;
+    const int y = (blockIdx.y % tiles_y) * kTileY + ly;
+    const int z = g.z_begin + blockIdx.y / tiles_y;
+    const long long base = (long long)blockIdx.z * g.plane;
+    const int c = taps.n / 2, lo = taps.n - 1 - c;
+    const int cols = kTileX + taps.n - 1;
+    const bool row_ok = y < g.ny;
+    const int row = row_ok ? vidx(g, 0, y, z) : 0;
+    for (int q = lx; q < cols; q += kTileX) {
+        const int xx = x0 - lo + q;
+        tile[ly][q] = (row_ok && xx >= 0 && xx < g.nx) ? in[base + row + xx] : 0.0f;
+    }
+    __syncthreads();
+    const int x = x0 + lx;
+    if (!row_ok || x >= g.nx) return;
+    double acc = 0.0;
+    for (int j = 0; j < taps.n; ++j) acc = acc + taps.k[j] * (double)tile[ly][lx + taps.n - 1 - j];
     float r = (float)acc;
-    if (mask_src && fabsf(mask_src[base + i]) < 1e-6f) r = 0.0f;
-    out[base + i] = r;
-    });
+    const long long o = base + row + x;
+    if (mask_src && fabsf(mask_src[o]) < 1e-6f) r = 0.0f;
+    out[o] = r;
 }
 
 extern "C" int lsf_convolve_axis(const float* in_planar, float* out_planar, const float* zero_mask_source,
@@ -294,14 +349,27 @@ extern "C" int lsf_convolve_axis(const float* in_planar, float* out_planar, cons
     if (n_taps < 1 || n_taps > LSF_MAX_KERNEL_TAPS) return LSF_ERR_KERNEL_TOO_LONG;
     if (axis < 0 || axis >= grid->dims || planes < 1 || planes > 4) return LSF_ERR_BAD_ARGUMENT;
     Grid g = make_grid(grid);
-    Tiling t = make_tiling(g);
-    if (t.total == 0) return 0;
+    const int slices = g.z_end - g.z_begin;
+    if (slices == 0) return 0;
     Taps taps;
     taps.n = n_taps;
     for (int j = 0; j < LSF_MAX_KERNEL_TAPS; ++j) taps.k[j] = j < n_taps ? taps_host[j] : 0.0;
     lsf_gate gt = gate ? *gate : lsf_gate{nullptr, 0, 0.0f, 0.0f};
-    hipLaunchKernelGGL(convolve_axis_kernel, dim3(launch_blocks(t.total), planes), dim3(kBlock), 0, as_stream(stream), in_planar,
-                       out_planar, zero_mask_source, g, axis, taps, gt);
+    const unsigned tiles_x = (unsigned)(g.nx + kTileX - 1) / kTileX;
+    hipStream_t s = as_stream(stream);
+    if (axis == 0) {
+        const unsigned tiles_y = (unsigned)(g.ny + kTileY - 1) / kTileY;
+        hipLaunchKernelGGL(convolve_x_kernel, dim3(tiles_x, tiles_y * slices, planes), dim3(kBlock), 0, s, in_planar,
+                           out_planar, zero_mask_source, g, taps, gt);
+    } else if (axis == 1) {
+        const unsigned runs = (unsigned)(g.ny + kConvRun - 1) / kConvRun;
+        hipLaunchKernelGGL(convolve_strided_kernel<1>, dim3(tiles_x, runs * slices, planes), dim3(kBlock), 0, s,
+                           in_planar, out_planar, zero_mask_source, g, taps, gt);
+    } else {
+        const unsigned runs = (unsigned)(slices + kConvRun - 1) / kConvRun;
+        hipLaunchKernelGGL(convolve_strided_kernel<2>, dim3(tiles_x, runs * g.ny, planes), dim3(kBlock), 0, s,
+                           in_planar, out_planar, zero_mask_source, g, taps, gt);
+    }
     return launch_status();
 }
 
