@@ -265,9 +265,12 @@ struct Taps {
 
 // One pass = one launch.  Every block stages its tile PLUS the taps' reach along the filter axis in LDS (zero outside
 // the array = np.convolve's zero padding), so each input is fetched from global memory once per block instead of once
-// per tap; the taps are then read from LDS.  Accumulation in float64 in tap order, one rounding to float32 per pass,
-// exactly as the oracle / the reference's float64-kernel path.
-constexpr int kConvRun = 32;  // outputs along the filter axis per block (strided axes)
+// per tap.  The tile is stored as float64: the conversion happens once per input, not once per tap, and the tap loop
+// is one ds_read_b64 + v_mul_f64 + v_add_f64 (the pass is otherwise FP64-issue bound next to its HBM time).
+// Accumulation in float64 in tap order, one rounding to float32 per pass, exactly as the oracle / the reference's
+// float64-kernel path.
+constexpr int kConvRun = 32;   // outputs along the filter axis per block (strided axes): 8 per thread
+constexpr int kConvRows = 16;  // rows per block for the x pass: 4 outputs per thread
 
 // filter along y (AXIS 1) or z (AXIS 2): tile = 64 x-lanes x kConvRun positions along the axis, fixed other coordinate
 template <int AXIS>
@@ -276,7 +279,9 @@ __global__ __launch_bounds__(kBlock) void convolve_strided_kernel(const float* _
                                                                   const float* __restrict__ mask_src, Grid g,
                                                                   Taps taps, lsf_gate gate) {
     if (gate_closed(gate)) return;
-    __shared__ float tile[kConvRun + LSF_MAX_KERNEL_TAPS - 1][kTileX];
+    // dynamic LDS sized to the ACTUAL reach: (kConvRun + n - 1) x 64 doubles (19 KiB for 7 taps -> 8 blocks per CU)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    double (*tile)[kTileX] = reinterpret_cast<double (*)[kTileX]>(lds_raw);
     const int lx = threadIdx.x & (kTileX - 1), lr = threadIdx.x / kTileX;  // lr in 0..3
     const int x = blockIdx.x * kTileX + lx;
     const int len = AXIS == 1 ? g.ny : g.nz;
@@ -295,14 +300,16 @@ __global__ __launch_bounds__(kBlock) void convolve_strided_kernel(const float* _
     if (x < g.nx) {
         for (int r = lr; r < rows; r += kBlock / kTileX) {
             const int a = a0 - lo + r;
-            tile[r][lx] = (a >= 0 && a < len) ? in[base + fixed + a * stride + x] : 0.0f;
+            const int ac = min(max(a, 0), len - 1);
+            const float v = in[base + fixed + ac * stride + x];
+            tile[r][lx] = (a >= 0 && a < len) ? (double)v : 0.0;
         }
     }
     __syncthreads();
     if (x >= g.nx) return;
     for (int m = lr; m < count; m += kBlock / kTileX) {
         double acc = 0.0;
-        for (int j = 0; j < taps.n; ++j) acc = acc + taps.k[j] * (double)tile[m + taps.n - 1 - j][lx];
+        for (int j = 0; j < taps.n; ++j) acc = acc + taps.k[j] * tile[m + taps.n - 1 - j][lx];
         float r = (float)acc;
         const long long o = base + fixed + (a0 + m) * stride + x;
         if (mask_src && fabsf(mask_src[o]) < 1e-6f) r = 0.0f;
@@ -310,35 +317,46 @@ __global__ __launch_bounds__(kBlock) void convolve_strided_kernel(const float* _
     }
 }
 
-// filter along x: tile = (64 + reach) x 4 rows of one z-slice
+// filter along x: tile = (64 + reach) x kConvRows rows of one z-slice
 __global__ __launch_bounds__(kBlock) void convolve_x_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                             const float* __restrict__ mask_src, Grid g, Taps taps,
                                                             lsf_gate gate) {
     if (gate_closed(gate)) return;
-    __shared__ float tile[kTileY][kTileX + LSF_MAX_KERNEL_TAPS - 1];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int pitch = kTileX + taps.n - 1;
+    double* tile = reinterpret_cast<double*>(lds_raw);  // [kConvRows][pitch]
     const int lx = threadIdx.x & (kTileX - 1), ly = threadIdx.x / kTileX;
-    const int tiles_y = (g.ny + kTileY - 1) / kTileY;
+    const int tiles_y = (g.ny + kConvRows - 1) / kConvRows;
     const int x0 = blockIdx.x * kTileX;
-    const int y = (blockIdx.y % tiles_y) * kTileY + ly;
+    const int y0 = (blockIdx.y % tiles_y) * kConvRows;
     const int z = g.z_begin + blockIdx.y / tiles_y;
     const long long base = (long long)blockIdx.z * g.plane;
     const int c = taps.n / 2, lo = taps.n - 1 - c;
     const int cols = kTileX + taps.n - 1;
-    const bool row_ok = y < g.ny;
-    const int row = row_ok ? vidx(g, 0, y, z) : 0;
-    for (int q = lx; q < cols; q += kTileX) {
-        const int xx = x0 - lo + q;
-        tile[ly][q] = (row_ok && xx >= 0 && xx < g.nx) ? in[base + row + xx] : 0.0f;
+    for (int r = ly; r < kConvRows; r += kBlock / kTileX) {
+        const int y = y0 + r;
+        if (y >= g.ny) break;
+        const int row = vidx(g, 0, y, z);
+        for (int q = lx; q < cols; q += kTileX) {
+            const int xx = x0 - lo + q;
+            const int xc = min(max(xx, 0), g.nx - 1);
+            const float v = in[base + row + xc];
+            tile[r * pitch + q] = (xx >= 0 && xx < g.nx) ? (double)v : 0.0;
+        }
     }
     __syncthreads();
     const int x = x0 + lx;
-    if (!row_ok || x >= g.nx) return;
-    double acc = 0.0;
-    for (int j = 0; j < taps.n; ++j) acc = acc + taps.k[j] * (double)tile[ly][lx + taps.n - 1 - j];
-    float r = (float)acc;
-    const long long o = base + row + x;
-    if (mask_src && fabsf(mask_src[o]) < 1e-6f) r = 0.0f;
-    out[o] = r;
+    if (x >= g.nx) return;
+    for (int r = ly; r < kConvRows; r += kBlock / kTileX) {
+        const int y = y0 + r;
+        if (y >= g.ny) break;
+        double acc = 0.0;
+        for (int j = 0; j < taps.n; ++j) acc = acc + taps.k[j] * tile[r * pitch + lx + taps.n - 1 - j];
+        float res = (float)acc;
+        const long long o = base + vidx(g, x, y, z);
+        if (mask_src && fabsf(mask_src[o]) < 1e-6f) res = 0.0f;
+        out[o] = res;
+    }
 }
 
 extern "C" int lsf_convolve_axis(const float* in_planar, float* out_planar, const float* zero_mask_source,
@@ -358,16 +376,19 @@ extern "C" int lsf_convolve_axis(const float* in_planar, float* out_planar, cons
     const unsigned tiles_x = (unsigned)(g.nx + kTileX - 1) / kTileX;
     hipStream_t s = as_stream(stream);
     if (axis == 0) {
-        const unsigned tiles_y = (unsigned)(g.ny + kTileY - 1) / kTileY;
-        hipLaunchKernelGGL(convolve_x_kernel, dim3(tiles_x, tiles_y * slices, planes), dim3(kBlock), 0, s, in_planar,
+        const unsigned tiles_y = (unsigned)(g.ny + kConvRows - 1) / kConvRows;
+        hipLaunchKernelGGL(convolve_x_kernel, dim3(tiles_x, tiles_y * slices, planes), dim3(kBlock),
+                           sizeof(double) * kConvRows * (kTileX + n_taps - 1), s, in_planar,
                            out_planar, zero_mask_source, g, taps, gt);
     } else if (axis == 1) {
         const unsigned runs = (unsigned)(g.ny + kConvRun - 1) / kConvRun;
-        hipLaunchKernelGGL(convolve_strided_kernel<1>, dim3(tiles_x, runs * slices, planes), dim3(kBlock), 0, s,
+        hipLaunchKernelGGL(convolve_strided_kernel<1>, dim3(tiles_x, runs * slices, planes), dim3(kBlock),
+                           sizeof(double) * kTileX * (kConvRun + n_taps - 1), s,
                            in_planar, out_planar, zero_mask_source, g, taps, gt);
     } else {
         const unsigned runs = (unsigned)(slices + kConvRun - 1) / kConvRun;
-        hipLaunchKernelGGL(convolve_strided_kernel<2>, dim3(tiles_x, runs * g.ny, planes), dim3(kBlock), 0, s,
+        hipLaunchKernelGGL(convolve_strided_kernel<2>, dim3(tiles_x, runs * g.ny, planes), dim3(kBlock),
+                           sizeof(double) * kTileX * (kConvRun + n_taps - 1), s,
                            in_planar, out_planar, zero_mask_source, g, taps, gt);
     }
     return launch_status();
