@@ -37,6 +37,11 @@ def parse():
     ap.add_argument("--size", type=int, default=256, help="edge of the per-GPU volume (256 = BASELINE config 4)")
     ap.add_argument("--iterations", type=int, default=50)
     ap.add_argument("--halo", type=int, default=2)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the real thing); gloo stages halos through the host -- only for "
+                         "exercising the N > 1 flow on a box with fewer GPUs than ranks (see --share-device)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="all ranks use cuda:0 (test rigs only; requires --backend gloo)")
     ap.add_argument("--workload", default="killing",
                     choices=["killing", "sobolev", "hier-tik", "hier-full"],
                     help="killing = BASELINE config 4 (default, the metric's configuration); the others are extra "
@@ -129,11 +134,18 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
         args.gpus = world
+    if args.share_device:
+        if args.backend != "gloo":
+            raise SystemExit("--share-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     if args.workload != "killing":
         if world > 1:
@@ -170,6 +182,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def max_over_ranks(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if args.backend == "gloo" else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     executed = 0
     for _ in range(args.warmup):
         executed = step()
@@ -180,9 +197,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = max_over_ranks(elapsed)
     assert executed == iters, "expected %d fixed iterations, the gate closed after %d" % (iters, executed)
     voxels_per_rank = n ** 3
     updates = voxels_per_rank * world * iters * args.steps
@@ -228,7 +243,8 @@ def main():
                config=dict(workload="3D %d^3 KillingFusion (Killing + level-set) SlavchevaOptimizer3d, %d fixed "
                                     "iterations per step, sphere-pair TSDF" % (n, iters),
                            voxels_per_gpu=voxels_per_rank, iterations_per_step=iters,
-                           parallelism="z-slab x%d, halo %d" % (world, args.halo) if world > 1 else "single GPU"),
+                           parallelism=("z-slab x%d, halo %d, %s" % (world, args.halo, args.backend)) if world > 1
+                           else "single GPU"),
                roofline=roofline)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

@@ -214,20 +214,53 @@ class SlavchevaEngine:
             return dev.make_grid(live.shape, L.z_begin, L.z_end, L.z_global_offset)
         return dev.make_grid(live.shape)
 
-    def _enqueue_iteration(self, i, live_in, live_out, warp_in, warp_out, canonical, grid, records, gbufs):
+    def _slab(self):
+        return self.comm is not None and self.comm.active
+
+    def _gate_for(self, records, i):
         # iteration i runs iff i < min_iterations or (i < max_iterations and lo < max_warp[i-1] < hi)
         # (slavcheva_optimizer2d.py:360-362)
-        gate = None if i < self.min_iterations else dev.make_gate(records, i - 1, _lib.GATE_SLAVCHEVA, self.lo,
+        return None if i < self.min_iterations else dev.make_gate(records, i - 1, _lib.GATE_SLAVCHEVA, self.lo,
                                                                   self.hi)
+
+    def _enqueue_iteration(self, i, live_in, live_out, warp_in, warp_out, canonical, grid, records, gbufs, limit):
+        gate = self._gate_for(records, i)
+        slab = self._slab()
         if not self.sobolev:
-            dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None, grid,
-                                    self.params, gate, records, i)
+            if not slab:
+                dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None,
+                                        grid, self.params, gate, records, i)
+            else:
+                # boundary slices first, then the halo exchange on a second stream WHILE the interior runs
+                L = self.comm.layout
+                h = L.halo
+                lo_b = (L.z_begin, L.z_begin + h) if L.rank > 0 else None
+                hi_b = (L.z_end - h, L.z_end) if L.rank < L.world - 1 else None
+                interior = (lo_b[1] if lo_b else L.z_begin, hi_b[0] if hi_b else L.z_end)
+                for rng in (lo_b, hi_b):
+                    if rng is not None:
+                        g = dev.make_grid(live_in.shape, rng[0], rng[1], grid.z_global_offset)
+                        dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out,
+                                                None, g, self.params, gate, records, i)
+                main = torch.cuda.current_stream()
+                boundary_done = torch.cuda.Event()
+                boundary_done.record(main)
+                with torch.cuda.stream(self._comm_stream):
+                    self._comm_stream.wait_event(boundary_done)
+                    self.comm.exchange_halos([live_out, warp_out])
+                    halos_done = torch.cuda.Event()
+                    halos_done.record(self._comm_stream)
+                if interior[1] > interior[0]:
+                    g = dev.make_grid(live_in.shape, interior[0], interior[1], grid.z_global_offset)
+                    dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None,
+                                            g, self.params, gate, records, i)
+                main.wait_event(halos_done)
         else:
             g0, t1, t2 = gbufs
             dev.slavcheva_iteration(_lib.STAGE_GRADIENT, live_in, canonical, warp_in, None, None, g0, grid,
                                     self.params, gate, records, i)
             in_plane_grid = grid
-            if self.comm is not None and self.comm.active:
+            if slab:
                 # the z pass of the filter reads len(kernel)//2 slices of the (x,y)-filtered field on either
                 # side: exchange the raw gradient's halo once and run the x and y passes on the halo slices too
                 self.comm.exchange_halos([g0])
@@ -240,9 +273,10 @@ class SlavchevaEngine:
             dev.slavcheva_update_rewarp(live_in, canonical, src, warp_out, live_out, grid, self.params, gate,
                                         records, i)
             self._last_g = src
-        if self.comm is not None and self.comm.active:
-            self.comm.exchange_halos([live_out, warp_out])
-            self.comm.reduce_records(records, i, i + 1)
+            if slab:
+                self.comm.exchange_halos([live_out, warp_out])
+        if slab and i + 1 < limit and i + 1 >= self.min_iterations:
+            self.comm.reduce_max(records, i)  # the next iteration's gate tests this record: make it global now
 
     def optimize(self, live, canonical):
         """live, canonical: float32 device tensors.  Returns (final live tensor, final warp PLANAR).  The
@@ -265,6 +299,8 @@ class SlavchevaEngine:
             lives[1].copy_(live)  # halo slices of both buffers start out valid
         gbufs = [torch.zeros_like(warps[0]) for _ in range(3)] if self.sobolev else None
         self._last_g = None
+        if slab and not hasattr(self, "_comm_stream"):
+            self._comm_stream = torch.cuda.Stream(device=live.device)
         # with min_iterations == 0 the reference never enters its loop (max_warp starts at +inf, :354,:360-362)
         limit = 0 if self.min_iterations == 0 else max(self.max_iterations, self.min_iterations)
         it, n_exec = 0, 0
@@ -273,7 +309,9 @@ class SlavchevaEngine:
             batch = min(self.check_interval, limit - it)
             for i in range(it, it + batch):
                 self._enqueue_iteration(i, lives[i % 2], lives[(i + 1) % 2], warps[i % 2], warps[(i + 1) % 2],
-                                        canonical, grid, records, gbufs)
+                                        canonical, grid, records, gbufs, limit)
+            if slab:  # global max (idempotent) and, once per record, the energy sums of this batch
+                self.comm.reduce_records(records, it, it + batch)
             it += batch
             dec = dev.decode_records(records[:it].cpu().numpy())
             n_exec = int(dec["executed"].sum())

@@ -44,6 +44,9 @@ class SlabComm:
     def __init__(self, layout, group=None):
         self.layout = layout
         self.group = group
+        # RCCL ("nccl") moves device buffers directly over xGMI.  gloo has no device point-to-point: device tensors
+        # are staged through host memory then (used by the 2-ranks-on-one-GPU test of the whole N > 1 flow).
+        self.stage_through_host = layout.world > 1 and dist.is_initialized() and dist.get_backend(group) == "gloo"
 
     @property
     def active(self):
@@ -53,8 +56,20 @@ class SlabComm:
         # scalar field [z,y,x] or planar vector field [c,z,y,x]
         return t[a:b] if t.dim() == 3 else t[:, a:b]
 
+    def _staging(self, key, shape, like):
+        """persistent send / receive staging buffers (allocated once per distinct message shape)"""
+        if not hasattr(self, "_buffers"):
+            self._buffers = {}
+        if key not in self._buffers:
+            device = "cpu" if (self.stage_through_host and like.is_cuda) else like.device
+            self._buffers[key] = (torch.empty(shape, dtype=like.dtype, device=device),
+                                  torch.empty(shape, dtype=like.dtype, device=device))
+        return self._buffers[key]
+
     def exchange_halos(self, tensors, width=None):
-        """fill the halo slices of every tensor from the neighbours' owned boundary slices"""
+        """fill the halo slices of every tensor from the neighbours' owned boundary slices.  All tensors travel in
+        ONE message per neighbour and direction (scalar fields [z,y,x] count one channel, planar vector fields
+        [c,z,y,x] c channels), through persistent staging buffers."""
         L = self.layout
         if not self.active:
             return
@@ -63,33 +78,61 @@ class SlabComm:
             return
         if h > L.halo:
             raise ValueError("requested halo width %d exceeds the layout's halo %d" % (h, L.halo))
-        ops, copies = [], []
-        for t in tensors:
-            if L.rank > 0:  # lower neighbour: send my first h owned slices, receive into my lower halo
-                send = self._z_view(t, L.z_begin, L.z_begin + h).contiguous()
-                recv = torch.empty_like(send)
-                ops.append(dist.P2POp(dist.isend, send, L.rank - 1, self.group))
-                ops.append(dist.P2POp(dist.irecv, recv, L.rank - 1, self.group))
-                copies.append((self._z_view(t, L.z_begin - h, L.z_begin), recv))
-            if L.rank < L.world - 1:  # upper neighbour
-                send = self._z_view(t, L.z_end - h, L.z_end).contiguous()
-                recv = torch.empty_like(send)
-                ops.append(dist.P2POp(dist.isend, send, L.rank + 1, self.group))
-                ops.append(dist.P2POp(dist.irecv, recv, L.rank + 1, self.group))
-                copies.append((self._z_view(t, L.z_end, L.z_end + h), recv))
+        channels = [1 if t.dim() == 3 else t.shape[0] for t in tensors]
+        plane = tuple(tensors[0].shape[-2:])
+        shape = (sum(channels), h) + plane
+        ops, unpack = [], []
+        # (neighbour rank, owned slices to send, halo slices to fill)
+        sides = []
+        if L.rank > 0:
+            sides.append(("lo", L.rank - 1, (L.z_begin, L.z_begin + h), (L.z_begin - h, L.z_begin)))
+        if L.rank < L.world - 1:
+            sides.append(("hi", L.rank + 1, (L.z_end - h, L.z_end), (L.z_end, L.z_end + h)))
+        for tag, peer, (sa, sb), (ra, rb) in sides:
+            send, recv = self._staging((tag, shape, tensors[0].dtype), shape, tensors[0])
+            k = 0
+            for t, c in zip(tensors, channels):
+                src = self._z_view(t, sa, sb)
+                send[k:k + c].copy_(src if t.dim() == 4 else src.unsqueeze(0))
+                k += c
+            ops.append(dist.P2POp(dist.isend, send, peer, self.group))
+            ops.append(dist.P2POp(dist.irecv, recv, peer, self.group))
+            unpack.append((recv, ra, rb))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
-        for dst, src in copies:
-            dst.copy_(src)
+        for recv, ra, rb in unpack:
+            k = 0
+            for t, c in zip(tensors, channels):
+                dst = self._z_view(t, ra, rb)
+                dst.copy_(recv[k:k + c] if t.dim() == 4 else recv[k])
+                k += c
 
-    def reduce_records(self, records, first, last):
-        """all-reduce records [first, last): column 0 (packed max, non-negative as int64) with MAX, the three
-        energy columns (float64 bit patterns) with SUM"""
+    def reduce_max(self, records, index):
+        """MAX all-reduce of the packed max of ONE record (needed before a gated iteration can test it)"""
+        if not self.active:
+            return
+        view = records[index, 0:1]
+        if self.stage_through_host and records.is_cuda:
+            host = view.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+            view.copy_(host)
+        else:
+            dist.all_reduce(view, op=dist.ReduceOp.MAX, group=self.group)
+
+    def reduce_records(self, records, first, last, energies=True):
+        """all-reduce records [first, last): column 0 (packed max, non-negative as int64) with MAX (idempotent), and
+        -- exactly once per record -- the three energy columns (float64 bit patterns) with SUM"""
         if not self.active or last <= first:
             return
+        stage = self.stage_through_host and records.is_cuda
         mx = records[first:last, 0].contiguous()
+        if stage:
+            mx = mx.cpu()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
-        records[first:last, 0] = mx
-        en = records[first:last, 1:4].contiguous().view(torch.float64)
-        dist.all_reduce(en, op=dist.ReduceOp.SUM, group=self.group)
-        records[first:last, 1:4] = en.view(torch.int64)
+        records[first:last, 0] = mx.to(records.device)
+        if energies:
+            en = records[first:last, 1:4].contiguous().view(torch.float64)
+            if stage:
+                en = en.cpu()
+            dist.all_reduce(en, op=dist.ReduceOp.SUM, group=self.group)
+            records[first:last, 1:4] = en.view(torch.int64).to(records.device)

@@ -1,0 +1,86 @@
+"""The complete N > 1 flow on ONE GPU: two processes (gloo, halos staged through the host) each run the slab engine --
+HIP kernels with z-range arguments, per-iteration halo exchange of live and warp, MAX/SUM reduction of the iteration
+records, the device-side gate on the reduced record -- and the stitched result must equal the single-process
+whole-volume run BIT FOR BIT.  On the 8-GPU node the only difference is the transport (RCCL instead of gloo)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n, nz, halo, kwargs, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    layout = SlabLayout(nz, rank, world, halo)
+    comm = SlabComm(layout)
+    sl = layout.local_slice()
+    canonical, live = sphere_pair(n, 3, "cuda", (sl.start, sl.stop))
+    opt = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, **kwargs)
+    opt.optimize(live, canonical)
+    own = layout.owned_local()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), live=live[own].cpu().numpy(),
+             warp=opt.warp_field[own].cpu().numpy(), max_warps=np.float32(opt.log.max_warps),
+             locations=np.int64(opt.log.max_warp_locations), data=np.float64(opt.log.data_energies),
+             smoothing=np.float64(opt.log.smoothing_energies), level_set=np.float64(opt.log.level_set_energies))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("config", ["killing_fixed", "killing_threshold", "sobolev"])
+def test_two_slab_ranks_equal_whole_volume(tmp_path, config):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    n, world = 64, 2
+    nz = n * world  # two periods of the sphere pattern stacked along z, as in bench.py's weak scaling
+    if config == "sobolev":
+        halo = 3
+        kwargs = dict(compute_method=lsf.ComputeMethod.DIRECT, sobolev_smoothing_enabled=True,
+                      sobolev_kernel=lsf.generate_1d_sobolev_kernel(7, 0.1),
+                      maximum_warp_length_lower_threshold=0.0, max_iterations=4, min_iterations=4, check_interval=3)
+    else:
+        halo = 2
+        kwargs = dict(compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                      smoothing_term_method=lsf.SmoothingTermMethod.KILLING, check_interval=4)
+        if config == "killing_fixed":
+            kwargs.update(maximum_warp_length_lower_threshold=0.0, max_iterations=6, min_iterations=6)
+        else:  # the gate closes on the REDUCED record: both ranks must stop after the same iteration
+            kwargs.update(maximum_warp_length_lower_threshold=0.0319, max_iterations=30, min_iterations=2)
+    mp.spawn(_worker, args=(world, _free_port(), n, nz, halo, kwargs, str(tmp_path)), nprocs=world, join=True)
+    canonical, live = sphere_pair(n, 3, "cuda", (0, nz))
+    ref = lsf.SlavchevaOptimizer3d(field_size=n, **kwargs)
+    ref._run_checks = lambda *a: None  # the stacked volume is not a cube
+    ref.optimize(live, canonical)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    if config == "killing_threshold":
+        assert 2 < len(ref.log.max_warps) < 30
+    assert np.array_equal(np.concatenate([p["live"] for p in parts], 0), live.cpu().numpy())
+    assert np.array_equal(np.concatenate([p["warp"] for p in parts], 0), ref.warp_field.cpu().numpy())
+    for p in parts:
+        assert np.array_equal(p["max_warps"], np.float32(ref.log.max_warps))
+        want = [np.ravel_multi_index(loc[::-1], (nz, n, n)) for loc in ref.log.max_warp_locations]
+        assert list(p["locations"]) == [int(w) for w in want]
+        assert np.allclose(p["data"], ref.log.data_energies, rtol=1e-10)
+        assert np.allclose(p["smoothing"], ref.log.smoothing_energies, rtol=1e-10)
+        assert np.allclose(p["level_set"], ref.log.level_set_energies, rtol=1e-10)
