@@ -207,6 +207,27 @@ int lsf_warp_statistics(const float *warp_planar, const float *canonical, const 
 int lsf_tsdf_difference_statistics(const float *canonical, const float *live, const lsf_grid *grid,
                                    double *out8, void *stream);
 
+/* ---- a21: TSDF from a depth image, nearest pixel (the input stage of the path) ------------------------
+ * replaces tsdf/generation.py:130-207 (generate_2d_tsdf_field_from_depth_image_no_interpolation: grid dims 2,
+ * field[y][x] with the field's y index as depth axis and y_voxel = 0, depth row image_y_coordinate) and
+ * :356-437 (generate_3d_tsdf_field_from_depth_image: grid dims 3, field[z][y][x]); tsdf/common.py:34-47.
+ * depth_image: DEVICE uint16 [image_height][image_width]. */
+typedef struct lsf_tsdf_params {
+    double intrinsics[4];        /* fx, fy, cx, cy */
+    double depth_unit_ratio;     /* metres per depth unit */
+    double voxel_size;           /* metres */
+    double narrow_band_half_width; /* metres: narrow_band_width_voxels / 2 * voxel_size */
+    float extrinsic[16];         /* camera_extrinsic_matrix, row-major 4x4, float32 */
+    int32_t array_offset[3];     /* voxels (x, y, z) */
+    int32_t image_width, image_height;
+    int32_t image_y_coordinate;  /* 2-D only */
+    float default_value;
+    int32_t intrinsics_are_f32;  /* project in float32 (float32 intrinsic matrix) or float64 */
+} lsf_tsdf_params;
+
+int lsf_tsdf_generate_nearest(const uint16_t *depth_image, float *field, const lsf_grid *grid,
+                              const lsf_tsdf_params *params, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

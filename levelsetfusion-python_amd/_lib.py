@@ -62,6 +62,15 @@ class SlavchevaParams(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+class TsdfParams(ctypes.Structure):
+    _fields_ = [("intrinsics", ctypes.c_double * 4), ("depth_unit_ratio", ctypes.c_double),
+                ("voxel_size", ctypes.c_double), ("narrow_band_half_width", ctypes.c_double),
+                ("extrinsic", ctypes.c_float * 16), ("array_offset", ctypes.c_int32 * 3),
+                ("image_width", ctypes.c_int32), ("image_height", ctypes.c_int32),
+                ("image_y_coordinate", ctypes.c_int32), ("default_value", ctypes.c_float),
+                ("intrinsics_are_f32", ctypes.c_int32)]
+
+
 _P = ctypes.POINTER
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 
@@ -86,6 +95,7 @@ PROTOTYPES = {
                                                    _P(Gate), _vp, _vp]),
     "lsf_warp_statistics": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp, _vp]),
     "lsf_tsdf_difference_statistics": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp, _vp]),
+    "lsf_tsdf_generate_nearest": (ctypes.c_int, [_vp, _vp, _P(Grid), _P(TsdfParams), _vp]),
 }
 
 

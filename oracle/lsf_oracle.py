@@ -708,3 +708,67 @@ def sphere_pair(n, d=3, dtype=F32, nz=None, z_offset=0, z_total=None):
     canonical = tsdf((0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
     live = tsdf((1.5, -1.0, 2.0), (1.05, 0.95, 1.0))
     return canonical, live
+
+
+# =====================================================================================================
+#  a21  TSDF generation from a depth image, nearest pixel (tsdf/generation.py:130-207 2-D row, :356-437 3-D)
+# =====================================================================================================
+def tsdf_nearest(depth_image, intrinsic_matrix, depth_unit_ratio, field_shape, image_y_coordinate=None,
+                 camera_extrinsic_matrix=None, default_value=1, voxel_size=0.004, array_offset=(-64, -64, 64),
+                 narrow_band_width_voxels=20):
+    """field_shape (n, n): 2-D slice -- x from the x index, depth axis ("z") from the y index, y_voxel = 0, the depth
+    row `image_y_coordinate` is used.  field_shape (n, n, n): volume [z][y][x].  dtype semantics of the reference
+    under numpy >= 2: voxel centre in float64 rounded to float32, float32 extrinsics product, projection in the
+    intrinsic matrix's dtype, depth * ratio and the signed distance in float64, result stored float32."""
+    P = np.asarray(intrinsic_matrix)
+    ptype = np.float32 if P.dtype == np.float32 else np.float64
+    E = np.eye(4, dtype=F32) if camera_extrinsic_matrix is None else np.asarray(camera_extrinsic_matrix, dtype=F32)
+    dims = len(field_shape)
+    field = np.full(field_shape, default_value, dtype=F32)
+    half = narrow_band_width_voxels / 2 * voxel_size
+    off = [int(o) for o in array_offset]
+    idx = np.meshgrid(*[np.arange(s, dtype=np.int64) for s in field_shape], indexing="ij")
+    if dims == 2:
+        xv = ((idx[1] + off[0]) * voxel_size).astype(F32)
+        yv = np.zeros(field_shape, dtype=F32)
+        zv = ((idx[0] + off[2]) * voxel_size).astype(F32)
+    else:
+        xv = ((idx[2] + off[0]) * voxel_size).astype(F32)
+        yv = ((idx[1] + off[1]) * voxel_size).astype(F32)
+        zv = ((idx[0] + off[2]) * voxel_size).astype(F32)
+    one = F32(1.0)
+
+    def row(i):
+        return ((((E[i, 0] * xv).astype(F32) + (E[i, 1] * yv).astype(F32)).astype(F32)
+                 + (E[i, 2] * zv).astype(F32)).astype(F32) + (E[i, 3] * one)).astype(F32)
+
+    pcx, pcy, pcz = row(0), row(1), row(2)
+    ok = pcz > 0
+    safe_z = np.where(ok, pcz, one).astype(ptype)
+    with np.errstate(invalid="ignore", over="ignore"):
+        ix = (((P[0, 0].astype(ptype) * pcx.astype(ptype)).astype(ptype) / safe_z).astype(ptype)
+              + P[0, 2].astype(ptype)).astype(ptype) + ptype(0.5)
+        ix = np.trunc(ix.astype(ptype)).astype(np.int64)  # int() truncates toward zero
+        if dims == 3:
+            iy = (((P[1, 1].astype(ptype) * pcy.astype(ptype)).astype(ptype) / safe_z).astype(ptype)
+                  + P[1, 2].astype(ptype)).astype(ptype) + ptype(0.5)
+            iy = np.trunc(iy.astype(ptype)).astype(np.int64)
+        else:
+            iy = np.full(field_shape, int(image_y_coordinate), dtype=np.int64)
+    h, w = depth_image.shape
+    ok &= (ix >= 0) & (ix < w) & (iy >= 0) & (iy < h)
+    depth = depth_image[np.clip(iy, 0, h - 1), np.clip(ix, 0, w - 1)].astype(np.float64) * depth_unit_ratio
+    ok &= depth > 0.0
+    sd = depth - pcz.astype(np.float64)
+    value = np.where(sd < -half, -1.0, np.where(sd > half, 1.0, sd / half))
+    field[ok] = value[ok].astype(F32)
+    return field
+
+
+def synthetic_depth_image(shift_px=0.0, nearer_m=0.0, width=640, height=480):
+    """SURVEY 8(d) 'depth->TSDF' input: a plane at ~1 m with a sinusoidal bump, uint16 millimetres"""
+    v, u = np.meshgrid(np.arange(height, dtype=np.float64), np.arange(width, dtype=np.float64), indexing="ij")
+    bump = 0.06 * np.exp(-(((u - 320.0 - shift_px) / 90.0) ** 2 + ((v - 240.0) / 70.0) ** 2)) \
+        * (1.0 + 0.3 * np.sin(u / 17.0) * np.cos(v / 23.0))
+    depth_m = 1.0 + 0.0002 * (u - 320.0) - bump - nearer_m
+    return np.round(depth_m * 1000.0).astype(np.uint16)

@@ -37,3 +37,8 @@ def ref_hierarchical():
 @pytest.fixture(scope="session")
 def ref_slavcheva():
     return load_golden("ref_slavcheva.npz")
+
+
+@pytest.fixture(scope="session")
+def ref_tsdf():
+    return load_golden("ref_tsdf.npz")

@@ -39,6 +39,7 @@ from nonrigid_opt.slavcheva.sobolev_filter import generate_1d_sobolev_kernel  # 
 import math_utils.convolution as mc  # noqa: E402
 import math_utils.resampling as mr  # noqa: E402
 import tsdf.generation as tsdf_gen  # noqa: E402
+gen_mod = tsdf_gen
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -332,12 +333,51 @@ def slavcheva():
     print("ref_slavcheva.npz:", len(out), "arrays")
 
 
+def tsdf():
+    """nearest-pixel TSDF generation (tsdf/generation.py:130-207, 356-437) on the closed-form synthetic depth image
+    (oracle.synthetic_depth_image; only its checksum is stored, the tests regenerate it)"""
+    from calib.camera import Camera, DepthCamera
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import lsf_oracle as O
+    out = {}
+    K = np.array([[700., 0., 320.], [0., 700., 240.], [0., 0., 1.]], dtype=np.float32)
+    cam = DepthCamera(intrinsics=Camera.Intrinsics((480, 640), intrinsic_matrix=K), depth_unit_ratio=0.001)
+    cam64 = DepthCamera(intrinsics=Camera.Intrinsics((480, 640), intrinsic_matrix=K.astype(np.float64)),
+                        depth_unit_ratio=0.001)
+    d0, d1 = O.synthetic_depth_image(), O.synthetic_depth_image(shift_px=2.0, nearer_m=0.008)
+    out["depth0.checksum"] = np.array([int(d0.astype(np.int64).sum()), int((d0.astype(np.int64) ** 2).sum())])
+    out["depth1.checksum"] = np.array([int(d1.astype(np.int64).sum()), int((d1.astype(np.int64) ** 2).sum())])
+    out["intrinsics"] = K
+    for tag, d in (("d0", d0), ("d1", d1)):
+        for y in (200, 240):
+            out["%s.row%d.n32" % (tag, y)] = gen_mod.generate_2d_tsdf_field_from_depth_image_no_interpolation(
+                d, cam, y, field_size=32, array_offset=np.array([-16, -16, 234]))
+        out["%s.vol16" % tag] = gen_mod.generate_3d_tsdf_field_from_depth_image(
+            d, cam, field_size=16, array_offset=np.array([-8, -8, 240]))
+    E = np.eye(4, dtype=np.float32)
+    E[0, 3], E[2, 3], E[0, 0], E[0, 2], E[2, 0], E[2, 2] = 0.013, -0.02, 0.9998, 0.02, -0.02, 0.9998
+    out["extrinsic"] = E
+    out["d0.vol12.extrinsic"] = gen_mod.generate_3d_tsdf_field_from_depth_image(
+        d0, cam, camera_extrinsic_matrix=E, field_size=12, array_offset=np.array([-6, -6, 244]))
+    out["d0.vol12.k64"] = gen_mod.generate_3d_tsdf_field_from_depth_image(
+        d0, cam64, field_size=12, array_offset=np.array([-6, -6, 244]))
+    out["d0.row240.n32.default0"] = gen_mod.generate_2d_tsdf_field_from_depth_image(
+        d0, cam, 240, field_size=32, default_value=0, array_offset=np.array([-16, -16, 234]),
+        narrow_band_width_voxels=10)
+    np.savez_compressed(os.path.join(HERE, "ref_tsdf.npz"), **out)
+    print("ref_tsdf.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.chdir(tempfile.mkdtemp())
+    if len(sys.argv) > 1 and sys.argv[1] == "tsdf":
+        tsdf()
+        sys.exit(0)
     literals()
     leaf()
     hierarchical()
     slavcheva()
+    tsdf()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%8d  %s" % (os.path.getsize(os.path.join(HERE, f)), f))

@@ -1,0 +1,81 @@
+"""TSDF generation on the GPU (nearest pixel) against the oracle (bit for bit) and the reference's
+own outputs; plus the depth -> TSDF -> optimizer chain staying on the device."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lsf_oracle as O
+from tests.test_oracle_golden import _tsdf_cases, maxdiff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gen():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from levelsetfusion_python_amd.tsdf import generation
+    return generation
+
+
+def _call(gen, depth, K, kw):
+    cam = gen.DepthCamera(intrinsic_matrix=K, depth_unit_ratio=0.001)
+    shape = kw["field_shape"]
+    common = dict(camera_extrinsic_matrix=kw.get("camera_extrinsic_matrix"), field_size=shape[0],
+                  default_value=kw.get("default_value", 1), array_offset=np.array(kw["array_offset"]),
+                  narrow_band_width_voxels=kw.get("narrow_band_width_voxels", 20))
+    if len(shape) == 2:
+        return gen.generate_2d_tsdf_field_from_depth_image(depth, cam, kw["image_y_coordinate"], **common)
+    return gen.generate_3d_tsdf_field_from_depth_image(depth, cam, **common)
+
+
+def test_tsdf_nearest_matches_oracle_and_reference(gen, ref_tsdf):
+    for key, depth, K, kw in _tsdf_cases(ref_tsdf):
+        got = _call(gen, depth, K, kw)
+        assert got.dtype == np.float32 and got.shape == tuple(kw["field_shape"])
+        assert maxdiff(got, O.tsdf_nearest(depth, K, 0.001, **kw)) == 0.0, key
+        assert maxdiff(got, ref_tsdf[key]) <= (2.5e-6 if "extrinsic" in key else 0.0), key
+
+
+def test_tsdf_larger_volume_and_edge_cases(gen):
+    K = np.array([[700., 0., 320.], [0., 700., 240.], [0., 0., 1.]], dtype=np.float32)
+    depth = O.synthetic_depth_image()
+    depth[100:140, 300:330] = 0  # holes (no measurement) keep the default value
+    kw = dict(field_shape=(64, 64, 64), array_offset=(-32, -32, 218))
+    got = _call(gen, depth, K, kw)
+    assert maxdiff(got, O.tsdf_nearest(depth, K, 0.001, **kw)) == 0.0
+    assert (np.abs(got) < 1).sum() > 10000
+    # volume entirely behind the camera / outside the image: everything stays at the default
+    behind = _call(gen, depth, K, dict(field_shape=(8, 8, 8), array_offset=(-4, -4, -300)))
+    assert np.all(behind == 1.0)
+    outside = _call(gen, depth, K, dict(field_shape=(8, 8, 8), array_offset=(4000, -4, 250)))
+    assert np.all(outside == 1.0)
+    with pytest.raises(ValueError):
+        gen.generate_3d_tsdf_field_from_depth_image(depth.astype(np.float32), gen.DepthCamera(intrinsic_matrix=K))
+    with pytest.raises(NotImplementedError):
+        gen.generate_2d_tsdf_field_from_depth_image(depth, gen.DepthCamera(intrinsic_matrix=K), 240,
+                                                    interpolation_method=gen.FilteringMethod.EWA_IMAGE_SPACE)
+    with pytest.raises(ValueError):
+        gen.generate_2d_tsdf_field_from_depth_image(depth, gen.DepthCamera(intrinsic_matrix=K), 240,
+                                                    interpolation_method="NONE")
+
+
+def test_depth_to_tsdf_to_optimizer_on_device(gen):
+    """two synthetic depth frames -> 64^3 TSDF pair -> hierarchical optimizer, nothing leaves the GPU in between;
+    result equals the oracle chain bit for bit"""
+    import levelsetfusion_python_amd as lsf
+    K = np.array([[700., 0., 320.], [0., 700., 240.], [0., 0., 1.]], dtype=np.float32)
+    cam = gen.DepthCamera(intrinsic_matrix=K, depth_unit_ratio=0.001)
+    d0, d1 = O.synthetic_depth_image(), O.synthetic_depth_image(shift_px=2.0, nearer_m=0.008)
+    off = np.array([-32, -32, 218])
+    canonical = gen.generate_3d_tsdf_field_from_depth_image(d0, cam, field_size=64, array_offset=off, as_tensor=True)
+    live = gen.generate_3d_tsdf_field_from_depth_image(d1, cam, field_size=64, array_offset=off, as_tensor=True)
+    assert canonical.is_cuda and live.is_cuda
+    kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=4, rate=0.1,
+              maximum_iteration_count=4, maximum_warp_update_threshold=0.0, tikhonov_strength=0.05)
+    warp = lsf.HierarchicalOptimizer3d(**kw).optimize(canonical, live)
+    assert warp.is_cuda and warp.shape == (64, 64, 64, 3)
+    c_ref = O.tsdf_nearest(d0, K, 0.001, (64, 64, 64), array_offset=tuple(off))
+    l_ref = O.tsdf_nearest(d1, K, 0.001, (64, 64, 64), array_offset=tuple(off))
+    assert maxdiff(warp.cpu().numpy(), O.HierarchicalOracle(**kw).optimize(c_ref, l_ref)) == 0.0
+    assert float(warp.abs().max()) > 1e-3

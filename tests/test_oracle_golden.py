@@ -300,3 +300,34 @@ def test_3d_embedding_of_2d_is_exact():
     ob.optimize(lb, c3)
     assert maxdiff(lb[nz // 2], la) == 0.0
     assert maxdiff(ob.warp_field[nz // 2][..., :2], oa.warp_field) == 0.0
+
+
+# ------------------------------------------------------------------------------------ a21 TSDF generation
+def _tsdf_cases(G):
+    K = G["intrinsics"]
+    d0, d1 = O.synthetic_depth_image(), O.synthetic_depth_image(shift_px=2.0, nearer_m=0.008)
+    for d, key in ((d0, "depth0.checksum"), (d1, "depth1.checksum")):
+        assert [int(d.astype(np.int64).sum()), int((d.astype(np.int64) ** 2).sum())] == list(G[key])
+    cases = []
+    for tag, d in (("d0", d0), ("d1", d1)):
+        for y in (200, 240):
+            cases.append(("%s.row%d.n32" % (tag, y), d, K, dict(field_shape=(32, 32), image_y_coordinate=y,
+                                                                array_offset=(-16, -16, 234))))
+        cases.append(("%s.vol16" % tag, d, K, dict(field_shape=(16, 16, 16), array_offset=(-8, -8, 240))))
+    cases.append(("d0.vol12.extrinsic", d0, K, dict(field_shape=(12, 12, 12), array_offset=(-6, -6, 244),
+                                                    camera_extrinsic_matrix=G["extrinsic"])))
+    cases.append(("d0.vol12.k64", d0, K.astype(np.float64), dict(field_shape=(12, 12, 12),
+                                                                 array_offset=(-6, -6, 244))))
+    cases.append(("d0.row240.n32.default0", d0, K, dict(field_shape=(32, 32), image_y_coordinate=240, default_value=0,
+                                                        array_offset=(-16, -16, 234), narrow_band_width_voxels=10)))
+    return cases
+
+
+def test_tsdf_nearest_matches_reference(ref_tsdf):
+    n_band = 0
+    for key, depth, K, kw in _tsdf_cases(ref_tsdf):
+        got = O.tsdf_nearest(depth, K, 0.001, **kw)
+        tol = 2.5e-6 if "extrinsic" in key else 0.0  # BLAS matvec order for a general extrinsic matrix
+        assert maxdiff(got, ref_tsdf[key]) <= tol, key
+        n_band += int((np.abs(ref_tsdf[key]) < 1).sum())
+    assert n_band > 3000
