@@ -14,6 +14,20 @@ def _close(a, b, tol=1e-6):
     return abs(a - b) <= tol
 
 
+class Location(tuple):
+    """voxel location (x, y[, z]); compares like a tuple and has the .x/.y/.z attributes of the reference's
+    Vector2i / Vector3i"""
+
+    def __new__(cls, *coords):
+        if len(coords) == 1 and not isinstance(coords[0], (int, np.integer)):
+            coords = tuple(coords[0])
+        return super().__new__(cls, tuple(int(c) for c in coords))
+
+    x = property(lambda self: self[0])
+    y = property(lambda self: self[1])
+    z = property(lambda self: self[2] if len(self) > 2 else 0)
+
+
 class WarpDeltaStatistics:
     def __init__(self, ratio_above_min_threshold=0.0, length_min=0.0, length_max=0.0, length_mean=0.0,
                  length_standard_deviation=0.0, longest_warp_location=(0, 0), is_largest_below_min_threshold=False,
@@ -23,7 +37,7 @@ class WarpDeltaStatistics:
         self.length_max = length_max
         self.length_mean = length_mean
         self.length_standard_deviation = length_standard_deviation
-        self.longest_warp_location = tuple(longest_warp_location)
+        self.longest_warp_location = Location(longest_warp_location)
         self.is_largest_below_min_threshold = is_largest_below_min_threshold
         self.is_largest_above_max_threshold = is_largest_above_max_threshold
 
@@ -47,7 +61,7 @@ class TsdfDifferenceStatistics:
         self.difference_max = difference_max
         self.difference_mean = difference_mean
         self.difference_standard_deviation = difference_standard_deviation
-        self.biggest_difference_location = tuple(biggest_difference_location)
+        self.biggest_difference_location = Location(biggest_difference_location)
 
     def __eq__(self, other):
         return (_close(self.difference_min, other.difference_min) and _close(self.difference_max, other.difference_max)

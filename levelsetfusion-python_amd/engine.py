@@ -63,7 +63,8 @@ class HierarchicalEngine:
 
     def __init__(self, tikhonov_term_enabled, gradient_kernel_enabled, maximum_chunk_size, rate,
                  maximum_iteration_count, maximum_warp_update_threshold, data_term_amplifier, tikhonov_strength,
-                 kernel, compute_energy=False, check_interval=8):
+                 kernel, compute_energy=False, check_interval=8, collect_reports=False):
+        self.collect_reports = collect_reports
         self.maximum_chunk_size = maximum_chunk_size
         self.rate = rate
         self.data_term_amplifier = data_term_amplifier
@@ -128,6 +129,7 @@ class HierarchicalEngine:
                                  int(tik), int(not ker), int(self.compute_energy))
         n_buf = 3 if ker else (2 if tik else 0)
         bufs = [torch.zeros_like(warp) for _ in range(n_buf)]
+        report_g = torch.zeros_like(warp) if (self.collect_reports and n_buf == 0) else None
         final = 0  # buffer that holds the previous iteration's final gradient (zeros at level start, :179)
         finals = []
         it = 0
@@ -153,7 +155,7 @@ class HierarchicalEngine:
                                        i)
                     final = out
                 else:
-                    dev.hier_iteration(packed, canonical, warp, None, None, grid, params, gate, records, i)
+                    dev.hier_iteration(packed, canonical, warp, None, report_g, grid, params, gate, records, i)
                 finals.append(final)
             it += batch
             dec = dev.decode_records(records[:it].cpu().numpy())  # the only host sync of the batch
@@ -167,7 +169,18 @@ class HierarchicalEngine:
                           [float(v) for v in dec["data_energy"][:n_exec]], dev.n_voxels(grid))
         res.iteration_limit_reached = n_exec >= max_it
         self.level_results.append(res)
-        self.last_gradient = bufs[finals[n_exec - 1]] if (n_buf and n_exec) else None
+        self.last_gradient = bufs[finals[n_exec - 1]] if (n_buf and n_exec) else report_g
+        if self.collect_reports:
+            # per-level ConvergenceReport (cpp get_per_level_convergence_reports, run_hierarchical_optimizer3d.py:104):
+            # statistics of the last iteration's update field and of |canonical - resampled live| at this level
+            from .convergence_report import (ConvergenceReport, build_tsdf_difference_statistics,
+                                             build_warp_delta_statistics)
+            resampled = dev.warp_field(packed[..., 0].contiguous(), warp, 1.0)
+            g_final = self.last_gradient if self.last_gradient is not None else torch.zeros_like(warp)
+            res.report = ConvergenceReport(n_exec, res.iteration_limit_reached,
+                                           build_warp_delta_statistics(g_final, canonical, resampled, thr,
+                                                                       float("inf")),
+                                           build_tsdf_difference_statistics(canonical, resampled))
         return warp
 
 

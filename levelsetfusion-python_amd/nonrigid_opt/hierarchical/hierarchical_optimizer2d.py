@@ -48,7 +48,8 @@ class _HierarchicalOptimizerBase:
             maximum_warp_update_threshold, data_term_amplifier, tikhonov_strength,
             None if kernel is None else np.asarray(kernel, dtype=np.float64),
             compute_energy=bool(getattr(self.verbosity_parameters, "print_iteration_data_energy", False)),
-            check_interval=check_interval)
+            check_interval=check_interval,
+            collect_reports=self.logging_parameters.collect_per_level_convergence_reports)
         e = self._engine
         self.maximum_chunk_size = e.maximum_chunk_size
         self.rate = e.rate
@@ -74,9 +75,7 @@ class _HierarchicalOptimizerBase:
         warp_planar = self._engine.optimize(canonical, live)
         self.hierarchy_level = len(self._engine.level_results)
         self._print_levels()
-        self._reports = []
-        if self.logging_parameters.collect_per_level_convergence_reports:
-            self._reports = self._build_reports(canonical, live, warp_planar)
+        self._reports = [r.report for r in self._engine.level_results if getattr(r, "report", None) is not None]
         warp = dev.interleave(warp_planar)
         return warp if on_device else warp.cpu().numpy()
 
@@ -91,23 +90,6 @@ class _HierarchicalOptimizerBase:
         """one ConvergenceReport per pyramid level (run_hierarchical_optimizer3d.py:104); needs
         LoggingParameters(collect_per_level_convergence_reports=True)"""
         return list(self._reports)
-
-    def _build_reports(self, canonical, live, warp_planar):
-        # statistics of the finest level are exact; coarser levels report iteration counts only (their fields
-        # are gone by the time optimize() returns; collect them with check_interval=1 hooks if needed)
-        reports = []
-        n = len(self._engine.level_results)
-        for k, r in enumerate(self._engine.level_results):
-            if k == n - 1:
-                resampled = dev.warp_field(live, warp_planar, 1.0)
-                ws = build_warp_delta_statistics(self._engine.last_gradient if self._engine.last_gradient is not None
-                                                 else warp_planar, canonical, resampled,
-                                                 self.maximum_warp_update_threshold, float("inf"))
-                ds = build_tsdf_difference_statistics(canonical, resampled)
-                reports.append(ConvergenceReport(r.iteration_count, r.iteration_limit_reached, ws, ds))
-            else:
-                reports.append(ConvergenceReport(r.iteration_count, r.iteration_limit_reached))
-        return reports
 
     def _print_levels(self):
         vp = self.verbosity_parameters

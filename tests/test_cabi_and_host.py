@@ -167,3 +167,34 @@ def test_slab_layout(pkg):
         SlabLayout(10, 0, 3, 1)
     with pytest.raises(ValueError):
         SlabLayout(8, 0, 4, 3)
+
+
+def test_multipair_report_tables(pkg, tmp_path):
+    """host side of the multi-pair driver: table layout (2 + 17 columns per level), analysis and case files"""
+    from levelsetfusion_python_amd.convergence_report import (ConvergenceReport, Location, TsdfDifferenceStatistics,
+                                                              WarpDeltaStatistics)
+    from levelsetfusion_python_amd.experiment import multipair as mp
+    loc = Location(3, 4)
+    assert loc == (3, 4) and loc.x == 3 and loc.y == 4 and Location((1, 2, 5)).z == 5
+
+    def report(count, reached):
+        return ConvergenceReport(count, reached, WarpDeltaStatistics(0.5, 0.0, 0.2, 0.1, 0.05, (3, 4), False, False),
+                                 TsdfDifferenceStatistics(0.0, 0.3, 0.1, 0.05, (5, 6)))
+    sets = [[report(10, False), report(100, True)], [report(20, False), report(50, False)]]
+    df = mp.post_process_convergence_report_sets(sets, [(7, 200), (8, 200)])
+    assert len(df.columns) == 2 + 17 * 2 and mp.infer_level_count(df) == 2
+    assert list(df.columns[:3]) == ["canonical_frame", "pixel_row", "l0_iter_count"]
+    assert list(df["l1_warp_delta_max_x"]) == [3, 3] and list(df["l1_diff_max_y"]) == [6, 6]
+    assert mp.get_converged_ratio_for_level(df, 0) == 1.0 and mp.get_converged_ratio_for_level(df, 1) == 0.5
+    assert mp.get_mean_iteration_count_for_level(df, 1) == 75.0
+    text = mp.analyze_convergence_data(df, str(tmp_path))
+    assert "level 1: 50.00%" in text and "level 0: 15.00" in text
+    assert len(mp.save_bad_cases(df, str(tmp_path))) == 1
+    mp.save_all_cases(df, str(tmp_path))
+    assert open(str(tmp_path / "bad_cases.csv")).read().strip() == "7,200,3,4"
+    assert len(open(str(tmp_path / "all_cases.csv")).read().strip().splitlines()) == 2
+    c = np.zeros((4, 4), np.float32)
+    mp.save_pair(str(tmp_path / "pairs"), 12, 300, c, c + 1)
+    mp.save_pair(str(tmp_path / "pairs"), 3, 300, c, c + 2)
+    pairs = mp.load_pairs(str(tmp_path / "pairs"))
+    assert [(p[0], p[1]) for p in pairs] == [(3, 300), (12, 300)] and float(pairs[1][3][0, 0]) == 1.0
