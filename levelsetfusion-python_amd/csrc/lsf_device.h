@@ -88,8 +88,15 @@ __host__ __device__ inline Tiling make_tiling(const Grid& g) {
 constexpr unsigned kMaxBlocks = 2048;
 constexpr unsigned kXcds = 8;
 
+// 251 blocks per XCD (prime): a block's stride through its XCD's tile sequence must not divide the number of tiles
+// in a z-slice (256 at 256^2), or every block would revisit the same (x, y) tile position in every slice and the
+// blocks whose position lies in the narrow band would do all the work (measured: 0.21 ms vs 0.13 ms at 256^3).
+constexpr unsigned kBlocksPerXcd = 251;
+
 __host__ inline unsigned launch_blocks(unsigned total_tiles) {
-    unsigned b = total_tiles < kMaxBlocks ? total_tiles : kMaxBlocks;
+    const unsigned full = kXcds * kBlocksPerXcd;  // 2008 <= kMaxBlocks
+    if (total_tiles >= full) return full;
+    unsigned b = total_tiles;
     if (b > kXcds) b -= b % kXcds;
     return b;
 }
@@ -144,6 +151,9 @@ __device__ inline void for_each_voxel(const Grid& g, F&& f) {
         if (x < g.nx && y < g.ny) f(x, y, z);
     }
 }
+
+// (A dynamic variant -- per-XCD work queues with atomic heads and stealing -- was measured and rejected: device-scope
+// returning atomics on a contended address serialise at ~140 ns here, 16 K grabs per 256^3 launch cost 0.29 ms.)
 
 __device__ inline unsigned linear_index(const Grid& g, int x, int y, int z) {
     return (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);

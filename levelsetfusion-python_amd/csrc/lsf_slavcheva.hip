@@ -297,9 +297,16 @@ __device__ inline unsigned long long update_and_rewarp(const float* __restrict__
     for (int c = 0; c < D; ++c) wv[c] = (-gv[c]) * p.rate;
     const float len = vec_length<D>(wv);
     const unsigned lin = linear_index(g, x, y, z);
-    const float px = (float)x + wv[0], py = (float)y + wv[1];
-    const float pz = D == 3 ? (float)(z + g.z_global_offset) + wv[2] : 0.0f;
-    float v = sample_linear<D>(live, g, px, py, pz, 1.0f);
+    float v;
+    if (wv[0] == 0.0f && wv[1] == 0.0f && wv[2] == 0.0f) {
+        // zero displacement (every voxel outside the narrow-band union): all ratios are 0, each lerp is
+        // a*1 + b*0 = a exactly, so the D-linear gather returns live[p] bit for bit -- skip its 2^D loads
+        v = live[i];
+    } else {
+        const float px = (float)x + wv[0], py = (float)y + wv[1];
+        const float pz = D == 3 ? (float)(z + g.z_global_offset) + wv[2] : 0.0f;
+        v = sample_linear<D>(live, g, px, py, pz, 1.0f);
+    }
     if (1.0f - fabsf(v) < 1e-6f) {  // field_warping.py:138-141
         v = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : v);
         wv[0] = wv[1] = wv[2] = 0.0f;
