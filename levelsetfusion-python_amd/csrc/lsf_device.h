@@ -17,12 +17,14 @@ struct Grid {
     int nz, ny, nx;
     int z_begin, z_end;
     int z_global_offset;
-    unsigned chunk_tiles;  // tiles per scheduling chunk (see tile_range)
+    unsigned chunk_tiles;  // tiles per scheduling chunk (see tile_walk)
+    int tile_y;            // rows per tile = waves per block (1..4); blockDim.x = 64 * tile_y
     long long plane;       // nz*ny*nx: stride between the planes of a planar vector field
 };
 
-__host__ inline Grid make_grid(const lsf_grid* g) {
+__host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
     Grid r;
+    r.tile_y = tile_y;
     r.nz = g->nz; r.ny = g->ny; r.nx = g->nx;
     r.z_begin = g->z_begin; r.z_end = g->z_end;
     r.z_global_offset = g->z_global_offset;
@@ -30,7 +32,7 @@ __host__ inline Grid make_grid(const lsf_grid* g) {
     // scheduling chunk: a few consecutive z-slices of tiles (3-D) or a few tile rows (2-D), so that the volume is
     // cut into >= ~32 chunks dealt round-robin to the 8 XCDs (load balance when the narrow band is localised)
     // while a chunk is still thick enough that most stencil / halo re-reads stay inside one XCD's L2
-    const unsigned tiles_x = (unsigned)(g->nx + 63) / 64, tiles_y = (unsigned)(g->ny + 3) / 4;
+    const unsigned tiles_x = (unsigned)(g->nx + 63) / 64, tiles_y = (unsigned)(g->ny + tile_y - 1) / tile_y;
     const unsigned slices = (unsigned)(g->z_end - g->z_begin);
     if (g->dims == 3) {
         unsigned s = slices / 32;
@@ -73,7 +75,7 @@ struct Tiling {
 __host__ __device__ inline Tiling make_tiling(const Grid& g) {
     Tiling t;
     t.tiles_x = (g.nx + kTileX - 1) / kTileX;
-    t.tiles_y = (g.ny + kTileY - 1) / kTileY;
+    t.tiles_y = (g.ny + g.tile_y - 1) / g.tile_y;
     t.tiles_z = g.z_end - g.z_begin;
     t.total = (unsigned)t.tiles_x * t.tiles_y * t.tiles_z;
     return t;
@@ -93,8 +95,8 @@ constexpr unsigned kXcds = 8;
 // blocks whose position lies in the narrow band would do all the work (measured: 0.21 ms vs 0.13 ms at 256^3).
 constexpr unsigned kBlocksPerXcd = 251;
 
-__host__ inline unsigned launch_blocks(unsigned total_tiles) {
-    const unsigned full = kXcds * kBlocksPerXcd;  // 2008 <= kMaxBlocks
+__host__ inline unsigned launch_blocks(unsigned total_tiles, unsigned per_xcd = kBlocksPerXcd) {
+    const unsigned full = kXcds * per_xcd;
     if (total_tiles >= full) return full;
     unsigned b = total_tiles;
     if (b > kXcds) b -= b % kXcds;
@@ -147,7 +149,7 @@ __device__ inline void for_each_voxel(const Grid& g, F&& f) {
         const unsigned rest = tile / t.tiles_x;
         const int ty = rest % t.tiles_y;
         const int tz = rest / t.tiles_y;
-        const int x = tx * kTileX + lx, y = ty * kTileY + ly, z = g.z_begin + tz;
+        const int x = tx * kTileX + lx, y = ty * g.tile_y + ly, z = g.z_begin + tz;
         if (x < g.nx && y < g.ny) f(x, y, z);
     }
 }
@@ -288,6 +290,7 @@ __device__ inline void block_reduce_commit(unsigned long long packed, const doub
     __shared__ unsigned long long s_max[kBlock / kWave];
     __shared__ double s_sum[(NS > 0 ? NS : 1)][kBlock / kWave];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    const int n_waves = blockDim.x / kWave;
     unsigned long long m = wave_max_u64(packed);
     double s[NS > 0 ? NS : 1];
 #pragma unroll
@@ -301,13 +304,13 @@ __device__ inline void block_reduce_commit(unsigned long long packed, const doub
     if (threadIdx.x == 0) {
         unsigned long long mm = s_max[0];
 #pragma unroll
-        for (int w = 1; w < kBlock / kWave; ++w) mm = s_max[w] > mm ? s_max[w] : mm;
+        for (int w = 1; w < n_waves; ++w) mm = s_max[w] > mm ? s_max[w] : mm;
         if (dst_max && mm != 0ull) atomicMax(dst_max, mm);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             double t = 0.0;
 #pragma unroll
-            for (int w = 0; w < kBlock / kWave; ++w) t += s_sum[i][w];
+            for (int w = 0; w < n_waves; ++w) t += s_sum[i][w];
             if (dst_sum[i] && t != 0.0) atomicAdd(dst_sum[i], t);
         }
     }

@@ -401,7 +401,7 @@ struct LaunchArgs {
 template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, bool FUSED>
 void launch_one(const LaunchArgs& a) {
     hipLaunchKernelGGL((slavcheva_iteration_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY, FUSED>), dim3(a.blocks),
-                       dim3(kBlock), 0, a.s, a.live, a.canonical, a.warp_prev, a.warp_out, a.live_out, a.g_out, a.g,
+                       dim3(kTileX * a.g.tile_y), 0, a.s, a.live, a.canonical, a.warp_prev, a.warp_out, a.live_out, a.g_out, a.g,
                        a.p, a.gate, a.record);
 }
 
@@ -447,11 +447,17 @@ extern "C" int lsf_slavcheva_iteration(int32_t stage, const float* live, const f
     } else {
         return LSF_ERR_BAD_ARGUMENT;
     }
-    Grid g = make_grid(grid);
+    // work unit = (64 x 4) tile, 4-wave blocks.  Finer units (1- or 2-wave blocks on 64 x 1 / 64 x 2 tiles, which
+    // would average the ~4x cost difference between band and non-band units over more units per block) were measured
+    // and lose: the four rows of a tile share stencil rows through L1 (256^3 all-in-band 0.39 / 0.46 / 0.59 ms for
+    // tile heights 4 / 2 / 1).
+    const int tile_y = 4;
+    const unsigned per_xcd = kBlocksPerXcd;
+    Grid g = make_grid(grid, tile_y);
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
-    LaunchArgs a{launch_blocks(t.total), as_stream(stream), live, canonical, warp_prev_planar, warp_out_planar, live_out,
-                 g_out_planar, g, make_params(params), gate_or_open(gate), record};
+    LaunchArgs a{launch_blocks(t.total, per_xcd), as_stream(stream), live, canonical, warp_prev_planar, warp_out_planar,
+                 live_out, g_out_planar, g, make_params(params), gate_or_open(gate), record};
     if (grid->dims == 2) {
         if (stage == LSF_STAGE_FUSED) pick_terms<2, true>(params, a); else pick_terms<2, false>(params, a);
     } else {
