@@ -63,8 +63,9 @@ class HierarchicalEngine:
 
     def __init__(self, tikhonov_term_enabled, gradient_kernel_enabled, maximum_chunk_size, rate,
                  maximum_iteration_count, maximum_warp_update_threshold, data_term_amplifier, tikhonov_strength,
-                 kernel, compute_energy=False, check_interval=8, collect_reports=False):
+                 kernel, compute_energy=False, check_interval=8, collect_reports=False, comm=None):
         self.collect_reports = collect_reports
+        self.comm = comm  # SlabComm of the FINEST level (z-slab runs), or None
         self.maximum_chunk_size = maximum_chunk_size
         self.rate = rate
         self.data_term_amplifier = data_term_amplifier
@@ -89,38 +90,91 @@ class HierarchicalEngine:
         self.last_gradient = None  # planar gradient of the finest level after the last iteration
 
     # ------------------------------------------------------------------------------------------------
+    def _slab(self):
+        return self.comm is not None and self.comm.active
+
     def build_pyramids(self, canonical, live):
         """canonical / live pyramids, coarsest first; live is packed with its full-resolution np.gradient
-        BEFORE restriction (gradients are averaged, not recomputed: hierarchical_optimizer2d.py:126-131)"""
-        n_levels = pyramid_level_count(live.shape, self.maximum_chunk_size)
-        canon_levels = [canonical]
-        packed_levels = [dev.pack_live_gradient(live)]
-        for _ in range(1, n_levels):
-            canon_levels.append(dev.restrict_mean(canon_levels[-1], 1))
-            packed_levels.append(dev.restrict_mean(packed_levels[-1], 4))
+        BEFORE restriction (gradients are averaged, not recomputed: hierarchical_optimizer2d.py:126-131).
+        Returns (canonical levels, packed levels, per-level SlabComm or None)."""
+        if not self._slab():
+            n_levels = pyramid_level_count(live.shape, self.maximum_chunk_size)
+            canon_levels = [canonical]
+            packed_levels = [dev.pack_live_gradient(live)]
+            for _ in range(1, n_levels):
+                canon_levels.append(dev.restrict_mean(canon_levels[-1], 1))
+                packed_levels.append(dev.restrict_mean(packed_levels[-1], 4))
+            canon_levels.reverse()
+            packed_levels.reverse()
+            return canon_levels, packed_levels, [None] * n_levels
+        # z-slab: every level keeps `halo` neighbour slices; a level's owned slices are the restriction of the finer
+        # level's owned slices (slab boundaries are multiples of 2^levels), its halos come from one exchange per level
+        L0 = self.comm.layout
+        if live.dim() != 3 or live.shape[0] != L0.nz_local:
+            raise ValueError("slab runs need 3-D local fields with %d slices, got %r" % (L0.nz_local, tuple(live.shape)))
+        global_shape = (L0.nz_global,) + tuple(live.shape[1:])
+        n_levels = pyramid_level_count(global_shape, self.maximum_chunk_size)
+        per = L0.z1 - L0.z0
+        if per % (1 << (n_levels - 1)) != 0 or (per >> (n_levels - 1)) < max(L0.halo, 1):
+            raise ValueError("a slab of %d slices cannot carry %d pyramid levels with a %d-slice halo"
+                             % (per, n_levels, L0.halo))
+        comms = [self.comm]
+        packed = dev.pack_live_gradient(live)
+        # the outermost halo slice got a one-sided z difference: refresh the halos from their owners
+        comms[0].exchange_halos([packed.view(packed.shape[0], packed.shape[1], -1)])
+        canon_levels, packed_levels = [canonical], [packed]
+        for k in range(1, n_levels):
+            fine_comm = comms[-1]
+            Lf = fine_comm.layout
+            Lc = SlabLayout(Lf.nz_global // 2, Lf.rank, Lf.world, Lf.halo)
+            cc = SlabComm(Lc, fine_comm.group)
+            own_f = Lf.owned_local()
+            c_own = dev.restrict_mean(canon_levels[-1][own_f].contiguous(), 1)
+            p_own = dev.restrict_mean(packed_levels[-1][own_f].contiguous(), 4)
+            c_loc = torch.zeros((Lc.nz_local,) + tuple(c_own.shape[1:]), dtype=torch.float32, device=live.device)
+            p_loc = torch.zeros((Lc.nz_local,) + tuple(p_own.shape[1:]), dtype=torch.float32, device=live.device)
+            c_loc[Lc.owned_local()] = c_own
+            p_loc[Lc.owned_local()] = p_own
+            cc.exchange_halos([c_loc])
+            cc.exchange_halos([p_loc.view(p_loc.shape[0], p_loc.shape[1], -1)])
+            canon_levels.append(c_loc)
+            packed_levels.append(p_loc)
+            comms.append(cc)
         canon_levels.reverse()
         packed_levels.reverse()
-        return canon_levels, packed_levels
+        comms.reverse()
+        return canon_levels, packed_levels, comms
 
     def optimize(self, canonical, live):
-        """canonical, live: float32 device tensors [z,]y,x.  Returns the warp field, PLANAR [c][z][y][x]."""
+        """canonical, live: float32 device tensors [z,]y,x (z-slab runs: the local slab incl. halos).
+        Returns the warp field, PLANAR [c][z][y][x] (z-slab runs: local extent, only owned slices are meaningful)."""
         if canonical.shape != live.shape:
             raise ValueError("canonical and live fields must have the same shape")
         dims = live.dim()
-        canon_levels, packed_levels = self.build_pyramids(canonical, live)
+        canon_levels, packed_levels, comms = self.build_pyramids(canonical, live)
         self.level_results = []
         warp = None
-        for level, (canon_l, packed_l) in enumerate(zip(canon_levels, packed_levels)):
+        for level, (canon_l, packed_l, comm_l) in enumerate(zip(canon_levels, packed_levels, comms)):
             if level == 0:
                 warp = torch.zeros((dims,) + tuple(canon_l.shape), dtype=torch.float32, device=live.device)
-            self.optimize_level(canon_l, packed_l, warp)
+            self.optimize_level(canon_l, packed_l, warp, comm_l)
             if level != len(canon_levels) - 1:
-                warp = dev.prolong_repeat(warp)
+                fine = dev.prolong_repeat(warp)
+                if comm_l is not None:  # keep [owned + halo] of the finer level's layout
+                    lo = comm_l.layout.halo_lo
+                    fine = fine[:, lo:lo + comms[level + 1].layout.nz_local].contiguous()
+                warp = fine
         return warp
 
-    def optimize_level(self, canonical, packed, warp):
+    def optimize_level(self, canonical, packed, warp, comm=None):
         dims = canonical.dim()
-        grid = dev.make_grid(canonical.shape)
+        slab = comm is not None and comm.active
+        if slab:
+            L = comm.layout
+            grid = dev.make_grid(canonical.shape, L.z_begin, L.z_end, L.z_global_offset)
+            full_grid = dev.make_grid(canonical.shape, 0, L.nz_local, L.z_global_offset)
+        else:
+            grid = full_grid = dev.make_grid(canonical.shape)
         max_it = self.maximum_iteration_count
         thr = float(self.maximum_warp_update_threshold)
         records = dev.new_records(max(max_it, 1), canonical.device)
@@ -130,6 +184,10 @@ class HierarchicalEngine:
         n_buf = 3 if ker else (2 if tik else 0)
         bufs = [torch.zeros_like(warp) for _ in range(n_buf)]
         report_g = torch.zeros_like(warp) if (self.collect_reports and n_buf == 0) else None
+        reach = len(self.gradient_kernel) // 2 if ker else 0
+        if slab and L.halo < max(reach, 2):
+            raise ValueError("slab halo of %d slices is too narrow: this configuration needs >= %d"
+                             % (L.halo, max(reach, 2)))
         final = 0  # buffer that holds the previous iteration's final gradient (zeros at level start, :179)
         finals = []
         it = 0
@@ -143,9 +201,12 @@ class HierarchicalEngine:
                     a, b = [k for k in range(3) if k != final]
                     dev.hier_iteration(packed, canonical, warp, bufs[final] if tik else None, bufs[a], grid, params,
                                        gate, records, i)
+                    if slab:  # the z pass reads `reach` slices of the (x,y)-filtered field on either side
+                        comm.exchange_halos([bufs[a]], width=reach)
                     src, dst = a, b
                     for axis in _conv_axis_order(dims):
-                        dev.convolve_axis(bufs[src], bufs[dst], None, grid, axis, self.gradient_kernel, gate)
+                        dev.convolve_axis(bufs[src], bufs[dst], None, grid if axis == 2 else full_grid, axis,
+                                          self.gradient_kernel, gate)
                         src, dst = dst, src
                     final = src
                     dev.hier_update(bufs[final], warp, grid, self.rate, gate, records, i)
@@ -157,20 +218,35 @@ class HierarchicalEngine:
                 else:
                     dev.hier_iteration(packed, canonical, warp, None, report_g, grid, params, gate, records, i)
                 finals.append(final)
+                if slab:
+                    if tik:  # the next iteration's Laplacian reads one slice of this gradient on either side
+                        comm.exchange_halos([bufs[final]], width=1)
+                    if i + 1 < max_it:
+                        comm.reduce_max(records, i)  # the next iteration's gate tests the GLOBAL max
+            if slab:
+                comm.reduce_records(records, it, it + batch)
             it += batch
             dec = dev.decode_records(records[:it].cpu().numpy())  # the only host sync of the batch
             n_exec = int(dec["executed"].sum())
+            if slab:
+                # the gather follows the cumulative warp: it must stay inside the halo of the static packed field
+                wz = warp[2][L.owned_local()].abs().max().reshape(1)
+                comm.reduce_scalar_max(wz)
+                if not (float(wz.item()) < L.halo - 1):
+                    raise RuntimeError("cumulative warp of %.3f slices reaches past the %d-slice slab halo; re-run "
+                                       "with a wider halo" % (float(wz.item()), L.halo))
             if n_exec < it or dec["max_value"][n_exec - 1] < np.float32(thr):
                 break
         if dec is None:  # maximum_iteration_count == 0: the reference's loop body never runs
             dec = dev.decode_records(records[:1].cpu().numpy())
+        n_vox = dev.n_voxels(grid) if not slab else (L.nz_global * grid.ny * grid.nx)
         res = LevelResult(n_exec, [float(v) for v in dec["max_value"][:n_exec]],
                           [int(v) for v in dec["argmax"][:n_exec]],
-                          [float(v) for v in dec["data_energy"][:n_exec]], dev.n_voxels(grid))
+                          [float(v) for v in dec["data_energy"][:n_exec]], n_vox)
         res.iteration_limit_reached = n_exec >= max_it
         self.level_results.append(res)
         self.last_gradient = bufs[finals[n_exec - 1]] if (n_buf and n_exec) else report_g
-        if self.collect_reports:
+        if self.collect_reports and not slab:
             # per-level ConvergenceReport (cpp get_per_level_convergence_reports, run_hierarchical_optimizer3d.py:104):
             # statistics of the last iteration's update field and of |canonical - resampled live| at this level
             from .convergence_report import (ConvergenceReport, build_tsdf_difference_statistics,

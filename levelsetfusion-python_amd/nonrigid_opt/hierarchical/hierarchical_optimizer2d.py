@@ -39,7 +39,7 @@ class _HierarchicalOptimizerBase:
     def __init__(self, tikhonov_term_enabled=True, gradient_kernel_enabled=True, maximum_chunk_size=8, rate=0.1,
                  maximum_iteration_count=100, maximum_warp_update_threshold=0.001, data_term_amplifier=1.0,
                  tikhonov_strength=0.2, kernel=None, verbosity_parameters=None, visualization_parameters=None,
-                 logging_parameters=None, check_interval=8):
+                 logging_parameters=None, check_interval=8, comm=None):
         self.verbosity_parameters = verbosity_parameters or self.VerbosityParameters()
         self.visualization_parameters = visualization_parameters  # accepted, unused: no video writers here
         self.logging_parameters = logging_parameters or self.LoggingParameters()
@@ -49,7 +49,7 @@ class _HierarchicalOptimizerBase:
             None if kernel is None else np.asarray(kernel, dtype=np.float64),
             compute_energy=bool(getattr(self.verbosity_parameters, "print_iteration_data_energy", False)),
             check_interval=check_interval,
-            collect_reports=self.logging_parameters.collect_per_level_convergence_reports)
+            collect_reports=self.logging_parameters.collect_per_level_convergence_reports, comm=comm)
         e = self._engine
         self.maximum_chunk_size = e.maximum_chunk_size
         self.rate = e.rate
@@ -76,6 +76,9 @@ class _HierarchicalOptimizerBase:
         self.hierarchy_level = len(self._engine.level_results)
         self._print_levels()
         self._reports = [r.report for r in self._engine.level_results if getattr(r, "report", None) is not None]
+        if self._engine.comm is not None and self._engine.comm.active:  # z-slab run: return the OWNED slices only
+            own = self._engine.comm.layout.owned_local()
+            warp_planar = warp_planar[:, own].contiguous()
         warp = dev.interleave(warp_planar)
         return warp if on_device else warp.cpu().numpy()
 

@@ -107,6 +107,17 @@ class SlabComm:
                 dst.copy_(recv[k:k + c] if t.dim() == 4 else recv[k])
                 k += c
 
+    def reduce_scalar_max(self, value):
+        """in-place MAX all-reduce of a small float tensor (slab guards)"""
+        if not self.active:
+            return
+        if self.stage_through_host and value.is_cuda:
+            host = value.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
+            value.copy_(host)
+        else:
+            dist.all_reduce(value, op=dist.ReduceOp.MAX, group=self.group)
+
     def reduce_max(self, records, index):
         """MAX all-reduce of the packed max of ONE record (needed before a gated iteration can test it)"""
         if not self.active:

@@ -84,3 +84,63 @@ def test_two_slab_ranks_equal_whole_volume(tmp_path, config):
         assert np.allclose(p["data"], ref.log.data_energies, rtol=1e-10)
         assert np.allclose(p["smoothing"], ref.log.smoothing_energies, rtol=1e-10)
         assert np.allclose(p["level_set"], ref.log.level_set_energies, rtol=1e-10)
+
+
+def _hier_worker(rank, world, port, n, nz, halo, kwargs, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    layout = SlabLayout(nz, rank, world, halo)
+    sl = layout.local_slice()
+    canonical, live = sphere_pair(n, 3, "cuda", (sl.start, sl.stop))
+    opt = lsf.HierarchicalOptimizer3d(comm=SlabComm(layout), **kwargs)
+    warp = opt.optimize(canonical, live)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), warp=warp.cpu().numpy(),
+             counts=np.int64(opt.get_per_level_iteration_counts()),
+             last_max=np.float32([m[-1] for m in opt.get_per_level_maximum_updates()]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("config", ["tikhonov_fixed", "tikhonov_kernel_fixed", "data_threshold"])
+def test_two_slab_ranks_hierarchical_equal_whole_volume(tmp_path, config):
+    """HierarchicalOptimizer3d on two z-slabs (per-level halos, gradient halo exchange, global gate) == whole volume"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    n, world, halo = 64, 2, 4
+    nz = n * world
+    kwargs = dict(maximum_chunk_size=4, rate=0.1, tikhonov_strength=0.05, check_interval=3)
+    if config == "tikhonov_fixed":
+        kwargs.update(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_iteration_count=5,
+                      maximum_warp_update_threshold=0.0)
+    elif config == "tikhonov_kernel_fixed":
+        kwargs.update(tikhonov_term_enabled=True, gradient_kernel_enabled=True,
+                      kernel=lsf.generate_1d_sobolev_kernel(7, 0.1), maximum_iteration_count=4,
+                      maximum_warp_update_threshold=0.0)
+    else:
+        kwargs.update(tikhonov_term_enabled=False, gradient_kernel_enabled=False, maximum_iteration_count=40,
+                      maximum_warp_update_threshold=0.0)
+        # pick a threshold that the coarsest level crosses in mid-run (probe run on the whole volume)
+        probe = lsf.HierarchicalOptimizer3d(**kwargs)
+        probe.optimize(*sphere_pair(n, 3, "cuda", (0, nz)))
+        trajectory = probe.get_per_level_maximum_updates()[0]
+        assert trajectory[12] < trajectory[2]
+        kwargs["maximum_warp_update_threshold"] = float(0.5 * (trajectory[11] + trajectory[12]))
+    mp.spawn(_hier_worker, args=(world, _free_port(), n, nz, halo, kwargs, str(tmp_path)), nprocs=world, join=True)
+    canonical, live = sphere_pair(n, 3, "cuda", (0, nz))
+    ref = lsf.HierarchicalOptimizer3d(**kwargs)
+    warp = ref.optimize(canonical, live).cpu().numpy()
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate([p["warp"] for p in parts], 0), warp)
+    for p in parts:
+        assert list(p["counts"]) == ref.get_per_level_iteration_counts()
+        assert np.array_equal(p["last_max"], np.float32([m[-1] for m in ref.get_per_level_maximum_updates()]))
+    if config == "data_threshold":
+        assert any(1 < c < 40 for c in ref.get_per_level_iteration_counts())
