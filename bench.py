@@ -48,8 +48,8 @@ def parse():
                          "single-GPU measurements: SobolevFusion-style Slavcheva, hierarchical Tikhonov-only, "
                          "hierarchical Tikhonov + 7-tap kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-size", type=int, default=96)
-    ap.add_argument("--cpu-sample-iterations", type=int, default=16)
+    ap.add_argument("--cpu-sample-size", type=int, default=128)
+    ap.add_argument("--cpu-sample-iterations", type=int, default=24)
     return ap.parse_args()
 
 
