@@ -228,6 +228,20 @@ typedef struct lsf_tsdf_params {
 int lsf_tsdf_generate_nearest(const uint16_t *depth_image, float *field, const lsf_grid *grid,
                               const lsf_tsdf_params *params, void *stream);
 
+/* EWA filters: replaces tsdf/ewa.py:230-353 (generate_tsdf_2d_ewa_image, method 3), :358-481 (…_ewa_tsdf, method 4),
+ * :485-624 (…_ewa_tsdf_inclusive, method 5) for grid dims 2, and :59-184 (generate_tsdf_3d_ewa_image, method 3) for
+ * grid dims 3 -- there field[a][b][c] has world x on array axis 0 and the depth axis on array axis 2 (the reference's
+ * deliberate flip, tsdf/ewa.py:115-119).  params->intrinsics is ignored; the full matrix travels in ewa. */
+typedef struct lsf_ewa_params {
+    double covariance_camera_space[9]; /* R * (gaussian_covariance_scale*voxel_size*I) * R^T, row-major, float64 */
+    double squared_radius_threshold;   /* 4 * gaussian_covariance_scale * voxel_size */
+    float intrinsic_matrix[9];         /* row-major 3x3, float32 */
+    int32_t method;                    /* 3 EWA_IMAGE_SPACE, 4 EWA_VOXEL_SPACE, 5 EWA_VOXEL_SPACE_INCLUSIVE */
+} lsf_ewa_params;
+
+int lsf_tsdf_generate_ewa(const uint16_t *depth_image, float *field, const lsf_grid *grid,
+                          const lsf_tsdf_params *params, const lsf_ewa_params *ewa, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

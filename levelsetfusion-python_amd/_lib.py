@@ -71,6 +71,11 @@ class TsdfParams(ctypes.Structure):
                 ("intrinsics_are_f32", ctypes.c_int32)]
 
 
+class EwaParams(ctypes.Structure):
+    _fields_ = [("covariance_camera_space", ctypes.c_double * 9), ("squared_radius_threshold", ctypes.c_double),
+                ("intrinsic_matrix", ctypes.c_float * 9), ("method", ctypes.c_int32)]
+
+
 _P = ctypes.POINTER
 _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
 
@@ -96,6 +101,7 @@ PROTOTYPES = {
     "lsf_warp_statistics": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp, _vp]),
     "lsf_tsdf_difference_statistics": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp, _vp]),
     "lsf_tsdf_generate_nearest": (ctypes.c_int, [_vp, _vp, _P(Grid), _P(TsdfParams), _vp]),
+    "lsf_tsdf_generate_ewa": (ctypes.c_int, [_vp, _vp, _P(Grid), _P(TsdfParams), _P(EwaParams), _vp]),
 }
 
 

@@ -55,7 +55,159 @@ __global__ __launch_bounds__(kBlock) void tsdf_nearest_kernel(const unsigned sho
     });
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// EWA filters (tsdf/ewa.py:59-184 3-D image space; :230-353, :358-481, :485-624 2-D image space / voxel space /
+// voxel space inclusive; math_utils/elliptical_gaussians.py:27-62,145-158).  Per voxel: project a spherical Gaussian
+// through the projection Jacobian into an image-space ellipse (+ unit pixel Gaussian), then average depth (image
+// space) or per-pixel TSDF values (voxel space) over the pixels inside the ellipse.  float32 voxel / camera / image
+// coordinates and Jacobian entries, everything else float64 -- as the reference evaluates it under numpy >= 2.
+// Windows are a handful of pixels; the kernel is bound by its output stream like the nearest-pixel one.
+struct EwaParams {
+    double cov[9];     // covariance of the voxel sphere in camera space: R * (scale*voxel_size*I) * R^T
+    double threshold;  // squared radius threshold F = 4 * scale * voxel_size
+    float k[9];        // intrinsic matrix, row-major
+    int method;        // 3 image space, 4 voxel space, 5 voxel space inclusive (FilteringMethod values)
+};
+
+__device__ inline double tsdf_value(double sd, double half) {
+    return sd < -half ? -1.0 : (sd > half ? 1.0 : sd / half);
+}
+
+template <int D>
+__global__ __launch_bounds__(kBlock) void tsdf_ewa_kernel(const unsigned short* __restrict__ depth,
+                                                          float* __restrict__ field, Grid g, TsdfParams p,
+                                                          EwaParams q) {
+    for_each_voxel(g, [&](int x, int y, int z) {
+        const int i = vidx(g, x, y, z);
+        // 2-D: field[y][x], depth axis = y index.  3-D: array axis 0 (z here) is world x, axis 2 (x here) is the
+        // depth axis -- the reference's deliberate flip (tsdf/ewa.py:115-119)
+        const float xv = (float)((double)((D == 3 ? z : x) + p.off[0]) * p.voxel_size);
+        const float yv = D == 3 ? (float)((double)(y + p.off[1]) * p.voxel_size) : 0.0f;
+        const float zv = (float)((double)((D == 3 ? x : y) + p.off[2]) * p.voxel_size);
+        const float vc0 = ((p.e[0] * xv + p.e[1] * yv) + p.e[2] * zv) + p.e[3] * 1.0f;
+        const float vc1 = ((p.e[4] * xv + p.e[5] * yv) + p.e[6] * zv) + p.e[7] * 1.0f;
+        const float vc2 = ((p.e[8] * xv + p.e[9] * yv) + p.e[10] * zv) + p.e[11] * 1.0f;
+        float result = p.default_value;
+        if (vc2 > 0.05f) {  // near clipping distance, tsdf/ewa.py:29
+            float vi0 = ((q.k[0] * vc0 + q.k[1] * vc1) + q.k[2] * vc2) / vc2;
+            float vi1 = ((q.k[3] * vc0 + q.k[4] * vc1) + q.k[5] * vc2) / vc2;
+            if (D == 2) vi1 = (float)p.image_y;
+            bool ok = true;
+            if (q.method == 5)
+                ok = !(vi1 < -3.0f || vi1 >= (float)(p.height + 3) || vi0 < -3.0f || vi0 >= (float)(p.width + 3));
+            if (ok) {
+                const float ray = sqrtf((vc0 * vc0 + vc1 * vc1) + vc2 * vc2);
+                const float z2 = vc2 * vc2;
+                // rows 0 and 1 of the projection Jacobian (float32 entries), row 2 does not reach the 2x2 block
+                const double j0[3] = {(double)(1.0f / vc2), 0.0, (double)(-vc0 / z2)};
+                const double j1[3] = {0.0, (double)(1.0f / vc2), (double)(-vc1 / z2)};
+                (void)ray;
+                double t0[3], t1[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    t0[c] = (j0[0] * q.cov[c] + j0[1] * q.cov[3 + c]) + j0[2] * q.cov[6 + c];
+                    t1[c] = (j1[0] * q.cov[c] + j1[1] * q.cov[3 + c]) + j1[2] * q.cov[6 + c];
+                }
+                const double m00 = (t0[0] * j0[0] + t0[1] * j0[1]) + t0[2] * j0[2];
+                const double m01 = (t0[0] * j1[0] + t0[1] * j1[1]) + t0[2] * j1[2];
+                const double m10 = (t1[0] * j0[0] + t1[1] * j0[1]) + t1[2] * j0[2];
+                const double m11 = (t1[0] * j1[0] + t1[1] * j1[1]) + t1[2] * j1[2];
+                const double s00 = q.k[0], s01 = q.k[1], s10 = q.k[3], s11 = q.k[4];
+                // final covariance = S * M * S^T + I
+                const double a00 = s00 * m00 + s01 * m10, a01 = s00 * m01 + s01 * m11;
+                const double a10 = s10 * m00 + s11 * m10, a11 = s10 * m01 + s11 * m11;
+                const double f00 = (a00 * s00 + a01 * s01) + 1.0, f01 = a00 * s10 + a01 * s11;
+                const double f10 = a10 * s00 + a11 * s01, f11 = (a10 * s10 + a11 * s11) + 1.0;
+                const double det = f00 * f11 - f01 * f10;
+                const double q00 = f11 / det, q01 = -f01 / det, q10 = -f10 / det, q11 = f00 / det;
+                // ellipse bounds (elliptical_gaussians.py:44-58)
+                const double A = q00, B = q01 * 2.0, C = q11, F = q.threshold;
+                double bx, by;
+                if (fabs(B) < 10e-6) {
+                    bx = sqrt(F / A);
+                    by = sqrt(F / C);
+                } else {
+                    bx = sqrt(F / (C - B * B / (4.0 * A)));
+                    by = sqrt(F / (A - B * B / (4.0 * C)));
+                }
+                const double vx = (double)vi0, vy = (double)vi1;
+                int sx = (int)(vx - bx), ex = (int)ceil(vx + bx + 1.0);
+                int sy = (int)(vy - by), ey = (int)ceil(vy + by + 1.0);
+                if (!(ey <= 0 || sy >= p.height || ex <= 0 || sx >= p.width)) {
+                    if (q.method != 5) {
+                        sy = max(0, sy); ey = min(p.height, ey);
+                        sx = max(0, sx); ex = min(p.width, ex);
+                    }
+                    double weights = 0.0, values = 0.0;
+                    for (int ys = sy; ys < ey; ++ys)
+                        for (int xs = sx; xs < ex; ++xs) {
+                            const double p0 = (double)xs - vx, p1 = (double)ys - vy;
+                            const double d2 = (p0 * q00 + p1 * q10) * p0 + (p0 * q01 + p1 * q11) * p1;
+                            if (d2 > F) continue;
+                            const double wgt = exp(-0.5 * d2);
+                            if (ys < 0 || ys >= p.height || xs < 0 || xs >= p.width) {  // inclusive variant only
+                                values += wgt * 1.0;
+                                weights += wgt;
+                                continue;
+                            }
+                            const double surface = (double)depth[ys * p.width + xs] * p.depth_unit_ratio;
+                            if (surface <= 0.0) continue;
+                            values += q.method == 3 ? wgt * surface
+                                                    : wgt * tsdf_value(surface - (double)vc2, p.half_width);
+                            weights += wgt;
+                        }
+                    if (q.method == 3) {
+                        if (values > 0.0) result = (float)tsdf_value(values / weights - (double)vc2, p.half_width);
+                    } else if (weights != 0.0) {
+                        result = (float)(values / weights);
+                    }
+                }
+            }
+        }
+        field[i] = result;
+    });
+}
+
+TsdfParams convert_params(const lsf_tsdf_params* params) {
+    TsdfParams p;
+    p.fx = params->intrinsics[0]; p.fy = params->intrinsics[1]; p.cx = params->intrinsics[2]; p.cy = params->intrinsics[3];
+    p.depth_unit_ratio = params->depth_unit_ratio;
+    p.voxel_size = params->voxel_size;
+    p.half_width = params->narrow_band_half_width;
+    for (int k = 0; k < 12; ++k) p.e[k] = params->extrinsic[k];
+    for (int k = 0; k < 3; ++k) p.off[k] = params->array_offset[k];
+    p.width = params->image_width; p.height = params->image_height; p.image_y = params->image_y_coordinate;
+    p.default_value = params->default_value;
+    return p;
+}
+
 }  // namespace
+
+extern "C" int lsf_tsdf_generate_ewa(const uint16_t* depth_image, float* field, const lsf_grid* grid,
+                                     const lsf_tsdf_params* params, const lsf_ewa_params* ewa, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!depth_image || !field || !params || !ewa) return LSF_ERR_BAD_ARGUMENT;
+    if (params->image_width <= 0 || params->image_height <= 0 || !(params->narrow_band_half_width > 0.0))
+        return LSF_ERR_BAD_ARGUMENT;
+    if (ewa->method < 3 || ewa->method > 5 || !(ewa->squared_radius_threshold > 0.0)) return LSF_ERR_BAD_ARGUMENT;
+    if (grid->dims == 2 && (params->image_y_coordinate < 0 || params->image_y_coordinate >= params->image_height))
+        return LSF_ERR_BAD_ARGUMENT;
+    Grid g = make_grid(grid);
+    Tiling t = make_tiling(g);
+    if (t.total == 0) return 0;
+    TsdfParams p = convert_params(params);
+    EwaParams q;
+    for (int k = 0; k < 9; ++k) { q.cov[k] = ewa->covariance_camera_space[k]; q.k[k] = ewa->intrinsic_matrix[k]; }
+    q.threshold = ewa->squared_radius_threshold;
+    q.method = ewa->method;
+    const unsigned blocks = launch_blocks(t.total);
+    const unsigned short* d = reinterpret_cast<const unsigned short*>(depth_image);
+    if (grid->dims == 2)
+        hipLaunchKernelGGL(tsdf_ewa_kernel<2>, dim3(blocks), dim3(kBlock), 0, as_stream(stream), d, field, g, p, q);
+    else
+        hipLaunchKernelGGL(tsdf_ewa_kernel<3>, dim3(blocks), dim3(kBlock), 0, as_stream(stream), d, field, g, p, q);
+    return launch_status();
+}
 
 extern "C" int lsf_tsdf_generate_nearest(const uint16_t* depth_image, float* field, const lsf_grid* grid,
                                          const lsf_tsdf_params* params, void* stream) {

@@ -1,7 +1,7 @@
 """TSDF generation from depth images on the GPU -- the input stage of the optimizers
 (reference: tsdf/generation.py:130-235, 356-437; camera model calib/camera.py:69-311 reduced to what is consumed:
-a 3x3 intrinsic matrix and the depth unit ratio).  Nearest-pixel lookup (FilteringMethod.NONE) in this round; the
-EWA / bilinear filters of tsdf/ewa.py are not built yet and raise NotImplementedError."""
+a 3x3 intrinsic matrix and the depth unit ratio).  Nearest-pixel lookup (FilteringMethod.NONE) here, the EWA filters in
+tsdf/ewa.py of this package; the two bilinear variants are not built and raise NotImplementedError."""
 import ctypes
 from enum import Enum
 
@@ -38,7 +38,7 @@ class DepthCamera:
 
 
 def _generate(depth_image, camera, field_shape, image_y_coordinate, camera_extrinsic_matrix, default_value,
-              voxel_size, array_offset, narrow_band_width_voxels):
+              voxel_size, array_offset, narrow_band_width_voxels, ewa_method=None, gaussian_covariance_scale=1.0):
     dev.require_gpu()
     P = np.asarray(camera.intrinsics.intrinsic_matrix)
     if isinstance(depth_image, torch.Tensor):
@@ -68,10 +68,23 @@ def _generate(depth_image, camera, field_shape, image_y_coordinate, camera_extri
     params.intrinsics_are_f32 = int(P.dtype == np.float32)
     grid = dev.make_grid(field_shape)
     field = torch.empty(tuple(field_shape), dtype=torch.float32, device="cuda")
-    _lib.check(_lib.lib.lsf_tsdf_generate_nearest(ctypes.c_void_p(depth.data_ptr()),
-                                                  ctypes.c_void_p(field.data_ptr()), ctypes.byref(grid),
-                                                  ctypes.byref(params), dev.stream_ptr()),
-               "lsf_tsdf_generate_nearest")
+    if ewa_method is None:
+        _lib.check(_lib.lib.lsf_tsdf_generate_nearest(ctypes.c_void_p(depth.data_ptr()),
+                                                      ctypes.c_void_p(field.data_ptr()), ctypes.byref(grid),
+                                                      ctypes.byref(params), dev.stream_ptr()),
+                   "lsf_tsdf_generate_nearest")
+        return field
+    ewa = _lib.EwaParams()
+    rotation = E[0:3, 0:3]
+    # float32 rotation, float64 sphere covariance: tsdf/ewa.py:103-106
+    cov = rotation.dot(np.eye(3) * (gaussian_covariance_scale * voxel_size)).dot(rotation.T)
+    ewa.covariance_camera_space[:] = [float(v) for v in np.asarray(cov, dtype=np.float64).reshape(-1)]
+    ewa.squared_radius_threshold = 4.0 * gaussian_covariance_scale * voxel_size
+    ewa.intrinsic_matrix[:] = [float(v) for v in np.asarray(P, dtype=np.float32).reshape(-1)]
+    ewa.method = int(ewa_method.value)
+    _lib.check(_lib.lib.lsf_tsdf_generate_ewa(ctypes.c_void_p(depth.data_ptr()), ctypes.c_void_p(field.data_ptr()),
+                                              ctypes.byref(grid), ctypes.byref(params), ctypes.byref(ewa),
+                                              dev.stream_ptr()), "lsf_tsdf_generate_ewa")
     return field
 
 
@@ -96,8 +109,14 @@ def generate_2d_tsdf_field_from_depth_image(depth_image, camera, image_y_coordin
     """dispatcher of tsdf/generation.py:219-235"""
     if not isinstance(interpolation_method, FilteringMethod):
         raise ValueError("Unrecognized GenerationMethod enum value: " + str(interpolation_method))
+    if interpolation_method in (FilteringMethod.EWA_IMAGE_SPACE, FilteringMethod.EWA_VOXEL_SPACE,
+                                FilteringMethod.EWA_VOXEL_SPACE_INCLUSIVE):
+        f = _generate(depth_image, camera, (field_size, field_size), image_y_coordinate, camera_extrinsic_matrix,
+                      default_value, voxel_size, array_offset, narrow_band_width_voxels, interpolation_method,
+                      smoothing_coefficient)
+        return f if as_tensor else f.cpu().numpy()
     if interpolation_method != FilteringMethod.NONE:
-        raise NotImplementedError("%s is not built yet (nearest-pixel TSDF only in this round)" % interpolation_method)
+        raise NotImplementedError("%s is not built (nearest-pixel and EWA filters only)" % interpolation_method)
     return generate_2d_tsdf_field_from_depth_image_no_interpolation(
         depth_image, camera, image_y_coordinate, camera_extrinsic_matrix, field_size, default_value, voxel_size,
         array_offset, narrow_band_width_voxels, back_cutoff_voxels, as_tensor)

@@ -772,3 +772,101 @@ def synthetic_depth_image(shift_px=0.0, nearer_m=0.0, width=640, height=480):
         * (1.0 + 0.3 * np.sin(u / 17.0) * np.cos(v / 23.0))
     depth_m = 1.0 + 0.0002 * (u - 320.0) - bump - nearer_m
     return np.round(depth_m * 1000.0).astype(np.uint16)
+
+
+# =====================================================================================================
+#  a21  EWA TSDF generation (tsdf/ewa.py:59-184 3-D image space, :230-353 / :358-481 / :485-624 2-D image space,
+#       voxel space, voxel space inclusive; math_utils/elliptical_gaussians.py:27-62,145-158)
+#  Per-voxel Python loops: small cases only.
+# =====================================================================================================
+EWA_IMAGE, EWA_VOXEL, EWA_VOXEL_INCLUSIVE = 3, 4, 5  # values of FilteringMethod
+EWA_NEAR_CLIPPING = 0.05                             # tsdf/ewa.py:29
+
+
+def _tsdf_value(sd, half):
+    """tsdf/common.py:34-47"""
+    return -1.0 if sd < -half else (1.0 if sd > half else sd / half)
+
+
+def tsdf_ewa(depth_image, intrinsic_matrix, depth_unit_ratio, field_shape, method=EWA_IMAGE, image_y_coordinate=None,
+             camera_extrinsic_matrix=None, default_value=1, voxel_size=0.004, array_offset=(-64, -64, 64),
+             narrow_band_width_voxels=20, gaussian_covariance_scale=1.0):
+    """2-D (field_shape (n, n), depth row image_y_coordinate) or 3-D (field_shape (s0, s1, s2): array axis 0 is world
+    x, axis 2 is the depth axis -- the reference's deliberate axis flip, tsdf/ewa.py:115-119).  dtypes as the reference
+    under numpy >= 2: float32 voxel / camera / image coordinates and Jacobian entries, float64 covariances, weights
+    and sums."""
+    K = np.asarray(intrinsic_matrix, dtype=np.float32)
+    E = np.eye(4, dtype=F32) if camera_extrinsic_matrix is None else np.asarray(camera_extrinsic_matrix, dtype=F32)
+    dims = len(field_shape)
+    field = np.full(tuple(field_shape), default_value, dtype=F32)
+    half = narrow_band_width_voxels / 2 * voxel_size
+    R = E[0:3, 0:3]
+    cov_cam = R.dot(np.eye(3) * (gaussian_covariance_scale * voxel_size)).dot(R.T)  # float64
+    S = K[0:2, 0:2].copy()
+    F = 4.0 * gaussian_covariance_scale * voxel_size
+    h, w = depth_image.shape
+    off = [int(o) for o in array_offset]
+    for idx in np.ndindex(*field_shape):
+        if dims == 2:
+            xw, yw, zw = (idx[1] + off[0]) * voxel_size, 0, (idx[0] + off[2]) * voxel_size
+        else:
+            xw, yw, zw = (idx[0] + off[0]) * voxel_size, (idx[1] + off[1]) * voxel_size, (idx[2] + off[2]) * voxel_size
+        voxel_world = np.array([[xw, yw, zw, 1.0]], dtype=F32).T
+        vc = E.dot(voxel_world).flatten()[:3]
+        if vc[2] <= EWA_NEAR_CLIPPING:
+            continue
+        vi = (K.dot(vc) / vc[2])[:2]
+        if dims == 2:
+            vi[1] = image_y_coordinate
+        if method == EWA_VOXEL_INCLUSIVE:
+            margin = 3
+            if vi[1] < -margin or vi[1] >= h + margin or vi[0] < -margin or vi[0] >= w + margin:
+                continue
+        ray = np.linalg.norm(vc)
+        z2 = vc[2] ** 2
+        J = np.array([[1 / vc[2], 0, -vc[0] / z2], [0, 1 / vc[2], -vc[1] / z2],
+                      [vc[0] / ray, vc[1] / ray, vc[2] / ray]])
+        remapped = J.dot(cov_cam).dot(J.T)
+        final = S.dot(remapped[0:2, 0:2]).dot(S.T) + np.eye(2)
+        Q = np.linalg.inv(final)
+        A, B, C = Q[0, 0], Q[0, 1] * 2, Q[1, 1]
+        if abs(float(B)) < 10e-6:
+            bx, by = math.sqrt(F / A), math.sqrt(F / C)
+        else:
+            bx, by = math.sqrt(F / (C - B ** 2 / (4 * A))), math.sqrt(F / (A - B ** 2 / (4 * C)))
+        vx, vy = np.float64(vi[0]), np.float64(vi[1])
+        sx, ex = int(vx - bx), int(math.ceil(vx + bx + 1))
+        sy, ey = int(vy - by), int(math.ceil(vy + by + 1))
+        if ey <= 0 or sy >= h or ex <= 0 or sx >= w:
+            continue
+        if method != EWA_VOXEL_INCLUSIVE:
+            sy, ey, sx, ex = max(0, sy), min(h, ey), max(0, sx), min(w, ex)
+        weights_sum, value_sum = 0.0, 0.0
+        for ys in range(sy, ey):
+            for xs in range(sx, ex):
+                p0, p1 = xs - vx, ys - vy
+                d2 = (p0 * Q[0, 0] + p1 * Q[1, 0]) * p0 + (p0 * Q[0, 1] + p1 * Q[1, 1]) * p1
+                if d2 > F:
+                    continue
+                weight = math.exp(-0.5 * d2)
+                if ys < 0 or ys >= h or xs < 0 or xs >= w:  # only reachable in the inclusive variant
+                    value_sum += weight * 1.0
+                    weights_sum += weight
+                    continue
+                surface = float(depth_image[ys, xs]) * depth_unit_ratio
+                if surface <= 0.0:
+                    continue
+                if method == EWA_IMAGE:
+                    value_sum += weight * surface
+                else:
+                    value_sum += weight * _tsdf_value(surface - float(vc[2]), half)
+                weights_sum += weight
+        if method == EWA_IMAGE:
+            if value_sum <= 0.0:
+                continue
+            field[idx] = _tsdf_value(value_sum / weights_sum - float(vc[2]), half)
+        else:
+            if weights_sum == 0.0:
+                continue
+            field[idx] = value_sum / weights_sum
+    return field

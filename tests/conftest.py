@@ -42,3 +42,8 @@ def ref_slavcheva():
 @pytest.fixture(scope="session")
 def ref_tsdf():
     return load_golden("ref_tsdf.npz")
+
+
+@pytest.fixture(scope="session")
+def ref_ewa():
+    return load_golden("ref_ewa.npz")

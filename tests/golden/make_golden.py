@@ -368,16 +368,98 @@ def tsdf():
     print("ref_tsdf.npz:", len(out), "arrays")
 
 
+def ewa():
+    """EWA TSDF generation (tsdf/ewa.py): the reference's own test cases (tests/test_tsdf_ewa.py:40-235: inline depth
+    patch, rows of its two synthetic zigzag depth PNGs, expected arrays of tests/test_data/ewa_test_data.py) plus
+    outputs of the reference on the closed-form synthetic depth image.  Depth PNG content is stored as a band of rows
+    [ROW0, ROW1) (all other rows are 65535 = "no measurement" as far as these cases can see: verified below)."""
+    import tsdf.ewa as ewa_mod
+    import tests.test_data.ewa_test_data as data
+    from calib.camera import Camera, DepthCamera
+    from PIL import Image
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import lsf_oracle as O
+    out = {}
+    K = np.array([[700., 0., 320.], [0., 700., 240.], [0., 0., 1.]], dtype=np.float32)
+    cam = DepthCamera(intrinsics=Camera.Intrinsics((480, 640), intrinsic_matrix=K), depth_unit_ratio=0.001)
+    ROW0, ROW1 = 150, 260
+    out["rows"] = np.array([ROW0, ROW1])
+
+    def load(name):
+        d = np.array(Image.open(os.path.join(REF, "tests", "test_data", name)))
+        d[d == 0] = np.iinfo(np.uint16).max  # tests/test_tsdf_ewa.py:36-38
+        return d
+
+    def banded(d):
+        b = np.full_like(d, np.iinfo(np.uint16).max)
+        b[ROW0:ROW1] = d[ROW0:ROW1]
+        return b
+
+    z1, z2 = load("zigzag1_depth_00064.png"), load("zigzag2_depth_00108.png")
+    out["zigzag1.rows"], out["zigzag2.rows"] = z1[ROW0:ROW1].copy(), z2[ROW0:ROW1].copy()
+    for name in dir(data):
+        v = getattr(data, name)
+        if isinstance(v, np.ndarray):
+            out["expected." + name] = v
+    patch = np.full((3, 640), np.iinfo(np.uint16).max, dtype=np.uint16)
+    region = np.array([3233, 3246, 3243, 3256, 3253, 3268, 3263, 3279, 3272, 3289, 3282, 3299, 3291, 3308, 3301, 3317,
+                       3310, 3326], dtype=np.uint16)
+    patch[:, 399:417] = region  # tests/test_tsdf_ewa.py:41-50 (three identical rows)
+    out["patch"] = patch
+    off2 = np.array([-256, 0, 0]) + np.array([210, 0, 103])
+    cases = {
+        "case1.image.patch": lambda d=patch: ewa_mod.generate_tsdf_2d_ewa_image(
+            d, cam, 1, field_size=16, array_offset=np.array([94, -256, 804]), voxel_size=0.004),
+        "case2.image.zigzag2": lambda d=z2: ewa_mod.generate_tsdf_2d_ewa_image(
+            d, cam, 200, field_size=16, array_offset=off2, voxel_size=0.004),
+        "case3.voxel.zigzag1": lambda d=z1: ewa_mod.generate_tsdf_2d_ewa_tsdf(
+            d, cam, 200, field_size=16, array_offset=np.array([-232, -256, 490]), voxel_size=0.004,
+            gaussian_covariance_scale=0.5),
+        "case4.inclusive.zigzag1": lambda d=z1: ewa_mod.generate_tsdf_2d_ewa_tsdf_inclusive(
+            d, cam, 200, field_size=16, array_offset=np.array([-232, -256, 490]), voxel_size=0.004,
+            gaussian_covariance_scale=0.5),
+        "case5.image3d.zigzag2": lambda d=z2: ewa_mod.generate_tsdf_3d_ewa_image(
+            d, cam, field_shape=np.array([16, 1, 16]), array_offset=np.array([-46, -8, 105]), voxel_size=0.004),
+    }
+    for key, fn in cases.items():
+        out[key] = fn()
+    # the stored row band is all these cases can see
+    assert np.array_equal(out["case2.image.zigzag2"], cases["case2.image.zigzag2"](banded(z2)))
+    assert np.array_equal(out["case3.voxel.zigzag1"], cases["case3.voxel.zigzag1"](banded(z1)))
+    assert np.array_equal(out["case4.inclusive.zigzag1"], cases["case4.inclusive.zigzag1"](banded(z1)))
+    assert np.array_equal(out["case5.image3d.zigzag2"], cases["case5.image3d.zigzag2"](banded(z2)))
+    # synthetic depth: all four generators, incl. a rotated camera and the image border (inclusive variant)
+    d0 = O.synthetic_depth_image()
+    E = np.eye(4, dtype=np.float32)
+    E[0, 3], E[2, 3], E[0, 0], E[0, 2], E[2, 0], E[2, 2] = 0.013, -0.02, 0.9998, 0.02, -0.02, 0.9998
+    out["extrinsic"] = E
+    out["syn.image2d"] = ewa_mod.generate_tsdf_2d_ewa_image(d0, cam, 240, field_size=20,
+                                                           array_offset=np.array([-10, -10, 236]))
+    out["syn.voxel2d"] = ewa_mod.generate_tsdf_2d_ewa_tsdf(d0, cam, 240, field_size=20,
+                                                          array_offset=np.array([-10, -10, 236]),
+                                                          gaussian_covariance_scale=2.0)
+    out["syn.inclusive2d.border"] = ewa_mod.generate_tsdf_2d_ewa_tsdf_inclusive(
+        d0, cam, 0, field_size=20, array_offset=np.array([100, -10, 236]), gaussian_covariance_scale=2.0)
+    out["syn.image3d.extrinsic"] = ewa_mod.generate_tsdf_3d_ewa_image(
+        d0, cam, camera_extrinsic_matrix=E, field_shape=np.array([10, 6, 10]), array_offset=np.array([-5, -3, 238]))
+    np.savez_compressed(os.path.join(HERE, "ref_ewa.npz"), **out)
+    print("ref_ewa.npz:", len(out), "arrays")
+
+
 if __name__ == "__main__":
     os.chdir(tempfile.mkdtemp())
     if len(sys.argv) > 1 and sys.argv[1] == "tsdf":
         tsdf()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ewa":
+        ewa()
         sys.exit(0)
     literals()
     leaf()
     hierarchical()
     slavcheva()
     tsdf()
+    ewa()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print("%8d  %s" % (os.path.getsize(os.path.join(HERE, f)), f))

@@ -54,7 +54,7 @@ def test_tsdf_larger_volume_and_edge_cases(gen):
         gen.generate_3d_tsdf_field_from_depth_image(depth.astype(np.float32), gen.DepthCamera(intrinsic_matrix=K))
     with pytest.raises(NotImplementedError):
         gen.generate_2d_tsdf_field_from_depth_image(depth, gen.DepthCamera(intrinsic_matrix=K), 240,
-                                                    interpolation_method=gen.FilteringMethod.EWA_IMAGE_SPACE)
+                                                    interpolation_method=gen.FilteringMethod.BILINEAR_VOXEL_SPACE)
     with pytest.raises(ValueError):
         gen.generate_2d_tsdf_field_from_depth_image(depth, gen.DepthCamera(intrinsic_matrix=K), 240,
                                                     interpolation_method="NONE")
@@ -79,3 +79,37 @@ def test_depth_to_tsdf_to_optimizer_on_device(gen):
     l_ref = O.tsdf_nearest(d1, K, 0.001, (64, 64, 64), array_offset=tuple(off))
     assert maxdiff(warp.cpu().numpy(), O.HierarchicalOracle(**kw).optimize(c_ref, l_ref)) == 0.0
     assert float(warp.abs().max()) > 1e-3
+
+
+def test_tsdf_ewa_matches_oracle_and_reference(gen, ref_ewa):
+    """the four EWA generators against the oracle (float64 sums; exp / 2x2 inverse may differ in the last place from
+    glibc / LAPACK: tolerance 2e-6) and against the reference's own known answers (its tolerance: atol=2e-5)"""
+    from levelsetfusion_python_amd.tsdf import ewa
+    from tests.test_oracle_golden import _ewa_cases
+    K, cases = _ewa_cases(ref_ewa)
+    cam = gen.DepthCamera(intrinsic_matrix=K, depth_unit_ratio=0.001)
+    fns = {O.EWA_IMAGE: ewa.generate_tsdf_2d_ewa_image, O.EWA_VOXEL: ewa.generate_tsdf_2d_ewa_tsdf,
+           O.EWA_VOXEL_INCLUSIVE: ewa.generate_tsdf_2d_ewa_tsdf_inclusive}
+    for key, depth, kw, expected in cases:
+        shape = kw["field_shape"]
+        common = dict(camera_extrinsic_matrix=kw.get("camera_extrinsic_matrix"), array_offset=np.array(kw["array_offset"]),
+                      gaussian_covariance_scale=kw.get("gaussian_covariance_scale", 1.0))
+        if len(shape) == 2:
+            got = fns[kw["method"]](depth, cam, kw["image_y_coordinate"], field_size=shape[0], **common)
+        else:
+            got = ewa.generate_tsdf_3d_ewa_image(depth, cam, field_shape=np.array(shape), **common)
+        assert got.shape == tuple(shape) and got.dtype == np.float32
+        assert maxdiff(got, O.tsdf_ewa(depth, K, 0.001, **kw)) <= 2e-6, key
+        assert maxdiff(got, ref_ewa[key]) <= 4e-6, key
+        if expected is not None:
+            assert maxdiff(got, ref_ewa[expected]) <= 2e-5, key
+    # dispatcher (tsdf/generation.py:219-235) with smoothing_coefficient
+    key, depth, kw, _ = cases[2]
+    got = gen.generate_2d_tsdf_field_from_depth_image(depth, cam, 200, field_size=16,
+                                                      array_offset=np.array(kw["array_offset"]),
+                                                      interpolation_method=gen.FilteringMethod.EWA_VOXEL_SPACE,
+                                                      smoothing_coefficient=0.5)
+    assert maxdiff(got, ref_ewa[key]) <= 4e-6
+    with pytest.raises(NotImplementedError):
+        gen.generate_2d_tsdf_field_from_depth_image(depth, cam, 200,
+                                                    interpolation_method=gen.FilteringMethod.BILINEAR_IMAGE_SPACE)

@@ -331,3 +331,49 @@ def test_tsdf_nearest_matches_reference(ref_tsdf):
         assert maxdiff(got, ref_tsdf[key]) <= tol, key
         n_band += int((np.abs(ref_tsdf[key]) < 1).sum())
     assert n_band > 3000
+
+
+# ------------------------------------------------------------------------------------ a21 EWA TSDF generation
+def _banded_image(rows, band):
+    img = np.full((480, 640), np.iinfo(np.uint16).max, dtype=np.uint16)
+    img[int(rows[0]):int(rows[1])] = band
+    return img
+
+
+def _ewa_cases(G):
+    """(key, depth image, kwargs of oracle.tsdf_ewa, expected-literal key of the reference's own test data or None)"""
+    K = np.array([[700., 0., 320.], [0., 700., 240.], [0., 0., 1.]], dtype=np.float32)
+    z1, z2 = _banded_image(G["rows"], G["zigzag1.rows"]), _banded_image(G["rows"], G["zigzag2.rows"])
+    d0 = O.synthetic_depth_image()
+    return K, [
+        ("case1.image.patch", G["patch"], dict(field_shape=(16, 16), method=O.EWA_IMAGE, image_y_coordinate=1,
+                                               array_offset=(94, -256, 804)), "expected.out_sdf_field01"),
+        ("case2.image.zigzag2", z2, dict(field_shape=(16, 16), method=O.EWA_IMAGE, image_y_coordinate=200,
+                                         array_offset=(-46, 0, 103)), "expected.out_sdf_chunk"),
+        ("case3.voxel.zigzag1", z1, dict(field_shape=(16, 16), method=O.EWA_VOXEL, image_y_coordinate=200,
+                                         array_offset=(-232, -256, 490), gaussian_covariance_scale=0.5),
+         "expected.out_sdf_field03"),
+        ("case4.inclusive.zigzag1", z1, dict(field_shape=(16, 16), method=O.EWA_VOXEL_INCLUSIVE,
+                                             image_y_coordinate=200, array_offset=(-232, -256, 490),
+                                             gaussian_covariance_scale=0.5), "expected.out_sdf_field04"),
+        ("case5.image3d.zigzag2", z2, dict(field_shape=(16, 1, 16), method=O.EWA_IMAGE,
+                                           array_offset=(-46, -8, 105)), "expected.sdf_3d_slice01"),
+        ("syn.image2d", d0, dict(field_shape=(20, 20), method=O.EWA_IMAGE, image_y_coordinate=240,
+                                 array_offset=(-10, -10, 236)), None),
+        ("syn.voxel2d", d0, dict(field_shape=(20, 20), method=O.EWA_VOXEL, image_y_coordinate=240,
+                                 array_offset=(-10, -10, 236), gaussian_covariance_scale=2.0), None),
+        ("syn.inclusive2d.border", d0, dict(field_shape=(20, 20), method=O.EWA_VOXEL_INCLUSIVE, image_y_coordinate=0,
+                                            array_offset=(100, -10, 236), gaussian_covariance_scale=2.0), None),
+        ("syn.image3d.extrinsic", d0, dict(field_shape=(10, 6, 10), method=O.EWA_IMAGE, array_offset=(-5, -3, 238),
+                                           camera_extrinsic_matrix=G["extrinsic"]), None),
+    ]
+
+
+def test_tsdf_ewa_matches_reference_and_its_known_answers(ref_ewa):
+    K, cases = _ewa_cases(ref_ewa)
+    for key, depth, kw, expected in cases:
+        got = O.tsdf_ewa(depth, K, 0.001, **kw)
+        assert maxdiff(got, ref_ewa[key]) <= (2.5e-6 if "extrinsic" in key else 0.0), key
+        if expected is not None:  # the reference's own tolerance for these literals is atol=2e-5
+            assert maxdiff(got, ref_ewa[expected]) <= 2e-5, key
+        assert (np.abs(got) < 1).sum() > 10, key
