@@ -63,8 +63,11 @@ class HierarchicalEngine:
 
     def __init__(self, tikhonov_term_enabled, gradient_kernel_enabled, maximum_chunk_size, rate,
                  maximum_iteration_count, maximum_warp_update_threshold, data_term_amplifier, tikhonov_strength,
-                 kernel, compute_energy=False, check_interval=8, collect_reports=False, comm=None):
+                 kernel, compute_energy=False, check_interval=8, collect_reports=False, comm=None,
+                 collect_iteration_data=False):
         self.collect_reports = collect_reports
+        self.collect_iteration_data = collect_iteration_data  # telemetry: per-iteration warp / gradient snapshots
+        self.iteration_data = []
         self.comm = comm  # SlabComm of the FINEST level (z-slab runs), or None
         self.maximum_chunk_size = maximum_chunk_size
         self.rate = rate
@@ -153,6 +156,7 @@ class HierarchicalEngine:
         dims = live.dim()
         canon_levels, packed_levels, comms = self.build_pyramids(canonical, live)
         self.level_results = []
+        self.iteration_data = []
         warp = None
         for level, (canon_l, packed_l, comm_l) in enumerate(zip(canon_levels, packed_levels, comms)):
             if level == 0:
@@ -190,6 +194,7 @@ class HierarchicalEngine:
                              % (L.halo, max(reach, 2)))
         final = 0  # buffer that holds the previous iteration's final gradient (zeros at level start, :179)
         finals = []
+        snapshots = []
         it = 0
         n_exec = 0
         dec = None
@@ -197,6 +202,19 @@ class HierarchicalEngine:
             batch = min(self.check_interval, max_it - it)
             for i in range(it, it + batch):
                 gate = dev.make_gate(records, i - 1, _lib.GATE_HIERARCHICAL, thr) if i > 0 else None
+                if self.collect_iteration_data:
+                    # telemetry (cpp LoggingParameters.collect_per_level_iteration_data): the two gradient terms
+                    # the reference hands to its visualiser (hierarchical_optimizer2d.py:196,202,242-245) are
+                    # produced by two extra launches of the same kernel on the pre-update warp
+                    d_snap = torch.zeros_like(warp)
+                    dev.hier_iteration(packed, canonical, warp, None, d_snap, grid,
+                                       _lib.HierParams(1.0, 0.0, 0.0, 0, 0, 0), gate, records, i)
+                    t_snap = None
+                    if tik:
+                        t_snap = torch.zeros_like(warp)  # = laplace(previous gradient): 0*gd - (-1)*lap
+                        dev.hier_iteration(packed, canonical, warp, bufs[final], t_snap, grid,
+                                           _lib.HierParams(0.0, -1.0, 0.0, 1, 0, 0), gate, records, i)
+                    snapshots.append([None, d_snap, t_snap])
                 if ker:
                     a, b = [k for k in range(3) if k != final]
                     dev.hier_iteration(packed, canonical, warp, bufs[final] if tik else None, bufs[a], grid, params,
@@ -218,6 +236,8 @@ class HierarchicalEngine:
                 else:
                     dev.hier_iteration(packed, canonical, warp, None, report_g, grid, params, gate, records, i)
                 finals.append(final)
+                if self.collect_iteration_data:
+                    snapshots[-1][0] = warp.clone()
                 if slab:
                     if tik:  # the next iteration's Laplacian reads one slice of this gradient on either side
                         comm.exchange_halos([bufs[final]], width=1)
@@ -246,6 +266,8 @@ class HierarchicalEngine:
         res.iteration_limit_reached = n_exec >= max_it
         self.level_results.append(res)
         self.last_gradient = bufs[finals[n_exec - 1]] if (n_buf and n_exec) else report_g
+        if self.collect_iteration_data:
+            self.iteration_data.append(snapshots[:n_exec])  # snapshots of gated (not executed) launches are dropped
         if self.collect_reports and not slab:
             # per-level ConvergenceReport (cpp get_per_level_convergence_reports, run_hierarchical_optimizer3d.py:104):
             # statistics of the last iteration's update field and of |canonical - resampled live| at this level

@@ -49,7 +49,8 @@ class _HierarchicalOptimizerBase:
             None if kernel is None else np.asarray(kernel, dtype=np.float64),
             compute_energy=bool(getattr(self.verbosity_parameters, "print_iteration_data_energy", False)),
             check_interval=check_interval,
-            collect_reports=self.logging_parameters.collect_per_level_convergence_reports, comm=comm)
+            collect_reports=self.logging_parameters.collect_per_level_convergence_reports, comm=comm,
+            collect_iteration_data=self.logging_parameters.collect_per_level_iteration_data)
         e = self._engine
         self.maximum_chunk_size = e.maximum_chunk_size
         self.rate = e.rate
@@ -93,6 +94,19 @@ class _HierarchicalOptimizerBase:
         """one ConvergenceReport per pyramid level (run_hierarchical_optimizer3d.py:104); needs
         LoggingParameters(collect_per_level_convergence_reports=True)"""
         return list(self._reports)
+
+    def get_per_level_iteration_data(self):
+        """telemetry of the last optimize() call: one OptimizationIterationData per level (warp field after every
+        iteration, data-term gradient, Tikhonov-term gradient), as numpy arrays in the interleaved API layout.
+        Needs LoggingParameters(collect_per_level_iteration_data=True)  (tests/test_hierarchical_optimizer2d.py:71-102)"""
+        from .telemetry import OptimizationIterationData
+        out = []
+        for level in self._engine.iteration_data:
+            def host(t):
+                return None if t is None else dev.interleave(t).cpu().numpy()
+            out.append(OptimizationIterationData([host(s[0]) for s in level], [host(s[1]) for s in level],
+                                                 [host(s[2]) for s in level if s[2] is not None]))
+        return out
 
     def _print_levels(self):
         vp = self.verbosity_parameters

@@ -1,0 +1,23 @@
+"""BASELINE config 2: 2-D 512x512 hierarchical optimizer, 3 levels, Tikhonov, 100 fixed iterations per level."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import levelsetfusion_python_amd as lsf
+from levelsetfusion_python_amd.synthetic import sphere_pair
+n = 512
+c, l = sphere_pair(n, 2, "cuda")
+for ci in (8, 100):
+    opt = lsf.HierarchicalOptimizer2d(maximum_chunk_size=4, tikhonov_strength=0.05, gradient_kernel_enabled=False,
+                                      rate=0.1, maximum_iteration_count=100, maximum_warp_update_threshold=0.0,
+                                      check_interval=ci)
+    opt.optimize(c, l)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        opt.optimize(c, l)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    updates = 100 * (512 ** 2 + 256 ** 2 + 128 ** 2)
+    print("check_interval %3d: %.2f ms per optimize(), %.1f us per iteration, %.2f G voxel-updates/s"
+          % (ci, dt * 1e3, dt / 300 * 1e6, updates / dt / 1e9))
