@@ -113,6 +113,14 @@ int lsf_restrict_mean(const float *fine, float *coarse, const lsf_grid *fine_gri
                       void *stream);
 int lsf_prolong_repeat(const float *coarse_planar, float *fine_planar, const lsf_grid *fine_grid, void *stream);
 
+/* LINEAR resampling strategy, 3-D only: replaces math_utils/resampling.py:29-80 (upsample2x_linear: 0.75 / 0.25
+ * trilinear prolongation, edge padded) and :83-126 (downsample2x_linear: 4x4x4 window with the reference's literal
+ * weights, edge padded).  `fine_grid` describes the FINE grid (even extents); interleaved channels 1 or 4. */
+int lsf_upsample2x_linear(const float *coarse, float *fine, const lsf_grid *fine_grid, int32_t channels,
+                          void *stream);
+int lsf_downsample2x_linear(const float *fine, float *coarse, const lsf_grid *fine_grid, int32_t channels,
+                            void *stream);
+
 /* ---- a9/a10: one pass of the separable convolution along one axis (0 = x, 1 = y, 2 = z) ------------
  * replaces math_utils/convolution.py:70-111 (convolve_with_kernel) and :114-132 (…_preserve_zeros) pass by
  * pass: out[i] = sum_j k[j]*in[i + n/2 - j], zero padded, accumulated in float64 in tap order, stored

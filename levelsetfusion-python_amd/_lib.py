@@ -90,6 +90,8 @@ PROTOTYPES = {
     "lsf_pack_live_gradient": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp]),
     "lsf_restrict_mean": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp]),
     "lsf_prolong_repeat": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp]),
+    "lsf_upsample2x_linear": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp]),
+    "lsf_downsample2x_linear": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp]),
     "lsf_convolve_axis": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _i32, _i32, _P(ctypes.c_double), _i32,
                                          _P(Gate), _vp]),
     "lsf_hier_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(HierParams), _P(Gate), _vp, _vp]),

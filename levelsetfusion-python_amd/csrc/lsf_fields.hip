@@ -256,6 +256,114 @@ extern "C" int lsf_prolong_repeat(const float* coarse_planar, float* fine_planar
 }
 
 // =====================================================================================================
+//  LINEAR resampling strategy (3-D): math_utils/resampling.py:29-126
+// =====================================================================================================
+// prolongation: out[2m] = 0.25 f[m-1] + 0.75 f[m], out[2m+1] = 0.75 f[m] + 0.25 f[m+1] (edge clamped), applied along
+// z, then y, then x with a float32 rounding after every lerp (oracle.upsample2x_linear)
+struct UpTap {
+    int a, b;      // clamped source indices
+    float wa, wb;  // weights
+};
+
+__device__ inline UpTap up_tap(int o, int n) {
+    UpTap t;
+    const int m = o >> 1;
+    if (o & 1) { t.a = m; t.b = min(m + 1, n - 1); t.wa = 0.75f; t.wb = 0.25f; }
+    else       { t.a = max(m - 1, 0); t.b = m; t.wa = 0.25f; t.wb = 0.75f; }
+    return t;
+}
+
+template <int C>
+__global__ __launch_bounds__(kBlock) void upsample2x_linear_kernel(const float* __restrict__ coarse,
+                                                                   float* __restrict__ fine, Grid gf) {
+    const int cnx = gf.nx / 2, cny = gf.ny / 2, cnz = gf.nz / 2;
+    for_each_voxel(gf, [&](int x, int y, int z) {
+        const UpTap tz = up_tap(z, cnz), ty = up_tap(y, cny), tx = up_tap(x, cnx);
+        const long long o = vidx(gf, x, y, z);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            auto at = [&](int zz, int yy, int xx) { return coarse[(((long long)zz * cny + yy) * cnx + xx) * C + c]; };
+            // z lerp for the four (y, x) source combinations
+            const float v00 = tz.wa * at(tz.a, ty.a, tx.a) + tz.wb * at(tz.b, ty.a, tx.a);
+            const float v01 = tz.wa * at(tz.a, ty.a, tx.b) + tz.wb * at(tz.b, ty.a, tx.b);
+            const float v10 = tz.wa * at(tz.a, ty.b, tx.a) + tz.wb * at(tz.b, ty.b, tx.a);
+            const float v11 = tz.wa * at(tz.a, ty.b, tx.b) + tz.wb * at(tz.b, ty.b, tx.b);
+            const float u0 = ty.wa * v00 + ty.wb * v10;
+            const float u1 = ty.wa * v01 + ty.wb * v11;
+            fine[o * C + c] = tx.wa * u0 + tx.wb * u1;
+        }
+    });
+}
+
+// restriction: 4x4x4 window f[clamp(2t-1) .. clamp(2t+2)], weight by the number of inner coordinates; the reference's
+// weights are its 8-decimal literals (resampling.py:90-109), accumulated in float64
+template <int C>
+__global__ __launch_bounds__(kBlock) void downsample2x_linear_kernel(const float* __restrict__ fine,
+                                                                     float* __restrict__ coarse, Grid gc, int fnx,
+                                                                     int fny, int fnz) {
+    const double w[4] = {0.00195312, 0.00585938, 0.01757812, 0.05273438};
+    for_each_voxel(gc, [&](int x, int y, int z) {
+        const long long o = vidx(gc, x, y, z);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            double acc = 0.0;
+            for (int dz = 0; dz < 4; ++dz) {
+                const int zz = min(max(2 * z - 1 + dz, 0), fnz - 1);
+                for (int dy = 0; dy < 4; ++dy) {
+                    const int yy = min(max(2 * y - 1 + dy, 0), fny - 1);
+                    const long long row = ((long long)zz * fny + yy) * fnx;
+#pragma unroll
+                    for (int dx = 0; dx < 4; ++dx) {
+                        const int xx = min(max(2 * x - 1 + dx, 0), fnx - 1);
+                        const int inner = ((dz == 1 || dz == 2) ? 1 : 0) + ((dy == 1 || dy == 2) ? 1 : 0) +
+                                          ((dx == 1 || dx == 2) ? 1 : 0);
+                        acc += w[inner] * (double)fine[(row + xx) * C + c];
+                    }
+                }
+            }
+            coarse[o * C + c] = (float)acc;
+        }
+    });
+}
+
+extern "C" int lsf_upsample2x_linear(const float* coarse, float* fine, const lsf_grid* fine_grid, int32_t channels,
+                                     void* stream) {
+    if (int e = check_grid(fine_grid)) return e;
+    if (!coarse || !fine || (channels != 1 && channels != 4)) return LSF_ERR_BAD_ARGUMENT;
+    if (fine_grid->dims != 3 || (fine_grid->nx & 1) || (fine_grid->ny & 1) || (fine_grid->nz & 1)) return LSF_ERR_BAD_DIMS;
+    Grid g = make_grid(fine_grid);
+    Tiling t = make_tiling(g);
+    if (t.total == 0) return 0;
+    if (channels == 1)
+        hipLaunchKernelGGL(upsample2x_linear_kernel<1>, dim3(launch_blocks(t.total)), dim3(kBlock), 0,
+                           as_stream(stream), coarse, fine, g);
+    else
+        hipLaunchKernelGGL(upsample2x_linear_kernel<4>, dim3(launch_blocks(t.total)), dim3(kBlock), 0,
+                           as_stream(stream), coarse, fine, g);
+    return launch_status();
+}
+
+extern "C" int lsf_downsample2x_linear(const float* fine, float* coarse, const lsf_grid* fine_grid, int32_t channels,
+                                       void* stream) {
+    if (int e = check_grid(fine_grid)) return e;
+    if (!coarse || !fine || (channels != 1 && channels != 4)) return LSF_ERR_BAD_ARGUMENT;
+    if (fine_grid->dims != 3 || (fine_grid->nx & 1) || (fine_grid->ny & 1) || (fine_grid->nz & 1)) return LSF_ERR_BAD_DIMS;
+    lsf_grid cg = *fine_grid;
+    cg.nx /= 2; cg.ny /= 2; cg.nz /= 2;
+    cg.z_begin = 0; cg.z_end = cg.nz;
+    Grid gc = make_grid(&cg);
+    Tiling t = make_tiling(gc);
+    if (t.total == 0) return 0;
+    if (channels == 1)
+        hipLaunchKernelGGL(downsample2x_linear_kernel<1>, dim3(launch_blocks(t.total)), dim3(kBlock), 0,
+                           as_stream(stream), fine, coarse, gc, fine_grid->nx, fine_grid->ny, fine_grid->nz);
+    else
+        hipLaunchKernelGGL(downsample2x_linear_kernel<4>, dim3(launch_blocks(t.total)), dim3(kBlock), 0,
+                           as_stream(stream), fine, coarse, gc, fine_grid->nx, fine_grid->ny, fine_grid->nz);
+    return launch_status();
+}
+
+// =====================================================================================================
 //  a9/a10  one separable-convolution pass
 // =====================================================================================================
 struct Taps {

@@ -172,6 +172,33 @@ def prolong_repeat(coarse_planar):
     return out
 
 
+def downsample2x_linear(fine, channels):
+    """3-D, fine: z,y,x (channels == 1) or z,y,x,4"""
+    spatial = tuple(fine.shape) if channels == 1 else tuple(fine.shape[:-1])
+    if len(spatial) != 3:
+        raise NotImplementedError("Cases other than 3D not yet implemented")
+    if any(s % 2 for s in spatial):
+        raise ValueError("Each field dimension must be evenly divisible by 2.")
+    grid = make_grid(spatial)
+    out = torch.empty(tuple(s // 2 for s in spatial) + (() if channels == 1 else (channels,)), dtype=torch.float32,
+                      device=fine.device)
+    check(lib.lsf_downsample2x_linear(_ptr(fine, n_voxels(grid) * channels, "fine"), _ptr(out, out.numel(), "coarse"),
+                                      ctypes.byref(grid), channels, stream_ptr()), "lsf_downsample2x_linear")
+    return out
+
+
+def upsample2x_linear(coarse, channels=1):
+    spatial = tuple(coarse.shape) if channels == 1 else tuple(coarse.shape[:-1])
+    if len(spatial) != 3:
+        raise NotImplementedError("Cases other than 3D not yet implemented")
+    fine_spatial = tuple(2 * s for s in spatial)
+    grid = make_grid(fine_spatial)
+    out = torch.empty(fine_spatial + (() if channels == 1 else (channels,)), dtype=torch.float32, device=coarse.device)
+    check(lib.lsf_upsample2x_linear(_ptr(coarse, coarse.numel(), "coarse"), _ptr(out, out.numel(), "fine"),
+                                    ctypes.byref(grid), channels, stream_ptr()), "lsf_upsample2x_linear")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------- a9/a10
 def convolve_axis(src, dst, zero_mask_source, grid, axis, taps, gate=None):
     taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float64))

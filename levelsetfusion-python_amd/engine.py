@@ -64,7 +64,8 @@ class HierarchicalEngine:
     def __init__(self, tikhonov_term_enabled, gradient_kernel_enabled, maximum_chunk_size, rate,
                  maximum_iteration_count, maximum_warp_update_threshold, data_term_amplifier, tikhonov_strength,
                  kernel, compute_energy=False, check_interval=8, collect_reports=False, comm=None,
-                 collect_iteration_data=False):
+                 collect_iteration_data=False, linear_resampling=False):
+        self.linear_resampling = linear_resampling  # ResamplingStrategy.LINEAR (3-D): math_utils/resampling.py
         self.collect_reports = collect_reports
         self.collect_iteration_data = collect_iteration_data  # telemetry: per-iteration warp / gradient snapshots
         self.iteration_data = []
@@ -104,12 +105,15 @@ class HierarchicalEngine:
             n_levels = pyramid_level_count(live.shape, self.maximum_chunk_size)
             canon_levels = [canonical]
             packed_levels = [dev.pack_live_gradient(live)]
+            restrict = dev.downsample2x_linear if self.linear_resampling else dev.restrict_mean
             for _ in range(1, n_levels):
-                canon_levels.append(dev.restrict_mean(canon_levels[-1], 1))
-                packed_levels.append(dev.restrict_mean(packed_levels[-1], 4))
+                canon_levels.append(restrict(canon_levels[-1], 1))
+                packed_levels.append(restrict(packed_levels[-1], 4))
             canon_levels.reverse()
             packed_levels.reverse()
             return canon_levels, packed_levels, [None] * n_levels
+        if self.linear_resampling:
+            raise NotImplementedError("ResamplingStrategy.LINEAR is not available for z-slab runs")
         # z-slab: every level keeps `halo` neighbour slices; a level's owned slices are the restriction of the finer
         # level's owned slices (slab boundaries are multiples of 2^levels), its halos come from one exchange per level
         L0 = self.comm.layout
@@ -163,7 +167,10 @@ class HierarchicalEngine:
                 warp = torch.zeros((dims,) + tuple(canon_l.shape), dtype=torch.float32, device=live.device)
             self.optimize_level(canon_l, packed_l, warp, comm_l)
             if level != len(canon_levels) - 1:
-                fine = dev.prolong_repeat(warp)
+                if self.linear_resampling:
+                    fine = torch.stack([dev.upsample2x_linear(warp[c].contiguous()) for c in range(dims)])
+                else:
+                    fine = dev.prolong_repeat(warp)
                 if comm_l is not None:  # keep [owned + halo] of the finer level's layout
                     lo = comm_l.layout.halo_lo
                     fine = fine[:, lo:lo + comms[level + 1].layout.nz_local].contiguous()

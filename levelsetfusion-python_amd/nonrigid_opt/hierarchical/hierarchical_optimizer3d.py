@@ -12,11 +12,12 @@ class HierarchicalOptimizer3d(_HierarchicalOptimizerBase):
 
     class ResamplingStrategy(Enum):
         NEAREST_AND_AVERAGE = 0   # 2x2x2 mean restrict, repeat prolong (the Python reference's only strategy)
-        LINEAR = 1                # math_utils/resampling.py prototype -- not wired into the optimizer yet
+        LINEAR = 1                # math_utils/resampling.py: 4x4x4 [1,3,3,1]/8 restrict, 0.75/0.25 trilinear prolong
 
     def __init__(self, *args, resampling_strategy=None, **kwargs):
-        super().__init__(*args, **kwargs)
         strategy = resampling_strategy or HierarchicalOptimizer3d.ResamplingStrategy.NEAREST_AND_AVERAGE
-        if strategy != HierarchicalOptimizer3d.ResamplingStrategy.NEAREST_AND_AVERAGE:
-            raise NotImplementedError("ResamplingStrategy.LINEAR is not available in this build")
+        if not isinstance(strategy, HierarchicalOptimizer3d.ResamplingStrategy):
+            raise ValueError("resampling_strategy must be a HierarchicalOptimizer3d.ResamplingStrategy")
+        super().__init__(*args, linear_resampling=strategy == HierarchicalOptimizer3d.ResamplingStrategy.LINEAR,
+                         **kwargs)
         self.resampling_strategy = strategy

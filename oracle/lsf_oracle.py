@@ -177,12 +177,12 @@ def pyramid_level_count(shape, maximum_chunk_size):
     return p + 1
 
 
-def pyramid(field, maximum_chunk_size=8):
-    """levels, coarsest first (pyramid.py:45-56)."""
+def pyramid(field, maximum_chunk_size=8, linear=False):
+    """levels, coarsest first (pyramid.py:45-56); linear=True: ResamplingStrategy.LINEAR restriction (3-D)."""
     n = pyramid_level_count(field.shape, maximum_chunk_size)
     levels = [np.array(field, dtype=F32, copy=True)]
     for _ in range(1, n):
-        levels.append(restrict_mean(levels[-1]))
+        levels.append(downsample2x_linear(levels[-1]).astype(F32) if linear else restrict_mean(levels[-1]))
     levels.reverse()
     return levels
 
@@ -306,7 +306,8 @@ def generate_1d_sobolev_kernel(size=7, strength=0.1, precision=np.float32):
 class HierarchicalOracle:
     def __init__(self, tikhonov_term_enabled=True, gradient_kernel_enabled=True, maximum_chunk_size=8, rate=0.1,
                  maximum_iteration_count=100, maximum_warp_update_threshold=0.001, data_term_amplifier=1.0,
-                 tikhonov_strength=0.2, kernel=None):
+                 tikhonov_strength=0.2, kernel=None, linear_resampling=False):
+        self.linear_resampling = linear_resampling
         self.maximum_chunk_size = maximum_chunk_size
         self.rate = rate
         self.data_term_amplifier = data_term_amplifier
@@ -359,9 +360,10 @@ class HierarchicalOracle:
         live_field = np.asarray(live_field, dtype=F32)
         d = live_field.ndim
         grads = gradient(live_field)  # at full resolution, THEN averaged (hierarchical_optimizer2d.py:126-131)
-        canonical_pyr = pyramid(canonical_field, self.maximum_chunk_size)
-        live_pyr = pyramid(live_field, self.maximum_chunk_size)
-        grad_pyrs = [pyramid(g, self.maximum_chunk_size) for g in grads]
+        lin = self.linear_resampling
+        canonical_pyr = pyramid(canonical_field, self.maximum_chunk_size, lin)
+        live_pyr = pyramid(live_field, self.maximum_chunk_size, lin)
+        grad_pyrs = [pyramid(g, self.maximum_chunk_size, lin) for g in grads]
         self.per_level_iteration_counts = []
         self.per_level_max_updates = []
         warp = None
@@ -372,7 +374,10 @@ class HierarchicalOracle:
             warp = self.optimize_level(level, canonical_pyr[level], live_pyr[level],
                                        [gp[level] for gp in grad_pyrs], warp)
             if level != n_levels - 1:
-                warp = prolong_repeat(warp)
+                if lin:
+                    warp = np.stack([upsample2x_linear(np.ascontiguousarray(warp[..., c])) for c in range(d)], axis=-1)
+                else:
+                    warp = prolong_repeat(warp)
         return warp
 
 
@@ -870,3 +875,48 @@ def tsdf_ewa(depth_image, intrinsic_matrix, depth_unit_ratio, field_shape, metho
                 continue
             field[idx] = value_sum / weights_sum
     return field
+
+
+# =====================================================================================================
+#  LINEAR resampling strategy, 3-D  (math_utils/resampling.py:29-126; known answers tests/test_math.py:54-221)
+# =====================================================================================================
+# the reference's 4x4x4 restriction weights are typed to 8 decimals (resampling.py:90-109), i.e. NOT exactly the
+# outer product of [1,3,3,1]/8; weight = DOWNSAMPLE_WEIGHTS[number of inner (index 1 or 2) coordinates]
+DOWNSAMPLE_WEIGHTS = (0.00195312, 0.00585938, 0.01757812, 0.05273438)
+
+
+def upsample2x_linear(field):
+    """2x trilinear prolongation with edge padding: out[2m] = 0.25 f[m-1] + 0.75 f[m], out[2m+1] = 0.75 f[m] + 0.25
+    f[m+1] along z, then y, then x, each lerp  0.75*a + 0.25*b  rounded in the field's dtype (resampling.py:29-80)."""
+    out = np.asarray(field)
+    dt = out.dtype if out.dtype in (np.float32, np.float64) else np.float64
+    out = out.astype(dt)
+    w75, w25 = dt.type(0.75), dt.type(0.25)
+    for axis in range(3):
+        f = np.moveaxis(out, axis, 0)
+        prev = np.concatenate((f[:1], f[:-1]), axis=0)
+        nxt = np.concatenate((f[1:], f[-1:]), axis=0)
+        res = np.empty((2 * f.shape[0],) + f.shape[1:], dtype=dt)
+        # reference: zv000 = 0.75 * v000 + 0.25 * v100 (the 0.75 product first in BOTH forms)
+        res[0::2] = (w25 * prev).astype(dt) + (w75 * f).astype(dt)
+        res[1::2] = (w75 * f).astype(dt) + (w25 * nxt).astype(dt)
+        out = np.moveaxis(res, 0, axis)
+    return np.ascontiguousarray(out)
+
+
+def downsample2x_linear(field):
+    """2x restriction: out[t] = sum over the 4x4x4 window f[clamp(2t-1) .. clamp(2t+2)] of weight * value, float64
+    (resampling.py:83-126)"""
+    f = np.asarray(field)
+    if any(s % 2 for s in f.shape):
+        raise ValueError("Each field dimension must be evenly divisible by 2.")
+    p = np.pad(f, 1, mode="edge").astype(np.float64)
+    nz, ny, nx = (s // 2 for s in f.shape)
+    out = np.zeros((nz, ny, nx), dtype=np.float64)
+    inner = (0, 1, 1, 0)
+    for dz in range(4):
+        for dy in range(4):
+            for dx in range(4):
+                wgt = DOWNSAMPLE_WEIGHTS[inner[dz] + inner[dy] + inner[dx]]
+                out += wgt * p[dz:dz + 2 * nz:2, dy:dy + 2 * ny:2, dx:dx + 2 * nx:2]
+    return out
