@@ -86,6 +86,13 @@ const char *lsf_target_arch(void);
 int lsf_deinterleave(const float *interleaved, float *planar, int64_t n_voxels, int32_t channels, void *stream);
 int lsf_interleave(const float *planar, float *interleaved, int64_t n_voxels, int32_t channels, void *stream);
 
+/* ---- z-slab halo staging (new design; the reference has no distributed code) -----------------
+ * Copies `halo` consecutive slices starting at z_lo / z_hi of a scalar field [z][y][x] (channel 0, may be NULL) and of
+ * the `planes` planes of a planar vector field (channels 1.., may be NULL) into (unpack = 0) or out of (unpack = 1) the
+ * contiguous messages msg_lo / msg_hi (each [1 + planes][halo][ny][nx] floats; NULL = no neighbour on that side). */
+int lsf_halo_copy(float *scalar, float *planar, float *msg_lo, float *msg_hi, const lsf_grid *grid, int32_t planes,
+                  int32_t halo, int32_t z_lo, int32_t z_hi, int32_t unpack, void *stream);
+
 /* ---- a1/a2: resample a scalar field under a warp ---------------------------------------------------
  * replaces nonrigid_opt/field_warping.py:67-85 (warp_field, oob_value = 1) and :88-109
  * (warp_field_replacement, oob_value = replacement) with utils/sampling.py:139-175,222-263. */

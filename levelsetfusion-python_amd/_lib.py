@@ -85,6 +85,7 @@ PROTOTYPES = {
     "lsf_target_arch": (ctypes.c_char_p, []),
     "lsf_deinterleave": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "lsf_interleave": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "lsf_halo_copy": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _i32, _i32, _i32, _i32, _i32, _vp]),
     "lsf_warp_field": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp]),
     "lsf_warp_field_advanced": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _i32, _vp]),
     "lsf_pack_live_gradient": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp]),

@@ -45,6 +45,48 @@ extern "C" int lsf_interleave(const float* planar, float* interleaved, int64_t n
 }
 
 // =====================================================================================================
+//  slab halo staging: pack the boundary slices of a scalar field + a planar vector field into one contiguous message
+//  per neighbour (and unpack received ones into the halo slices) -- one launch per direction instead of 4-8 copies
+// =====================================================================================================
+// message layout per side: [channel][h][ny][nx], channel 0 = scalar field, 1..planes = vector planes.
+// side 0 = lower neighbour, side 1 = upper neighbour; z0[side] = first slice to copy from / into.
+__global__ __launch_bounds__(kBlock) void halo_copy_kernel(float* __restrict__ scalar, float* __restrict__ planar,
+                                                           float* __restrict__ msg_lo, float* __restrict__ msg_hi,
+                                                           long long plane, int slice, int h, int planes, int z_lo,
+                                                           int z_hi, int unpack) {
+    const int side = blockIdx.z;
+    float* msg = side == 0 ? msg_lo : msg_hi;
+    if (!msg) return;
+    const int z0 = side == 0 ? z_lo : z_hi;
+    const int channel = blockIdx.y;  // 0 .. planes
+    const long long per_channel = (long long)h * slice;
+    float* field = channel == 0 ? scalar : planar + (long long)(channel - 1) * plane;
+    if (!field) return;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < per_channel;
+         i += (long long)gridDim.x * kBlock) {
+        const long long f = (long long)z0 * slice + i;  // h consecutive slices are contiguous
+        if (unpack) field[f] = msg[channel * per_channel + i];
+        else msg[channel * per_channel + i] = field[f];
+    }
+}
+
+extern "C" int lsf_halo_copy(float* scalar, float* planar, float* msg_lo, float* msg_hi, const lsf_grid* grid,
+                             int32_t planes, int32_t halo, int32_t z_lo, int32_t z_hi, int32_t unpack, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if ((!scalar && !planar) || (!msg_lo && !msg_hi) || halo < 1 || planes < 0 || planes > 3)
+        return LSF_ERR_BAD_ARGUMENT;
+    if ((msg_lo && (z_lo < 0 || z_lo + halo > grid->nz)) || (msg_hi && (z_hi < 0 || z_hi + halo > grid->nz)))
+        return LSF_ERR_BAD_ARGUMENT;
+    const int slice = grid->ny * grid->nx;
+    const long long per_channel = (long long)halo * slice;
+    unsigned bx = (unsigned)((per_channel + kBlock - 1) / kBlock);
+    if (bx > 512) bx = 512;
+    hipLaunchKernelGGL(halo_copy_kernel, dim3(bx, planes + 1, 2), dim3(kBlock), 0, as_stream(stream), scalar, planar,
+                       msg_lo, msg_hi, (long long)grid->nz * slice, slice, halo, planes, z_lo, z_hi, unpack);
+    return launch_status();
+}
+
+// =====================================================================================================
 //  a1/a2  warp_field / warp_field_replacement
 // =====================================================================================================
 template <int D>

@@ -115,6 +115,21 @@ def interleave(planar):
     return out
 
 
+def halo_copy(scalar, planar, msg_lo, msg_hi, halo, z_lo, z_hi, unpack):
+    """pack (unpack=False) / unpack the halo messages of a scalar field [z,y,x] and a planar vector field [c,z,y,x]"""
+    ref = scalar if scalar is not None else planar[0]
+    grid = make_grid(ref.shape)
+    planes = 0 if planar is None else planar.shape[0]
+    n = n_voxels(grid)
+    per_msg = (1 + planes) * halo * grid.ny * grid.nx
+    check(lib.lsf_halo_copy(_ptr(scalar, n, "scalar", allow_none=True),
+                            _ptr(planar, n * planes, "planar", allow_none=True) if planar is not None
+                            else ctypes.c_void_p(0),
+                            _ptr(msg_lo, per_msg, "msg_lo", allow_none=True),
+                            _ptr(msg_hi, per_msg, "msg_hi", allow_none=True), ctypes.byref(grid), planes, int(halo),
+                            int(z_lo), int(z_hi), int(bool(unpack)), stream_ptr()), "lsf_halo_copy")
+
+
 # ---------------------------------------------------------------------------------------------- a1-a3
 def warp_field(field, warp_planar, oob_value, grid=None, out=None):
     grid = grid or make_grid(field.shape)

@@ -361,12 +361,11 @@ class SlavchevaEngine:
                         dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out,
                                                 None, g, self.params, gate, records, i)
                 main = torch.cuda.current_stream()
-                boundary_done = torch.cuda.Event()
+                boundary_done, halos_done = self._events[i % 2]
                 boundary_done.record(main)
                 with torch.cuda.stream(self._comm_stream):
                     self._comm_stream.wait_event(boundary_done)
-                    self.comm.exchange_halos([live_out, warp_out])
-                    halos_done = torch.cuda.Event()
+                    self.comm.exchange_live_and_warp(live_out, warp_out)
                     halos_done.record(self._comm_stream)
                 if interior[1] > interior[0]:
                     g = dev.make_grid(live_in.shape, interior[0], interior[1], grid.z_global_offset)
@@ -392,7 +391,7 @@ class SlavchevaEngine:
                                         records, i)
             self._last_g = src
             if slab:
-                self.comm.exchange_halos([live_out, warp_out])
+                self.comm.exchange_live_and_warp(live_out, warp_out)
         if slab and i + 1 < limit and i + 1 >= self.min_iterations:
             self.comm.reduce_max(records, i)  # the next iteration's gate tests this record: make it global now
 
@@ -419,6 +418,7 @@ class SlavchevaEngine:
         self._last_g = None
         if slab and not hasattr(self, "_comm_stream"):
             self._comm_stream = torch.cuda.Stream(device=live.device)
+            self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
         # with min_iterations == 0 the reference never enters its loop (max_warp starts at +inf, :354,:360-362)
         limit = 0 if self.min_iterations == 0 else max(self.max_iterations, self.min_iterations)
         it, n_exec = 0, 0

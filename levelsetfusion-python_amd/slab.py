@@ -107,6 +107,33 @@ class SlabComm:
                 dst.copy_(recv[k:k + c] if t.dim() == 4 else recv[k])
                 k += c
 
+    def exchange_live_and_warp(self, live, warp_planar):
+        """the per-iteration exchange of the Slavcheva engine: one device kernel packs the boundary slices of the live
+        field and the warp for BOTH neighbours, one batch of point-to-point operations moves them, one kernel unpacks
+        into the halos (device tensors, width = the layout's halo)"""
+        L = self.layout
+        if not self.active or L.halo == 0:
+            return
+        if self.stage_through_host or not live.is_cuda:
+            return self.exchange_halos([live, warp_planar])
+        from . import device as dev
+        h = L.halo
+        shape = (1 + warp_planar.shape[0], h) + tuple(live.shape[-2:])
+        lo = self._staging(("lo", shape, live.dtype), shape, live) if L.rank > 0 else (None, None)
+        hi = self._staging(("hi", shape, live.dtype), shape, live) if L.rank < L.world - 1 else (None, None)
+        dev.halo_copy(live, warp_planar, lo[0], hi[0], h, L.z_begin, L.z_end - h, unpack=False)
+        ops = []
+        if lo[0] is not None:
+            ops += [dist.P2POp(dist.isend, lo[0], L.rank - 1, self.group),
+                    dist.P2POp(dist.irecv, lo[1], L.rank - 1, self.group)]
+        if hi[0] is not None:
+            ops += [dist.P2POp(dist.isend, hi[0], L.rank + 1, self.group),
+                    dist.P2POp(dist.irecv, hi[1], L.rank + 1, self.group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        dev.halo_copy(live, warp_planar, lo[1], hi[1], h, L.z_begin - h if lo[1] is not None else 0, L.z_end,
+                      unpack=True)
+
     def reduce_scalar_max(self, value):
         """in-place MAX all-reduce of a small float tensor (slab guards)"""
         if not self.active:

@@ -144,3 +144,30 @@ def test_two_slab_ranks_hierarchical_equal_whole_volume(tmp_path, config):
         assert np.array_equal(p["last_max"], np.float32([m[-1] for m in ref.get_per_level_maximum_updates()]))
     if config == "data_threshold":
         assert any(1 < c < 40 for c in ref.get_per_level_iteration_counts())
+
+
+def test_halo_copy_kernel_matches_slicing():
+    """lsf_halo_copy (the RCCL path's pack / unpack kernel) == the tensor slicing the gloo path uses"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import levelsetfusion_python_amd  # noqa: F401
+    from levelsetfusion_python_amd import device as dev
+    g = torch.Generator("cuda").manual_seed(7)
+    nz, ny, nx, h = 12, 10, 70, 3
+    live = torch.randn((nz, ny, nx), device="cuda", generator=g)
+    warp = torch.randn((3, nz, ny, nx), device="cuda", generator=g)
+    lo = torch.zeros((4, h, ny, nx), device="cuda")
+    hi = torch.zeros_like(lo)
+    z_lo, z_hi = 3, nz - 3 - h
+    dev.halo_copy(live, warp, lo, hi, h, z_lo, z_hi, unpack=False)
+    assert torch.equal(lo, torch.cat([live[z_lo:z_lo + h][None], warp[:, z_lo:z_lo + h]]))
+    assert torch.equal(hi, torch.cat([live[z_hi:z_hi + h][None], warp[:, z_hi:z_hi + h]]))
+    live2, warp2 = live.clone(), warp.clone()
+    dev.halo_copy(live2, warp2, hi, lo, h, 0, nz - h, unpack=True)  # swapped messages into the end slices
+    assert torch.equal(live2[:h], hi[0]) and torch.equal(warp2[:, :h], hi[1:])
+    assert torch.equal(live2[nz - h:], lo[0]) and torch.equal(warp2[:, nz - h:], lo[1:])
+    assert torch.equal(live2[h:nz - h], live[h:nz - h])
+    # one-sided (end ranks): the missing neighbour's message is None and nothing else is touched
+    only = torch.zeros_like(lo)
+    dev.halo_copy(live, warp, None, only, h, 0, z_hi, unpack=False)
+    assert torch.equal(only, hi)
