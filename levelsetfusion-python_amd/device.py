@@ -271,6 +271,33 @@ def slavcheva_update_rewarp(live, canonical, g, warp_out, live_out, grid, params
           "lsf_slavcheva_update_rewarp")
 
 
+class IterationLauncher:
+    """Pre-validated launch arguments for the per-iteration kernels of one level: tensors are checked ONCE, their
+    device pointers, the grid, the parameter block and one gate / record pointer per iteration slot are materialised as
+    ctypes objects up front, so that enqueueing an iteration is a bare foreign call (the 2-D levels and coarse 3-D levels
+    are launch-bound: ~4 us of kernel against ~15 us of per-call Python otherwise)."""
+
+    def __init__(self, grid, records, gate_mode, gate_a, gate_b=0.0):
+        self.grid = grid
+        self.grid_ref = ctypes.byref(grid)
+        self.records = records
+        n = records.shape[0]
+        base = records.data_ptr()
+        self.record_ptrs = [ctypes.c_void_p(base + i * _lib.RECORD_BYTES) for i in range(n)]
+        self.gates = [Gate(base + i * _lib.RECORD_BYTES, int(gate_mode), float(gate_a), float(gate_b))
+                      for i in range(n)]
+        self.gate_refs = [ctypes.byref(g) for g in self.gates]
+        self._keep = []
+
+    def pointer(self, t, numel, name, allow_none=False):
+        p = _ptr(t, numel, name, allow_none=allow_none)
+        self._keep.append(t)
+        return p
+
+    def gate_ref(self, prev_index):
+        return None if prev_index is None or prev_index < 0 else self.gate_refs[prev_index]
+
+
 # ---------------------------------------------------------------------------------------------- a20
 def warp_statistics(warp_planar, canonical, live, lower_threshold, grid=None):
     grid = grid or make_grid(live.shape)

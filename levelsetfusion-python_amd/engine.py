@@ -5,6 +5,8 @@ All state lives in torch ROCm tensors; every per-voxel operation is a hand-writt
 the C ABI (device.py -> liblsf_hip.so).  The host loop only enqueues launches and, every `check_interval`
 iterations, reads back the tiny iteration records to learn whether the device-side convergence gate has closed.
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -199,6 +201,16 @@ class HierarchicalEngine:
         if slab and L.halo < max(reach, 2):
             raise ValueError("slab halo of %d slices is too narrow: this configuration needs >= %d"
                              % (L.halo, max(reach, 2)))
+        # pre-validated launch arguments of the hot kernel (see device.IterationLauncher)
+        fast = dev.IterationLauncher(grid, records, _lib.GATE_HIERARCHICAL, thr)
+        n_vox_local = dev.n_voxels(grid)
+        p_packed = fast.pointer(packed, 4 * n_vox_local, "packed live")
+        p_canon = fast.pointer(canonical, n_vox_local, "canonical")
+        p_warp = fast.pointer(warp, n_vox_local * dims, "warp")
+        p_bufs = [fast.pointer(b, n_vox_local * dims, "gradient buffer") for b in bufs]
+        p_report = fast.pointer(report_g, n_vox_local * dims, "gradient", allow_none=True)
+        params_ref = ctypes.byref(params)
+        lib_hier = _lib.lib.lsf_hier_iteration
         final = 0  # buffer that holds the previous iteration's final gradient (zeros at level start, :179)
         finals = []
         snapshots = []
@@ -237,11 +249,14 @@ class HierarchicalEngine:
                     dev.hier_update(bufs[final], warp, grid, self.rate, gate, records, i)
                 elif tik:
                     out = 1 - final
-                    dev.hier_iteration(packed, canonical, warp, bufs[final], bufs[out], grid, params, gate, records,
-                                       i)
+                    _lib.check(lib_hier(p_packed, p_canon, p_warp, p_bufs[final], p_bufs[out], fast.grid_ref,
+                                        params_ref, fast.gate_ref(i - 1), fast.record_ptrs[i], dev.stream_ptr()),
+                               "lsf_hier_iteration")
                     final = out
                 else:
-                    dev.hier_iteration(packed, canonical, warp, None, report_g, grid, params, gate, records, i)
+                    _lib.check(lib_hier(p_packed, p_canon, p_warp, None, p_report, fast.grid_ref, params_ref,
+                                        fast.gate_ref(i - 1), fast.record_ptrs[i], dev.stream_ptr()),
+                               "lsf_hier_iteration")
                 finals.append(final)
                 if self.collect_iteration_data:
                     snapshots[-1][0] = warp.clone()
@@ -346,8 +361,13 @@ class SlavchevaEngine:
         slab = self._slab()
         if not self.sobolev:
             if not slab:
-                dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None,
-                                        grid, self.params, gate, records, i)
+                f = self._fast
+                _lib.check(_lib.lib.lsf_slavcheva_iteration(_lib.STAGE_FUSED, f.p_live[i % 2], f.p_canon,
+                                                            f.p_warp[i % 2], f.p_warp[(i + 1) % 2],
+                                                            f.p_live[(i + 1) % 2], None, f.grid_ref, f.params_ref,
+                                                            None if i < self.min_iterations else f.gate_ref(i - 1),
+                                                            f.record_ptrs[i], dev.stream_ptr()),
+                           "lsf_slavcheva_iteration")
             else:
                 # boundary slices first, then the halo exchange on a second stream WHILE the interior runs
                 L = self.comm.layout
@@ -416,6 +436,14 @@ class SlavchevaEngine:
             lives[1].copy_(live)  # halo slices of both buffers start out valid
         gbufs = [torch.zeros_like(warps[0]) for _ in range(3)] if self.sobolev else None
         self._last_g = None
+        if not slab and not self.sobolev:  # pre-validated launch arguments of the fused kernel
+            n = dev.n_voxels(grid)
+            f = dev.IterationLauncher(grid, records, _lib.GATE_SLAVCHEVA, self.lo, self.hi)
+            f.p_live = [f.pointer(t, n, "live") for t in lives]
+            f.p_warp = [f.pointer(t, n * dims, "warp") for t in warps]
+            f.p_canon = f.pointer(canonical, n, "canonical")
+            f.params_ref = ctypes.byref(self.params)
+            self._fast = f
         if slab and not hasattr(self, "_comm_stream"):
             self._comm_stream = torch.cuda.Stream(device=live.device)
             self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
