@@ -65,8 +65,11 @@ class HierarchicalEngine:
 
     def __init__(self, tikhonov_term_enabled, gradient_kernel_enabled, maximum_chunk_size, rate,
                  maximum_iteration_count, maximum_warp_update_threshold, data_term_amplifier, tikhonov_strength,
-                 kernel, compute_energy=False, check_interval=8, collect_reports=False, comm=None,
-                 collect_iteration_data=False, linear_resampling=False):
+                 kernel, compute_energy=False, check_interval=32, collect_reports=False, comm=None,
+                 collect_iteration_data=False, linear_resampling=False, use_graphs=True, graph_max_voxels=1 << 20):
+        self.use_graphs = use_graphs                # HIP-graph replay for launch-bound levels
+        self.graph_max_voxels = graph_max_voxels    # ... i.e. levels of at most this many voxels
+        self._graphs = {}
         self.linear_resampling = linear_resampling  # ResamplingStrategy.LINEAR (3-D): math_utils/resampling.py
         self.collect_reports = collect_reports
         self.collect_iteration_data = collect_iteration_data  # telemetry: per-iteration warp / gradient snapshots
@@ -179,40 +182,118 @@ class HierarchicalEngine:
                 warp = fine
         return warp
 
-    def optimize_level(self, canonical, packed, warp, comm=None):
+    # ------------------------------------------------------------------------------------------------
+    # One level.  Gradient buffers: F[0], F[1] alternate as "previous gradient" / "this iteration's final gradient"
+    # (iteration i reads F[i % 2], leaves its result in F[(i + 1) % 2]); with a gradient kernel the raw gradient and the
+    # intermediate filter passes ping-pong between two scratch buffers and the LAST pass writes F[(i + 1) % 2].  The
+    # buffer roles therefore repeat with period 2, which is what lets a batch of iterations be captured ONCE as a HIP
+    # graph and replayed (launch-bound levels: 2-D fields, coarse 3-D levels).
+    class _Level:
+        pass
+
+    def _make_level(self, canonical, packed, warp, grid, full_grid, n_records):
+        lv = HierarchicalEngine._Level()
         dims = canonical.dim()
+        tik, ker = self.tikhonov_term_enabled, self.gradient_kernel_enabled
+        lv.canonical, lv.packed, lv.warp, lv.grid, lv.full_grid, lv.dims = canonical, packed, warp, grid, full_grid, dims
+        lv.params = _lib.HierParams(float(self.data_term_amplifier), float(self.tikhonov_strength), float(self.rate),
+                                    int(tik), int(not ker), int(self.compute_energy))
+        lv.F = [torch.zeros_like(warp) for _ in range(2)] if (tik or ker) else []
+        lv.S = [torch.zeros_like(warp) for _ in range(2)] if ker else []
+        lv.report_g = torch.zeros_like(warp) if (self.collect_reports and not lv.F) else None
+        lv.records = dev.new_records(n_records, canonical.device)
+        f = dev.IterationLauncher(grid, lv.records, _lib.GATE_HIERARCHICAL, float(self.maximum_warp_update_threshold))
+        n = dev.n_voxels(grid)
+        lv.p_packed = f.pointer(packed, 4 * n, "packed live")
+        lv.p_canon = f.pointer(canonical, n, "canonical")
+        lv.p_warp = f.pointer(warp, n * dims, "warp")
+        lv.p_F = [f.pointer(t, n * dims, "gradient buffer") for t in lv.F]
+        lv.p_S = [f.pointer(t, n * dims, "scratch buffer") for t in lv.S]
+        lv.p_report = f.pointer(lv.report_g, n * dims, "gradient", allow_none=True)
+        lv.params_ref = ctypes.byref(lv.params)
+        lv.launcher = f
+        return lv
+
+    def _enqueue(self, lv, rec_idx, prev_idx, parity, comm=None):
+        """one iteration: record slot rec_idx, gated on record prev_idx (None: always runs), buffer parity 0/1"""
+        f = lv.launcher
+        tik, ker = self.tikhonov_term_enabled, self.gradient_kernel_enabled
+        gate_ref = f.gate_ref(prev_idx)
+        gate = None if prev_idx is None or prev_idx < 0 else f.gates[prev_idx]
+        lib_hier = _lib.lib.lsf_hier_iteration
+        if ker:
+            prev, out = (lv.p_F[parity] if tik else None), lv.F[1 - parity]
+            _lib.check(lib_hier(lv.p_packed, lv.p_canon, lv.p_warp, prev, lv.p_S[0], f.grid_ref, lv.params_ref, gate_ref,
+                                f.record_ptrs[rec_idx], dev.stream_ptr()), "lsf_hier_iteration")
+            slab = comm is not None and comm.active
+            if slab:  # the z pass reads taps/2 slices of the (x,y)-filtered field on either side
+                comm.exchange_halos([lv.S[0]], width=len(self.gradient_kernel) // 2)
+            axes = _conv_axis_order(lv.dims)
+            src = lv.S[0]
+            for k, axis in enumerate(axes):
+                dst = out if k == len(axes) - 1 else lv.S[(k + 1) % 2]
+                dev.convolve_axis(src, dst, None, lv.grid if axis == 2 else lv.full_grid, axis, self.gradient_kernel,
+                                  gate)
+                src = dst
+            dev.hier_update(out, lv.warp, lv.grid, self.rate, gate, lv.records, rec_idx)
+        elif tik:
+            _lib.check(lib_hier(lv.p_packed, lv.p_canon, lv.p_warp, lv.p_F[parity], lv.p_F[1 - parity], f.grid_ref,
+                                lv.params_ref, gate_ref, f.record_ptrs[rec_idx], dev.stream_ptr()),
+                       "lsf_hier_iteration")
+        else:
+            _lib.check(lib_hier(lv.p_packed, lv.p_canon, lv.p_warp, None, lv.p_report, f.grid_ref, lv.params_ref,
+                                gate_ref, f.record_ptrs[rec_idx], dev.stream_ptr()), "lsf_hier_iteration")
+
+    def _final_gradient(self, lv, n_exec):
+        if lv.F and n_exec:
+            return lv.F[n_exec % 2]  # iteration n_exec - 1 wrote F[((n_exec - 1) + 1) % 2]
+        return lv.report_g
+
+    def _finish_level(self, lv, n_exec, dec, slab_layout=None):
+        thr = float(self.maximum_warp_update_threshold)
+        n_vox = dev.n_voxels(lv.grid) if slab_layout is None else slab_layout.nz_global * lv.grid.ny * lv.grid.nx
+        res = LevelResult(n_exec, [float(v) for v in dec["max_value"][:n_exec]],
+                          [int(v) for v in dec["argmax"][:n_exec]],
+                          [float(v) for v in dec["data_energy"][:n_exec]], n_vox)
+        res.iteration_limit_reached = n_exec >= self.maximum_iteration_count
+        self.level_results.append(res)
+        self.last_gradient = self._final_gradient(lv, n_exec)
+        if self.collect_reports and slab_layout is None:
+            # per-level ConvergenceReport (cpp get_per_level_convergence_reports, run_hierarchical_optimizer3d.py:104):
+            # statistics of the last iteration's update field and of |canonical - resampled live| at this level
+            from .convergence_report import (ConvergenceReport, build_tsdf_difference_statistics,
+                                             build_warp_delta_statistics)
+            resampled = dev.warp_field(lv.packed[..., 0].contiguous(), lv.warp, 1.0)
+            g_final = self.last_gradient if self.last_gradient is not None else torch.zeros_like(lv.warp)
+            res.report = ConvergenceReport(n_exec, res.iteration_limit_reached,
+                                           build_warp_delta_statistics(g_final, lv.canonical, resampled, thr,
+                                                                       float("inf")),
+                                           build_tsdf_difference_statistics(lv.canonical, resampled))
+
+    OPEN_RECORD = 0x7F800000FFFFFFFF  # packed max = +inf: "previous iteration has not converged" for the gate
+
+    def optimize_level(self, canonical, packed, warp, comm=None):
         slab = comm is not None and comm.active
+        max_it = self.maximum_iteration_count
+        n_vox = canonical.numel()
+        if (self.use_graphs and not slab and not self.collect_iteration_data and max_it >= 4
+                and self.check_interval >= 2 and n_vox <= self.graph_max_voxels):
+            return self._optimize_level_graph(canonical, packed, warp)
         if slab:
             L = comm.layout
             grid = dev.make_grid(canonical.shape, L.z_begin, L.z_end, L.z_global_offset)
             full_grid = dev.make_grid(canonical.shape, 0, L.nz_local, L.z_global_offset)
+            reach = len(self.gradient_kernel) // 2 if self.gradient_kernel_enabled else 0
+            if L.halo < max(reach, 2):
+                raise ValueError("slab halo of %d slices is too narrow: this configuration needs >= %d"
+                                 % (L.halo, max(reach, 2)))
         else:
+            L = None
             grid = full_grid = dev.make_grid(canonical.shape)
-        max_it = self.maximum_iteration_count
         thr = float(self.maximum_warp_update_threshold)
-        records = dev.new_records(max(max_it, 1), canonical.device)
-        tik, ker = self.tikhonov_term_enabled, self.gradient_kernel_enabled
-        params = _lib.HierParams(float(self.data_term_amplifier), float(self.tikhonov_strength), float(self.rate),
-                                 int(tik), int(not ker), int(self.compute_energy))
-        n_buf = 3 if ker else (2 if tik else 0)
-        bufs = [torch.zeros_like(warp) for _ in range(n_buf)]
-        report_g = torch.zeros_like(warp) if (self.collect_reports and n_buf == 0) else None
-        reach = len(self.gradient_kernel) // 2 if ker else 0
-        if slab and L.halo < max(reach, 2):
-            raise ValueError("slab halo of %d slices is too narrow: this configuration needs >= %d"
-                             % (L.halo, max(reach, 2)))
-        # pre-validated launch arguments of the hot kernel (see device.IterationLauncher)
-        fast = dev.IterationLauncher(grid, records, _lib.GATE_HIERARCHICAL, thr)
-        n_vox_local = dev.n_voxels(grid)
-        p_packed = fast.pointer(packed, 4 * n_vox_local, "packed live")
-        p_canon = fast.pointer(canonical, n_vox_local, "canonical")
-        p_warp = fast.pointer(warp, n_vox_local * dims, "warp")
-        p_bufs = [fast.pointer(b, n_vox_local * dims, "gradient buffer") for b in bufs]
-        p_report = fast.pointer(report_g, n_vox_local * dims, "gradient", allow_none=True)
-        params_ref = ctypes.byref(params)
-        lib_hier = _lib.lib.lsf_hier_iteration
-        final = 0  # buffer that holds the previous iteration's final gradient (zeros at level start, :179)
-        finals = []
+        tik = self.tikhonov_term_enabled
+        lv = self._make_level(canonical, packed, warp, grid, full_grid, max(max_it, 1))
+        records = lv.records
         snapshots = []
         it = 0
         n_exec = 0
@@ -220,49 +301,26 @@ class HierarchicalEngine:
         while it < max_it:
             batch = min(self.check_interval, max_it - it)
             for i in range(it, it + batch):
-                gate = dev.make_gate(records, i - 1, _lib.GATE_HIERARCHICAL, thr) if i > 0 else None
                 if self.collect_iteration_data:
                     # telemetry (cpp LoggingParameters.collect_per_level_iteration_data): the two gradient terms
                     # the reference hands to its visualiser (hierarchical_optimizer2d.py:196,202,242-245) are
                     # produced by two extra launches of the same kernel on the pre-update warp
+                    gate = lv.launcher.gates[i - 1] if i > 0 else None
                     d_snap = torch.zeros_like(warp)
                     dev.hier_iteration(packed, canonical, warp, None, d_snap, grid,
                                        _lib.HierParams(1.0, 0.0, 0.0, 0, 0, 0), gate, records, i)
                     t_snap = None
                     if tik:
                         t_snap = torch.zeros_like(warp)  # = laplace(previous gradient): 0*gd - (-1)*lap
-                        dev.hier_iteration(packed, canonical, warp, bufs[final], t_snap, grid,
+                        dev.hier_iteration(packed, canonical, warp, lv.F[i % 2], t_snap, grid,
                                            _lib.HierParams(0.0, -1.0, 0.0, 1, 0, 0), gate, records, i)
                     snapshots.append([None, d_snap, t_snap])
-                if ker:
-                    a, b = [k for k in range(3) if k != final]
-                    dev.hier_iteration(packed, canonical, warp, bufs[final] if tik else None, bufs[a], grid, params,
-                                       gate, records, i)
-                    if slab:  # the z pass reads `reach` slices of the (x,y)-filtered field on either side
-                        comm.exchange_halos([bufs[a]], width=reach)
-                    src, dst = a, b
-                    for axis in _conv_axis_order(dims):
-                        dev.convolve_axis(bufs[src], bufs[dst], None, grid if axis == 2 else full_grid, axis,
-                                          self.gradient_kernel, gate)
-                        src, dst = dst, src
-                    final = src
-                    dev.hier_update(bufs[final], warp, grid, self.rate, gate, records, i)
-                elif tik:
-                    out = 1 - final
-                    _lib.check(lib_hier(p_packed, p_canon, p_warp, p_bufs[final], p_bufs[out], fast.grid_ref,
-                                        params_ref, fast.gate_ref(i - 1), fast.record_ptrs[i], dev.stream_ptr()),
-                               "lsf_hier_iteration")
-                    final = out
-                else:
-                    _lib.check(lib_hier(p_packed, p_canon, p_warp, None, p_report, fast.grid_ref, params_ref,
-                                        fast.gate_ref(i - 1), fast.record_ptrs[i], dev.stream_ptr()),
-                               "lsf_hier_iteration")
-                finals.append(final)
+                self._enqueue(lv, i, i - 1 if i > 0 else None, i % 2, comm)
                 if self.collect_iteration_data:
                     snapshots[-1][0] = warp.clone()
                 if slab:
                     if tik:  # the next iteration's Laplacian reads one slice of this gradient on either side
-                        comm.exchange_halos([bufs[final]], width=1)
+                        comm.exchange_halos([lv.F[(i + 1) % 2]], width=1)
                     if i + 1 < max_it:
                         comm.reduce_max(records, i)  # the next iteration's gate tests the GLOBAL max
             if slab:
@@ -281,26 +339,80 @@ class HierarchicalEngine:
                 break
         if dec is None:  # maximum_iteration_count == 0: the reference's loop body never runs
             dec = dev.decode_records(records[:1].cpu().numpy())
-        n_vox = dev.n_voxels(grid) if not slab else (L.nz_global * grid.ny * grid.nx)
-        res = LevelResult(n_exec, [float(v) for v in dec["max_value"][:n_exec]],
-                          [int(v) for v in dec["argmax"][:n_exec]],
-                          [float(v) for v in dec["data_energy"][:n_exec]], n_vox)
-        res.iteration_limit_reached = n_exec >= max_it
-        self.level_results.append(res)
-        self.last_gradient = bufs[finals[n_exec - 1]] if (n_buf and n_exec) else report_g
         if self.collect_iteration_data:
             self.iteration_data.append(snapshots[:n_exec])  # snapshots of gated (not executed) launches are dropped
-        if self.collect_reports and not slab:
-            # per-level ConvergenceReport (cpp get_per_level_convergence_reports, run_hierarchical_optimizer3d.py:104):
-            # statistics of the last iteration's update field and of |canonical - resampled live| at this level
-            from .convergence_report import (ConvergenceReport, build_tsdf_difference_statistics,
-                                             build_warp_delta_statistics)
-            resampled = dev.warp_field(packed[..., 0].contiguous(), warp, 1.0)
-            g_final = self.last_gradient if self.last_gradient is not None else torch.zeros_like(warp)
-            res.report = ConvergenceReport(n_exec, res.iteration_limit_reached,
-                                           build_warp_delta_statistics(g_final, canonical, resampled, thr,
-                                                                       float("inf")),
-                                           build_tsdf_difference_statistics(canonical, resampled))
+        self._finish_level(lv, n_exec, dec, L)
+        return warp
+
+    # ------------------------------------------------------------------------------------------------
+    def _optimize_level_graph(self, canonical, packed, warp):
+        """launch-bound levels: K iterations (K even) are captured once per level shape as a HIP graph over persistent
+        buffers and replayed; a replay costs one launch instead of K x (1..5).  Record slots 0..K-1 form a ring that the
+        graph itself re-zeroes, slot K keeps the previous batch's last record for the first gate of the next batch, so
+        iteration counts and results are exactly those of the eager path (tests demand equality)."""
+        max_it = self.maximum_iteration_count
+        thr = np.float32(self.maximum_warp_update_threshold)
+        K = min(self.check_interval, max_it)
+        K -= K % 2
+        key = (tuple(canonical.shape), canonical.device, K)
+        entry = self._graphs.get(key)
+        if entry is None:
+            grid = dev.make_grid(canonical.shape)
+            lv = self._make_level(torch.empty_like(canonical), torch.empty_like(packed), torch.empty_like(warp), grid,
+                                  grid, K + 1)
+            side = torch.cuda.Stream(device=canonical.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):  # warm-up launch outside capture (first-use initialisation of the kernels)
+                lv.warp.zero_()
+                lv.canonical.zero_()
+                lv.packed.zero_()
+                self._enqueue(lv, 0, None, 0)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                lv.records[K].copy_(lv.records[K - 1])
+                lv.records[:K].zero_()
+                for j in range(K):
+                    self._enqueue(lv, j, K if j == 0 else j - 1, j % 2)
+            entry = self._graphs[key] = (lv, graph)
+        lv, graph = entry
+        lv.canonical.copy_(canonical)
+        lv.packed.copy_(packed)
+        lv.warp.copy_(warp)
+        for t in lv.F + lv.S:
+            t.zero_()
+        lv.records.zero_()
+        lv.records[K - 1, 0] = HierarchicalEngine.OPEN_RECORD
+        done, n_exec, converged = 0, 0, False
+        parts = []
+        while done + K <= max_it and not converged:
+            graph.replay()
+            dec = dev.decode_records(lv.records[:K].cpu().numpy())  # host sync once per K iterations
+            k_exec = int(dec["executed"].sum())
+            parts.append({k: v[:k_exec].copy() for k, v in dec.items()})
+            n_exec += k_exec
+            done += K
+            converged = k_exec < K or dec["max_value"][k_exec - 1] < thr
+        rest = max_it - done
+        if not converged and rest > 0:  # the remainder of a limit that is not a multiple of K: eager, same buffers
+            rem = self._make_level(lv.canonical, lv.packed, lv.warp, lv.grid, lv.full_grid, rest + 1)
+            rem.F, rem.S, rem.report_g = lv.F, lv.S, lv.report_g
+            rem.p_F, rem.p_S, rem.p_report = lv.p_F, lv.p_S, lv.p_report
+            rem.records[0].copy_(lv.records[K - 1])
+            for t in range(rest):
+                self._enqueue(rem, t + 1, t, (done + t) % 2)
+            dec = dev.decode_records(rem.records[1:rest + 1].cpu().numpy())
+            k_exec = int(dec["executed"].sum())
+            parts.append({k: v[:k_exec].copy() for k, v in dec.items()})
+            n_exec += k_exec
+        merged = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]} if parts else \
+            dev.decode_records(np.zeros((1, dev.RECORD_WORDS), np.int64))
+        warp.copy_(lv.warp)
+        final_level = lv
+        self._finish_level(final_level, n_exec, merged)
+        # _finish_level looked at the persistent buffers; hand out copies so that the next optimize() cannot alias them
+        if self.last_gradient is not None:
+            self.last_gradient = self.last_gradient.clone()
         return warp
 
 
@@ -311,7 +423,7 @@ class SlavchevaEngine:
     def __init__(self, direct, level_set_term_enabled, sobolev_smoothing_enabled, data_term_method,
                  smoothing_term_method, gradient_descent_rate, data_term_weight, smoothing_term_weight,
                  isomorphic_enforcement_factor, level_set_term_weight, lower_threshold, upper_threshold,
-                 max_iterations, min_iterations, sobolev_kernel, compute_energies=True, check_interval=8,
+                 max_iterations, min_iterations, sobolev_kernel, compute_energies=True, check_interval=32,
                  comm=None):
         self.direct = bool(direct)
         self.sobolev = bool(sobolev_smoothing_enabled)

@@ -39,7 +39,7 @@ class _HierarchicalOptimizerBase:
     def __init__(self, tikhonov_term_enabled=True, gradient_kernel_enabled=True, maximum_chunk_size=8, rate=0.1,
                  maximum_iteration_count=100, maximum_warp_update_threshold=0.001, data_term_amplifier=1.0,
                  tikhonov_strength=0.2, kernel=None, verbosity_parameters=None, visualization_parameters=None,
-                 logging_parameters=None, check_interval=8, comm=None, linear_resampling=False):
+                 logging_parameters=None, check_interval=32, comm=None, linear_resampling=False, use_graphs=True):
         self.verbosity_parameters = verbosity_parameters or self.VerbosityParameters()
         self.visualization_parameters = visualization_parameters  # accepted, unused: no video writers here
         self.logging_parameters = logging_parameters or self.LoggingParameters()
@@ -51,7 +51,7 @@ class _HierarchicalOptimizerBase:
             check_interval=check_interval,
             collect_reports=self.logging_parameters.collect_per_level_convergence_reports, comm=comm,
             collect_iteration_data=self.logging_parameters.collect_per_level_iteration_data,
-            linear_resampling=linear_resampling)
+            linear_resampling=linear_resampling, use_graphs=use_graphs)
         e = self._engine
         self.maximum_chunk_size = e.maximum_chunk_size
         self.rate = e.rate

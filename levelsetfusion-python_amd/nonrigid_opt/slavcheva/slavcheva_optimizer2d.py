@@ -49,7 +49,7 @@ class _SlavchevaOptimizerBase:
                  level_set_term_weight=0.2, maximum_warp_length_lower_threshold=0.1,
                  maximum_warp_length_upper_threshold=10000, max_iterations=100, min_iterations=1,
                  sobolev_kernel=None, visualization_settings=None, enable_convergence_status_logging=True,
-                 verbose=False, check_interval=8, comm=None):
+                 verbose=False, check_interval=32, comm=None):
         self.visualization_settings = visualization_settings  # accepted, unused
         self.field_size = field_size
         self.out_path = out_path

@@ -6,7 +6,7 @@ import levelsetfusion_python_amd as lsf
 from levelsetfusion_python_amd.synthetic import sphere_pair
 n = 512
 c, l = sphere_pair(n, 2, "cuda")
-for ci in (8, 100):
+for ci in (32, 100):
     opt = lsf.HierarchicalOptimizer2d(maximum_chunk_size=4, tikhonov_strength=0.05, gradient_kernel_enabled=False,
                                       rate=0.1, maximum_iteration_count=100, maximum_warp_update_threshold=0.0,
                                       check_interval=ci)
