@@ -49,16 +49,26 @@ typedef struct lsf_grid {
     int32_t reserved;
 } lsf_grid;
 
-/* per-iteration reduction record written by the iteration kernels (one record per iteration slot).
+/* per-iteration reduction record written by the iteration kernels (one record per iteration).
  * max_packed = (float bits of the maximum vector length << 32) | ~(linear voxel index): the largest value
  * with the smallest index wins an unsigned 64-bit max, which reproduces numpy's first-arg-max tie break
- * (hierarchical_optimizer2d.py:223-225, slavcheva_optimizer2d.py:213-215).  0 = slot not executed. */
-typedef struct lsf_iteration_record {
+ * (hierarchical_optimizer2d.py:223-225, slavcheva_optimizer2d.py:213-215).  0 = iteration not executed.
+ *
+ * A record is kept as LSF_RECORD_SLOTS partial records 256 bytes apart; a block accumulates into slot
+ * (block id mod 8), i.e. the slot of its XCD.  The record's VALUE is the max over the slots' max_packed and the sum
+ * over the slots' energies -- the gate below, and the host when it decodes records, combine them that way.  (Atomics
+ * of ~2000 blocks on one address serialise at ~12 ns each: 0.10 -> 0.055 ms for the band-list kernel at 256^3.) */
+#define LSF_RECORD_SLOTS 8
+typedef struct lsf_record_slot {
     uint64_t max_packed;
     double data_energy;      /* Slavcheva: sum over band of 0.5*diff^2 ; hierarchical: sum diff^2 */
     double smoothing_energy; /* un-weighted */
     double level_set_energy; /* un-weighted */
-} lsf_iteration_record;
+    uint64_t pad[28];
+} lsf_record_slot; /* 256 bytes */
+typedef struct lsf_iteration_record {
+    lsf_record_slot slot[LSF_RECORD_SLOTS];
+} lsf_iteration_record; /* 2048 bytes */
 
 /* Device-side convergence gate.  The reference tests its stop condition on the host after every iteration
  * (hierarchical_optimizer2d.py:169-171, slavcheva_optimizer2d.py:360-362); here every kernel of iteration i
@@ -151,7 +161,7 @@ typedef struct lsf_hier_params {
     float rate;
     int32_t tikhonov_enabled;
     int32_t apply_update;
-    int32_t compute_energy;    /* accumulate sum(diff^2) into record->data_energy */
+    int32_t compute_energy;    /* accumulate sum(diff^2) into the record's data_energy */
     int32_t reserved[2];
 } lsf_hier_params;
 
@@ -160,7 +170,7 @@ int lsf_hier_iteration(const float *packed_live4, const float *canonical, float 
                        const lsf_hier_params *params, const lsf_gate *gate, lsf_iteration_record *record,
                        void *stream);
 
-/* warp -= rate*g ; record->max_packed = max |g|   (hierarchical_optimizer2d.py:220-225) */
+/* warp -= rate*g ; the record's max_packed = max |g|   (hierarchical_optimizer2d.py:220-225) */
 int lsf_hier_update(const float *g_planar, float *warp_planar, const lsf_grid *grid, float rate,
                     const lsf_gate *gate, lsf_iteration_record *record, void *stream);
 
@@ -200,11 +210,31 @@ typedef struct lsf_slavcheva_params {
     int32_t reserved;
 } lsf_slavcheva_params;
 
+/* band_list (may be NULL; FUSED stage without g_out only): ascending voxel indices (z * ny + y) * nx + x from
+ * lsf_band_list_fill, band_count of them, covering this grid's z-range.  Only listed voxels are visited.  This is exact,
+ * not an approximation: a voxel outside the narrow-band union (|live| == |canonical| == 1, the test of
+ * slavcheva_optimizer2d.py:251-252 / tsdf_set_routines.py:19-52) gets a zero gradient, hence warp 0 and live' = live,
+ * and so stays outside for the rest of the optimisation.  The CALLER must have initialised live_out / warp_out of BOTH
+ * ping-pong buffer sets with (live, 0) at the unlisted voxels, and must keep canonical and params unchanged while the
+ * list is in use.  Records, live and warp are identical with and without a list. */
 int lsf_slavcheva_iteration(int32_t stage, const float *live, const float *canonical,
                             const float *warp_prev_planar, float *warp_out_planar, float *live_out,
                             float *g_out_planar /* may be NULL in FUSED */, const lsf_grid *grid,
                             const lsf_slavcheva_params *params, const lsf_gate *gate,
-                            lsf_iteration_record *record, void *stream);
+                            lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,
+                            void *stream);
+
+/* Band list of the grid's z-range [z_begin, z_end): the voxels with |live| != 1 or |canonical| != 1
+ * (tsdf_set_routines.py:19-52; the `continue` of slavcheva_optimizer2d.py:251-252), in ascending index order.
+ *   1. lsf_band_count     counts per 1024-voxel chunk into scratch (lsf_band_scratch_elements(grid) int32 elements),
+ *                         scans them, and writes the total to *count_out (device memory);
+ *   2. the caller reads the total and allocates the list;
+ *   3. lsf_band_list_fill writes the indices (same live / canonical / grid / scratch as step 1). */
+int64_t lsf_band_scratch_elements(const lsf_grid *grid);
+int lsf_band_count(const float *live, const float *canonical, const lsf_grid *grid, int32_t *scratch,
+                   int64_t *count_out, void *stream);
+int lsf_band_list_fill(const float *live, const float *canonical, const lsf_grid *grid, const int32_t *scratch,
+                       int32_t *list, void *stream);
 
 int lsf_slavcheva_update_rewarp(const float *live, const float *canonical, float *g_planar /* inout */,
                                 float *warp_out_planar, float *live_out, const lsf_grid *grid,

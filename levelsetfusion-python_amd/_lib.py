@@ -33,12 +33,22 @@ class Grid(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
-class IterationRecord(ctypes.Structure):
+RECORD_SLOTS = 8
+
+
+class RecordSlot(ctypes.Structure):
     _fields_ = [("max_packed", ctypes.c_uint64), ("data_energy", ctypes.c_double),
-                ("smoothing_energy", ctypes.c_double), ("level_set_energy", ctypes.c_double)]
+                ("smoothing_energy", ctypes.c_double), ("level_set_energy", ctypes.c_double),
+                ("pad", ctypes.c_uint64 * 28)]
 
 
-RECORD_BYTES = ctypes.sizeof(IterationRecord)  # 32
+class IterationRecord(ctypes.Structure):
+    """8 partial records 256 bytes apart; value = max over the slots' max_packed, sum over their energies"""
+    _fields_ = [("slot", RecordSlot * RECORD_SLOTS)]
+
+
+RECORD_BYTES = ctypes.sizeof(IterationRecord)  # 2048
+SLOT_WORDS = ctypes.sizeof(RecordSlot) // 8    # 32
 
 
 class Gate(ctypes.Structure):
@@ -98,7 +108,10 @@ PROTOTYPES = {
     "lsf_hier_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(HierParams), _P(Gate), _vp, _vp]),
     "lsf_hier_update": (ctypes.c_int, [_vp, _vp, _P(Grid), _f32, _P(Gate), _vp, _vp]),
     "lsf_slavcheva_iteration": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _P(Grid),
-                                               _P(SlavchevaParams), _P(Gate), _vp, _vp]),
+                                               _P(SlavchevaParams), _P(Gate), _vp, _vp, _i64, _vp]),
+    "lsf_band_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
+    "lsf_band_count": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp, _vp, _vp]),
+    "lsf_band_list_fill": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp, _vp, _vp]),
     "lsf_slavcheva_update_rewarp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),
                                                    _P(Gate), _vp, _vp]),
     "lsf_warp_statistics": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp, _vp]),

@@ -4,6 +4,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 
 #include "../../include/lsf_hip.h"
@@ -13,6 +14,23 @@ namespace lsf {
 constexpr int kWave = 64;
 constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
 
+// n / d for n < 2^31 by multiply-high and shift (Granlund & Montgomery): the tile walk decomposes a tile number per
+// tile and per wave, and the compiler's expansion of a 32-bit division by a run-time divisor is ~30 instructions each
+struct FastDiv {
+    unsigned d, m, l;
+};
+
+__host__ inline FastDiv make_fast_div(unsigned d) {
+    FastDiv f;
+    f.d = d;
+    f.l = 0;
+    while ((1ull << f.l) < d) ++f.l;
+    f.m = (unsigned)(((1ull << 32) * ((1ull << f.l) - d)) / d + 1ull);
+    return f;
+}
+
+__device__ inline unsigned fast_div(unsigned n, const FastDiv& f) { return (__umulhi(n, f.m) + n) >> f.l; }
+
 struct Grid {
     int nz, ny, nx;
     int z_begin, z_end;
@@ -20,6 +38,7 @@ struct Grid {
     unsigned chunk_tiles;  // tiles per scheduling chunk (see tile_walk)
     int tile_y;            // rows per tile = waves per block (1..4); blockDim.x = 64 * tile_y
     long long plane;       // nz*ny*nx: stride between the planes of a planar vector field
+    FastDiv div_tiles_x, div_tiles_y, div_chunk, div_nx, div_ny;
 };
 
 __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
@@ -42,6 +61,11 @@ __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
         unsigned rows = tiles_y / 32;
         r.chunk_tiles = tiles_x * (rows < 1 ? 1 : rows);
     }
+    r.div_tiles_x = make_fast_div(tiles_x);
+    r.div_tiles_y = make_fast_div(tiles_y);
+    r.div_chunk = make_fast_div(r.chunk_tiles);
+    r.div_nx = make_fast_div((unsigned)g->nx);
+    r.div_ny = make_fast_div((unsigned)g->ny);
     return r;
 }
 
@@ -95,6 +119,17 @@ constexpr unsigned kXcds = 8;
 // blocks whose position lies in the narrow band would do all the work (measured: 0.21 ms vs 0.13 ms at 256^3).
 constexpr unsigned kBlocksPerXcd = 251;
 
+// tuning knob for measurements (tools/kernel_cases.py): LSF_BLOCKS_PER_XCD overrides the persistent-grid size of the
+// Slavcheva iteration kernel; read once per process
+__host__ inline unsigned blocks_per_xcd() {
+    static const unsigned v = [] {
+        const char* e = getenv("LSF_BLOCKS_PER_XCD");
+        const int n = e ? atoi(e) : 0;
+        return n > 0 ? (unsigned)n : kBlocksPerXcd;
+    }();
+    return v;
+}
+
 __host__ inline unsigned launch_blocks(unsigned total_tiles, unsigned per_xcd = kBlocksPerXcd) {
     const unsigned full = kXcds * per_xcd;
     if (total_tiles >= full) return full;
@@ -108,13 +143,16 @@ __host__ inline unsigned launch_blocks(unsigned total_tiles, unsigned per_xcd = 
 // the blocks of one XCD walk that XCD's chunks side by side.
 struct TileWalk {
     unsigned q, count, step, xcd, chunk;  // XCD-local sequence position / length / stride
+    FastDiv div_chunk;
     bool plain;                            // tiny grids: plain grid-stride over [0, count)
 };
 
-__device__ inline TileWalk tile_walk(unsigned total, unsigned chunk) {
+__device__ inline TileWalk tile_walk(unsigned total, const Grid& g) {
     TileWalk w;
     const unsigned nb = gridDim.x, bid = blockIdx.x;
+    const unsigned chunk = g.chunk_tiles;
     w.chunk = chunk;
+    w.div_chunk = g.div_chunk;
     if (nb % kXcds != 0) {
         w.plain = true; w.q = bid; w.count = total; w.step = nb; w.xcd = 0;
         return w;
@@ -133,7 +171,7 @@ __device__ inline TileWalk tile_walk(unsigned total, unsigned chunk) {
 
 __device__ inline unsigned tile_of(const TileWalk& w, unsigned q) {
     if (w.plain) return q;
-    const unsigned m = q / w.chunk, within = q % w.chunk;
+    const unsigned m = fast_div(q, w.div_chunk), within = q - m * w.chunk;
     return (w.xcd + kXcds * m) * w.chunk + within;
 }
 
@@ -141,17 +179,80 @@ __device__ inline unsigned tile_of(const TileWalk& w, unsigned q) {
 template <class F>
 __device__ inline void for_each_voxel(const Grid& g, F&& f) {
     const Tiling t = make_tiling(g);
-    const TileWalk w = tile_walk(t.total, g.chunk_tiles);
+    const TileWalk w = tile_walk(t.total, g);
     const int lx = threadIdx.x & (kTileX - 1), ly = threadIdx.x / kTileX;
     for (unsigned q = w.q; q < w.count; q += w.step) {
         const unsigned tile = tile_of(w, q);
-        const int tx = tile % t.tiles_x;
-        const unsigned rest = tile / t.tiles_x;
-        const int ty = rest % t.tiles_y;
-        const int tz = rest / t.tiles_y;
+        const unsigned rest = fast_div(tile, g.div_tiles_x);
+        const int tx = (int)(tile - rest * (unsigned)t.tiles_x);
+        const int tz = (int)fast_div(rest, g.div_tiles_y);
+        const int ty = (int)rest - tz * t.tiles_y;
         const int x = tx * kTileX + lx, y = ty * g.tile_y + ly, z = g.z_begin + tz;
         if (x < g.nx && y < g.ny) f(x, y, z);
     }
+}
+
+// Walk over a BAND LIST (lsf_band_list_fill): `count` voxel indices (z * ny + y) * nx + x in ascending order.  Work
+// unit = 256 consecutive entries = one block step; entries are short x-runs of consecutive rows, so the four waves of
+// a block share stencil rows through L1 much like a tile does.  XCD k owns the k-th eighth of the units (a contiguous
+// z-range -> its own L2), and the blocks of an XCD interleave over that eighth.  The host sizes the grid so that all
+// blocks get the same number of units (band_list_blocks).  Calls f(x, y, z) for every listed voxel.
+// list == nullptr: the dense tile walk of for_each_voxel (one loop for both so that f is instantiated once).
+template <class F>
+__device__ inline void for_each_listed_voxel(const Grid& g, const int* __restrict__ list, unsigned count, F&& f) {
+    const bool listed = list != nullptr;
+    const Tiling t = make_tiling(g);
+    const TileWalk w = tile_walk(t.total, g);
+    const int lx = threadIdx.x & (kTileX - 1), ly = threadIdx.x / kTileX;
+    unsigned first = w.q, step = w.step, end = w.count;
+    if (listed) {
+        const unsigned units = (count + kBlock - 1) / kBlock;
+        const unsigned nb = gridDim.x, bid = blockIdx.x;
+        if (nb % kXcds == 0) {
+            const unsigned per_xcd = (units + kXcds - 1) / kXcds, xcd = bid % kXcds;
+            first = xcd * per_xcd + bid / kXcds;
+            step = nb / kXcds;
+            end = (xcd + 1) * per_xcd < units ? (xcd + 1) * per_xcd : units;
+        } else {
+            first = bid; step = nb; end = units;
+        }
+    }
+    for (unsigned u = first; u < end; u += step) {
+        int x, y, z;
+        bool inside;
+        if (listed) {
+            const unsigned k = u * kBlock + threadIdx.x;
+            inside = k < count;
+            const unsigned i = inside ? (unsigned)list[k] : 0u;
+            const unsigned zy = fast_div(i, g.div_nx);
+            x = (int)(i - zy * (unsigned)g.nx);
+            z = (int)fast_div(zy, g.div_ny);
+            y = (int)zy - z * g.ny;
+        } else {
+            const unsigned tile = tile_of(w, u);
+            const unsigned rest = fast_div(tile, g.div_tiles_x);
+            const int tx = (int)(tile - rest * (unsigned)t.tiles_x);
+            const int tz = (int)fast_div(rest, g.div_tiles_y);
+            const int ty = (int)rest - tz * t.tiles_y;
+            x = tx * kTileX + lx; y = ty * g.tile_y + ly; z = g.z_begin + tz;
+            inside = x < g.nx && y < g.ny;
+        }
+        if (inside) f(x, y, z);
+    }
+}
+
+// grid size for a list walk: <= 8 * kBlocksPerXcd-ish persistent blocks, every block the same number of units
+__host__ inline unsigned band_list_blocks(unsigned count) {
+    const unsigned units = (count + kBlock - 1) / kBlock;
+    if (units <= kXcds) return units < 1 ? 1 : units;
+    const unsigned per_xcd = (units + kXcds - 1) / kXcds;
+    static const unsigned cap = [] {
+        const char* e = getenv("LSF_LIST_BLOCKS_PER_XCD");  // measurement knob, see blocks_per_xcd()
+        const int n = e ? atoi(e) : 0;
+        return n > 0 ? (unsigned)n : 256u;
+    }();
+    const unsigned rounds = (per_xcd + cap - 1) / cap;
+    return kXcds * ((per_xcd + rounds - 1) / rounds);
 }
 
 // (A dynamic variant -- per-XCD work queues with atomic heads and stealing -- was measured and rejected: device-scope
@@ -332,15 +433,25 @@ __device__ inline float second_difference_f64(float am, float a0, float ap) {
 // device-side convergence gate (see lsf_gate in include/lsf_hip.h) ------------------------------------------
 __device__ inline bool gate_closed(const lsf_gate& gate) {
     if (!gate.prev_record) return false;
-    unsigned long long p = gate.prev_record->max_packed;
+    unsigned long long p = 0ull;
+#pragma unroll
+    for (int k = 0; k < LSF_RECORD_SLOTS; ++k) {
+        const unsigned long long q = gate.prev_record->slot[k].max_packed;
+        p = q > p ? q : p;
+    }
     if (p == 0ull) return true;  // previous iteration was itself a no-op
     float m = unpack_max_value(p);
     if (gate.mode == LSF_GATE_HIERARCHICAL) return m < gate.a;
     return !(gate.a < m && m < gate.b);
 }
 
+// the partial record this block accumulates into (see lsf_iteration_record)
+__device__ inline lsf_record_slot* record_slot(lsf_iteration_record* r) {
+    return &r->slot[blockIdx.x % LSF_RECORD_SLOTS];
+}
+
 __device__ inline unsigned long long* record_max(lsf_iteration_record* r) {
-    return reinterpret_cast<unsigned long long*>(&r->max_packed);
+    return reinterpret_cast<unsigned long long*>(&record_slot(r)->max_packed);
 }
 
 __host__ inline lsf_gate gate_or_open(const lsf_gate* gate) {

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(kBlock) void hier_iteration_kernel(const float4* __
         if (ENERGY) sums[0] += (double)diff * (double)diff;
     });
     if (UPDATE || ENERGY) {
-        double* dst[1] = {ENERGY ? &record->data_energy : nullptr};
+        double* dst[1] = {ENERGY ? &record_slot(record)->data_energy : nullptr};
         block_reduce_commit<1>(best, sums, UPDATE ? record_max(record) : nullptr, dst);
     }
 }

@@ -325,11 +325,11 @@ template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, bool FUSED>
 __global__ __launch_bounds__(kBlock) void slavcheva_iteration_kernel(
     const float* __restrict__ live, const float* __restrict__ canonical, const float* __restrict__ warp_prev,
     float* __restrict__ warp_out, float* __restrict__ live_out, float* __restrict__ g_out, Grid g, Params p,
-    lsf_gate gate, lsf_iteration_record* record) {
+    lsf_gate gate, lsf_iteration_record* record, const int* __restrict__ band_list, unsigned band_count) {
     if (gate_closed(gate)) return;
     unsigned long long best = 0ull;
     double en[3] = {0.0, 0.0, 0.0};
-    for_each_voxel(g, [&](int x, int y, int z) {
+    auto voxel = [&](int x, int y, int z) {
         const int i = vidx(g, x, y, z);
         float gv[3];
         double e[3] = {0.0, 0.0, 0.0};
@@ -344,11 +344,20 @@ __global__ __launch_bounds__(kBlock) void slavcheva_iteration_kernel(
 #pragma unroll
             for (int c = 0; c < D; ++c) g_out[c * g.plane + i] = gv[c];
         }
-    });
+    };
+    // Band list (lsf_band_list_fill): only voxels that can be in the narrow-band union are visited.  Every other voxel
+    // has |live| == |canonical| == 1: zero gradient, zero warp, live' = live -- the caller initialised both ping-pong
+    // buffer sets with exactly that, and such a voxel can never enter the band.  Their arg-max candidates are all
+    // (length 0, own index); the smallest index of the launch's z-range stands for them.
+    for_each_listed_voxel(g, FUSED ? band_list : nullptr, band_count, voxel);
+    if (FUSED && band_list && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long q = pack_max(0.0f, linear_index(g, 0, 0, g.z_begin));
+        best = q > best ? q : best;
+    }
     if (FUSED || ENERGY != LSF_ENERGY_NONE) {
-        double* dst[3] = {ENERGY != LSF_ENERGY_NONE ? &record->data_energy : nullptr,
-                          ENERGY != LSF_ENERGY_NONE ? &record->smoothing_energy : nullptr,
-                          ENERGY != LSF_ENERGY_NONE ? &record->level_set_energy : nullptr};
+        double* dst[3] = {ENERGY != LSF_ENERGY_NONE ? &record_slot(record)->data_energy : nullptr,
+                          ENERGY != LSF_ENERGY_NONE ? &record_slot(record)->smoothing_energy : nullptr,
+                          ENERGY != LSF_ENERGY_NONE ? &record_slot(record)->level_set_energy : nullptr};
         block_reduce_commit<3>(best, en, FUSED ? record_max(record) : nullptr, dst);
     }
 }
@@ -396,13 +405,15 @@ struct LaunchArgs {
     Params p;
     lsf_gate gate;
     lsf_iteration_record* record;
+    const int* band_list;
+    unsigned band_count;
 };
 
 template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, bool FUSED>
 void launch_one(const LaunchArgs& a) {
     hipLaunchKernelGGL((slavcheva_iteration_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY, FUSED>), dim3(a.blocks),
                        dim3(kTileX * a.g.tile_y), 0, a.s, a.live, a.canonical, a.warp_prev, a.warp_out, a.live_out, a.g_out, a.g,
-                       a.p, a.gate, a.record);
+                       a.p, a.gate, a.record, a.band_list, a.band_count);
 }
 
 template <int D, int SMOOTH, bool LEVELSET, int DATA, bool FUSED>
@@ -431,12 +442,81 @@ void pick_terms(const lsf_slavcheva_params* q, const LaunchArgs& a) {
 #undef LSF_PICK
 }
 
+// ------------------------------------------------------------------------------------------------------
+// band list: ascending indices of the voxels inside the narrow-band union, by count -> scan -> fill
+// ------------------------------------------------------------------------------------------------------
+constexpr unsigned kBandChunk = 4 * kBlock;  // voxels per block of the count / fill kernels
+
+// FILL == false: block_sums[b] = number of band voxels in chunk b.  FILL == true: block_sums holds the exclusive
+// prefix sums; writes the chunk's band voxels, in ascending order, to list[block_sums[b] ...].
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void band_list_kernel(const float* __restrict__ live,
+                                                           const float* __restrict__ canonical, unsigned first,
+                                                           unsigned n, int* __restrict__ block_sums,
+                                                           int* __restrict__ list) {
+    __shared__ int part[16];  // [pass j][wave]
+    const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
+    unsigned long long masks[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned v = blockIdx.x * kBandChunk + j * kBlock + t;
+        bool in_band = false;
+        if (v < n) in_band = !(fabsf(live[first + v]) == 1.0f && fabsf(canonical[first + v]) == 1.0f);
+        masks[j] = __ballot(in_band);
+        if (lane == 0) part[j * 4 + wave] = __popcll(masks[j]);
+    }
+    __syncthreads();
+    if (!FILL) {
+        if (t == 0) {
+            int sum = 0;
+            for (int k = 0; k < 16; ++k) sum += part[k];
+            block_sums[blockIdx.x] = sum;
+        }
+        return;
+    }
+    int at = block_sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+            if (wv == wave && ((masks[j] >> lane) & 1ull))
+                list[at + __popcll(masks[j] & ((1ull << lane) - 1ull))] =
+                    (int)(first + blockIdx.x * kBandChunk + j * kBlock + t);
+            at += part[j * 4 + wv];
+        }
+    }
+}
+
+// exclusive prefix sums of sums[0..n) in place by ONE block (n <= 2^21 chunks; runs once per optimize() call)
+__global__ __launch_bounds__(1024) void band_scan_kernel(int* __restrict__ sums, unsigned n, long long* total) {
+    __shared__ int buf[1024];
+    const unsigned t = threadIdx.x;
+    int carry = 0;
+    for (unsigned base = 0; base < n; base += 1024) {
+        const unsigned i = base + t;
+        const int v = i < n ? sums[i] : 0;
+        buf[t] = v;
+        __syncthreads();
+        for (unsigned off = 1; off < 1024; off <<= 1) {
+            const int add = t >= off ? buf[t - off] : 0;
+            __syncthreads();
+            buf[t] += add;
+            __syncthreads();
+        }
+        if (i < n) sums[i] = carry + buf[t] - v;
+        carry += buf[1023];
+        __syncthreads();
+    }
+    if (t == 0) *total = carry;
+}
+
 }  // namespace
 
 extern "C" int lsf_slavcheva_iteration(int32_t stage, const float* live, const float* canonical,
                                        const float* warp_prev_planar, float* warp_out_planar, float* live_out,
                                        float* g_out_planar, const lsf_grid* grid, const lsf_slavcheva_params* params,
-                                       const lsf_gate* gate, lsf_iteration_record* record, void* stream) {
+                                       const lsf_gate* gate, lsf_iteration_record* record, const int32_t* band_list,
+                                       int64_t band_count, void* stream) {
     if (int e = check_grid(grid)) return e;
     if (!live || !canonical || !warp_prev_planar || !params || !record) return LSF_ERR_BAD_ARGUMENT;
     if (stage == LSF_STAGE_FUSED) {
@@ -452,12 +532,17 @@ extern "C" int lsf_slavcheva_iteration(int32_t stage, const float* live, const f
     // and lose: the four rows of a tile share stencil rows through L1 (256^3 all-in-band 0.39 / 0.46 / 0.59 ms for
     // tile heights 4 / 2 / 1).
     const int tile_y = 4;
-    const unsigned per_xcd = kBlocksPerXcd;
+    const unsigned per_xcd = blocks_per_xcd();
     Grid g = make_grid(grid, tile_y);
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
-    LaunchArgs a{launch_blocks(t.total, per_xcd), as_stream(stream), live, canonical, warp_prev_planar, warp_out_planar,
-                 live_out, g_out_planar, g, make_params(params), gate_or_open(gate), record};
+    const bool listed = band_list != nullptr;
+    if (listed && (stage != LSF_STAGE_FUSED || g_out_planar || band_count < 0 || band_count > 0x7fffffffll))
+        return LSF_ERR_BAD_ARGUMENT;
+    const unsigned blocks = listed ? band_list_blocks((unsigned)band_count) : launch_blocks(t.total, per_xcd);
+    LaunchArgs a{blocks, as_stream(stream), live, canonical, warp_prev_planar, warp_out_planar,
+                 live_out, g_out_planar, g, make_params(params), gate_or_open(gate), record,
+                 band_list, (unsigned)band_count};
     if (grid->dims == 2) {
         if (stage == LSF_STAGE_FUSED) pick_terms<2, true>(params, a); else pick_terms<2, false>(params, a);
     } else {
@@ -485,5 +570,46 @@ extern "C" int lsf_slavcheva_update_rewarp(const float* live, const float* canon
     else
         hipLaunchKernelGGL(slavcheva_update_rewarp_kernel<3>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream), live,
                            g_planar, warp_out_planar, live_out, g, p, gt, record);
+    return launch_status();
+}
+
+// ---- band list (see include/lsf_hip.h)
+static inline bool band_range(const lsf_grid* grid, unsigned& first, unsigned& n, unsigned& chunks) {
+    const long long slice = (long long)grid->ny * grid->nx;
+    first = (unsigned)(slice * grid->z_begin);
+    n = (unsigned)(slice * (grid->z_end - grid->z_begin));
+    chunks = (n + kBandChunk - 1) / kBandChunk;
+    return n > 0;
+}
+
+extern "C" int64_t lsf_band_scratch_elements(const lsf_grid* grid) {
+    if (check_grid(grid)) return 0;
+    unsigned first, n, chunks;
+    band_range(grid, first, n, chunks);
+    return (int64_t)chunks + 1;
+}
+
+extern "C" int lsf_band_count(const float* live, const float* canonical, const lsf_grid* grid, int32_t* scratch,
+                              int64_t* count_out, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!live || !canonical || !scratch || !count_out) return LSF_ERR_BAD_ARGUMENT;
+    unsigned first, n, chunks;
+    band_range(grid, first, n, chunks);
+    hipStream_t s = as_stream(stream);
+    if (chunks > 0)
+        hipLaunchKernelGGL(band_list_kernel<false>, dim3(chunks), dim3(kBlock), 0, s, live, canonical, first, n, scratch,
+                           (int*)nullptr);
+    hipLaunchKernelGGL(band_scan_kernel, dim3(1), dim3(1024), 0, s, scratch, chunks, (long long*)count_out);
+    return launch_status();
+}
+
+extern "C" int lsf_band_list_fill(const float* live, const float* canonical, const lsf_grid* grid,
+                                  const int32_t* scratch, int32_t* list, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!live || !canonical || !scratch || !list) return LSF_ERR_BAD_ARGUMENT;
+    unsigned first, n, chunks;
+    if (!band_range(grid, first, n, chunks)) return 0;
+    hipLaunchKernelGGL(band_list_kernel<true>, dim3(chunks), dim3(kBlock), 0, as_stream(stream), live, canonical, first, n,
+                       const_cast<int32_t*>(scratch), list);
     return launch_status();
 }

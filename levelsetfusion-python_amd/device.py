@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import Gate, Grid, HierParams, SlavchevaParams, check, lib
 
-RECORD_WORDS = _lib.RECORD_BYTES // 8  # an iteration record is 4 x 8 bytes
+RECORD_WORDS = _lib.RECORD_BYTES // 8  # an iteration record is 8 slots x 32 int64 words (see lsf_iteration_record)
 
 
 def require_gpu():
@@ -85,16 +85,28 @@ def _gate_ref(gate):
     return ctypes.byref(gate) if gate is not None else None
 
 
+def slot_view(records):
+    """[n, RECORD_WORDS] (tensor or array) -> [n, slots, 32]: word 0 = packed max, words 1..3 = energies"""
+    return records.reshape(records.shape[0], _lib.RECORD_SLOTS, _lib.SLOT_WORDS)
+
+
+def set_record_max(records, index, packed):
+    """make record `index` read as `packed` to a gate (slot 0 holds it, the other slots are cleared)"""
+    records[index].zero_()
+    records[index, 0] = packed
+
+
 def decode_records(records_host):
-    """records_host: numpy int64 [n,4] -> dict of arrays (max value, linear arg-max index, energies, executed)"""
-    raw = np.ascontiguousarray(records_host)
-    packed = raw[:, 0].view(np.uint64)
+    """records_host: numpy int64 [n, RECORD_WORDS] -> dict of arrays (max value, linear arg-max index, energies,
+    executed); combines the slots of every record: max of the packed maxima, sum of the energies"""
+    raw = slot_view(np.ascontiguousarray(records_host))
+    packed = np.ascontiguousarray(raw[:, :, 0]).view(np.uint64).max(axis=1)
+    energies = np.ascontiguousarray(raw[:, :, 1:4]).view(np.float64).sum(axis=1)
     executed = packed != 0
     max_value = (packed >> np.uint64(32)).astype(np.uint32).view(np.float32)
     index = (~packed.astype(np.uint32)).astype(np.int64) & 0xFFFFFFFF
-    return dict(executed=executed, max_value=max_value, argmax=index,
-                data_energy=raw[:, 1].view(np.float64), smoothing_energy=raw[:, 2].view(np.float64),
-                level_set_energy=raw[:, 3].view(np.float64))
+    return dict(executed=executed, max_value=max_value, argmax=index, data_energy=energies[:, 0],
+                smoothing_energy=energies[:, 1], level_set_energy=energies[:, 2])
 
 
 # ---------------------------------------------------------------------------------------------- layout
@@ -248,8 +260,39 @@ def hier_update(g, warp, grid, rate, gate, records, index):
                               _gate_ref(gate), _record_ptr(records, index), stream_ptr()), "lsf_hier_update")
 
 
+class BandList:
+    """ascending voxel indices of the narrow-band union inside the grid's z-range (lsf_band_list_fill)"""
+
+    def __init__(self, indices, count):
+        self.indices, self.count = indices, int(count)
+        self.pointer = ctypes.c_void_p(indices.data_ptr() if indices is not None else 0)
+
+    @classmethod
+    def none(cls):
+        """no list: the kernel walks every voxel"""
+        return cls(None, 0)
+
+
+def band_list(live, canonical, grid=None):
+    """build the band list of (live, canonical): count -> (one host read of the total) -> fill"""
+    grid = grid or make_grid(live.shape)
+    n = n_voxels(grid)
+    scratch = torch.empty(int(lib.lsf_band_scratch_elements(ctypes.byref(grid))), dtype=torch.int32,
+                          device=live.device)
+    total = torch.zeros(1, dtype=torch.int64, device=live.device)
+    p_live, p_canon = _ptr(live, n, "live"), _ptr(canonical, n, "canonical")
+    check(lib.lsf_band_count(p_live, p_canon, ctypes.byref(grid), ctypes.c_void_p(scratch.data_ptr()),
+                             ctypes.c_void_p(total.data_ptr()), stream_ptr()), "lsf_band_count")
+    count = int(total.item())
+    indices = torch.empty(max(count, 1), dtype=torch.int32, device=live.device)
+    if count:
+        check(lib.lsf_band_list_fill(p_live, p_canon, ctypes.byref(grid), ctypes.c_void_p(scratch.data_ptr()),
+                                     ctypes.c_void_p(indices.data_ptr()), stream_ptr()), "lsf_band_list_fill")
+    return BandList(indices, count)
+
+
 def slavcheva_iteration(stage, live, canonical, warp_prev, warp_out, live_out, g_out, grid, params, gate, records,
-                        index):
+                        index, band=None):
     n = n_voxels(grid)
     nd = n * grid.dims
     check(lib.lsf_slavcheva_iteration(int(stage), _ptr(live, n, "live"), _ptr(canonical, n, "canonical"),
@@ -258,7 +301,9 @@ def slavcheva_iteration(stage, live, canonical, warp_prev, warp_out, live_out, g
                                       _ptr(live_out, n, "live_out", allow_none=True),
                                       _ptr(g_out, nd, "g_out", allow_none=True), ctypes.byref(grid),
                                       ctypes.byref(params), _gate_ref(gate), _record_ptr(records, index),
-                                      stream_ptr()), "lsf_slavcheva_iteration")
+                                      band.pointer if band is not None else ctypes.c_void_p(0),
+                                      band.count if band is not None else 0, stream_ptr()),
+          "lsf_slavcheva_iteration")
 
 
 def slavcheva_update_rewarp(live, canonical, g, warp_out, live_out, grid, params, gate, records, index):

@@ -382,7 +382,7 @@ class HierarchicalEngine:
         for t in lv.F + lv.S:
             t.zero_()
         lv.records.zero_()
-        lv.records[K - 1, 0] = HierarchicalEngine.OPEN_RECORD
+        dev.set_record_max(lv.records, K - 1, HierarchicalEngine.OPEN_RECORD)
         done, n_exec, converged = 0, 0, False
         parts = []
         while done + K <= max_it and not converged:
@@ -424,7 +424,7 @@ class SlavchevaEngine:
                  smoothing_term_method, gradient_descent_rate, data_term_weight, smoothing_term_weight,
                  isomorphic_enforcement_factor, level_set_term_weight, lower_threshold, upper_threshold,
                  max_iterations, min_iterations, sobolev_kernel, compute_energies=True, check_interval=32,
-                 comm=None):
+                 comm=None, use_band_list=True):
         self.direct = bool(direct)
         self.sobolev = bool(sobolev_smoothing_enabled)
         self.sobolev_kernel = sobolev_kernel
@@ -446,6 +446,7 @@ class SlavchevaEngine:
         self.max_iterations, self.min_iterations = int(max_iterations), int(min_iterations)
         self.check_interval = max(1, int(check_interval))
         self.comm = comm
+        self.use_band_list = bool(use_band_list)  # False: the fused kernel walks every voxel (measurements, tests)
         self.iteration_count = 0
         self.log = None
         self._gradient_state = None
@@ -478,20 +479,14 @@ class SlavchevaEngine:
                                                             f.p_warp[i % 2], f.p_warp[(i + 1) % 2],
                                                             f.p_live[(i + 1) % 2], None, f.grid_ref, f.params_ref,
                                                             None if i < self.min_iterations else f.gate_ref(i - 1),
-                                                            f.record_ptrs[i], dev.stream_ptr()),
+                                                            f.record_ptrs[i], f.band.pointer, f.band.count, dev.stream_ptr()),
                            "lsf_slavcheva_iteration")
             else:
                 # boundary slices first, then the halo exchange on a second stream WHILE the interior runs
-                L = self.comm.layout
-                h = L.halo
-                lo_b = (L.z_begin, L.z_begin + h) if L.rank > 0 else None
-                hi_b = (L.z_end - h, L.z_end) if L.rank < L.world - 1 else None
-                interior = (lo_b[1] if lo_b else L.z_begin, hi_b[0] if hi_b else L.z_end)
-                for rng in (lo_b, hi_b):
-                    if rng is not None:
-                        g = dev.make_grid(live_in.shape, rng[0], rng[1], grid.z_global_offset)
-                        dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out,
-                                                None, g, self.params, gate, records, i)
+                boundary, interior = self._slab_parts
+                for g, band in boundary:
+                    dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None, g,
+                                            self.params, gate, records, i, band)
                 main = torch.cuda.current_stream()
                 boundary_done, halos_done = self._events[i % 2]
                 boundary_done.record(main)
@@ -499,10 +494,9 @@ class SlavchevaEngine:
                     self._comm_stream.wait_event(boundary_done)
                     self.comm.exchange_live_and_warp(live_out, warp_out)
                     halos_done.record(self._comm_stream)
-                if interior[1] > interior[0]:
-                    g = dev.make_grid(live_in.shape, interior[0], interior[1], grid.z_global_offset)
-                    dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None,
-                                            g, self.params, gate, records, i)
+                for g, band in interior:
+                    dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None, g,
+                                            self.params, gate, records, i, band)
                 main.wait_event(halos_done)
         else:
             g0, t1, t2 = gbufs
@@ -542,10 +536,10 @@ class SlavchevaEngine:
                 raise ValueError("slab halo of %d slices is too narrow: this configuration needs >= %d"
                                  % (self.comm.layout.halo, need))
         records = dev.new_records(n_rec, live.device)
-        lives = [live.clone(), torch.empty_like(live)]
+        # Both ping-pong sets start as (live, warp 0): the fused kernel only visits the voxels of the band list and the
+        # rest must already hold their final values (see lsf_slavcheva_iteration); slab halos start out valid too.
+        lives = [live.clone(), live.clone()]
         warps = [torch.zeros((dims,) + tuple(live.shape), dtype=torch.float32, device=live.device) for _ in range(2)]
-        if self.comm is not None and self.comm.active:
-            lives[1].copy_(live)  # halo slices of both buffers start out valid
         gbufs = [torch.zeros_like(warps[0]) for _ in range(3)] if self.sobolev else None
         self._last_g = None
         if not slab and not self.sobolev:  # pre-validated launch arguments of the fused kernel
@@ -555,7 +549,20 @@ class SlavchevaEngine:
             f.p_warp = [f.pointer(t, n * dims, "warp") for t in warps]
             f.p_canon = f.pointer(canonical, n, "canonical")
             f.params_ref = ctypes.byref(self.params)
+            f.band = dev.band_list(live, canonical, grid) if self.use_band_list else dev.BandList.none()
             self._fast = f
+        if slab and not self.sobolev:
+            L = self.comm.layout
+            h = L.halo
+            lo_b = (L.z_begin, L.z_begin + h) if L.rank > 0 else None
+            hi_b = (L.z_end - h, L.z_end) if L.rank < L.world - 1 else None
+            mid = (lo_b[1] if lo_b else L.z_begin, hi_b[0] if hi_b else L.z_end)
+
+            def part(rng):
+                g = dev.make_grid(live.shape, rng[0], rng[1], grid.z_global_offset)
+                return g, (dev.band_list(live, canonical, g) if self.use_band_list else None)
+            self._slab_parts = ([part(r) for r in (lo_b, hi_b) if r is not None],
+                                [part(mid)] if mid[1] > mid[0] else [])
         if slab and not hasattr(self, "_comm_stream"):
             self._comm_stream = torch.cuda.Stream(device=live.device)
             self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]

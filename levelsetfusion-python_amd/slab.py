@@ -14,6 +14,14 @@ import torch
 import torch.distributed as dist
 
 
+# lsf_iteration_record (include/lsf_hip.h): 8 partial slots of 32 int64 words; word 0 = packed max, 1..3 = energies
+RECORD_SLOTS, SLOT_WORDS = 8, 32
+
+
+def _slot_view(records):
+    return records.view(records.shape[0], RECORD_SLOTS, SLOT_WORDS)
+
+
 class SlabLayout:
     def __init__(self, nz_global, rank=0, world=1, halo=0):
         if nz_global % world != 0:
@@ -146,31 +154,32 @@ class SlabComm:
             dist.all_reduce(value, op=dist.ReduceOp.MAX, group=self.group)
 
     def reduce_max(self, records, index):
-        """MAX all-reduce of the packed max of ONE record (needed before a gated iteration can test it)"""
+        """MAX all-reduce of the packed maxima of ONE record (needed before a gated iteration can test it); a record
+        is 8 partial slots (lsf_iteration_record), reduced slot by slot"""
         if not self.active:
             return
-        view = records[index, 0:1]
+        view = _slot_view(records)[index, :, 0]
+        mx = view.contiguous()
         if self.stage_through_host and records.is_cuda:
-            host = view.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.MAX, group=self.group)
-            view.copy_(host)
-        else:
-            dist.all_reduce(view, op=dist.ReduceOp.MAX, group=self.group)
+            mx = mx.cpu()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        view.copy_(mx.to(records.device))
 
     def reduce_records(self, records, first, last, energies=True):
-        """all-reduce records [first, last): column 0 (packed max, non-negative as int64) with MAX (idempotent), and
-        -- exactly once per record -- the three energy columns (float64 bit patterns) with SUM"""
+        """all-reduce records [first, last) slot by slot: the packed maxima (non-negative as int64) with MAX
+        (idempotent), and -- exactly once per record -- the three energies (float64 bit patterns) with SUM"""
         if not self.active or last <= first:
             return
         stage = self.stage_through_host and records.is_cuda
-        mx = records[first:last, 0].contiguous()
+        slots = _slot_view(records)
+        mx = slots[first:last, :, 0].contiguous()
         if stage:
             mx = mx.cpu()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
-        records[first:last, 0] = mx.to(records.device)
+        slots[first:last, :, 0] = mx.to(records.device)
         if energies:
-            en = records[first:last, 1:4].contiguous().view(torch.float64)
+            en = slots[first:last, :, 1:4].contiguous().view(torch.float64)
             if stage:
                 en = en.cpu()
             dist.all_reduce(en, op=dist.ReduceOp.SUM, group=self.group)
-            records[first:last, 1:4] = en.view(torch.int64).to(records.device)
+            slots[first:last, :, 1:4] = en.view(torch.int64).to(records.device)

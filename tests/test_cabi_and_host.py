@@ -54,7 +54,9 @@ def test_code_object_targets_gfx950_only(pkg):
 def test_ctypes_structs_match_header_layout(pkg):
     L = pkg._lib
     assert ctypes.sizeof(L.Grid) == 32
-    assert ctypes.sizeof(L.IterationRecord) == 32 == L.RECORD_BYTES
+    assert ctypes.sizeof(L.IterationRecord) == 2048 == L.RECORD_BYTES and ctypes.sizeof(L.RecordSlot) == 256
+    from levelsetfusion_python_amd import slab
+    assert (slab.RECORD_SLOTS, slab.SLOT_WORDS) == (L.RECORD_SLOTS, L.SLOT_WORDS)
     assert ctypes.sizeof(L.Gate) == 24 and L.Gate.mode.offset == 8 and L.Gate.a.offset == 12
     assert ctypes.sizeof(L.HierParams) == 32
     assert ctypes.sizeof(L.SlavchevaParams) == 56 and L.SlavchevaParams.rate.offset == 8
@@ -140,16 +142,23 @@ def test_sobolev_filter_host_code(pkg, ref_leaf):
 
 
 def test_record_decoding(pkg):
+    """a record is 8 partial slots (lsf_iteration_record): value = max of the packed maxima, sum of the energies"""
     from levelsetfusion_python_amd import device as dev
-    raw = np.zeros((3, 4), np.int64)
-    val, idx = np.float32(0.125), 77
-    packed = (np.uint64(val.view(np.uint32)) << np.uint64(32)) | np.uint64((~np.uint32(idx)) & 0xFFFFFFFF)
-    raw[0, 0] = np.array([packed], np.uint64).view(np.int64)[0]
-    raw[0, 1:] = np.array([1.5, 2.5, 3.5]).view(np.int64)
+
+    def pack(val, idx):
+        p = (np.uint64(np.float32(val).view(np.uint32)) << np.uint64(32)) | np.uint64((~np.uint32(idx)) & 0xFFFFFFFF)
+        return np.array([p], np.uint64).view(np.int64)[0]
+    raw = np.zeros((3, dev.RECORD_WORDS), np.int64)
+    slots = dev.slot_view(raw)
+    slots[0, 2, 0] = pack(0.125, 77)
+    slots[0, 5, 0] = pack(0.125, 12)       # same length, smaller index: numpy's first arg-max
+    slots[0, 7, 0] = pack(0.0625, 3)
+    slots[0, 2, 1:4] = np.array([1.5, 2.5, 3.5]).view(np.int64)
+    slots[0, 6, 1:4] = np.array([0.25, 0.5, 1.0]).view(np.int64)
     d = dev.decode_records(raw)
     assert list(d["executed"]) == [True, False, False]
-    assert d["max_value"][0] == val and d["argmax"][0] == idx
-    assert (d["data_energy"][0], d["smoothing_energy"][0], d["level_set_energy"][0]) == (1.5, 2.5, 3.5)
+    assert d["max_value"][0] == np.float32(0.125) and d["argmax"][0] == 12
+    assert (d["data_energy"][0], d["smoothing_energy"][0], d["level_set_energy"][0]) == (1.75, 3.0, 4.5)
 
 
 def test_slab_layout(pkg):

@@ -420,6 +420,98 @@ def test_slavcheva_3d_random_fields_match_oracle(lsf):
     assert maxdiff(live, live_ref) == EXACT and maxdiff(opt.warp_field, o.warp_field) == EXACT
 
 
+@pytest.mark.parametrize("shape,zr", [((12, 20, 200), None), ((5, 3, 7), None), ((9, 33, 65), (2, 7)),
+                                      ((1, 40, 70), None), ((6, 8, 8), (3, 3))])
+def test_band_list_matches_numpy(lsf, shape, zr):
+    """lsf_band_count / lsf_band_list_fill: ascending indices of the voxels with |live| != 1 or |canonical| != 1
+    (tsdf_set_routines.py:19-52) inside the z-range, ragged sizes, 2-D, empty range, all / none in band"""
+    from levelsetfusion_python_amd import device as dev
+    rng = np.random.default_rng(5)
+    for fill in ("mixed", "none", "all"):
+        live = rng.uniform(-1, 1, shape).astype(np.float32)
+        canon = rng.uniform(-1, 1, shape).astype(np.float32)
+        if fill != "all":
+            live[rng.uniform(size=shape) < (0.7 if fill == "mixed" else 2.0)] = 1.0
+            canon[rng.uniform(size=shape) < (0.7 if fill == "mixed" else 2.0)] = -1.0
+        if shape[0] == 1:
+            grid = dev.make_grid(shape[1:])
+            lo, hi = 0, 1
+        else:
+            lo, hi = zr if zr else (0, shape[0])
+            grid = dev.make_grid(shape, lo, hi, 0)
+        t_shape = shape if shape[0] > 1 else shape[1:]
+        band = dev.band_list(torch.from_numpy(live.reshape(t_shape)).cuda(),
+                             torch.from_numpy(canon.reshape(t_shape)).cuda(), grid)
+        mask = ~((np.abs(live) == 1) & (np.abs(canon) == 1))
+        mask[:lo] = False
+        mask[hi:] = False
+        expect = np.flatnonzero(mask.ravel())
+        assert band.count == len(expect)
+        assert np.array_equal(band.indices.cpu().numpy()[:band.count], expect)
+
+
+def test_slavcheva_band_list_is_invisible(lsf):
+    """lsf_slavcheva_iteration with a band list visits only the listed voxels; with both ping-pong sets initialised
+    as the header demands, buffers and records must equal those of the dense walk -- 200-voxel lines, voxels that
+    leave the band by snapping, and the oracle as third opinion"""
+    from levelsetfusion_python_amd import _lib, device as dev
+    n_it = 9
+    shape = (12, 20, 200)
+    canon, live0 = O.sphere_pair(32, 3)
+    canon = np.ascontiguousarray(np.tile(canon[10:22, 6:26, :], (1, 1, 7))[:, :, :200])
+    live0 = np.ascontiguousarray(np.tile(live0[10:22, 6:26, :], (1, 1, 7))[:, :, :200])
+    live0[:, :, 130:] = 1.0
+    canon[:, :, 130:] = -1.0
+    eng = lsf.SlavchevaOptimizer3d(field_size=32, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
+                                   gradient_descent_rate=0.5)._engine
+    grid = dev.make_grid(shape)
+    outs = []
+    for listed in (False, True):
+        c = torch.from_numpy(canon).cuda()
+        lives = [torch.from_numpy(live0).cuda(), torch.from_numpy(live0).cuda()]
+        warps = [torch.zeros((3,) + shape, device="cuda") for _ in range(2)]
+        rec = dev.new_records(n_it, "cuda")
+        band = dev.band_list(lives[0], c, grid) if listed else None
+        if listed:
+            assert 0 < band.count < live0.size * 0.7
+        for i in range(n_it):
+            dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2],
+                                    lives[(i + 1) % 2], None, grid, eng.params, None, rec, i, band)
+        outs.append([t.cpu().numpy() for t in lives + warps + [rec]])
+    for a, b in zip(outs[0][:4], outs[1][:4]):
+        assert np.array_equal(a, b)
+    ra, rb = dev.decode_records(outs[0][4]), dev.decode_records(outs[1][4])
+    assert np.array_equal(ra["max_value"], rb["max_value"]) and np.array_equal(ra["argmax"], rb["argmax"])
+    for k in ("data_energy", "smoothing_energy", "level_set_energy"):
+        # the energy sums are float64 atomics whose order varies from launch to launch
+        assert np.allclose(ra[k], rb[k], rtol=1e-9, atol=1e-12) and np.all(ra[k][1:] > 0)
+    o = O.SlavchevaOracle(compute_method=O.DIRECT, level_set_term_enabled=True, smoothing_term_method=O.KILLING,
+                          gradient_descent_rate=0.5, max_iterations=n_it, min_iterations=n_it,
+                          maximum_warp_length_lower_threshold=0.0)
+    live_ref = live0.copy()
+    o.optimize(live_ref, canon)
+    assert maxdiff(outs[1][n_it % 2], live_ref) == EXACT
+
+
+def test_slavcheva_band_list_all_zero_update_reports_first_voxel(lsf):
+    """nothing in the band: every update has length 0 and np.argmax reports voxel 0 (slavcheva_optimizer2d.py:222-224);
+    the list is empty and the kernel must still say so"""
+    from levelsetfusion_python_amd import _lib, device as dev
+    shape = (4, 8, 70)
+    ones = torch.ones(shape, device="cuda")
+    eng = lsf.SlavchevaOptimizer3d(field_size=8)._engine
+    grid = dev.make_grid(shape, 1, 3, 5)
+    band = dev.band_list(ones, ones, grid)
+    assert band.count == 0
+    rec = dev.new_records(1, "cuda")
+    dev.slavcheva_iteration(_lib.STAGE_FUSED, ones, ones, torch.zeros((3,) + shape, device="cuda"),
+                            torch.zeros((3,) + shape, device="cuda"), ones.clone(), None, grid, eng.params, None, rec, 0,
+                            band)
+    dec = dev.decode_records(rec.cpu().numpy())
+    assert dec["max_value"][0] == 0.0 and dec["argmax"][0] == (1 + 5) * 8 * 70
+
+
 # ------------------------------------------------------------ full-size, size-independent properties
 def test_full_size_2d_embedding_256(lsf):
     """BASELINE size 256^3: a z-constant volume must reproduce the 2-D result (computed by the ORACLE at 256^2)

@@ -31,7 +31,7 @@ def _worker(rank, world, port, n, nz, halo, iterations, sobolev, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
+    from levelsetfusion_python_amd.slab import RECORD_SLOTS, SLOT_WORDS, SlabComm, SlabLayout
     from oracle import lsf_oracle as O
     canonical, live = O.sphere_pair(n, d=3, nz=nz)
     layout = SlabLayout(nz, rank, world, halo)
@@ -44,7 +44,7 @@ def _worker(rank, world, port, n, nz, halo, iterations, sobolev, out_dir):
     opt = O.SlavchevaOracle(compute_method=O.DIRECT, level_set_term_enabled=not sobolev,
                             smoothing_term_method=O.TIKHONOV if sobolev else O.KILLING,
                             sobolev_smoothing_enabled=sobolev, sobolev_kernel=kernel)
-    records = torch.zeros((iterations, 4), dtype=torch.int64)
+    records = torch.zeros((iterations, RECORD_SLOTS * SLOT_WORDS), dtype=torch.int64)
     own = layout.owned_local()
     opt.max_region = own
     for it in range(iterations):

@@ -10,28 +10,33 @@ from levelsetfusion_python_amd.synthetic import sphere_pair
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 eng = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
                                smoothing_term_method=lsf.SmoothingTermMethod.KILLING)._engine
+if os.environ.get("ENERGY", "1") == "0":
+    eng.params.energy_mode = _lib.ENERGY_NONE
 grid = dev.make_grid((n, n, n))
-rec = dev.new_records(1, "cuda")
+rec = dev.new_records(128, "cuda")
 c_s, l_s = sphere_pair(n, 3, "cuda")
 ones = torch.ones_like(c_s)
 z, y, x = torch.meshgrid(*[torch.arange(n, device="cuda", dtype=torch.float32)] * 3, indexing="ij")
 ramp_c = (0.8 * torch.sin(x * 0.05) * torch.cos(y * 0.04) * torch.cos(z * 0.03)).contiguous()
 ramp_l = (0.8 * torch.sin(x * 0.05 + 0.1) * torch.cos(y * 0.04 - 0.05) * torch.cos(z * 0.03 + 0.08)).contiguous()
 for name, c, l in (("none in band", ones, ones.clone()), ("sphere pair", c_s, l_s), ("all in band", ramp_c, ramp_l)):
-    lives = [l.clone(), torch.empty_like(l)]
-    warps = [torch.zeros((3, n, n, n), device="cuda") for _ in range(2)]
     band = float((~((l.abs() == 1) & (c.abs() == 1))).float().mean())
-    for i in range(4):
-        dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2], lives[(i + 1) % 2],
-                                None, grid, eng.params, None, rec, 0)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    reps = 20
-    for i in range(reps):
-        dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2], lives[(i + 1) % 2],
-                                None, grid, eng.params, None, rec, 0)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    print("%-14s band fraction %.3f  %.4f ms  -> %.1f G voxel-updates/s" % (name, band, ms, n ** 3 / ms / 1e6))
+    for listed in (False, True):
+        lives = [l.clone(), l.clone()]
+        warps = [torch.zeros((3, n, n, n), device="cuda") for _ in range(2)]
+        state = dev.band_list(l, c, grid) if listed else None
+        for i in range(4):
+            dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2],
+                                    lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0, state)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        reps = 20
+        for i in range(reps):
+            dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2],
+                                    lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0, state)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        print("%-14s band fraction %.3f  band list %-5s %.4f ms  -> %.1f G voxel-updates/s"
+              % (name, band, listed, ms, n ** 3 / ms / 1e6))
