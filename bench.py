@@ -208,7 +208,7 @@ def main():
     eng = opt._engine
     grid = eng._grid(live0)
     rec = dev.new_records(2, device)
-    band = dev.band_list(live0, canonical, grid) if eng.use_band_list else None
+    bands = dev.band_lists(live0, canonical, grid) if eng.use_band_list else [None]
     n_launch = iters
 
     def launches():
@@ -218,8 +218,9 @@ def main():
         torch.cuda.synchronize()
         e0.record()
         for i in range(n_launch):
-            dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], canonical, warps[i % 2], warps[(i + 1) % 2],
-                                    lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0, band)
+            for band in bands:  # interior + (usually empty, then absent) boundary band voxels
+                dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], canonical, warps[i % 2], warps[(i + 1) % 2],
+                                        lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0, band)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n_launch
@@ -229,7 +230,7 @@ def main():
     # is not touched).  52 B per visited voxel-update is SURVEY 8(d)'s figure.  The dense-
     # equivalent rate (52 B x ALL voxels / time) is reported next to it: it is what a kernel streaming the whole
     # volume every iteration would have to sustain to be this fast, and may exceed the HBM peak.
-    units = band.count if band is not None else voxels_per_rank
+    units = sum(b.count for b in bands) if bands[0] is not None else voxels_per_rank
     alg_bytes = B_ALG["killing"] * units
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     dense_equivalent = B_ALG["killing"] * voxels_per_rank / (kernel_ms * 1e-3) / 1e9

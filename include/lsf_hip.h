@@ -217,24 +217,31 @@ typedef struct lsf_slavcheva_params {
  * and so stays outside for the rest of the optimisation.  The CALLER must have initialised live_out / warp_out of BOTH
  * ping-pong buffer sets with (live, 0) at the unlisted voxels, and must keep canonical and params unchanged while the
  * list is in use.  Records, live and warp are identical with and without a list. */
+#define LSF_BAND_ALL 0      /* every voxel of the narrow-band union */
+#define LSF_BAND_INTERIOR 1 /* ... whose whole 3^D neighbourhood lies inside the (allocated) array */
+#define LSF_BAND_BOUNDARY 2 /* ... the others (voxels on a face of the array) */
 int lsf_slavcheva_iteration(int32_t stage, const float *live, const float *canonical,
                             const float *warp_prev_planar, float *warp_out_planar, float *live_out,
                             float *g_out_planar /* may be NULL in FUSED */, const lsf_grid *grid,
                             const lsf_slavcheva_params *params, const lsf_gate *gate,
                             lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,
-                            void *stream);
+                            int32_t band_subset /* LSF_BAND_* the list was built with */, void *stream);
 
 /* Band list of the grid's z-range [z_begin, z_end): the voxels with |live| != 1 or |canonical| != 1
- * (tsdf_set_routines.py:19-52; the `continue` of slavcheva_optimizer2d.py:251-252), in ascending index order.
+ * (tsdf_set_routines.py:19-52; the `continue` of slavcheva_optimizer2d.py:251-252), in ascending index order --
+ * all of them, or split into INTERIOR and BOUNDARY voxels.  An INTERIOR list lets lsf_slavcheva_iteration run a
+ * kernel that never applies the reference's out-of-bounds rules (none can fire) and addresses all neighbours from one
+ * per-lane offset; it requires 12 * nz * ny * nx < 2^32 (32-bit buffer offsets; LSF_ERR_BAD_ARGUMENT otherwise).
+ * One iteration = one launch per non-empty list, all on the same record.
  *   1. lsf_band_count     counts per 1024-voxel chunk into scratch (lsf_band_scratch_elements(grid) int32 elements),
  *                         scans them, and writes the total to *count_out (device memory);
  *   2. the caller reads the total and allocates the list;
- *   3. lsf_band_list_fill writes the indices (same live / canonical / grid / scratch as step 1). */
+ *   3. lsf_band_list_fill writes the indices (same live / canonical / grid / subset / scratch as step 1). */
 int64_t lsf_band_scratch_elements(const lsf_grid *grid);
-int lsf_band_count(const float *live, const float *canonical, const lsf_grid *grid, int32_t *scratch,
-                   int64_t *count_out, void *stream);
-int lsf_band_list_fill(const float *live, const float *canonical, const lsf_grid *grid, const int32_t *scratch,
-                       int32_t *list, void *stream);
+int lsf_band_count(const float *live, const float *canonical, const lsf_grid *grid, int32_t subset,
+                   int32_t *scratch, int64_t *count_out, void *stream);
+int lsf_band_list_fill(const float *live, const float *canonical, const lsf_grid *grid, int32_t subset,
+                       const int32_t *scratch, int32_t *list, void *stream);
 
 int lsf_slavcheva_update_rewarp(const float *live, const float *canonical, float *g_planar /* inout */,
                                 float *warp_out_planar, float *live_out, const lsf_grid *grid,

@@ -33,6 +33,7 @@ class Grid(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+BAND_ALL, BAND_INTERIOR, BAND_BOUNDARY = 0, 1, 2
 RECORD_SLOTS = 8
 
 
@@ -108,10 +109,10 @@ PROTOTYPES = {
     "lsf_hier_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(HierParams), _P(Gate), _vp, _vp]),
     "lsf_hier_update": (ctypes.c_int, [_vp, _vp, _P(Grid), _f32, _P(Gate), _vp, _vp]),
     "lsf_slavcheva_iteration": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _P(Grid),
-                                               _P(SlavchevaParams), _P(Gate), _vp, _vp, _i64, _vp]),
+                                               _P(SlavchevaParams), _P(Gate), _vp, _vp, _i64, _i32, _vp]),
     "lsf_band_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
-    "lsf_band_count": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp, _vp, _vp]),
-    "lsf_band_list_fill": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp, _vp, _vp]),
+    "lsf_band_count": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),
+    "lsf_band_list_fill": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),
     "lsf_slavcheva_update_rewarp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),
                                                    _P(Gate), _vp, _vp]),
     "lsf_warp_statistics": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp, _vp]),

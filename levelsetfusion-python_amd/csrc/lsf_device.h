@@ -39,6 +39,7 @@ struct Grid {
     int tile_y;            // rows per tile = waves per block (1..4); blockDim.x = 64 * tile_y
     long long plane;       // nz*ny*nx: stride between the planes of a planar vector field
     FastDiv div_tiles_x, div_tiles_y, div_chunk, div_nx, div_ny;
+    int fast_ok;           // 32-bit buffer addressing is possible: 3 planes of a vector field stay below 4 GiB
 };
 
 __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
@@ -66,6 +67,7 @@ __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
     r.div_chunk = make_fast_div(r.chunk_tiles);
     r.div_nx = make_fast_div((unsigned)g->nx);
     r.div_ny = make_fast_div((unsigned)g->ny);
+    r.fast_ok = r.plane * 3 * 4 < 0xffffffffll;
     return r;
 }
 
@@ -313,9 +315,8 @@ __device__ inline AxisTaps axis_taps(float p, int n, int global_offset) {
 }
 
 template <int D>
-__device__ inline float sample_linear(const float* __restrict__ f, const Grid& g, float px, float py, float pz,
-                                      float oob) {
-    const AxisTaps ax = axis_taps(px, g.nx, 0), ay = axis_taps(py, g.ny, 0);
+__device__ inline float sample_linear_taps(const float* __restrict__ f, const Grid& g, const AxisTaps& ax,
+                                           const AxisTaps& ay, const AxisTaps& az, float oob) {
     const int row0 = ay.c0 * g.nx, row1 = ay.c1 * g.nx;
     if (D == 2) {
         float v00 = f[row0 + ax.c0], v01 = f[row1 + ax.c0], v10 = f[row0 + ax.c1], v11 = f[row1 + ax.c1];
@@ -327,7 +328,6 @@ __device__ inline float sample_linear(const float* __restrict__ f, const Grid& g
         const float i1 = v10 * ay.i + v11 * ay.r;
         return i0 * ax.i + i1 * ax.r;
     } else {
-        const AxisTaps az = axis_taps(pz, g.nz, g.z_global_offset);
         const int slice = g.nx * g.ny;
         const int s0 = az.c0 * slice, s1 = az.c1 * slice;
         float c[2][2];  // [x offset][y offset] after the z lerp
@@ -346,6 +346,15 @@ __device__ inline float sample_linear(const float* __restrict__ f, const Grid& g
         const float i1 = c[1][0] * ay.i + c[1][1] * ay.r;
         return i0 * ax.i + i1 * ax.r;
     }
+}
+
+template <int D>
+__device__ inline float sample_linear(const float* __restrict__ f, const Grid& g, float px, float py, float pz,
+                                      float oob) {
+    const AxisTaps ax = axis_taps(px, g.nx, 0), ay = axis_taps(py, g.ny, 0);
+    AxisTaps az = ax;
+    if (D == 3) az = axis_taps(pz, g.nz, g.z_global_offset);
+    return sample_linear_taps<D>(f, g, ax, ay, az, oob);
 }
 
 // ------------------------------------------------------------------------------------------------------

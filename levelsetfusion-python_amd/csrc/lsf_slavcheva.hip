@@ -28,6 +28,7 @@ struct Params {
 //   np.gradient       one-sided first-order difference at the array border
 template <int D>
 struct Nbh {
+    using Field = const float*;  // base of one scalar plane
     int i;          // index of the voxel inside a plane
     int off[3][2];  // clamped element offsets of the -1 / +1 neighbours along x, y, z
     bool has[3][2]; // neighbour exists
@@ -45,20 +46,76 @@ struct Nbh {
             off[a][1] = has[a][1] ? stride[a] : 0;
         }
     }
+    __device__ static inline Field field(const float* base, const Grid& g, int plane) { return base + plane * g.plane; }
+    __device__ inline bool exists(int a, int s) const { return has[a][s]; }
+    __device__ inline float centre(Field f) const { return f[i]; }
     // axis neighbour of a scalar plane; clamped (== centre when missing)
-    __device__ inline float axis(const float* __restrict__ f, int a, int s) const { return f[i + off[a][s]]; }
+    __device__ inline float axis(Field f, int a, int s) const { return f[i + off[a][s]]; }
     // diagonal neighbour in the (a, b) plane, sa/sb in {0: -1, 1: +1}; clamped
-    __device__ inline float diag(const float* __restrict__ f, int a, int sa, int b, int sb) const {
+    __device__ inline float diag(Field f, int a, int sa, int b, int sb) const {
         return f[i + off[a][sa] + off[b][sb]];
     }
     __device__ inline bool diag_exists(int a, int sa, int b, int sb) const { return has[a][sa] && has[b][sb]; }
 };
 
-// np.gradient along axis a from the clamped neighbours: (f+ - f-)/2 inside, one-sided at the border, 0 for n == 1
+// The same interface for a voxel whose whole 3^D neighbourhood lies inside the array (decided per WAVE: all its
+// active lanes).  Every neighbour exists, so the reference's OOB rules never fire, and the neighbour offsets are the
+// same for all lanes: loads go through buffer resources with ONE per-lane byte offset (the neighbourhood's lowest
+// corner) and the neighbour selected by the instruction's SCALAR offset operand -- no per-neighbour VALU address
+// arithmetic, no selects.  (The generic path spends 107 of its ~950 VALU instructions per 64 voxels on 64-bit
+// address adds and 100 on OOB selects.)  Buffer offsets are 32-bit: the host enables this path only when a scalar
+// plane and the D planes of a vector field each stay below 4 GiB (Grid::fast_ok).
+struct BufField {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned plane_bytes;  // byte offset of the addressed plane inside the resource
+};
+
 template <int D>
-__device__ inline float np_gradient_from(const Nbh<D>& n, int a, float fm, float fp) {
+struct NbhFast {
+    using Field = BufField;
+    // byte offset of voxel (x-1, y-1[, z-1]) inside a plane = wave_base (scalar: the offset of the wave's first
+    // active lane, which is its smallest -- both walks hand out ascending voxel indices by lane) + lane_delta.
+    // Keeping the scalar part tied to the voxel makes every neighbour's scalar offset a one-instruction SALU add at
+    // the point of use instead of ~70 loop-invariant values that would have to live in (spilled) SGPRs.
+    unsigned wave_base, lane_delta;
+    unsigned sy, sz;   // byte strides of y and z (uniform)
+
+    __device__ inline NbhFast(const Grid& g, int x, int y, int z) {
+        sy = (unsigned)g.nx * 4u;
+        sz = (unsigned)(g.nx * g.ny) * 4u;
+        const unsigned corner = (unsigned)vidx(g, x, y, z) * 4u - 4u - sy - (D == 3 ? sz : 0u);
+        wave_base = (unsigned)__builtin_amdgcn_readfirstlane((int)corner);
+        lane_delta = corner - wave_base;
+    }
+    __device__ static inline Field field(const float* base, const Grid& g, int plane) {
+        // one resource spans all planes of the field (D * plane * 4 bytes < 4 GiB, see Grid::fast_ok)
+        return BufField{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000),
+                        (unsigned)plane * (unsigned)g.plane * 4u};
+    }
+    __device__ inline float at(const Field& f, int dx, int dy, int dz) const {
+        const unsigned soff = wave_base + f.plane_bytes + (unsigned)(dy + 1) * sy + (D == 3 ? (unsigned)(dz + 1) * sz : 0u);
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                             f.rsrc, (int)(lane_delta + (unsigned)(dx + 1) * 4u), (int)soff, 0));
+    }
+    __device__ static constexpr bool exists(int, int) { return true; }
+    __device__ static constexpr bool diag_exists(int, int, int, int) { return true; }
+    __device__ inline float centre(const Field& f) const { return at(f, 0, 0, 0); }
+    __device__ inline float axis(const Field& f, int a, int s) const {
+        const int d = s ? 1 : -1;
+        return at(f, a == 0 ? d : 0, a == 1 ? d : 0, a == 2 ? d : 0);
+    }
+    __device__ inline float diag(const Field& f, int a, int sa, int b, int sb) const {
+        const int da = sa ? 1 : -1, db = sb ? 1 : -1;
+        return at(f, (a == 0 ? da : 0) + (b == 0 ? db : 0), (a == 1 ? da : 0) + (b == 1 ? db : 0),
+                  (a == 2 ? da : 0) + (b == 2 ? db : 0));
+    }
+};
+
+// np.gradient along axis a from the clamped neighbours: (f+ - f-)/2 inside, one-sided at the border, 0 for n == 1
+template <class NB>
+__device__ inline float np_gradient_from(const NB& n, int a, float fm, float fp) {
     const float d = fp - fm;  // at a border the missing side was read as the centre
-    return (n.has[a][0] && n.has[a][1]) ? d * 0.5f : d;
+    return (n.exists(a, 0) && n.exists(a, 1)) ? d * 0.5f : d;
 }
 
 // a14 (vectorised form used for both compute methods): -Laplacian, edge replicated, scipy rounding
@@ -83,8 +140,8 @@ __device__ inline void tikhonov_gradient(const float (&wm)[3][3], const float (&
 // a15: Killing regulariser, smoothing_term.py:50-100, every quirk kept (w_yy uses the +1 neighbour twice; the
 // -2(1+lambda) factor multiplies the xx term only); 3-D extension per DESIGN.md section 3.
 // wm/wp[a][i]: component i at the -1/+1 neighbour along axis a (missing neighbour = centre).
-template <int D>
-__device__ inline void killing_gradient(const Nbh<D>& n, const float* const (&w)[3], const float (&wm)[3][3],
+template <int D, class NB>
+__device__ inline void killing_gradient(const NB& n, const typename NB::Field (&w)[3], const float (&wm)[3][3],
                                         const float (&wp)[3][3], const float (&wc)[3], const Params& p,
                                         float (&gs)[3], double& energy, bool want_energy) {
     float first[3][3];   // first[a][i]  = d w_i / d a
@@ -145,8 +202,8 @@ __device__ inline void killing_gradient(const Nbh<D>& n, const float* const (&w)
 
 // a16: level-set term, level_set_term.py:28-64 (OOB -> 1; second derivatives use the +1 neighbour twice)
 // lm/lp[a]: live at the -1/+1 neighbour along axis a with OOB already replaced by 1
-template <int D>
-__device__ inline void level_set_gradient(const Nbh<D>& n, const float* __restrict__ live, const float (&lm)[3],
+template <int D, class NB>
+__device__ inline void level_set_gradient(const NB& n, const typename NB::Field& live, const float (&lm)[3],
                                           const float (&lp)[3], float l, float (&gl)[3], double& energy) {
     float grad[3] = {0.0f, 0.0f, 0.0f};
     float hess[3][3];
@@ -187,16 +244,14 @@ __device__ inline void level_set_gradient(const Nbh<D>& n, const float* __restri
     energy = 0.5 * dn * dn;
 }
 
-// gradient of the energy at one voxel (a12-a17); zero outside the narrow-band union
-template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
-__device__ inline void voxel_gradient(const float* __restrict__ live, const float* __restrict__ canonical,
-                                      const float* __restrict__ warp_prev, const Grid& g, const Params& p, int x,
-                                      int y, int z, int i, float (&gv)[3], double (&en)[3]) {
-    gv[0] = gv[1] = gv[2] = 0.0f;
-    const float l = live[i], cn = canonical[i];
+// gradient of the energy at one voxel of the narrow-band union (a12-a17); NB = Nbh<D> or NbhFast<D>
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, class NB>
+__device__ inline void band_voxel_gradient(const float* __restrict__ live_base, const float* __restrict__ warp_prev,
+                                           const Grid& g, const Params& p, int x, int y, int z, float l, float cn,
+                                           float (&gv)[3], double (&en)[3]) {
     const bool live_truncated = fabsf(l) == 1.0f;
-    if (live_truncated && fabsf(cn) == 1.0f) return;  // outside the narrow-band union (tsdf_set_routines.py:19-52)
-    const Nbh<D> n(g, x, y, z);
+    const NB n(g, x, y, z);
+    const typename NB::Field live = NB::field(live_base, g, 0);
     // ---- live neighbours (shared by np.gradient, the thresholded data term and the level-set term)
     float lmc[3], lpc[3];  // clamped: a missing neighbour reads the centre
 #pragma unroll
@@ -208,12 +263,12 @@ __device__ inline void voxel_gradient(const float* __restrict__ live, const floa
     const float diff = l - cn;
     float lg[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
-    for (int a = 0; a < D; ++a) lg[a] = np_gradient_from<D>(n, a, lmc[a], lpc[a]);
+    for (int a = 0; a < D; ++a) lg[a] = np_gradient_from(n, a, lmc[a], lpc[a]);
     if (DATA == LSF_DATA_THRESHOLDED_FDM) {
 #pragma unroll
         for (int a = 0; a < D; ++a) {
-            const float fwd = (n.has[a][1] ? lpc[a] : 1.0f) - l;
-            const float bwd = l - (n.has[a][0] ? lmc[a] : 1.0f);
+            const float fwd = (n.exists(a, 1) ? lpc[a] : 1.0f) - l;
+            const float bwd = l - (n.exists(a, 0) ? lmc[a] : 1.0f);
             float alt = fabsf(fwd) < fabsf(bwd) ? fwd : bwd;
             alt = fabsf(alt) > 0.5f ? 0.0f : alt;
             lg[a] = fabsf(lg[a]) > 0.5f ? alt : lg[a];
@@ -227,22 +282,23 @@ __device__ inline void voxel_gradient(const float* __restrict__ live, const floa
         float lm1[3], lp1[3];
 #pragma unroll
         for (int a = 0; a < D; ++a) {
-            lm1[a] = n.has[a][0] ? lmc[a] : 1.0f;
-            lp1[a] = n.has[a][1] ? lpc[a] : 1.0f;
+            lm1[a] = n.exists(a, 0) ? lmc[a] : 1.0f;
+            lp1[a] = n.exists(a, 1) ? lpc[a] : 1.0f;
         }
         float gl[3];
         double e;
-        level_set_gradient<D>(n, live, lm1, lp1, l, gl, e);
+        level_set_gradient<D, NB>(n, live, lm1, lp1, l, gl, e);
 #pragma unroll
         for (int c = 0; c < D; ++c) gv[c] = gv[c] + p.w_level_set * gl[c];
         if (ENERGY != LSF_ENERGY_NONE) en[2] = e;
     }
     // ---- smoothing term on the previous warp: axis neighbours with "missing -> centre" come free from clamping
-    const float* const w[3] = {warp_prev, warp_prev + g.plane, warp_prev + (D == 3 ? 2 : 0) * g.plane};
+    const typename NB::Field w[3] = {NB::field(warp_prev, g, 0), NB::field(warp_prev, g, 1),
+                                     NB::field(warp_prev, g, D == 3 ? 2 : 0)};
     float wc[3] = {0.0f, 0.0f, 0.0f}, wm[3][3], wp[3][3];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        wc[c] = w[c][i];
+        wc[c] = n.centre(w[c]);
 #pragma unroll
         for (int a = 0; a < D; ++a) {
             wm[a][c] = n.axis(w[c], a, 0);
@@ -252,7 +308,7 @@ __device__ inline void voxel_gradient(const float* __restrict__ live, const floa
     float gs[3] = {0.0f, 0.0f, 0.0f};
     if (SMOOTH == LSF_SMOOTHING_KILLING) {
         double e = 0.0;
-        killing_gradient<D>(n, w, wm, wp, wc, p, gs, e, ENERGY != LSF_ENERGY_NONE);
+        killing_gradient<D, NB>(n, w, wm, wp, wc, p, gs, e, ENERGY != LSF_ENERGY_NONE);
         if (ENERGY != LSF_ENERGY_NONE) en[1] = e;
     } else {
         tikhonov_gradient<D>(wm, wp, wc, gs);
@@ -276,7 +332,7 @@ __device__ inline void voxel_gradient(const float* __restrict__ live, const floa
             for (int c = 0; c < D; ++c)
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
-                    const float d = np_gradient_from<D>(n, a, wm[a][c], wp[a][c]);
+                    const float d = np_gradient_from(n, a, wm[a][c], wp[a][c]);
                     e += (double)d * (double)d;
                 }
             en[1] = 0.5 * e;
@@ -284,6 +340,56 @@ __device__ inline void voxel_gradient(const float* __restrict__ live, const floa
     }
 #pragma unroll
     for (int c = 0; c < D; ++c) gv[c] = gv[c] + p.w_smooth * gs[c];
+}
+
+// gradient of the energy at one voxel (a12-a17); zero outside the narrow-band union
+// ALL_INTERIOR: the caller guarantees the neighbourhood of every voxel it visits (an INTERIOR band list): the generic
+// path is not even compiled in, which keeps that kernel at 85 VGPRs / 5 waves per SIMD and ~620 VALU instructions
+// per 64 voxels (the two-path kernel needs 111 VGPRs, the generic path ~850 instructions).
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, bool ALL_INTERIOR>
+__device__ inline void voxel_gradient(const float* __restrict__ live, const float* __restrict__ canonical,
+                                      const float* __restrict__ warp_prev, const Grid& g, const Params& p, int x,
+                                      int y, int z, int i, float (&gv)[3], double (&en)[3]) {
+    gv[0] = gv[1] = gv[2] = 0.0f;
+    const float l = live[i], cn = canonical[i];
+    if (fabsf(l) == 1.0f && fabsf(cn) == 1.0f) return;  // outside the narrow-band union (tsdf_set_routines.py:19-52)
+    const bool interior = x > 0 && x < g.nx - 1 && y > 0 && y < g.ny - 1 && (D == 2 || (z > 0 && z < g.nz - 1));
+    if (ALL_INTERIOR || (g.fast_ok && __all(interior)))  // wave-uniform: every band lane has its whole neighbourhood
+        band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY, NbhFast<D>>(live, warp_prev, g, p, x, y, z, l, cn, gv, en);
+    else
+        band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY, Nbh<D>>(live, warp_prev, g, p, x, y, z, l, cn, gv, en);
+}
+
+// the re-warp's D-linear gather (OOB -> 1).  When the 2^D-voxel cell of every active lane lies inside the array (wave
+// vote) the taps are buffer loads at one per-lane offset (the cell's lowest corner) + scalar tap offsets and need no
+// OOB selects; the lerp order (z, then y, then x) and therefore the result is that of sample_linear.
+template <int D>
+__device__ inline float rewarp_gather(const float* __restrict__ live, const Grid& g, float px, float py, float pz) {
+    const AxisTaps ax = axis_taps(px, g.nx, 0), ay = axis_taps(py, g.ny, 0);
+    AxisTaps az = ax;
+    if (D == 3) az = axis_taps(pz, g.nz, g.z_global_offset);
+    const bool cell_inside = ax.v0 && ax.v1 && ay.v0 && ay.v1 && (D == 2 || (az.v0 && az.v1));
+    if (!(g.fast_ok && __all(cell_inside))) return sample_linear_taps<D>(live, g, ax, ay, az, 1.0f);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(live), 0, -1, 0x00020000);
+    const unsigned sy = (unsigned)g.nx * 4u, sz = (unsigned)(g.nx * g.ny) * 4u;
+    const unsigned corner = (unsigned)(((D == 3 ? az.c0 : 0) * g.ny + ay.c0) * g.nx + ax.c0) * 4u;
+    auto tap = [&](int dx, int dy, int dz) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                             rsrc, (int)(corner + (unsigned)dx * 4u), (int)((unsigned)dy * sy + (unsigned)dz * sz), 0));
+    };
+    if (D == 2) {
+        const float i0 = tap(0, 0, 0) * ay.i + tap(0, 1, 0) * ay.r;
+        const float i1 = tap(1, 0, 0) * ay.i + tap(1, 1, 0) * ay.r;
+        return i0 * ax.i + i1 * ax.r;
+    }
+    float c[2][2];
+#pragma unroll
+    for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+        for (int oy = 0; oy < 2; ++oy) c[ox][oy] = tap(ox, oy, 0) * az.i + tap(ox, oy, 1) * az.r;
+    const float i0 = c[0][0] * ay.i + c[0][1] * ay.r;
+    const float i1 = c[1][0] * ay.i + c[1][1] * ay.r;
+    return i0 * ax.i + i1 * ax.r;
 }
 
 // warp = -g*rate, |warp| for the arg-max, truncation-aware re-warp of the live field (a18 + a3)
@@ -305,7 +411,7 @@ __device__ inline unsigned long long update_and_rewarp(const float* __restrict__
     } else {
         const float px = (float)x + wv[0], py = (float)y + wv[1];
         const float pz = D == 3 ? (float)(z + g.z_global_offset) + wv[2] : 0.0f;
-        v = sample_linear<D>(live, g, px, py, pz, 1.0f);
+        v = rewarp_gather<D>(live, g, px, py, pz);
     }
     if (1.0f - fabsf(v) < 1e-6f) {  // field_warping.py:138-141
         v = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : v);
@@ -321,11 +427,15 @@ __device__ inline unsigned long long update_and_rewarp(const float* __restrict__
     return pack_max(len, lin);
 }
 
-template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, bool FUSED>
+// MODE: 0 = gradient only (Sobolev path), 1 = fused, 2 = fused over an all-interior band list
+constexpr int kModeGradient = 0, kModeFused = 1, kModeFusedInterior = 2;
+
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, int MODE>
 __global__ __launch_bounds__(kBlock) void slavcheva_iteration_kernel(
     const float* __restrict__ live, const float* __restrict__ canonical, const float* __restrict__ warp_prev,
     float* __restrict__ warp_out, float* __restrict__ live_out, float* __restrict__ g_out, Grid g, Params p,
     lsf_gate gate, lsf_iteration_record* record, const int* __restrict__ band_list, unsigned band_count) {
+    constexpr bool FUSED = MODE != kModeGradient;
     if (gate_closed(gate)) return;
     unsigned long long best = 0ull;
     double en[3] = {0.0, 0.0, 0.0};
@@ -333,7 +443,8 @@ __global__ __launch_bounds__(kBlock) void slavcheva_iteration_kernel(
         const int i = vidx(g, x, y, z);
         float gv[3];
         double e[3] = {0.0, 0.0, 0.0};
-        voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(live, canonical, warp_prev, g, p, x, y, z, i, gv, e);
+        voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY, MODE == kModeFusedInterior>(live, canonical, warp_prev, g, p, x,
+                                                                                      y, z, i, gv, e);
         en[0] += e[0];
         en[1] += e[1];
         en[2] += e[2];
@@ -409,29 +520,29 @@ struct LaunchArgs {
     unsigned band_count;
 };
 
-template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, bool FUSED>
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, int MODE>
 void launch_one(const LaunchArgs& a) {
-    hipLaunchKernelGGL((slavcheva_iteration_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY, FUSED>), dim3(a.blocks),
+    hipLaunchKernelGGL((slavcheva_iteration_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY, MODE>), dim3(a.blocks),
                        dim3(kTileX * a.g.tile_y), 0, a.s, a.live, a.canonical, a.warp_prev, a.warp_out, a.live_out, a.g_out, a.g,
                        a.p, a.gate, a.record, a.band_list, a.band_count);
 }
 
-template <int D, int SMOOTH, bool LEVELSET, int DATA, bool FUSED>
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int MODE>
 void pick_energy(int energy, const LaunchArgs& a) {
     switch (energy) {
-        case LSF_ENERGY_DIRECT: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_DIRECT, FUSED>(a); break;
-        case LSF_ENERGY_VECTORIZED: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_VECTORIZED, FUSED>(a); break;
-        default: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_NONE, FUSED>(a); break;
+        case LSF_ENERGY_DIRECT: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_DIRECT, MODE>(a); break;
+        case LSF_ENERGY_VECTORIZED: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_VECTORIZED, MODE>(a); break;
+        default: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_NONE, MODE>(a); break;
     }
 }
 
-template <int D, bool FUSED>
+template <int D, int MODE>
 void pick_terms(const lsf_slavcheva_params* q, const LaunchArgs& a) {
     const bool killing = q->smoothing_method == LSF_SMOOTHING_KILLING;
     const bool ls = q->level_set_enabled != 0;
     const bool fdm = q->data_method == LSF_DATA_THRESHOLDED_FDM;
     const int e = q->energy_mode;
-#define LSF_PICK(S, L, DM) pick_energy<D, S, L, DM, FUSED>(e, a)
+#define LSF_PICK(S, L, DM) pick_energy<D, S, L, DM, MODE>(e, a)
     if (killing) {
         if (ls) { if (fdm) LSF_PICK(LSF_SMOOTHING_KILLING, true, LSF_DATA_THRESHOLDED_FDM); else LSF_PICK(LSF_SMOOTHING_KILLING, true, LSF_DATA_BASIC); }
         else    { if (fdm) LSF_PICK(LSF_SMOOTHING_KILLING, false, LSF_DATA_THRESHOLDED_FDM); else LSF_PICK(LSF_SMOOTHING_KILLING, false, LSF_DATA_BASIC); }
@@ -449,11 +560,13 @@ constexpr unsigned kBandChunk = 4 * kBlock;  // voxels per block of the count / 
 
 // FILL == false: block_sums[b] = number of band voxels in chunk b.  FILL == true: block_sums holds the exclusive
 // prefix sums; writes the chunk's band voxels, in ascending order, to list[block_sums[b] ...].
+// subset: LSF_BAND_ALL, or only the band voxels whose whole 3^D neighbourhood lies inside the array (INTERIOR) / the
+// others (BOUNDARY).
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void band_list_kernel(const float* __restrict__ live,
                                                            const float* __restrict__ canonical, unsigned first,
-                                                           unsigned n, int* __restrict__ block_sums,
-                                                           int* __restrict__ list) {
+                                                           unsigned n, Grid g, int dims, int subset,
+                                                           int* __restrict__ block_sums, int* __restrict__ list) {
     __shared__ int part[16];  // [pass j][wave]
     const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
     unsigned long long masks[4];
@@ -462,6 +575,15 @@ __global__ __launch_bounds__(kBlock) void band_list_kernel(const float* __restri
         const unsigned v = blockIdx.x * kBandChunk + j * kBlock + t;
         bool in_band = false;
         if (v < n) in_band = !(fabsf(live[first + v]) == 1.0f && fabsf(canonical[first + v]) == 1.0f);
+        if (in_band && subset != LSF_BAND_ALL) {
+            const unsigned i = first + v;
+            const unsigned zy = fast_div(i, g.div_nx);
+            const int x = (int)(i - zy * (unsigned)g.nx);
+            const int z = (int)fast_div(zy, g.div_ny);
+            const int y = (int)zy - z * g.ny;
+            const bool interior = x > 0 && x < g.nx - 1 && y > 0 && y < g.ny - 1 && (dims == 2 || (z > 0 && z < g.nz - 1));
+            in_band = interior == (subset == LSF_BAND_INTERIOR);
+        }
         masks[j] = __ballot(in_band);
         if (lane == 0) part[j * 4 + wave] = __popcll(masks[j]);
     }
@@ -512,11 +634,15 @@ __global__ __launch_bounds__(1024) void band_scan_kernel(int* __restrict__ sums,
 
 }  // namespace
 
+static inline bool band_subset_ok(int32_t subset) {
+    return subset == LSF_BAND_ALL || subset == LSF_BAND_INTERIOR || subset == LSF_BAND_BOUNDARY;
+}
+
 extern "C" int lsf_slavcheva_iteration(int32_t stage, const float* live, const float* canonical,
                                        const float* warp_prev_planar, float* warp_out_planar, float* live_out,
                                        float* g_out_planar, const lsf_grid* grid, const lsf_slavcheva_params* params,
                                        const lsf_gate* gate, lsf_iteration_record* record, const int32_t* band_list,
-                                       int64_t band_count, void* stream) {
+                                       int64_t band_count, int32_t band_subset, void* stream) {
     if (int e = check_grid(grid)) return e;
     if (!live || !canonical || !warp_prev_planar || !params || !record) return LSF_ERR_BAD_ARGUMENT;
     if (stage == LSF_STAGE_FUSED) {
@@ -537,16 +663,24 @@ extern "C" int lsf_slavcheva_iteration(int32_t stage, const float* live, const f
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
     const bool listed = band_list != nullptr;
-    if (listed && (stage != LSF_STAGE_FUSED || g_out_planar || band_count < 0 || band_count > 0x7fffffffll))
+    if (listed && (stage != LSF_STAGE_FUSED || g_out_planar || band_count < 0 || band_count > 0x7fffffffll ||
+                   !band_subset_ok(band_subset)))
         return LSF_ERR_BAD_ARGUMENT;
+    // an INTERIOR list runs the kernel without the generic neighbourhood path; it needs 32-bit buffer offsets
+    const bool all_interior = listed && band_subset == LSF_BAND_INTERIOR;
+    if (all_interior && !g.fast_ok) return LSF_ERR_BAD_ARGUMENT;
     const unsigned blocks = listed ? band_list_blocks((unsigned)band_count) : launch_blocks(t.total, per_xcd);
     LaunchArgs a{blocks, as_stream(stream), live, canonical, warp_prev_planar, warp_out_planar,
                  live_out, g_out_planar, g, make_params(params), gate_or_open(gate), record,
                  band_list, (unsigned)band_count};
     if (grid->dims == 2) {
-        if (stage == LSF_STAGE_FUSED) pick_terms<2, true>(params, a); else pick_terms<2, false>(params, a);
+        if (all_interior) pick_terms<2, kModeFusedInterior>(params, a);
+        else if (stage == LSF_STAGE_FUSED) pick_terms<2, kModeFused>(params, a);
+        else pick_terms<2, kModeGradient>(params, a);
     } else {
-        if (stage == LSF_STAGE_FUSED) pick_terms<3, true>(params, a); else pick_terms<3, false>(params, a);
+        if (all_interior) pick_terms<3, kModeFusedInterior>(params, a);
+        else if (stage == LSF_STAGE_FUSED) pick_terms<3, kModeFused>(params, a);
+        else pick_terms<3, kModeGradient>(params, a);
     }
     return launch_status();
 }
@@ -589,27 +723,27 @@ extern "C" int64_t lsf_band_scratch_elements(const lsf_grid* grid) {
     return (int64_t)chunks + 1;
 }
 
-extern "C" int lsf_band_count(const float* live, const float* canonical, const lsf_grid* grid, int32_t* scratch,
-                              int64_t* count_out, void* stream) {
+extern "C" int lsf_band_count(const float* live, const float* canonical, const lsf_grid* grid, int32_t subset,
+                              int32_t* scratch, int64_t* count_out, void* stream) {
     if (int e = check_grid(grid)) return e;
-    if (!live || !canonical || !scratch || !count_out) return LSF_ERR_BAD_ARGUMENT;
+    if (!live || !canonical || !scratch || !count_out || !band_subset_ok(subset)) return LSF_ERR_BAD_ARGUMENT;
     unsigned first, n, chunks;
     band_range(grid, first, n, chunks);
     hipStream_t s = as_stream(stream);
     if (chunks > 0)
-        hipLaunchKernelGGL(band_list_kernel<false>, dim3(chunks), dim3(kBlock), 0, s, live, canonical, first, n, scratch,
-                           (int*)nullptr);
+        hipLaunchKernelGGL(band_list_kernel<false>, dim3(chunks), dim3(kBlock), 0, s, live, canonical, first, n,
+                           make_grid(grid), grid->dims, subset, scratch, (int*)nullptr);
     hipLaunchKernelGGL(band_scan_kernel, dim3(1), dim3(1024), 0, s, scratch, chunks, (long long*)count_out);
     return launch_status();
 }
 
-extern "C" int lsf_band_list_fill(const float* live, const float* canonical, const lsf_grid* grid,
+extern "C" int lsf_band_list_fill(const float* live, const float* canonical, const lsf_grid* grid, int32_t subset,
                                   const int32_t* scratch, int32_t* list, void* stream) {
     if (int e = check_grid(grid)) return e;
-    if (!live || !canonical || !scratch || !list) return LSF_ERR_BAD_ARGUMENT;
+    if (!live || !canonical || !scratch || !list || !band_subset_ok(subset)) return LSF_ERR_BAD_ARGUMENT;
     unsigned first, n, chunks;
     if (!band_range(grid, first, n, chunks)) return 0;
     hipLaunchKernelGGL(band_list_kernel<true>, dim3(chunks), dim3(kBlock), 0, as_stream(stream), live, canonical, first, n,
-                       const_cast<int32_t*>(scratch), list);
+                       make_grid(grid), grid->dims, subset, const_cast<int32_t*>(scratch), list);
     return launch_status();
 }

@@ -261,10 +261,11 @@ def hier_update(g, warp, grid, rate, gate, records, index):
 
 
 class BandList:
-    """ascending voxel indices of the narrow-band union inside the grid's z-range (lsf_band_list_fill)"""
+    """ascending voxel indices of (a subset of) the narrow-band union inside the grid's z-range
+    (lsf_band_list_fill); subset = _lib.BAND_ALL / BAND_INTERIOR / BAND_BOUNDARY"""
 
-    def __init__(self, indices, count):
-        self.indices, self.count = indices, int(count)
+    def __init__(self, indices, count, subset=_lib.BAND_ALL):
+        self.indices, self.count, self.subset = indices, int(count), int(subset)
         self.pointer = ctypes.c_void_p(indices.data_ptr() if indices is not None else 0)
 
     @classmethod
@@ -273,22 +274,56 @@ class BandList:
         return cls(None, 0)
 
 
-def band_list(live, canonical, grid=None):
-    """build the band list of (live, canonical): count -> (one host read of the total) -> fill"""
+def buffer_addressing_ok(grid):
+    """INTERIOR lists need 32-bit buffer offsets over the D planes of a vector field (see lsf_band_count)"""
+    return 12 * n_voxels(grid) < 0xffffffff
+
+
+def band_lists(live, canonical, grid=None, split=True):
+    """the band list(s) one fused iteration launches over, built with ONE host read of the totals: with `split` (and a
+    field small enough for 32-bit buffer offsets) the INTERIOR voxels -- served by the kernel without out-of-bounds
+    handling -- and the BOUNDARY voxels, empty lists dropped (but never both); otherwise one list of ALL band voxels"""
+    grid = grid or make_grid(live.shape)
+    n = n_voxels(grid)
+    subsets = (_lib.BAND_INTERIOR, _lib.BAND_BOUNDARY) if split and buffer_addressing_ok(grid) else (_lib.BAND_ALL,)
+    n_scratch = int(lib.lsf_band_scratch_elements(ctypes.byref(grid)))
+    scratch = torch.empty((len(subsets), n_scratch), dtype=torch.int32, device=live.device)
+    totals = torch.zeros(len(subsets), dtype=torch.int64, device=live.device)
+    p_live, p_canon = _ptr(live, n, "live"), _ptr(canonical, n, "canonical")
+    for k, subset in enumerate(subsets):
+        check(lib.lsf_band_count(p_live, p_canon, ctypes.byref(grid), subset, ctypes.c_void_p(scratch[k].data_ptr()),
+                                 ctypes.c_void_p(totals[k:].data_ptr()), stream_ptr()), "lsf_band_count")
+    counts = [int(c) for c in totals.cpu()]
+    lists = []
+    for k, (subset, count) in enumerate(zip(subsets, counts)):
+        if count == 0 and not (k == len(subsets) - 1 and not lists):
+            continue
+        indices = torch.empty(max(count, 1), dtype=torch.int32, device=live.device)
+        if count:
+            check(lib.lsf_band_list_fill(p_live, p_canon, ctypes.byref(grid), subset,
+                                         ctypes.c_void_p(scratch[k].data_ptr()), ctypes.c_void_p(indices.data_ptr()),
+                                         stream_ptr()), "lsf_band_list_fill")
+        lists.append(BandList(indices, count, subset))
+    return lists
+
+
+def band_list(live, canonical, grid=None, subset=_lib.BAND_ALL):
+    """one band list of the given subset"""
     grid = grid or make_grid(live.shape)
     n = n_voxels(grid)
     scratch = torch.empty(int(lib.lsf_band_scratch_elements(ctypes.byref(grid))), dtype=torch.int32,
                           device=live.device)
     total = torch.zeros(1, dtype=torch.int64, device=live.device)
     p_live, p_canon = _ptr(live, n, "live"), _ptr(canonical, n, "canonical")
-    check(lib.lsf_band_count(p_live, p_canon, ctypes.byref(grid), ctypes.c_void_p(scratch.data_ptr()),
+    check(lib.lsf_band_count(p_live, p_canon, ctypes.byref(grid), int(subset), ctypes.c_void_p(scratch.data_ptr()),
                              ctypes.c_void_p(total.data_ptr()), stream_ptr()), "lsf_band_count")
     count = int(total.item())
     indices = torch.empty(max(count, 1), dtype=torch.int32, device=live.device)
     if count:
-        check(lib.lsf_band_list_fill(p_live, p_canon, ctypes.byref(grid), ctypes.c_void_p(scratch.data_ptr()),
-                                     ctypes.c_void_p(indices.data_ptr()), stream_ptr()), "lsf_band_list_fill")
-    return BandList(indices, count)
+        check(lib.lsf_band_list_fill(p_live, p_canon, ctypes.byref(grid), int(subset),
+                                     ctypes.c_void_p(scratch.data_ptr()), ctypes.c_void_p(indices.data_ptr()),
+                                     stream_ptr()), "lsf_band_list_fill")
+    return BandList(indices, count, subset)
 
 
 def slavcheva_iteration(stage, live, canonical, warp_prev, warp_out, live_out, g_out, grid, params, gate, records,
@@ -302,7 +337,8 @@ def slavcheva_iteration(stage, live, canonical, warp_prev, warp_out, live_out, g
                                       _ptr(g_out, nd, "g_out", allow_none=True), ctypes.byref(grid),
                                       ctypes.byref(params), _gate_ref(gate), _record_ptr(records, index),
                                       band.pointer if band is not None else ctypes.c_void_p(0),
-                                      band.count if band is not None else 0, stream_ptr()),
+                                      band.count if band is not None else 0,
+                                      band.subset if band is not None else 0, stream_ptr()),
           "lsf_slavcheva_iteration")
 
 

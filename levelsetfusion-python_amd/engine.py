@@ -475,18 +475,20 @@ class SlavchevaEngine:
         if not self.sobolev:
             if not slab:
                 f = self._fast
-                _lib.check(_lib.lib.lsf_slavcheva_iteration(_lib.STAGE_FUSED, f.p_live[i % 2], f.p_canon,
-                                                            f.p_warp[i % 2], f.p_warp[(i + 1) % 2],
-                                                            f.p_live[(i + 1) % 2], None, f.grid_ref, f.params_ref,
-                                                            None if i < self.min_iterations else f.gate_ref(i - 1),
-                                                            f.record_ptrs[i], f.band.pointer, f.band.count, dev.stream_ptr()),
-                           "lsf_slavcheva_iteration")
+                for band in f.bands:  # interior + boundary band voxels (or one list / the dense walk)
+                    _lib.check(_lib.lib.lsf_slavcheva_iteration(_lib.STAGE_FUSED, f.p_live[i % 2], f.p_canon,
+                                                                f.p_warp[i % 2], f.p_warp[(i + 1) % 2],
+                                                                f.p_live[(i + 1) % 2], None, f.grid_ref, f.params_ref,
+                                                                None if i < self.min_iterations else f.gate_ref(i - 1),
+                                                                f.record_ptrs[i], band.pointer, band.count, band.subset,
+                                                                dev.stream_ptr()), "lsf_slavcheva_iteration")
             else:
                 # boundary slices first, then the halo exchange on a second stream WHILE the interior runs
                 boundary, interior = self._slab_parts
-                for g, band in boundary:
-                    dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None, g,
-                                            self.params, gate, records, i, band)
+                for g, bands in boundary:
+                    for band in bands:
+                        dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None,
+                                                g, self.params, gate, records, i, band)
                 main = torch.cuda.current_stream()
                 boundary_done, halos_done = self._events[i % 2]
                 boundary_done.record(main)
@@ -494,9 +496,10 @@ class SlavchevaEngine:
                     self._comm_stream.wait_event(boundary_done)
                     self.comm.exchange_live_and_warp(live_out, warp_out)
                     halos_done.record(self._comm_stream)
-                for g, band in interior:
-                    dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None, g,
-                                            self.params, gate, records, i, band)
+                for g, bands in interior:
+                    for band in bands:
+                        dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None,
+                                                g, self.params, gate, records, i, band)
                 main.wait_event(halos_done)
         else:
             g0, t1, t2 = gbufs
@@ -549,7 +552,7 @@ class SlavchevaEngine:
             f.p_warp = [f.pointer(t, n * dims, "warp") for t in warps]
             f.p_canon = f.pointer(canonical, n, "canonical")
             f.params_ref = ctypes.byref(self.params)
-            f.band = dev.band_list(live, canonical, grid) if self.use_band_list else dev.BandList.none()
+            f.bands = dev.band_lists(live, canonical, grid) if self.use_band_list else [dev.BandList.none()]
             self._fast = f
         if slab and not self.sobolev:
             L = self.comm.layout
@@ -560,7 +563,7 @@ class SlavchevaEngine:
 
             def part(rng):
                 g = dev.make_grid(live.shape, rng[0], rng[1], grid.z_global_offset)
-                return g, (dev.band_list(live, canonical, g) if self.use_band_list else None)
+                return g, (dev.band_lists(live, canonical, g) if self.use_band_list else [None])
             self._slab_parts = ([part(r) for r in (lo_b, hi_b) if r is not None],
                                 [part(mid)] if mid[1] > mid[0] else [])
         if slab and not hasattr(self, "_comm_stream"):

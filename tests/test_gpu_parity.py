@@ -425,7 +425,7 @@ def test_slavcheva_3d_random_fields_match_oracle(lsf):
 def test_band_list_matches_numpy(lsf, shape, zr):
     """lsf_band_count / lsf_band_list_fill: ascending indices of the voxels with |live| != 1 or |canonical| != 1
     (tsdf_set_routines.py:19-52) inside the z-range, ragged sizes, 2-D, empty range, all / none in band"""
-    from levelsetfusion_python_amd import device as dev
+    from levelsetfusion_python_amd import _lib, device as dev
     rng = np.random.default_rng(5)
     for fill in ("mixed", "none", "all"):
         live = rng.uniform(-1, 1, shape).astype(np.float32)
@@ -440,14 +440,20 @@ def test_band_list_matches_numpy(lsf, shape, zr):
             lo, hi = zr if zr else (0, shape[0])
             grid = dev.make_grid(shape, lo, hi, 0)
         t_shape = shape if shape[0] > 1 else shape[1:]
-        band = dev.band_list(torch.from_numpy(live.reshape(t_shape)).cuda(),
-                             torch.from_numpy(canon.reshape(t_shape)).cuda(), grid)
+        tl, tc = torch.from_numpy(live.reshape(t_shape)).cuda(), torch.from_numpy(canon.reshape(t_shape)).cuda()
         mask = ~((np.abs(live) == 1) & (np.abs(canon) == 1))
         mask[:lo] = False
         mask[hi:] = False
-        expect = np.flatnonzero(mask.ravel())
-        assert band.count == len(expect)
-        assert np.array_equal(band.indices.cpu().numpy()[:band.count], expect)
+        inner = np.zeros(shape, bool)
+        inner[(slice(1, -1),) * 3 if shape[0] > 1 else (slice(None), slice(1, -1), slice(1, -1))] = True
+        for subset, want in ((_lib.BAND_ALL, mask), (_lib.BAND_INTERIOR, mask & inner), (_lib.BAND_BOUNDARY, mask & ~inner)):
+            band = dev.band_list(tl, tc, grid, subset)
+            expect = np.flatnonzero(want.ravel())
+            assert band.count == len(expect) and band.subset == subset
+            assert np.array_equal(band.indices.cpu().numpy()[:band.count], expect)
+        lists = dev.band_lists(tl, tc, grid)
+        assert 1 <= len(lists) <= 2 and sum(b.count for b in lists) == int(mask.sum())
+        assert all(b.count > 0 for b in lists) or (len(lists) == 1 and lists[0].count == 0)
 
 
 def test_slavcheva_band_list_is_invisible(lsf):
@@ -467,31 +473,35 @@ def test_slavcheva_band_list_is_invisible(lsf):
                                    gradient_descent_rate=0.5)._engine
     grid = dev.make_grid(shape)
     outs = []
-    for listed in (False, True):
+    for mode in ("dense", "one list", "interior + boundary"):
         c = torch.from_numpy(canon).cuda()
         lives = [torch.from_numpy(live0).cuda(), torch.from_numpy(live0).cuda()]
         warps = [torch.zeros((3,) + shape, device="cuda") for _ in range(2)]
         rec = dev.new_records(n_it, "cuda")
-        band = dev.band_list(lives[0], c, grid) if listed else None
-        if listed:
-            assert 0 < band.count < live0.size * 0.7
+        bands = [None] if mode == "dense" else dev.band_lists(lives[0], c, grid, split=mode != "one list")
+        if mode == "one list":
+            assert len(bands) == 1 and 0 < bands[0].count < live0.size * 0.7
+        if mode == "interior + boundary":
+            assert [b.subset for b in bands] == [_lib.BAND_INTERIOR, _lib.BAND_BOUNDARY]
         for i in range(n_it):
-            dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2],
-                                    lives[(i + 1) % 2], None, grid, eng.params, None, rec, i, band)
+            for band in bands:
+                dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2],
+                                        lives[(i + 1) % 2], None, grid, eng.params, None, rec, i, band)
         outs.append([t.cpu().numpy() for t in lives + warps + [rec]])
-    for a, b in zip(outs[0][:4], outs[1][:4]):
-        assert np.array_equal(a, b)
-    ra, rb = dev.decode_records(outs[0][4]), dev.decode_records(outs[1][4])
-    assert np.array_equal(ra["max_value"], rb["max_value"]) and np.array_equal(ra["argmax"], rb["argmax"])
-    for k in ("data_energy", "smoothing_energy", "level_set_energy"):
-        # the energy sums are float64 atomics whose order varies from launch to launch
-        assert np.allclose(ra[k], rb[k], rtol=1e-9, atol=1e-12) and np.all(ra[k][1:] > 0)
+    for other in outs[1:]:
+        for a, b in zip(outs[0][:4], other[:4]):
+            assert np.array_equal(a, b)
+        ra, rb = dev.decode_records(outs[0][4]), dev.decode_records(other[4])
+        assert np.array_equal(ra["max_value"], rb["max_value"]) and np.array_equal(ra["argmax"], rb["argmax"])
+        for k in ("data_energy", "smoothing_energy", "level_set_energy"):
+            # the energy sums are float64 atomics whose order varies from launch to launch
+            assert np.allclose(ra[k], rb[k], rtol=1e-9, atol=1e-12) and np.all(ra[k][1:] > 0)
     o = O.SlavchevaOracle(compute_method=O.DIRECT, level_set_term_enabled=True, smoothing_term_method=O.KILLING,
                           gradient_descent_rate=0.5, max_iterations=n_it, min_iterations=n_it,
                           maximum_warp_length_lower_threshold=0.0)
     live_ref = live0.copy()
     o.optimize(live_ref, canon)
-    assert maxdiff(outs[1][n_it % 2], live_ref) == EXACT
+    assert maxdiff(outs[2][n_it % 2], live_ref) == EXACT
 
 
 def test_slavcheva_band_list_all_zero_update_reports_first_voxel(lsf):

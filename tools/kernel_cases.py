@@ -24,17 +24,19 @@ for name, c, l in (("none in band", ones, ones.clone()), ("sphere pair", c_s, l_
     for listed in (False, True):
         lives = [l.clone(), l.clone()]
         warps = [torch.zeros((3, n, n, n), device="cuda") for _ in range(2)]
-        state = dev.band_list(l, c, grid) if listed else None
+        bands = dev.band_lists(l, c, grid, split=os.environ.get("SPLIT", "1") == "1") if listed else [None]
         for i in range(4):
-            dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2],
-                                    lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0, state)
+            for b in bands:
+                dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2],
+                                        lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0, b)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         reps = 20
         for i in range(reps):
-            dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2],
-                                    lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0, state)
+            for b in bands:
+                dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2],
+                                        lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0, b)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
