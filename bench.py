@@ -204,48 +204,56 @@ def main():
     value = updates / elapsed
 
     # ---- roofline of the dominant kernel: the fused warp-update kernel alone, HIP events on its stream, over exactly
-    # the launch sequence of one step (band list of the initial pair, `iters` ping-pong launches)
+    # the launch sequence of one step (band lists of the initial pair, `iters` ping-pong launches on the float4 state)
     eng = opt._engine
     grid = eng._grid(live0)
     rec = dev.new_records(2, device)
-    bands = dev.band_lists(live0, canonical, grid) if eng.use_band_list else [None]
-    n_launch = iters
 
-    def launches():
-        lives = [live0.clone(), live0.clone()]
-        warps = [torch.zeros((3,) + tuple(live0.shape), dtype=torch.float32, device=device) for _ in range(2)]
+    def launches(bands):
+        states = dev.state_pack(live0, None, grid, copies=2)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        for i in range(n_launch):
+        for i in range(iters):
             for band in bands:  # interior + (usually empty, then absent) boundary band voxels
-                dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], canonical, warps[i % 2], warps[(i + 1) % 2],
-                                        lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0, band)
+                dev.slavcheva_state_iteration(states[i % 2], canonical, states[(i + 1) % 2], grid, eng.params, None,
+                                              rec, 0, band)
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / n_launch
-    launches()
-    kernel_ms = launches()
+        return e0.elapsed_time(e1) / iters
+
+    def roofline_of(bands, units, kernel_name, traffic):
+        launches(bands)
+        kernel_ms = launches(bands)
+        alg_bytes = B_ALG["killing"] * units
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        return dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                    traffic=traffic, kernel=kernel_name, kernel_ms=kernel_ms, units_per_launch=units,
+                    algorithmic_bytes_per_launch=alg_bytes, voxels_per_launch=voxels_per_rank)
+
+    def committed_traffic(key):
+        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md), default size only
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                t = json.load(f)
+            if t.get("size") == n and t.get("workload") == "killing":
+                return t.get(key)
+        except (OSError, ValueError, KeyError):
+            pass
+        return None
+
     # Units one launch processes = the voxels it visits: the band list (every other voxel is provably unchanged and
-    # is not touched).  52 B per visited voxel-update is SURVEY 8(d)'s figure.  The dense-
-    # equivalent rate (52 B x ALL voxels / time) is reported next to it: it is what a kernel streaming the whole
-    # volume every iteration would have to sustain to be this fast, and may exceed the HBM peak.
-    units = sum(b.count for b in bands) if bands[0] is not None else voxels_per_rank
-    alg_bytes = B_ALG["killing"] * units
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    dense_equivalent = B_ALG["killing"] * voxels_per_rank / (kernel_ms * 1e-3) / 1e9
-    traffic = None
-    try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md), default size only
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f)
-        if t.get("size") == n and t.get("workload") == "killing":
-            traffic = t["hbm_bytes_per_launch"]
-    except (OSError, ValueError, KeyError):
-        pass
-    roofline = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
-                    traffic=traffic, kernel="slavcheva_iteration_kernel<3,KILLING,LEVELSET,BASIC,DIRECT,FUSED>",
-                    kernel_ms=kernel_ms, units_per_launch=units, algorithmic_bytes_per_launch=alg_bytes,
-                    dense_equivalent_gbs=dense_equivalent, voxels_per_launch=voxels_per_rank)
+    # is not touched).  52 B per visited voxel-update is SURVEY 8(d)'s figure.  Next to it: the
+    # SAME kernel walking every voxel (use_band_list=False: streams the whole state every iteration) -- the data point
+    # that is bound by HBM rather than by the per-band-voxel arithmetic.
+    name = "slavcheva_state_kernel<3,KILLING,LEVELSET,BASIC,DIRECT,%s>"
+    if eng.use_band_list:
+        bands = dev.band_lists(live0, canonical, grid)
+        roofline = roofline_of(bands, sum(b.count for b in bands), name % "LIST", committed_traffic("hbm_bytes_per_launch"))
+        roofline["dense_equivalent_gbs"] = B_ALG["killing"] * voxels_per_rank / (roofline["kernel_ms"] * 1e-3) / 1e9
+    else:
+        roofline = roofline_of([None], voxels_per_rank, name % "DENSE", committed_traffic("dense_hbm_bytes_per_launch"))
+    roofline_dense = roofline_of([None], voxels_per_rank, name % "DENSE",
+                                 committed_traffic("dense_hbm_bytes_per_launch")) if eng.use_band_list else None
 
     out = dict(metric="voxel-warp-updates/sec", value=value, unit="voxel-warp-updates/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
@@ -256,6 +264,8 @@ def main():
                            parallelism=("z-slab x%d, halo %d, %s" % (world, args.halo, args.backend)) if world > 1
                            else "single GPU"),
                roofline=roofline)
+    if roofline_dense is not None:
+        out["roofline_dense_walk"] = roofline_dense
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_size, args.cpu_sample_iterations)

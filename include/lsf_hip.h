@@ -178,14 +178,11 @@ int lsf_hier_update(const float *g_planar, float *warp_planar, const lsf_grid *g
  * replaces nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:163-236 (VECTORIZED) and :238-330 (DIRECT)
  * with data_term.py:169-227,334-358, smoothing_term.py:50-177, level_set_term.py:28-64.
  *
- * lsf_slavcheva_iteration, stage = LSF_STAGE_FUSED: one kernel does gradient, warp = -g*rate, max-warp
- *   reduction, energies and the truncation-aware re-warp of the live field (a12-a18 + a3): the "fused
- *   per-voxel warp-update kernel".  Used when no Sobolev filter sits between gradient and update.
- * stage = LSF_STAGE_GRADIENT: gradient + energies only (g_out), for the Sobolev path; then
- *   lsf_convolve_axis passes (zero-preserving) and lsf_slavcheva_update_rewarp. */
-#define LSF_STAGE_FUSED 0
-#define LSF_STAGE_GRADIENT 1
-
+ * No Sobolev filter: lsf_slavcheva_state_iteration -- ONE kernel does gradient, warp = -g*rate, max-warp reduction,
+ *   energies and the truncation-aware re-warp of the live field (a12-a18 + a3): the "fused per-voxel warp-update
+ *   kernel", on the float4 state layout.
+ * With a Sobolev filter: lsf_slavcheva_gradient (gradient + energies into g_out), lsf_convolve_axis passes
+ *   (zero-preserving), lsf_slavcheva_update_rewarp -- planar fields. */
 #define LSF_SMOOTHING_TIKHONOV 0
 #define LSF_SMOOTHING_KILLING 1
 #define LSF_DATA_BASIC 0
@@ -210,28 +207,24 @@ typedef struct lsf_slavcheva_params {
     int32_t reserved;
 } lsf_slavcheva_params;
 
-/* band_list (may be NULL; FUSED stage without g_out only): ascending voxel indices (z * ny + y) * nx + x from
- * lsf_band_list_fill, band_count of them, covering this grid's z-range.  Only listed voxels are visited.  This is exact,
- * not an approximation: a voxel outside the narrow-band union (|live| == |canonical| == 1, the test of
- * slavcheva_optimizer2d.py:251-252 / tsdf_set_routines.py:19-52) gets a zero gradient, hence warp 0 and live' = live,
- * and so stays outside for the rest of the optimisation.  The CALLER must have initialised live_out / warp_out of BOTH
- * ping-pong buffer sets with (live, 0) at the unlisted voxels, and must keep canonical and params unchanged while the
- * list is in use.  Records, live and warp are identical with and without a list. */
+int lsf_slavcheva_gradient(const float *live, const float *canonical, const float *warp_prev_planar,
+                           float *g_out_planar, const lsf_grid *grid, const lsf_slavcheva_params *params,
+                           const lsf_gate *gate, lsf_iteration_record *record, void *stream);
+
+/* Band lists for lsf_slavcheva_state_iteration: only listed voxels are visited.  This is exact, not an approximation:
+ * a voxel outside the narrow-band union (|live| == |canonical| == 1, the test of slavcheva_optimizer2d.py:251-252 /
+ * tsdf_set_routines.py:19-52) gets a zero gradient, hence warp 0 and live' = live, and so stays outside for the rest of
+ * the optimisation.  The caller keeps canonical and params unchanged while a list is in use.  Records, live and warp
+ * are identical with and without a list. */
 #define LSF_BAND_ALL 0      /* every voxel of the narrow-band union */
 #define LSF_BAND_INTERIOR 1 /* ... whose whole 3^D neighbourhood lies inside the (allocated) array */
 #define LSF_BAND_BOUNDARY 2 /* ... the others (voxels on a face of the array) */
-int lsf_slavcheva_iteration(int32_t stage, const float *live, const float *canonical,
-                            const float *warp_prev_planar, float *warp_out_planar, float *live_out,
-                            float *g_out_planar /* may be NULL in FUSED */, const lsf_grid *grid,
-                            const lsf_slavcheva_params *params, const lsf_gate *gate,
-                            lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,
-                            int32_t band_subset /* LSF_BAND_* the list was built with */, void *stream);
 
 /* Band list of the grid's z-range [z_begin, z_end): the voxels with |live| != 1 or |canonical| != 1
  * (tsdf_set_routines.py:19-52; the `continue` of slavcheva_optimizer2d.py:251-252), in ascending index order --
- * all of them, or split into INTERIOR and BOUNDARY voxels.  An INTERIOR list lets lsf_slavcheva_iteration run a
+ * all of them, or split into INTERIOR and BOUNDARY voxels.  An INTERIOR list lets lsf_slavcheva_state_iteration run a
  * kernel that never applies the reference's out-of-bounds rules (none can fire) and addresses all neighbours from one
- * per-lane offset; it requires 12 * nz * ny * nx < 2^32 (32-bit buffer offsets; LSF_ERR_BAD_ARGUMENT otherwise).
+ * per-lane offset; it requires 16 * nz * ny * nx < 2^32 (32-bit buffer offsets; LSF_ERR_BAD_ARGUMENT otherwise).
  * One iteration = one launch per non-empty list, all on the same record.
  *   1. lsf_band_count     counts per 1024-voxel chunk into scratch (lsf_band_scratch_elements(grid) int32 elements),
  *                         scans them, and writes the total to *count_out (device memory);
@@ -242,6 +235,33 @@ int lsf_band_count(const float *live, const float *canonical, const lsf_grid *gr
                    int32_t *scratch, int64_t *count_out, void *stream);
 int lsf_band_list_fill(const float *live, const float *canonical, const lsf_grid *grid, int32_t subset,
                        const int32_t *scratch, int32_t *list, void *stream);
+
+/* ---- the fused iteration on the STATE layout (what the optimizers run when no Sobolev filter is configured) --------
+ * state: float4 [z][y][x] = (live, u, v, w) (w = 0 in 2-D) -- the live field and the per-iteration warp travel together:
+ * an iteration reads both through the same 3^D neighbourhood and writes both, so one 16-byte access replaces four
+ * dword accesses to four planes.  band_list (may be NULL = every voxel of the z-range): ascending
+ * voxel indices (z * ny + y) * nx + x from lsf_band_list_fill, band_count of them, band_subset the LSF_BAND_* it was
+ * built with; state_out of BOTH ping-pong states must hold (live, 0) at unlisted voxels (lsf_state_pack with two
+ * destinations does exactly that).  An INTERIOR list requires 16 * nz * ny * nx < 2^32.
+ * lsf_state_pack: (live, warp planar or NULL = 0) -> state_a and, if not NULL, state_b, slices [z_begin, z_end).
+ * lsf_state_unpack: state -> live and / or planar warp [c][z][y][x] and / or interleaved warp [z][y][x][c]. */
+int lsf_state_pack(const float *live, const float *warp_planar, float *state_a, float *state_b,
+                   const lsf_grid *grid, void *stream);
+int lsf_state_unpack(const float *state, float *live_out, float *warp_planar_out, float *warp_interleaved_out,
+                     const lsf_grid *grid, void *stream);
+/* end of an optimize() call in one pass over slices [z_begin, z_end): state -> live_out, planar and / or interleaved warp
+ * (each may be NULL) and -- when statistics16 is not NULL -- the convergence statistics of
+ * lsf_warp_statistics (statistics16[0..8)) and lsf_tsdf_difference_statistics (statistics16[8..16)) of the final
+ * fields (a20; cpp.build_warp_delta_statistics_2d / build_tsdf_difference_statistics_2d, slavcheva_optimizer2d.py:394-398).
+ * scratch: lsf_state_finalize_scratch_elements(grid) doubles of device memory. */
+int64_t lsf_state_finalize_scratch_elements(const lsf_grid *grid);
+int lsf_state_finalize(const float *state, const float *canonical, float *live_out, float *warp_planar_out,
+                       float *warp_interleaved_out, const lsf_grid *grid, float lower_threshold,
+                       double *statistics16, double *scratch, void *stream);
+int lsf_slavcheva_state_iteration(const float *state_in, const float *canonical, float *state_out,
+                                  const lsf_grid *grid, const lsf_slavcheva_params *params, const lsf_gate *gate,
+                                  lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,
+                                  int32_t band_subset, void *stream);
 
 int lsf_slavcheva_update_rewarp(const float *live, const float *canonical, float *g_planar /* inout */,
                                 float *warp_out_planar, float *live_out, const lsf_grid *grid,

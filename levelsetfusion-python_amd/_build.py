@@ -8,8 +8,8 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "liblsf_hip.so")
-SOURCES = ["lsf_fields.hip", "lsf_hierarchical.hip", "lsf_slavcheva.hip", "lsf_tsdf.hip"]
-HEADERS = ["lsf_device.h", os.path.join("..", "..", "include", "lsf_hip.h")]
+SOURCES = ["lsf_fields.hip", "lsf_hierarchical.hip", "lsf_slavcheva.hip", "lsf_slavcheva_state.hip", "lsf_tsdf.hip"]
+HEADERS = ["lsf_device.h", "lsf_slavcheva_terms.h", os.path.join("..", "..", "include", "lsf_hip.h")]
 # -ffp-contract=off: multiply and add stay separately rounded so that results are bit-identical to the numpy
 # oracle (numpy never fuses); the path is HBM/L1-bound, the lost FMAs do not show.
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++17",

@@ -20,7 +20,6 @@ ABI_VERSION = 1
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG"}
 
-STAGE_FUSED, STAGE_GRADIENT = 0, 1
 SMOOTHING_TIKHONOV, SMOOTHING_KILLING = 0, 1
 DATA_BASIC, DATA_THRESHOLDED_FDM = 0, 2
 ENERGY_NONE, ENERGY_DIRECT, ENERGY_VECTORIZED = 0, 1, 2
@@ -108,8 +107,14 @@ PROTOTYPES = {
                                          _P(Gate), _vp]),
     "lsf_hier_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(HierParams), _P(Gate), _vp, _vp]),
     "lsf_hier_update": (ctypes.c_int, [_vp, _vp, _P(Grid), _f32, _P(Gate), _vp, _vp]),
-    "lsf_slavcheva_iteration": (ctypes.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _P(Grid),
-                                               _P(SlavchevaParams), _P(Gate), _vp, _vp, _i64, _i32, _vp]),
+    "lsf_slavcheva_gradient": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp,
+                                              _vp]),
+    "lsf_state_pack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp]),
+    "lsf_state_unpack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp]),
+    "lsf_state_finalize_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
+    "lsf_state_finalize": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _f32, _vp, _vp, _vp]),
+    "lsf_slavcheva_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp,
+                                                     _vp, _i64, _i32, _vp]),
     "lsf_band_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
     "lsf_band_count": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),
     "lsf_band_list_fill": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),

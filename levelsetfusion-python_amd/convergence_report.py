@@ -109,21 +109,29 @@ def build_warp_delta_statistics(warp_planar, canonical, live, lower_threshold, u
     tests/test_slavcheva_optimizer.py:141-145: ratio / max / mean / population std / arg-max over band-union
     voxels, length_min reported as 0)."""
     raw = dev.warp_statistics(warp_planar, canonical, live, lower_threshold).cpu().numpy()
+    return warp_delta_statistics_from_raw(raw, tuple(live.shape), lower_threshold, upper_threshold)
+
+
+def warp_delta_statistics_from_raw(raw, shape, lower_threshold, upper_threshold):
+    """raw: the 8 doubles of lsf_warp_statistics (or lsf_state_finalize's statistics16[0:8])"""
     count, above, mx, s1, s2, arg = raw[0], raw[1], raw[2], raw[3], raw[4], raw[5]
     if count == 0:
         return WarpDeltaStatistics()
     mean = s1 / count
     var = max(s2 / count - mean * mean, 0.0)
     return WarpDeltaStatistics(above / count, 0.0, float(mx), float(mean), math.sqrt(var),
-                               _location(arg, tuple(live.shape)), bool(mx < lower_threshold),
-                               bool(mx > upper_threshold))
+                               _location(arg, shape), bool(mx < lower_threshold), bool(mx > upper_threshold))
 
 
 def build_tsdf_difference_statistics(canonical, live):
     """statistics of |canonical - live| over ALL voxels (same known answer)."""
     raw = dev.tsdf_difference_statistics(canonical, live).cpu().numpy()
+    return tsdf_difference_statistics_from_raw(raw, tuple(live.shape))
+
+
+def tsdf_difference_statistics_from_raw(raw, shape):
+    """raw: the 8 doubles of lsf_tsdf_difference_statistics (or lsf_state_finalize's statistics16[8:16])"""
     count, mn, mx, s1, s2, arg = raw[0], raw[1], raw[2], raw[3], raw[4], raw[5]
     mean = s1 / count
     var = max(s2 / count - mean * mean, 0.0)
-    return TsdfDifferenceStatistics(float(mn), float(mx), float(mean), math.sqrt(var),
-                                    _location(arg, tuple(live.shape)))
+    return TsdfDifferenceStatistics(float(mn), float(mx), float(mean), math.sqrt(var), _location(arg, shape))

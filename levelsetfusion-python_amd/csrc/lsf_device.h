@@ -200,6 +200,26 @@ __device__ inline void for_each_voxel(const Grid& g, F&& f) {
 // z-range -> its own L2), and the blocks of an XCD interleave over that eighth.  The host sizes the grid so that all
 // blocks get the same number of units (band_list_blocks).  Calls f(x, y, z) for every listed voxel.
 // list == nullptr: the dense tile walk of for_each_voxel (one loop for both so that f is instantiated once).
+// the units [first, end) with stride `step` this block owns in a list walk over `count` entries
+struct ListWalk {
+    unsigned first, step, end;
+};
+
+__device__ inline ListWalk list_walk(unsigned count) {
+    ListWalk w;
+    const unsigned units = (count + kBlock - 1) / kBlock;
+    const unsigned nb = gridDim.x, bid = blockIdx.x;
+    if (nb % kXcds == 0) {
+        const unsigned per_xcd = (units + kXcds - 1) / kXcds, xcd = bid % kXcds;
+        w.first = xcd * per_xcd + bid / kXcds;
+        w.step = nb / kXcds;
+        w.end = (xcd + 1) * per_xcd < units ? (xcd + 1) * per_xcd : units;
+    } else {
+        w.first = bid; w.step = nb; w.end = units;
+    }
+    return w;
+}
+
 template <class F>
 __device__ inline void for_each_listed_voxel(const Grid& g, const int* __restrict__ list, unsigned count, F&& f) {
     const bool listed = list != nullptr;

@@ -2,351 +2,23 @@
 // (SURVEY 8a rows a3, a12-a18).  Reference: nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:163-330 with
 // data_term.py, smoothing_term.py, level_set_term.py and field_warping.warp_field_advanced.
 //
-// FUSED stage (no Sobolev filter between gradient and update): ONE kernel per iteration reads
-//   live (4 B, 3^D-neighbourhood through cache), canonical (4 B), previous warp (4D B, neighbourhood)
-// and writes the new warp (4D B) and the re-warped live field (4 B): 36 B / voxel-update of compulsory HBM
-// traffic in 3-D (SURVEY 8d books 52 B for the two-pass formulation).  The max-warp arg-max and the three
-// energies are wave-shuffle + LDS block reductions ending in one atomic per block.
+// This file: the planar-layout kernels of the SobolevFusion path -- gradient (+ energies), then the caller's
+// zero-preserving separable filter (lsf_convolve_axis), then update + truncation-aware re-warp -- and the band-list
+// builders.  Without a Sobolev filter the optimizers run ONE fused kernel per iteration on the float4 state layout:
+// lsf_slavcheva_state.hip.
 #include "lsf_device.h"
 
 using namespace lsf;
 
+#include "lsf_slavcheva_terms.h"
+
+using namespace lsf::slav;
+
 namespace {
 
-struct Params {
-    double lambda64;
-    float rate, w_data, w_smooth, w_level_set, lambda32, killing_c1;
-    int zero_gradient_on_snap;
-};
-
-// Neighbourhood addressing of one voxel.  Every neighbour is read from a CLAMPED offset (always a valid address,
-// equal to the centre when the neighbour does not exist along that axis) and the reference's three different
-// out-of-bounds rules are applied afterwards with selects -- the loads themselves are unconditional, so the
-// compiler emits no exec-mask branches around them:
-//   warp neighbours   OOB -> centre value  (utils/sampling.py:84-88 with replacement = warp[y, x])
-//   level-set / FDM   OOB -> 1             (utils/sampling.py:35-55)
-//   np.gradient       one-sided first-order difference at the array border
-template <int D>
-struct Nbh {
-    using Field = const float*;  // base of one scalar plane
-    int i;          // index of the voxel inside a plane
-    int off[3][2];  // clamped element offsets of the -1 / +1 neighbours along x, y, z
-    bool has[3][2]; // neighbour exists
-
-    __device__ inline Nbh(const Grid& g, int x, int y, int z) {
-        i = vidx(g, x, y, z);
-        const int stride[3] = {1, g.nx, g.nx * g.ny};
-        const int coord[3] = {x, y, z};
-        const int extent[3] = {g.nx, g.ny, g.nz};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            has[a][0] = a < D && coord[a] > 0;
-            has[a][1] = a < D && coord[a] < extent[a] - 1;
-            off[a][0] = has[a][0] ? -stride[a] : 0;
-            off[a][1] = has[a][1] ? stride[a] : 0;
-        }
-    }
-    __device__ static inline Field field(const float* base, const Grid& g, int plane) { return base + plane * g.plane; }
-    __device__ inline bool exists(int a, int s) const { return has[a][s]; }
-    __device__ inline float centre(Field f) const { return f[i]; }
-    // axis neighbour of a scalar plane; clamped (== centre when missing)
-    __device__ inline float axis(Field f, int a, int s) const { return f[i + off[a][s]]; }
-    // diagonal neighbour in the (a, b) plane, sa/sb in {0: -1, 1: +1}; clamped
-    __device__ inline float diag(Field f, int a, int sa, int b, int sb) const {
-        return f[i + off[a][sa] + off[b][sb]];
-    }
-    __device__ inline bool diag_exists(int a, int sa, int b, int sb) const { return has[a][sa] && has[b][sb]; }
-};
-
-// The same interface for a voxel whose whole 3^D neighbourhood lies inside the array (decided per WAVE: all its
-// active lanes).  Every neighbour exists, so the reference's OOB rules never fire, and the neighbour offsets are the
-// same for all lanes: loads go through buffer resources with ONE per-lane byte offset (the neighbourhood's lowest
-// corner) and the neighbour selected by the instruction's SCALAR offset operand -- no per-neighbour VALU address
-// arithmetic, no selects.  (The generic path spends 107 of its ~950 VALU instructions per 64 voxels on 64-bit
-// address adds and 100 on OOB selects.)  Buffer offsets are 32-bit: the host enables this path only when a scalar
-// plane and the D planes of a vector field each stay below 4 GiB (Grid::fast_ok).
-struct BufField {
-    __amdgpu_buffer_rsrc_t rsrc;
-    unsigned plane_bytes;  // byte offset of the addressed plane inside the resource
-};
-
-template <int D>
-struct NbhFast {
-    using Field = BufField;
-    // byte offset of voxel (x-1, y-1[, z-1]) inside a plane = wave_base (scalar: the offset of the wave's first
-    // active lane, which is its smallest -- both walks hand out ascending voxel indices by lane) + lane_delta.
-    // Keeping the scalar part tied to the voxel makes every neighbour's scalar offset a one-instruction SALU add at
-    // the point of use instead of ~70 loop-invariant values that would have to live in (spilled) SGPRs.
-    unsigned wave_base, lane_delta;
-    unsigned sy, sz;   // byte strides of y and z (uniform)
-
-    __device__ inline NbhFast(const Grid& g, int x, int y, int z) {
-        sy = (unsigned)g.nx * 4u;
-        sz = (unsigned)(g.nx * g.ny) * 4u;
-        const unsigned corner = (unsigned)vidx(g, x, y, z) * 4u - 4u - sy - (D == 3 ? sz : 0u);
-        wave_base = (unsigned)__builtin_amdgcn_readfirstlane((int)corner);
-        lane_delta = corner - wave_base;
-    }
-    __device__ static inline Field field(const float* base, const Grid& g, int plane) {
-        // one resource spans all planes of the field (D * plane * 4 bytes < 4 GiB, see Grid::fast_ok)
-        return BufField{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, -1, 0x00020000),
-                        (unsigned)plane * (unsigned)g.plane * 4u};
-    }
-    __device__ inline float at(const Field& f, int dx, int dy, int dz) const {
-        const unsigned soff = wave_base + f.plane_bytes + (unsigned)(dy + 1) * sy + (D == 3 ? (unsigned)(dz + 1) * sz : 0u);
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                                             f.rsrc, (int)(lane_delta + (unsigned)(dx + 1) * 4u), (int)soff, 0));
-    }
-    __device__ static constexpr bool exists(int, int) { return true; }
-    __device__ static constexpr bool diag_exists(int, int, int, int) { return true; }
-    __device__ inline float centre(const Field& f) const { return at(f, 0, 0, 0); }
-    __device__ inline float axis(const Field& f, int a, int s) const {
-        const int d = s ? 1 : -1;
-        return at(f, a == 0 ? d : 0, a == 1 ? d : 0, a == 2 ? d : 0);
-    }
-    __device__ inline float diag(const Field& f, int a, int sa, int b, int sb) const {
-        const int da = sa ? 1 : -1, db = sb ? 1 : -1;
-        return at(f, (a == 0 ? da : 0) + (b == 0 ? db : 0), (a == 1 ? da : 0) + (b == 1 ? db : 0),
-                  (a == 2 ? da : 0) + (b == 2 ? db : 0));
-    }
-};
-
-// np.gradient along axis a from the clamped neighbours: (f+ - f-)/2 inside, one-sided at the border, 0 for n == 1
-template <class NB>
-__device__ inline float np_gradient_from(const NB& n, int a, float fm, float fp) {
-    const float d = fp - fm;  // at a border the missing side was read as the centre
-    return (n.exists(a, 0) && n.exists(a, 1)) ? d * 0.5f : d;
-}
-
-// a14 (vectorised form used for both compute methods): -Laplacian, edge replicated, scipy rounding
-template <int D>
-__device__ inline void tikhonov_gradient(const float (&wm)[3][3], const float (&wp)[3][3], const float (&wc)[3],
-                                         float (&gs)[3]) {
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-        const float d2y = second_difference_f64(wm[1][c], wc[c], wp[1][c]);
-        const float d2x = second_difference_f64(wm[0][c], wc[c], wp[0][c]);
-        float lap;
-        if (D == 3) {
-            const float d2z = second_difference_f64(wm[2][c], wc[c], wp[2][c]);
-            lap = (d2z + d2y) + d2x;
-        } else {
-            lap = d2y + d2x;
-        }
-        gs[c] = -lap;
-    }
-}
-
-// a15: Killing regulariser, smoothing_term.py:50-100, every quirk kept (w_yy uses the +1 neighbour twice; the
-// -2(1+lambda) factor multiplies the xx term only); 3-D extension per DESIGN.md section 3.
-// wm/wp[a][i]: component i at the -1/+1 neighbour along axis a (missing neighbour = centre).
-template <int D, class NB>
-__device__ inline void killing_gradient(const NB& n, const typename NB::Field (&w)[3], const float (&wm)[3][3],
-                                        const float (&wp)[3][3], const float (&wc)[3], const Params& p,
-                                        float (&gs)[3], double& energy, bool want_energy) {
-    float first[3][3];   // first[a][i]  = d w_i / d a
-    float second[3][3];  // second[a][i] = d2 w_i / d a2 (quirky for a == y)
-    float cross[3][3];   // cross[k][i], k = 0:(x,y) 1:(x,z) 2:(y,z)
-#pragma unroll
-    for (int a = 0; a < D; ++a)
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            const float pl = wp[a][i], mi = wm[a][i];
-            first[a][i] = 0.5f * (pl - mi);
-            const float t = pl - 2.0f * wc[i];
-            second[a][i] = a == 1 ? t + pl : t + mi;
-        }
-#pragma unroll
-    for (int a = 0; a < D; ++a)
-#pragma unroll
-        for (int b = a + 1; b < D; ++b) {
-            const int k = a + b - 1;
-            const bool epp = n.diag_exists(a, 1, b, 1), epm = n.diag_exists(a, 1, b, 0);
-            const bool emp = n.diag_exists(a, 0, b, 1), emm = n.diag_exists(a, 0, b, 0);
-#pragma unroll
-            for (int i = 0; i < D; ++i) {
-                float pp = n.diag(w[i], a, 1, b, 1), pm = n.diag(w[i], a, 1, b, 0);
-                float mp = n.diag(w[i], a, 0, b, 1), mm = n.diag(w[i], a, 0, b, 0);
-                pp = epp ? pp : wc[i];
-                pm = epm ? pm : wc[i];
-                mp = emp ? mp : wc[i];
-                mm = emm ? mm : wc[i];
-                cross[k][i] = (((pp - pm) - mp) + mm) / 4.0f;
-            }
-        }
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        float g = p.killing_c1 * second[0][i];
-#pragma unroll
-        for (int a = 1; a < D; ++a) g = g + second[a][i];
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            if (j == i) continue;
-            const int k = i + j - 1;
-            g = g + p.lambda32 * cross[k][j];
-        }
-        gs[i] = g;
-    }
-    if (want_energy) {
-        double e = 0.0;
-#pragma unroll
-        for (int i = 0; i < D; ++i)
-#pragma unroll
-            for (int c = 0; c < D; ++c) {
-                const double jic = (double)first[c][i], jci = (double)first[i][c];
-                e += jic * jic + p.lambda64 * jic * jci;
-            }
-        energy = e;
-    }
-}
-
-// a16: level-set term, level_set_term.py:28-64 (OOB -> 1; second derivatives use the +1 neighbour twice)
-// lm/lp[a]: live at the -1/+1 neighbour along axis a with OOB already replaced by 1
-template <int D, class NB>
-__device__ inline void level_set_gradient(const NB& n, const typename NB::Field& live, const float (&lm)[3],
-                                          const float (&lp)[3], float l, float (&gl)[3], double& energy) {
-    float grad[3] = {0.0f, 0.0f, 0.0f};
-    float hess[3][3];
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-        grad[c] = (0.5f * (lp[c] - lm[c])) * 10.0f;
-        hess[c][c] = ((lp[c] - 2.0f * l) + lp[c]) * 10.0f;
-    }
-#pragma unroll
-    for (int a = 0; a < D; ++a)
-#pragma unroll
-        for (int b = a + 1; b < D; ++b) {
-            float pp = n.diag(live, a, 1, b, 1), mp = n.diag(live, a, 0, b, 1);
-            float pm = n.diag(live, a, 1, b, 0), mm = n.diag(live, a, 0, b, 0);
-            pp = n.diag_exists(a, 1, b, 1) ? pp : 1.0f;
-            mp = n.diag_exists(a, 0, b, 1) ? mp : 1.0f;
-            pm = n.diag_exists(a, 1, b, 0) ? pm : 1.0f;
-            mm = n.diag_exists(a, 0, b, 0) ? mm : 1.0f;
-            const float s = (a == 0 && b == 1) ? ((pp - mp) - pm) + mm   // level_set_term.py:52-53
-                                               : ((pp - pm) - mp) + mm;  // pairs with z: z difference first
-            const float h = (0.25f * s) * 10.0f;
-            hess[a][b] = h;
-            hess[b][a] = h;
-        }
-    float sq = grad[0] * grad[0];
-#pragma unroll
-    for (int c = 1; c < D; ++c) sq = sq + grad[c] * grad[c];
-    const float nrm = sqrtf(sq);
-    const float coef = (1.0f - nrm) / (nrm + 1e-5f);
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        float hv = hess[i][0] * grad[0];
-#pragma unroll
-        for (int j = 1; j < D; ++j) hv = hv + hess[i][j] * grad[j];
-        gl[i] = coef * hv;
-    }
-    const double dn = (double)nrm - 1.0;
-    energy = 0.5 * dn * dn;
-}
-
-// gradient of the energy at one voxel of the narrow-band union (a12-a17); NB = Nbh<D> or NbhFast<D>
-template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, class NB>
-__device__ inline void band_voxel_gradient(const float* __restrict__ live_base, const float* __restrict__ warp_prev,
-                                           const Grid& g, const Params& p, int x, int y, int z, float l, float cn,
-                                           float (&gv)[3], double (&en)[3]) {
-    const bool live_truncated = fabsf(l) == 1.0f;
-    const NB n(g, x, y, z);
-    const typename NB::Field live = NB::field(live_base, g, 0);
-    // ---- live neighbours (shared by np.gradient, the thresholded data term and the level-set term)
-    float lmc[3], lpc[3];  // clamped: a missing neighbour reads the centre
-#pragma unroll
-    for (int a = 0; a < D; ++a) {
-        lmc[a] = n.axis(live, a, 0);
-        lpc[a] = n.axis(live, a, 1);
-    }
-    // ---- data term (data_term.py:169-187 / :334-349; thresholded variant :190-227)
-    const float diff = l - cn;
-    float lg[3] = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int a = 0; a < D; ++a) lg[a] = np_gradient_from(n, a, lmc[a], lpc[a]);
-    if (DATA == LSF_DATA_THRESHOLDED_FDM) {
-#pragma unroll
-        for (int a = 0; a < D; ++a) {
-            const float fwd = (n.exists(a, 1) ? lpc[a] : 1.0f) - l;
-            const float bwd = l - (n.exists(a, 0) ? lmc[a] : 1.0f);
-            float alt = fabsf(fwd) < fabsf(bwd) ? fwd : bwd;
-            alt = fabsf(alt) > 0.5f ? 0.0f : alt;
-            lg[a] = fabsf(lg[a]) > 0.5f ? alt : lg[a];
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < D; ++c) gv[c] = p.w_data * ((diff * lg[c]) * 10.0f);
-    if (ENERGY != LSF_ENERGY_NONE) en[0] = 0.5 * (double)diff * (double)diff;
-    // ---- level-set term (DIRECT only; skipped where live is truncated, slavcheva_optimizer2d.py:274)
-    if (LEVELSET && !live_truncated) {
-        float lm1[3], lp1[3];
-#pragma unroll
-        for (int a = 0; a < D; ++a) {
-            lm1[a] = n.exists(a, 0) ? lmc[a] : 1.0f;
-            lp1[a] = n.exists(a, 1) ? lpc[a] : 1.0f;
-        }
-        float gl[3];
-        double e;
-        level_set_gradient<D, NB>(n, live, lm1, lp1, l, gl, e);
-#pragma unroll
-        for (int c = 0; c < D; ++c) gv[c] = gv[c] + p.w_level_set * gl[c];
-        if (ENERGY != LSF_ENERGY_NONE) en[2] = e;
-    }
-    // ---- smoothing term on the previous warp: axis neighbours with "missing -> centre" come free from clamping
-    const typename NB::Field w[3] = {NB::field(warp_prev, g, 0), NB::field(warp_prev, g, 1),
-                                     NB::field(warp_prev, g, D == 3 ? 2 : 0)};
-    float wc[3] = {0.0f, 0.0f, 0.0f}, wm[3][3], wp[3][3];
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-        wc[c] = n.centre(w[c]);
-#pragma unroll
-        for (int a = 0; a < D; ++a) {
-            wm[a][c] = n.axis(w[c], a, 0);
-            wp[a][c] = n.axis(w[c], a, 1);
-        }
-    }
-    float gs[3] = {0.0f, 0.0f, 0.0f};
-    if (SMOOTH == LSF_SMOOTHING_KILLING) {
-        double e = 0.0;
-        killing_gradient<D, NB>(n, w, wm, wp, wc, p, gs, e, ENERGY != LSF_ENERGY_NONE);
-        if (ENERGY != LSF_ENERGY_NONE) en[1] = e;
-    } else {
-        tikhonov_gradient<D>(wm, wp, wc, gs);
-        if (ENERGY == LSF_ENERGY_DIRECT) {
-            // smoothing_term.py:134-139: 0.5 * sum_axis |0.5 (w[+1] - w[-1])|^2, OOB -> centre
-            double e = 0.0;
-#pragma unroll
-            for (int a = 0; a < D; ++a)
-#pragma unroll
-                for (int c = 0; c < D; ++c) {
-                    const float der = 0.5f * (wp[a][c] - wm[a][c]);
-                    e += (double)der * (double)der;
-                }
-            en[1] = 0.5 * e;
-        } else if (ENERGY == LSF_ENERGY_VECTORIZED) {
-            // smoothing_term.py:162-177: 0.5 * sum_{c,axis} np.gradient(warp_c)[axis]^2 over the band.
-            // accumulation order (per component: x, y, z) as in oracle.smoothing_energy_vectorized is irrelevant
-            // to the float64 sum at the 1e-9 level the tests ask for
-            double e = 0.0;
-#pragma unroll
-            for (int c = 0; c < D; ++c)
-#pragma unroll
-                for (int a = 0; a < D; ++a) {
-                    const float d = np_gradient_from(n, a, wm[a][c], wp[a][c]);
-                    e += (double)d * (double)d;
-                }
-            en[1] = 0.5 * e;
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < D; ++c) gv[c] = gv[c] + p.w_smooth * gs[c];
-}
 
 // gradient of the energy at one voxel (a12-a17); zero outside the narrow-band union
-// ALL_INTERIOR: the caller guarantees the neighbourhood of every voxel it visits (an INTERIOR band list): the generic
-// path is not even compiled in, which keeps that kernel at 85 VGPRs / 5 waves per SIMD and ~620 VALU instructions
-// per 64 voxels (the two-path kernel needs 111 VGPRs, the generic path ~850 instructions).
-template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, bool ALL_INTERIOR>
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
 __device__ inline void voxel_gradient(const float* __restrict__ live, const float* __restrict__ canonical,
                                       const float* __restrict__ warp_prev, const Grid& g, const Params& p, int x,
                                       int y, int z, int i, float (&gv)[3], double (&en)[3]) {
@@ -354,10 +26,13 @@ __device__ inline void voxel_gradient(const float* __restrict__ live, const floa
     const float l = live[i], cn = canonical[i];
     if (fabsf(l) == 1.0f && fabsf(cn) == 1.0f) return;  // outside the narrow-band union (tsdf_set_routines.py:19-52)
     const bool interior = x > 0 && x < g.nx - 1 && y > 0 && y < g.ny - 1 && (D == 2 || (z > 0 && z < g.nz - 1));
-    if (ALL_INTERIOR || (g.fast_ok && __all(interior)))  // wave-uniform: every band lane has its whole neighbourhood
-        band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY, NbhFast<D>>(live, warp_prev, g, p, x, y, z, l, cn, gv, en);
-    else
-        band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY, Nbh<D>>(live, warp_prev, g, p, x, y, z, l, cn, gv, en);
+    if (g.fast_ok && __all(interior)) {  // wave-uniform: every band lane has its whole neighbourhood
+        const NbhFast<D> n(live, warp_prev, g, x, y, z);
+        band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, en);
+    } else {
+        const Nbh<D> n(live, warp_prev, g, x, y, z);
+        band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, en);
+    }
 }
 
 // the re-warp's D-linear gather (OOB -> 1).  When the 2^D-voxel cell of every active lane lies inside the array (wave
@@ -427,49 +102,28 @@ __device__ inline unsigned long long update_and_rewarp(const float* __restrict__
     return pack_max(len, lin);
 }
 
-// MODE: 0 = gradient only (Sobolev path), 1 = fused, 2 = fused over an all-interior band list
-constexpr int kModeGradient = 0, kModeFused = 1, kModeFusedInterior = 2;
-
-template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, int MODE>
-__global__ __launch_bounds__(kBlock) void slavcheva_iteration_kernel(
+// gradient + energies of one iteration (the Sobolev path filters the gradient before the update)
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
+__global__ __launch_bounds__(kBlock) void slavcheva_gradient_kernel(
     const float* __restrict__ live, const float* __restrict__ canonical, const float* __restrict__ warp_prev,
-    float* __restrict__ warp_out, float* __restrict__ live_out, float* __restrict__ g_out, Grid g, Params p,
-    lsf_gate gate, lsf_iteration_record* record, const int* __restrict__ band_list, unsigned band_count) {
-    constexpr bool FUSED = MODE != kModeGradient;
+    float* __restrict__ g_out, Grid g, Params p, lsf_gate gate, lsf_iteration_record* record) {
     if (gate_closed(gate)) return;
-    unsigned long long best = 0ull;
     double en[3] = {0.0, 0.0, 0.0};
-    auto voxel = [&](int x, int y, int z) {
+    for_each_voxel(g, [&](int x, int y, int z) {
         const int i = vidx(g, x, y, z);
         float gv[3];
         double e[3] = {0.0, 0.0, 0.0};
-        voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY, MODE == kModeFusedInterior>(live, canonical, warp_prev, g, p, x,
-                                                                                      y, z, i, gv, e);
+        voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(live, canonical, warp_prev, g, p, x, y, z, i, gv, e);
         en[0] += e[0];
         en[1] += e[1];
         en[2] += e[2];
-        if (FUSED) {
-            unsigned long long q = update_and_rewarp<D>(live, g, p, x, y, z, i, gv, warp_out, live_out, g_out);
-            best = q > best ? q : best;
-        } else {
 #pragma unroll
-            for (int c = 0; c < D; ++c) g_out[c * g.plane + i] = gv[c];
-        }
-    };
-    // Band list (lsf_band_list_fill): only voxels that can be in the narrow-band union are visited.  Every other voxel
-    // has |live| == |canonical| == 1: zero gradient, zero warp, live' = live -- the caller initialised both ping-pong
-    // buffer sets with exactly that, and such a voxel can never enter the band.  Their arg-max candidates are all
-    // (length 0, own index); the smallest index of the launch's z-range stands for them.
-    for_each_listed_voxel(g, FUSED ? band_list : nullptr, band_count, voxel);
-    if (FUSED && band_list && blockIdx.x == 0 && threadIdx.x == 0) {
-        const unsigned long long q = pack_max(0.0f, linear_index(g, 0, 0, g.z_begin));
-        best = q > best ? q : best;
-    }
-    if (FUSED || ENERGY != LSF_ENERGY_NONE) {
-        double* dst[3] = {ENERGY != LSF_ENERGY_NONE ? &record_slot(record)->data_energy : nullptr,
-                          ENERGY != LSF_ENERGY_NONE ? &record_slot(record)->smoothing_energy : nullptr,
-                          ENERGY != LSF_ENERGY_NONE ? &record_slot(record)->level_set_energy : nullptr};
-        block_reduce_commit<3>(best, en, FUSED ? record_max(record) : nullptr, dst);
+        for (int c = 0; c < D; ++c) g_out[c * g.plane + i] = gv[c];
+    });
+    if (ENERGY != LSF_ENERGY_NONE) {
+        double* dst[3] = {&record_slot(record)->data_energy, &record_slot(record)->smoothing_energy,
+                          &record_slot(record)->level_set_energy};
+        block_reduce_commit<3>(0ull, en, nullptr, dst);
     }
 }
 
@@ -511,38 +165,35 @@ struct LaunchArgs {
     unsigned blocks;
     hipStream_t s;
     const float *live, *canonical, *warp_prev;
-    float *warp_out, *live_out, *g_out;
+    float* g_out;
     Grid g;
     Params p;
     lsf_gate gate;
     lsf_iteration_record* record;
-    const int* band_list;
-    unsigned band_count;
 };
 
-template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, int MODE>
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
 void launch_one(const LaunchArgs& a) {
-    hipLaunchKernelGGL((slavcheva_iteration_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY, MODE>), dim3(a.blocks),
-                       dim3(kTileX * a.g.tile_y), 0, a.s, a.live, a.canonical, a.warp_prev, a.warp_out, a.live_out, a.g_out, a.g,
-                       a.p, a.gate, a.record, a.band_list, a.band_count);
+    hipLaunchKernelGGL((slavcheva_gradient_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY>), dim3(a.blocks), dim3(kBlock), 0,
+                       a.s, a.live, a.canonical, a.warp_prev, a.g_out, a.g, a.p, a.gate, a.record);
 }
 
-template <int D, int SMOOTH, bool LEVELSET, int DATA, int MODE>
+template <int D, int SMOOTH, bool LEVELSET, int DATA>
 void pick_energy(int energy, const LaunchArgs& a) {
     switch (energy) {
-        case LSF_ENERGY_DIRECT: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_DIRECT, MODE>(a); break;
-        case LSF_ENERGY_VECTORIZED: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_VECTORIZED, MODE>(a); break;
-        default: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_NONE, MODE>(a); break;
+        case LSF_ENERGY_DIRECT: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_DIRECT>(a); break;
+        case LSF_ENERGY_VECTORIZED: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_VECTORIZED>(a); break;
+        default: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_NONE>(a); break;
     }
 }
 
-template <int D, int MODE>
+template <int D>
 void pick_terms(const lsf_slavcheva_params* q, const LaunchArgs& a) {
     const bool killing = q->smoothing_method == LSF_SMOOTHING_KILLING;
     const bool ls = q->level_set_enabled != 0;
     const bool fdm = q->data_method == LSF_DATA_THRESHOLDED_FDM;
     const int e = q->energy_mode;
-#define LSF_PICK(S, L, DM) pick_energy<D, S, L, DM, MODE>(e, a)
+#define LSF_PICK(S, L, DM) pick_energy<D, S, L, DM>(e, a)
     if (killing) {
         if (ls) { if (fdm) LSF_PICK(LSF_SMOOTHING_KILLING, true, LSF_DATA_THRESHOLDED_FDM); else LSF_PICK(LSF_SMOOTHING_KILLING, true, LSF_DATA_BASIC); }
         else    { if (fdm) LSF_PICK(LSF_SMOOTHING_KILLING, false, LSF_DATA_THRESHOLDED_FDM); else LSF_PICK(LSF_SMOOTHING_KILLING, false, LSF_DATA_BASIC); }
@@ -638,50 +289,20 @@ static inline bool band_subset_ok(int32_t subset) {
     return subset == LSF_BAND_ALL || subset == LSF_BAND_INTERIOR || subset == LSF_BAND_BOUNDARY;
 }
 
-extern "C" int lsf_slavcheva_iteration(int32_t stage, const float* live, const float* canonical,
-                                       const float* warp_prev_planar, float* warp_out_planar, float* live_out,
-                                       float* g_out_planar, const lsf_grid* grid, const lsf_slavcheva_params* params,
-                                       const lsf_gate* gate, lsf_iteration_record* record, const int32_t* band_list,
-                                       int64_t band_count, int32_t band_subset, void* stream) {
+extern "C" int lsf_slavcheva_gradient(const float* live, const float* canonical, const float* warp_prev_planar,
+                                      float* g_out_planar, const lsf_grid* grid, const lsf_slavcheva_params* params,
+                                      const lsf_gate* gate, lsf_iteration_record* record, void* stream) {
     if (int e = check_grid(grid)) return e;
-    if (!live || !canonical || !warp_prev_planar || !params || !record) return LSF_ERR_BAD_ARGUMENT;
-    if (stage == LSF_STAGE_FUSED) {
-        if (!warp_out_planar || !live_out || live_out == live || warp_out_planar == warp_prev_planar)
-            return LSF_ERR_BAD_ARGUMENT;
-    } else if (stage == LSF_STAGE_GRADIENT) {
-        if (!g_out_planar || g_out_planar == warp_prev_planar) return LSF_ERR_BAD_ARGUMENT;
-    } else {
+    if (!live || !canonical || !warp_prev_planar || !params || !record || !g_out_planar ||
+        g_out_planar == warp_prev_planar)
         return LSF_ERR_BAD_ARGUMENT;
-    }
-    // work unit = (64 x 4) tile, 4-wave blocks.  Finer units (1- or 2-wave blocks on 64 x 1 / 64 x 2 tiles, which
-    // would average the ~4x cost difference between band and non-band units over more units per block) were measured
-    // and lose: the four rows of a tile share stencil rows through L1 (256^3 all-in-band 0.39 / 0.46 / 0.59 ms for
-    // tile heights 4 / 2 / 1).
-    const int tile_y = 4;
-    const unsigned per_xcd = blocks_per_xcd();
-    Grid g = make_grid(grid, tile_y);
+    Grid g = make_grid(grid);
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
-    const bool listed = band_list != nullptr;
-    if (listed && (stage != LSF_STAGE_FUSED || g_out_planar || band_count < 0 || band_count > 0x7fffffffll ||
-                   !band_subset_ok(band_subset)))
-        return LSF_ERR_BAD_ARGUMENT;
-    // an INTERIOR list runs the kernel without the generic neighbourhood path; it needs 32-bit buffer offsets
-    const bool all_interior = listed && band_subset == LSF_BAND_INTERIOR;
-    if (all_interior && !g.fast_ok) return LSF_ERR_BAD_ARGUMENT;
-    const unsigned blocks = listed ? band_list_blocks((unsigned)band_count) : launch_blocks(t.total, per_xcd);
-    LaunchArgs a{blocks, as_stream(stream), live, canonical, warp_prev_planar, warp_out_planar,
-                 live_out, g_out_planar, g, make_params(params), gate_or_open(gate), record,
-                 band_list, (unsigned)band_count};
-    if (grid->dims == 2) {
-        if (all_interior) pick_terms<2, kModeFusedInterior>(params, a);
-        else if (stage == LSF_STAGE_FUSED) pick_terms<2, kModeFused>(params, a);
-        else pick_terms<2, kModeGradient>(params, a);
-    } else {
-        if (all_interior) pick_terms<3, kModeFusedInterior>(params, a);
-        else if (stage == LSF_STAGE_FUSED) pick_terms<3, kModeFused>(params, a);
-        else pick_terms<3, kModeGradient>(params, a);
-    }
+    LaunchArgs a{launch_blocks(t.total), as_stream(stream), live, canonical, warp_prev_planar, g_out_planar, g,
+                 make_params(params), gate_or_open(gate), record};
+    if (grid->dims == 2) pick_terms<2>(params, a);
+    else pick_terms<3>(params, a);
     return launch_status();
 }
 

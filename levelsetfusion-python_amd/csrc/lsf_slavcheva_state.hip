@@ -1,0 +1,611 @@
+// The fused per-voxel warp-update kernel of the Slavcheva-style (KillingFusion) optimizer on the STATE layout,
+// D = 2, 3.  Reference: nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:238-330 with
+// data_term.py, smoothing_term.py, level_set_term.py and field_warping.warp_field_advanced (:112-151).
+//
+// State layout: float4 [z][y][x] = (live, u, v, w) -- the two fields an iteration reads through the SAME 3^D
+// neighbourhood and ping-pongs together.  One 16-byte load per neighbour instead of four dword loads from four planes:
+// a wave of band-list voxels (2-3 short x-runs) touches partially used 64-byte sectors at every run end, and the
+// vector L1 coalesces per 16 lanes -- 16 lanes x 16 B fill four sectors where 16 lanes x 4 B fill a quarter of one to
+// two.  Measured on the 256^3 sphere pair: ~13 L1 accesses per dword wave-load on the planar layout (76 loads per
+// voxel), DESIGN.md section 7.  One iteration reads state (16 B) + canonical (4 B) and writes state' (16 B):
+// 36 B / voxel-update of compulsory HBM traffic in 3-D (SURVEY 8d books 52 B for the two-pass formulation).
+// Arithmetic and operation order are those of the planar kernels (lsf_slavcheva_terms.h): results are bit-identical.
+#include "lsf_slavcheva_terms.h"
+
+using namespace lsf;
+using namespace lsf::slav;
+
+namespace {
+
+typedef float vf4 __attribute__((ext_vector_type(4)));
+typedef unsigned vu4 __attribute__((ext_vector_type(4)));
+
+__device__ inline float comp(const vf4& v, int f) { return f == 0 ? v.x : (f == 1 ? v.y : (f == 2 ? v.z : v.w)); }
+
+// 3^D neighbourhood of one voxel held in registers: tap (dx, dy, dz) with at most two non-zero offsets (the 19-point
+// stencil of the Killing cross derivatives; 9 points in 2-D).  Field = component of the state.
+template <int D>
+struct TapsBase {
+    using Field = int;
+    vf4 t[3][3][3];  // [dz + 1][dy + 1][dx + 1]; only the taps the stencils use are ever loaded
+    __device__ inline Field live() const { return 0; }
+    __device__ inline Field warp(int c) const { return 1 + c; }
+    __device__ inline float centre(Field f) const { return comp(t[1][1][1], f); }
+    __device__ inline float axis(Field f, int a, int s) const {
+        const int d = s ? 1 : -1;
+        return comp(t[1 + (a == 2 ? d : 0)][1 + (a == 1 ? d : 0)][1 + (a == 0 ? d : 0)], f);
+    }
+    __device__ inline float diag(Field f, int a, int sa, int b, int sb) const {
+        const int da = sa ? 1 : -1, db = sb ? 1 : -1;
+        return comp(t[1 + (a == 2 ? da : 0) + (b == 2 ? db : 0)][1 + (a == 1 ? da : 0) + (b == 1 ? db : 0)]
+                     [1 + (a == 0 ? da : 0) + (b == 0 ? db : 0)], f);
+    }
+};
+
+// generic: every neighbour read from a CLAMPED offset, the reference's OOB rules applied by the terms with selects
+template <int D>
+struct NbhState : TapsBase<D> {
+    bool has[3][2];
+    __device__ inline NbhState(const vf4* __restrict__ s, const Grid& g, int x, int y, int z, const vf4& centre_value) {
+        const int i = vidx(g, x, y, z);
+        const int stride[3] = {1, g.nx, g.nx * g.ny};
+        const int coord[3] = {x, y, z};
+        const int extent[3] = {g.nx, g.ny, g.nz};
+        int off[3][3];  // [axis][d + 1]
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            has[a][0] = a < D && coord[a] > 0;
+            has[a][1] = a < D && coord[a] < extent[a] - 1;
+            off[a][0] = has[a][0] ? -stride[a] : 0;
+            off[a][1] = 0;
+            off[a][2] = has[a][1] ? stride[a] : 0;
+        }
+#pragma unroll
+        for (int dz = (D == 3 ? -1 : 0); dz <= (D == 3 ? 1 : 0); ++dz)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int nz = (dx != 0) + (dy != 0) + (dz != 0);
+                    if (nz > 2) continue;
+                    this->t[dz + 1][dy + 1][dx + 1] =
+                        nz == 0 ? centre_value : s[i + off[0][dx + 1] + off[1][dy + 1] + off[2][dz + 1]];
+                }
+    }
+    __device__ inline bool exists(int a, int s) const { return has[a][s]; }
+    __device__ inline bool diag_exists(int a, int sa, int b, int sb) const { return has[a][sa] && has[b][sb]; }
+};
+
+// every lane's whole neighbourhood lies inside the array (wave vote or an INTERIOR band list): one per-lane byte offset
+// (the neighbourhood's lowest corner relative to the wave's first lane), the tap chosen by the instruction's scalar
+// offset (dy, dz) and immediate (dx) -- no per-tap VALU address arithmetic, no OOB selects.  32-bit buffer offsets:
+// 16 * nz * ny * nx < 2^32 (Grid::fast_ok as set by the launcher).
+template <int D>
+struct NbhStateFast : TapsBase<D> {
+    __device__ inline NbhStateFast(const vf4* __restrict__ s, const Grid& g, int x, int y, int z,
+                                   const vf4& centre_value) {
+        const __amdgpu_buffer_rsrc_t rsrc =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<vf4*>(s), 0, -1, 0x00020000);
+        const unsigned sy = (unsigned)g.nx * 16u, sz = (unsigned)(g.nx * g.ny) * 16u;
+        const unsigned corner = (unsigned)vidx(g, x, y, z) * 16u - 16u - sy - (D == 3 ? sz : 0u);
+        const unsigned wave_base = (unsigned)__builtin_amdgcn_readfirstlane((int)corner);  // smallest: ascending by lane
+        const unsigned lane_delta = corner - wave_base;
+#pragma unroll
+        for (int dz = (D == 3 ? -1 : 0); dz <= (D == 3 ? 1 : 0); ++dz)
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int nz = (dx != 0) + (dy != 0) + (dz != 0);
+                    if (nz > 2) continue;
+                    if (nz == 0) {
+                        this->t[1][1][1] = centre_value;
+                        continue;
+                    }
+                    const unsigned soff = wave_base + (unsigned)(dy + 1) * sy + (D == 3 ? (unsigned)(dz + 1) * sz : 0u);
+                    this->t[dz + 1][dy + 1][dx + 1] = __builtin_bit_cast(
+                        vf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane_delta + (unsigned)(dx + 1) * 16u),
+                                                                   (int)soff, 0));
+                }
+    }
+    __device__ static constexpr bool exists(int, int) { return true; }
+    __device__ static constexpr bool diag_exists(int, int, int, int) { return true; }
+};
+
+// the re-warp's D-linear gather of the live component (OOB -> 1): lerp z, then y, then x as sample_linear does
+template <int D>
+__device__ inline float state_gather(const vf4* __restrict__ s, const Grid& g, float px, float py, float pz) {
+    const AxisTaps ax = axis_taps(px, g.nx, 0), ay = axis_taps(py, g.ny, 0);
+    AxisTaps az = ax;
+    if (D == 3) az = axis_taps(pz, g.nz, g.z_global_offset);
+    const bool cell_inside = ax.v0 && ax.v1 && ay.v0 && ay.v1 && (D == 2 || (az.v0 && az.v1));
+    if (!(g.fast_ok && __all(cell_inside))) {
+        const float* f = reinterpret_cast<const float*>(s);
+        auto rd = [&](const AxisTaps& tx, int ox, const AxisTaps& ty, int oy, const AxisTaps& tz, int oz) {
+            const long long idx = ((long long)(D == 3 ? (oz ? tz.c1 : tz.c0) : 0) * g.ny + (oy ? ty.c1 : ty.c0)) * g.nx +
+                                  (ox ? tx.c1 : tx.c0);
+            const bool valid = (ox ? tx.v1 : tx.v0) && (oy ? ty.v1 : ty.v0) && (D == 2 || (oz ? tz.v1 : tz.v0));
+            const float v = f[idx * 4];
+            return valid ? v : 1.0f;
+        };
+        if (D == 2) {
+            const float i0 = rd(ax, 0, ay, 0, az, 0) * ay.i + rd(ax, 0, ay, 1, az, 0) * ay.r;
+            const float i1 = rd(ax, 1, ay, 0, az, 0) * ay.i + rd(ax, 1, ay, 1, az, 0) * ay.r;
+            return i0 * ax.i + i1 * ax.r;
+        }
+        float c[2][2];
+#pragma unroll
+        for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+            for (int oy = 0; oy < 2; ++oy) c[ox][oy] = rd(ax, ox, ay, oy, az, 0) * az.i + rd(ax, ox, ay, oy, az, 1) * az.r;
+        const float i0 = c[0][0] * ay.i + c[0][1] * ay.r;
+        const float i1 = c[1][0] * ay.i + c[1][1] * ay.r;
+        return i0 * ax.i + i1 * ax.r;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<vf4*>(s), 0, -1, 0x00020000);
+    const unsigned sy = (unsigned)g.nx * 16u, sz = (unsigned)(g.nx * g.ny) * 16u;
+    const unsigned corner = (unsigned)(((D == 3 ? az.c0 : 0) * g.ny + ay.c0) * g.nx + ax.c0) * 16u;
+    auto tap = [&](int dx, int dy, int dz) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                             rsrc, (int)(corner + (unsigned)dx * 16u),
+                                             (int)((unsigned)dy * sy + (unsigned)dz * sz), 0));
+    };
+    if (D == 2) {
+        const float i0 = tap(0, 0, 0) * ay.i + tap(0, 1, 0) * ay.r;
+        const float i1 = tap(1, 0, 0) * ay.i + tap(1, 1, 0) * ay.r;
+        return i0 * ax.i + i1 * ax.r;
+    }
+    float c[2][2];
+#pragma unroll
+    for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+        for (int oy = 0; oy < 2; ++oy) c[ox][oy] = tap(ox, oy, 0) * az.i + tap(ox, oy, 1) * az.r;
+    const float i0 = c[0][0] * ay.i + c[0][1] * ay.r;
+    const float i1 = c[1][0] * ay.i + c[1][1] * ay.r;
+    return i0 * ax.i + i1 * ax.r;
+}
+
+// WALK: the dense tile walk over every voxel, a band list (ALL or BOUNDARY subset), an INTERIOR band list
+constexpr int kWalkDense = 0, kWalkList = 1, kWalkListInterior = 2;
+
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, int WALK>
+__global__ __launch_bounds__(kBlock) void slavcheva_state_kernel(const vf4* __restrict__ state_in,
+                                                                 const float* __restrict__ canonical,
+                                                                 vf4* __restrict__ state_out, Grid g, Params p,
+                                                                 lsf_gate gate, lsf_iteration_record* record,
+                                                                 const int* __restrict__ band_list,
+                                                                 unsigned band_count) {
+    if (gate_closed(gate)) return;
+    unsigned long long best = 0ull;
+    double en[3] = {0.0, 0.0, 0.0};
+    auto voxel = [&](int x, int y, int z, int i, const vf4& sc, float cn) {
+        const float l = sc.x;
+        float gv[3] = {0.0f, 0.0f, 0.0f};
+        // outside the narrow-band union (tsdf_set_routines.py:19-52; the `continue` of slavcheva_optimizer2d.py:251-252)
+        const bool in_band = !(fabsf(l) == 1.0f && fabsf(cn) == 1.0f);
+        if (in_band) {
+            double e[3] = {0.0, 0.0, 0.0};
+            const bool interior = x > 0 && x < g.nx - 1 && y > 0 && y < g.ny - 1 && (D == 2 || (z > 0 && z < g.nz - 1));
+            if (WALK == kWalkListInterior || (g.fast_ok && __all(interior))) {
+                const NbhStateFast<D> n(state_in, g, x, y, z, sc);
+                band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
+            } else {
+                const NbhState<D> n(state_in, g, x, y, z, sc);
+                band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
+            }
+            en[0] += e[0];
+            en[1] += e[1];
+            en[2] += e[2];
+        }
+        // warp = -g * rate, its length for the arg-max, truncation-aware re-warp of the live field (a18 + a3)
+        float wv[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < D; ++c) wv[c] = (-gv[c]) * p.rate;
+        const float len = vec_length<D>(wv);
+        float v;
+        if (wv[0] == 0.0f && wv[1] == 0.0f && wv[2] == 0.0f) {
+            v = l;  // zero displacement: every lerp is a*1 + b*0 = a exactly, the gather returns live[p] bit for bit
+        } else {
+            const float px = (float)x + wv[0], py = (float)y + wv[1];
+            const float pz = D == 3 ? (float)(z + g.z_global_offset) + wv[2] : 0.0f;
+            v = state_gather<D>(state_in, g, px, py, pz);
+        }
+        if (1.0f - fabsf(v) < 1e-6f) {  // field_warping.py:138-141
+            v = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : v);
+            wv[0] = wv[1] = wv[2] = 0.0f;
+        }
+        vf4 o;
+        o.x = v; o.y = wv[0]; o.z = wv[1]; o.w = wv[2];
+        state_out[i] = o;
+        const unsigned long long q = pack_max(len, linear_index(g, x, y, z));
+        best = q > best ? q : best;
+    };
+    // Band list (lsf_band_list_fill): only voxels that can be in the narrow-band union are visited; every other voxel
+    // holds (live, 0) in BOTH ping-pong states and never changes.  Their arg-max candidates are all (length 0, own
+    // index); the smallest index of the launch's z-range stands for them.
+    if (WALK == kWalkDense) {
+        for_each_voxel(g, [&](int x, int y, int z) {
+            const int i = vidx(g, x, y, z);
+            voxel(x, y, z, i, state_in[i], canonical[i]);
+        });
+    } else {
+        // Software-pipelined list walk: a unit's critical path would be list entry -> state / canonical -> neighbourhood
+        // -> arithmetic -> re-warp gather, four dependent memory round trips with only 4 waves per SIMD to hide them.
+        // The list entry is fetched two units ahead and the voxel's own state one unit ahead, so that a unit starts
+        // with its neighbourhood loads.  Entries past the end read voxel 0 (a valid address) and are not processed.
+        const ListWalk w = list_walk(band_count);
+        auto entry = [&](unsigned unit, bool& listed) {
+            const unsigned k = unit * kBlock + threadIdx.x;
+            listed = unit < w.end && k < band_count;
+            return listed ? (unsigned)band_list[k] : 0u;
+        };
+        unsigned u = w.first;
+        bool in0, in1, in2;
+        unsigned i0 = entry(u, in0);
+        unsigned i1 = entry(u + w.step, in1);
+        vf4 s0 = state_in[i0];
+        float c0 = canonical[i0];
+        while (u < w.end) {
+            const vf4 s1 = state_in[i1];
+            const float c1 = canonical[i1];
+            const unsigned i2 = entry(u + 2 * w.step, in2);
+            if (in0) {
+                const unsigned zy = fast_div(i0, g.div_nx);
+                const int x = (int)(i0 - zy * (unsigned)g.nx);
+                const int z = (int)fast_div(zy, g.div_ny);
+                const int y = (int)zy - z * g.ny;
+                voxel(x, y, z, (int)i0, s0, c0);
+            }
+            u += w.step;
+            i0 = i1; in0 = in1; s0 = s1; c0 = c1;
+            i1 = i2; in1 = in2;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const unsigned long long q = pack_max(0.0f, linear_index(g, 0, 0, g.z_begin));
+            best = q > best ? q : best;
+        }
+    }
+    double* dst[3] = {ENERGY != LSF_ENERGY_NONE ? &record_slot(record)->data_energy : nullptr,
+                      ENERGY != LSF_ENERGY_NONE ? &record_slot(record)->smoothing_energy : nullptr,
+                      ENERGY != LSF_ENERGY_NONE ? &record_slot(record)->level_set_energy : nullptr};
+    block_reduce_commit<3>(best, en, record_max(record), dst);
+}
+
+// (live, warp planar or 0) -> state, optionally into two buffers (both ping-pong states start equal)
+__global__ __launch_bounds__(kBlock) void state_pack_kernel(const float* __restrict__ live,
+                                                            const float* __restrict__ warp, vf4* __restrict__ a,
+                                                            vf4* __restrict__ b, long long first, long long n,
+                                                            long long plane, int dims) {
+    for (long long k = blockIdx.x * (long long)kBlock + threadIdx.x; k < n; k += (long long)gridDim.x * kBlock) {
+        const long long i = first + k;
+        vf4 o;
+        o.x = live[i];
+        o.y = warp ? warp[i] : 0.0f;
+        o.z = warp ? warp[plane + i] : 0.0f;
+        o.w = (warp && dims == 3) ? warp[2 * plane + i] : 0.0f;
+        a[i] = o;
+        if (b) b[i] = o;
+    }
+}
+
+// state -> live, warp planar [c][z][y][x] and / or interleaved [z][y][x][c] (any of them may be NULL)
+__global__ __launch_bounds__(kBlock) void state_unpack_kernel(const vf4* __restrict__ s, float* __restrict__ live,
+                                                              float* __restrict__ planar,
+                                                              float* __restrict__ interleaved, long long first,
+                                                              long long n, long long plane, int dims) {
+    for (long long k = blockIdx.x * (long long)kBlock + threadIdx.x; k < n; k += (long long)gridDim.x * kBlock) {
+        const long long i = first + k;
+        const vf4 v = s[i];
+        if (live) live[i] = v.x;
+        if (planar) {
+            planar[i] = v.y;
+            planar[plane + i] = v.z;
+            if (dims == 3) planar[2 * plane + i] = v.w;
+        }
+        if (interleaved) {
+            interleaved[i * dims] = v.y;
+            interleaved[i * dims + 1] = v.z;
+            if (dims == 3) interleaved[i * dims + 2] = v.w;
+        }
+    }
+}
+
+// ---- end of an optimize() call: state -> caller's fields AND the convergence statistics (a20) in ONE pass ------------
+// Per-block partial results go to scratch rows (no same-address atomics: ~2000 of them serialise at ~12 ns each and
+// made the two separate statistics kernels take 0.35 ms at 256^3 for 0.13 GB of reads); a one-block kernel combines.
+constexpr int kFinalizeWords = 12;  // per block: packed warp max, packed diff max, diff min, 4 warp sums, 2 diff sums
+
+__global__ __launch_bounds__(kBlock) void state_finalize_kernel(const vf4* __restrict__ s,
+                                                                const float* __restrict__ canonical,
+                                                                float* __restrict__ live, float* __restrict__ planar,
+                                                                float* __restrict__ interleaved, long long first,
+                                                                long long n, long long plane, int dims,
+                                                                long long index_offset, float lo,
+                                                                double* __restrict__ scratch) {
+    unsigned long long best_w = 0ull, best_d = 0ull;
+    double sums[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // band count, above lo, sum len, sum len^2, sum d, sum d^2
+    double mn = __longlong_as_double(0x7ff0000000000000ll);
+    for (long long k = blockIdx.x * (long long)kBlock + threadIdx.x; k < n; k += (long long)gridDim.x * kBlock) {
+        const long long i = first + k;
+        const vf4 v = s[i];
+        if (live) live[i] = v.x;
+        if (planar) {
+            planar[i] = v.y;
+            planar[plane + i] = v.z;
+            if (dims == 3) planar[2 * plane + i] = v.w;
+        }
+        if (interleaved) {
+            interleaved[i * dims] = v.y;
+            interleaved[i * dims + 1] = v.z;
+            if (dims == 3) interleaved[i * dims + 2] = v.w;
+        }
+        if (scratch) {
+            const float cn = canonical[i];
+            const unsigned lin = (unsigned)(i + index_offset);
+            if (!(fabsf(v.x) == 1.0f && fabsf(cn) == 1.0f)) {
+                const float wv[3] = {v.y, v.z, v.w};
+                const float len = dims == 3 ? vec_length<3>(wv) : vec_length<2>(wv);
+                const unsigned long long p = pack_max(len, lin);
+                best_w = p > best_w ? p : best_w;
+                sums[0] += 1.0;
+                sums[1] += len > lo ? 1.0 : 0.0;
+                sums[2] += (double)len;
+                sums[3] += (double)len * (double)len;
+            }
+            const double d = fabs((double)cn - (double)v.x);
+            const unsigned long long q = pack_max((float)d, lin);
+            best_d = q > best_d ? q : best_d;
+            sums[4] += d;
+            sums[5] += d * d;
+            mn = fmin(mn, d);
+        }
+    }
+    if (!scratch) return;
+    __shared__ unsigned long long s_w[kBlock / kWave], s_d[kBlock / kWave];
+    __shared__ double s_mn[kBlock / kWave], s_sum[6][kBlock / kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    best_w = wave_max_u64(best_w);
+    best_d = wave_max_u64(best_d);
+    for (int dl = kWave / 2; dl > 0; dl >>= 1) mn = fmin(mn, shfl_down_f64(mn, dl));
+#pragma unroll
+    for (int j = 0; j < 6; ++j) sums[j] = wave_sum_f64(sums[j]);
+    if (lane == 0) {
+        s_w[wave] = best_w; s_d[wave] = best_d; s_mn[wave] = mn;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s_sum[j][wave] = sums[j];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* row = scratch + (long long)blockIdx.x * kFinalizeWords;
+        unsigned long long w = 0ull, d = 0ull;
+        double m = s_mn[0];
+        for (int k = 0; k < kBlock / kWave; ++k) {
+            w = s_w[k] > w ? s_w[k] : w;
+            d = s_d[k] > d ? s_d[k] : d;
+            m = fmin(m, s_mn[k]);
+        }
+        row[0] = __longlong_as_double((long long)w);
+        row[1] = __longlong_as_double((long long)d);
+        row[2] = m;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            double t = 0.0;
+            for (int k = 0; k < kBlock / kWave; ++k) t += s_sum[j][k];
+            row[3 + j] = t;
+        }
+    }
+}
+
+// one block: rows -> out16 = the 8-double layouts of lsf_warp_statistics and lsf_tsdf_difference_statistics
+__global__ __launch_bounds__(kBlock) void state_finalize_combine_kernel(const double* __restrict__ scratch,
+                                                                        unsigned rows, double voxels,
+                                                                        double* __restrict__ out16) {
+    unsigned long long best_w = 0ull, best_d = 0ull;
+    double sums[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double mn = __longlong_as_double(0x7ff0000000000000ll);
+    for (unsigned r = threadIdx.x; r < rows; r += kBlock) {
+        const double* row = scratch + (long long)r * kFinalizeWords;
+        const unsigned long long w = (unsigned long long)__double_as_longlong(row[0]);
+        const unsigned long long d = (unsigned long long)__double_as_longlong(row[1]);
+        best_w = w > best_w ? w : best_w;
+        best_d = d > best_d ? d : best_d;
+        mn = fmin(mn, row[2]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sums[j] += row[3 + j];
+    }
+    __shared__ unsigned long long s_w[kBlock / kWave], s_d[kBlock / kWave];
+    __shared__ double s_mn[kBlock / kWave], s_sum[6][kBlock / kWave];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    best_w = wave_max_u64(best_w);
+    best_d = wave_max_u64(best_d);
+    for (int dl = kWave / 2; dl > 0; dl >>= 1) mn = fmin(mn, shfl_down_f64(mn, dl));
+#pragma unroll
+    for (int j = 0; j < 6; ++j) sums[j] = wave_sum_f64(sums[j]);
+    if (lane == 0) {
+        s_w[wave] = best_w; s_d[wave] = best_d; s_mn[wave] = mn;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) s_sum[j][wave] = sums[j];
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    unsigned long long w = 0ull, d = 0ull;
+    double m = s_mn[0], t[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int k = 0; k < kBlock / kWave; ++k) {
+        w = s_w[k] > w ? s_w[k] : w;
+        d = s_d[k] > d ? s_d[k] : d;
+        m = fmin(m, s_mn[k]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) t[j] += s_sum[j][k];
+    }
+    // warp: [count_band, count_above_lo, max_len, sum_len, sum_len^2, argmax, 0, 0]
+    out16[0] = t[0]; out16[1] = t[1];
+    out16[2] = w ? (double)unpack_max_value(w) : 0.0;
+    out16[3] = t[2]; out16[4] = t[3];
+    out16[5] = w ? (double)(~(unsigned)w) : -1.0;
+    out16[6] = 0.0; out16[7] = 0.0;
+    // tsdf: [count, min, max, sum, sum^2, argmax, 0, 0] of |canonical - live|
+    out16[8] = voxels; out16[9] = m;
+    out16[10] = d ? (double)unpack_max_value(d) : 0.0;
+    out16[11] = t[4]; out16[12] = t[5];
+    out16[13] = d ? (double)(~(unsigned)d) : -1.0;
+    out16[14] = 0.0; out16[15] = 0.0;
+}
+
+struct LaunchArgs {
+    unsigned blocks;
+    hipStream_t s;
+    const vf4* state_in;
+    const float* canonical;
+    vf4* state_out;
+    Grid g;
+    Params p;
+    lsf_gate gate;
+    lsf_iteration_record* record;
+    const int* band_list;
+    unsigned band_count;
+};
+
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, int WALK>
+void launch_one(const LaunchArgs& a) {
+    hipLaunchKernelGGL((slavcheva_state_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY, WALK>), dim3(a.blocks),
+                       dim3(kTileX * a.g.tile_y), 0, a.s, a.state_in, a.canonical, a.state_out, a.g, a.p, a.gate,
+                       a.record, a.band_list, a.band_count);
+}
+
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int WALK>
+void pick_energy(int energy, const LaunchArgs& a) {
+    switch (energy) {
+        case LSF_ENERGY_DIRECT: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_DIRECT, WALK>(a); break;
+        case LSF_ENERGY_VECTORIZED: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_VECTORIZED, WALK>(a); break;
+        default: launch_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_NONE, WALK>(a); break;
+    }
+}
+
+template <int D, int WALK>
+void pick_terms(const lsf_slavcheva_params* q, const LaunchArgs& a) {
+    const bool killing = q->smoothing_method == LSF_SMOOTHING_KILLING;
+    const bool ls = q->level_set_enabled != 0;
+    const bool fdm = q->data_method == LSF_DATA_THRESHOLDED_FDM;
+    const int e = q->energy_mode;
+#define LSF_PICK(S, L, DM) pick_energy<D, S, L, DM, WALK>(e, a)
+    if (killing) {
+        if (ls) { if (fdm) LSF_PICK(LSF_SMOOTHING_KILLING, true, LSF_DATA_THRESHOLDED_FDM); else LSF_PICK(LSF_SMOOTHING_KILLING, true, LSF_DATA_BASIC); }
+        else    { if (fdm) LSF_PICK(LSF_SMOOTHING_KILLING, false, LSF_DATA_THRESHOLDED_FDM); else LSF_PICK(LSF_SMOOTHING_KILLING, false, LSF_DATA_BASIC); }
+    } else {
+        if (ls) { if (fdm) LSF_PICK(LSF_SMOOTHING_TIKHONOV, true, LSF_DATA_THRESHOLDED_FDM); else LSF_PICK(LSF_SMOOTHING_TIKHONOV, true, LSF_DATA_BASIC); }
+        else    { if (fdm) LSF_PICK(LSF_SMOOTHING_TIKHONOV, false, LSF_DATA_THRESHOLDED_FDM); else LSF_PICK(LSF_SMOOTHING_TIKHONOV, false, LSF_DATA_BASIC); }
+    }
+#undef LSF_PICK
+}
+
+Params make_params(const lsf_slavcheva_params* q) {
+    Params p;
+    p.lambda64 = q->isomorphic_enforcement_factor_f64;
+    p.rate = q->rate;
+    p.w_data = q->data_term_weight;
+    p.w_smooth = q->smoothing_term_weight;
+    p.w_level_set = q->level_set_term_weight;
+    p.lambda32 = q->isomorphic_enforcement_factor;
+    p.killing_c1 = q->killing_c1;
+    p.zero_gradient_on_snap = q->zero_gradient_on_snap;
+    return p;
+}
+
+inline bool range_of(const lsf_grid* grid, long long& first, long long& n) {
+    const long long slice = (long long)grid->ny * grid->nx;
+    first = slice * grid->z_begin;
+    n = slice * (grid->z_end - grid->z_begin);
+    return n > 0;
+}
+
+inline unsigned stream_blocks(long long n) {
+    const long long want = (n + kBlock - 1) / kBlock;
+    return (unsigned)(want < 8192 ? want : 8192);
+}
+
+}  // namespace
+
+extern "C" int lsf_state_pack(const float* live, const float* warp_planar, float* state_a, float* state_b,
+                              const lsf_grid* grid, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!live || !state_a) return LSF_ERR_BAD_ARGUMENT;
+    long long first, n;
+    if (!range_of(grid, first, n)) return 0;
+    hipLaunchKernelGGL(state_pack_kernel, dim3(stream_blocks(n)), dim3(kBlock), 0, as_stream(stream), live, warp_planar,
+                       reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b), first, n,
+                       (long long)grid->nz * grid->ny * grid->nx, grid->dims);
+    return launch_status();
+}
+
+extern "C" int lsf_state_unpack(const float* state, float* live_out, float* warp_planar_out,
+                                float* warp_interleaved_out, const lsf_grid* grid, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!state) return LSF_ERR_BAD_ARGUMENT;
+    long long first, n;
+    if (!range_of(grid, first, n)) return 0;
+    hipLaunchKernelGGL(state_unpack_kernel, dim3(stream_blocks(n)), dim3(kBlock), 0, as_stream(stream),
+                       reinterpret_cast<const vf4*>(state), live_out, warp_planar_out, warp_interleaved_out, first, n,
+                       (long long)grid->nz * grid->ny * grid->nx, grid->dims);
+    return launch_status();
+}
+
+extern "C" int64_t lsf_state_finalize_scratch_elements(const lsf_grid* grid) {
+    if (check_grid(grid)) return 0;
+    long long first, n;
+    range_of(grid, first, n);
+    return (int64_t)stream_blocks(n > 0 ? n : 1) * kFinalizeWords;
+}
+
+extern "C" int lsf_state_finalize(const float* state, const float* canonical, float* live_out,
+                                  float* warp_planar_out, float* warp_interleaved_out, const lsf_grid* grid,
+                                  float lower_threshold, double* statistics16, double* scratch, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!state || (statistics16 && (!canonical || !scratch))) return LSF_ERR_BAD_ARGUMENT;
+    long long first, n;
+    if (!range_of(grid, first, n)) return statistics16 ? LSF_ERR_BAD_ARGUMENT : 0;
+    const unsigned blocks = stream_blocks(n);
+    const long long slice = (long long)grid->ny * grid->nx;
+    hipLaunchKernelGGL(state_finalize_kernel, dim3(blocks), dim3(kBlock), 0, as_stream(stream),
+                       reinterpret_cast<const vf4*>(state), canonical, live_out, warp_planar_out, warp_interleaved_out,
+                       first, n, (long long)grid->nz * slice, grid->dims, slice * grid->z_global_offset,
+                       lower_threshold, statistics16 ? scratch : (double*)nullptr);
+    if (statistics16)
+        hipLaunchKernelGGL(state_finalize_combine_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), scratch, blocks,
+                           (double)n, statistics16);
+    return launch_status();
+}
+
+extern "C" int lsf_slavcheva_state_iteration(const float* state_in, const float* canonical, float* state_out,
+                                             const lsf_grid* grid, const lsf_slavcheva_params* params,
+                                             const lsf_gate* gate, lsf_iteration_record* record,
+                                             const int32_t* band_list, int64_t band_count, int32_t band_subset,
+                                             void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!state_in || !canonical || !state_out || state_out == state_in || !params || !record)
+        return LSF_ERR_BAD_ARGUMENT;
+    const int tile_y = 4;
+    Grid g = make_grid(grid, tile_y);
+    g.fast_ok = g.plane * 16 < 0xffffffffll;  // 32-bit byte offsets into the float4 state
+    Tiling t = make_tiling(g);
+    if (t.total == 0) return 0;
+    const bool listed = band_list != nullptr;
+    if (listed && (band_count < 0 || band_count > 0x7fffffffll ||
+                   !(band_subset == LSF_BAND_ALL || band_subset == LSF_BAND_INTERIOR || band_subset == LSF_BAND_BOUNDARY)))
+        return LSF_ERR_BAD_ARGUMENT;
+    const bool all_interior = listed && band_subset == LSF_BAND_INTERIOR;
+    if (all_interior && !g.fast_ok) return LSF_ERR_BAD_ARGUMENT;
+    const unsigned blocks = listed ? band_list_blocks((unsigned)band_count) : launch_blocks(t.total, blocks_per_xcd());
+    LaunchArgs a{blocks, as_stream(stream), reinterpret_cast<const vf4*>(state_in), canonical,
+                 reinterpret_cast<vf4*>(state_out), g, make_params(params), gate_or_open(gate), record, band_list,
+                 (unsigned)band_count};
+    if (grid->dims == 2) {
+        if (all_interior) pick_terms<2, kWalkListInterior>(params, a);
+        else if (listed) pick_terms<2, kWalkList>(params, a);
+        else pick_terms<2, kWalkDense>(params, a);
+    } else {
+        if (all_interior) pick_terms<3, kWalkListInterior>(params, a);
+        else if (listed) pick_terms<3, kWalkList>(params, a);
+        else pick_terms<3, kWalkDense>(params, a);
+    }
+    return launch_status();
+}

@@ -274,18 +274,20 @@ class BandList:
         return cls(None, 0)
 
 
-def buffer_addressing_ok(grid):
-    """INTERIOR lists need 32-bit buffer offsets over the D planes of a vector field (see lsf_band_count)"""
-    return 12 * n_voxels(grid) < 0xffffffff
+def buffer_addressing_ok(grid, bytes_per_voxel=16):
+    """INTERIOR lists need 32-bit buffer offsets over the float4 state (16 B per voxel, see
+    lsf_slavcheva_state_iteration)"""
+    return bytes_per_voxel * n_voxels(grid) < 0xffffffff
 
 
-def band_lists(live, canonical, grid=None, split=True):
+def band_lists(live, canonical, grid=None, split=True, bytes_per_voxel=16):
     """the band list(s) one fused iteration launches over, built with ONE host read of the totals: with `split` (and a
     field small enough for 32-bit buffer offsets) the INTERIOR voxels -- served by the kernel without out-of-bounds
     handling -- and the BOUNDARY voxels, empty lists dropped (but never both); otherwise one list of ALL band voxels"""
     grid = grid or make_grid(live.shape)
     n = n_voxels(grid)
-    subsets = (_lib.BAND_INTERIOR, _lib.BAND_BOUNDARY) if split and buffer_addressing_ok(grid) else (_lib.BAND_ALL,)
+    subsets = (_lib.BAND_INTERIOR, _lib.BAND_BOUNDARY) if split and buffer_addressing_ok(grid, bytes_per_voxel) \
+        else (_lib.BAND_ALL,)
     n_scratch = int(lib.lsf_band_scratch_elements(ctypes.byref(grid)))
     scratch = torch.empty((len(subsets), n_scratch), dtype=torch.int32, device=live.device)
     totals = torch.zeros(len(subsets), dtype=torch.int64, device=live.device)
@@ -326,20 +328,74 @@ def band_list(live, canonical, grid=None, subset=_lib.BAND_ALL):
     return BandList(indices, count, subset)
 
 
-def slavcheva_iteration(stage, live, canonical, warp_prev, warp_out, live_out, g_out, grid, params, gate, records,
-                        index, band=None):
+def slavcheva_gradient(live, canonical, warp_prev, g_out, grid, params, gate, records, index):
+    """gradient + energies of one iteration on planar fields (the Sobolev path; lsf_slavcheva_gradient)"""
     n = n_voxels(grid)
     nd = n * grid.dims
-    check(lib.lsf_slavcheva_iteration(int(stage), _ptr(live, n, "live"), _ptr(canonical, n, "canonical"),
-                                      _ptr(warp_prev, nd, "warp_prev"),
-                                      _ptr(warp_out, nd, "warp_out", allow_none=True),
-                                      _ptr(live_out, n, "live_out", allow_none=True),
-                                      _ptr(g_out, nd, "g_out", allow_none=True), ctypes.byref(grid),
-                                      ctypes.byref(params), _gate_ref(gate), _record_ptr(records, index),
-                                      band.pointer if band is not None else ctypes.c_void_p(0),
-                                      band.count if band is not None else 0,
-                                      band.subset if band is not None else 0, stream_ptr()),
-          "lsf_slavcheva_iteration")
+    check(lib.lsf_slavcheva_gradient(_ptr(live, n, "live"), _ptr(canonical, n, "canonical"),
+                                     _ptr(warp_prev, nd, "warp_prev"), _ptr(g_out, nd, "g_out"), ctypes.byref(grid),
+                                     ctypes.byref(params), _gate_ref(gate), _record_ptr(records, index), stream_ptr()),
+          "lsf_slavcheva_gradient")
+
+
+def state_pack(live, warp_planar=None, grid=None, copies=2):
+    """(live, planar warp or zeros) -> `copies` identical float4 state tensors [z,]y,x,4 (lsf_state_pack)"""
+    grid = grid or make_grid(live.shape)
+    n = n_voxels(grid)
+    states = [torch.empty(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device) for _ in range(copies)]
+    check(lib.lsf_state_pack(_ptr(live, n, "live"), _ptr(warp_planar, n * grid.dims, "warp", allow_none=True),
+                             _ptr(states[0], 4 * n, "state"),
+                             _ptr(states[1], 4 * n, "state") if copies > 1 else ctypes.c_void_p(0),
+                             ctypes.byref(full_range(grid)), stream_ptr()), "lsf_state_pack")
+    return states
+
+
+def state_unpack(state, grid, live_out=None, warp_planar_out=None, warp_interleaved_out=None):
+    """float4 state -> live and / or planar warp and / or interleaved warp (lsf_state_unpack), all slices"""
+    n = n_voxels(grid)
+    check(lib.lsf_state_unpack(_ptr(state, 4 * n, "state"), _ptr(live_out, n, "live_out", allow_none=True),
+                               _ptr(warp_planar_out, n * grid.dims, "warp_planar_out", allow_none=True),
+                               _ptr(warp_interleaved_out, n * grid.dims, "warp_interleaved_out", allow_none=True),
+                               ctypes.byref(full_range(grid)), stream_ptr()), "lsf_state_unpack")
+
+
+def state_finalize(state, canonical, grid, live_out=None, warp_planar_out=None, warp_interleaved_out=None,
+                   lower_threshold=0.0, statistics=False):
+    """one pass over the grid's z-range: float4 state -> the caller's fields and, with `statistics`, the raw
+    convergence statistics (float64 [16] device tensor: warp statistics [0:8], |canonical - live| statistics [8:16])"""
+    n = n_voxels(grid)
+    stats = scratch = None
+    if statistics:
+        stats = torch.empty(16, dtype=torch.float64, device=state.device)
+        scratch = torch.empty(int(lib.lsf_state_finalize_scratch_elements(ctypes.byref(grid))), dtype=torch.float64,
+                              device=state.device)
+    check(lib.lsf_state_finalize(_ptr(state, 4 * n, "state"), _ptr(canonical, n, "canonical", allow_none=not statistics),
+                                 _ptr(live_out, n, "live_out", allow_none=True),
+                                 _ptr(warp_planar_out, n * grid.dims, "warp_planar_out", allow_none=True),
+                                 _ptr(warp_interleaved_out, n * grid.dims, "warp_interleaved_out", allow_none=True),
+                                 ctypes.byref(grid), float(lower_threshold),
+                                 _ptr(stats, 16, "statistics", dtype=torch.float64, allow_none=True),
+                                 _ptr(scratch, scratch.numel() if scratch is not None else 0, "scratch",
+                                      dtype=torch.float64, allow_none=True), stream_ptr()), "lsf_state_finalize")
+    return stats
+
+
+def full_range(grid):
+    """the same grid with the launch range widened to every allocated slice"""
+    g = Grid.from_buffer_copy(grid)
+    g.z_begin, g.z_end = 0, g.nz
+    return g
+
+
+def slavcheva_state_iteration(state_in, canonical, state_out, grid, params, gate, records, index, band=None):
+    n = n_voxels(grid)
+    check(lib.lsf_slavcheva_state_iteration(_ptr(state_in, 4 * n, "state_in"), _ptr(canonical, n, "canonical"),
+                                            _ptr(state_out, 4 * n, "state_out"), ctypes.byref(grid),
+                                            ctypes.byref(params), _gate_ref(gate), _record_ptr(records, index),
+                                            band.pointer if band is not None else ctypes.c_void_p(0),
+                                            band.count if band is not None else 0,
+                                            band.subset if band is not None else 0, stream_ptr()),
+          "lsf_slavcheva_state_iteration")
 
 
 def slavcheva_update_rewarp(live, canonical, g, warp_out, live_out, grid, params, gate, records, index):

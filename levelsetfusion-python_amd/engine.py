@@ -416,6 +416,61 @@ class HierarchicalEngine:
         return warp
 
 
+class SlavchevaOutcome:
+    """final fields of one SlavchevaEngine.optimize() call, left on the device in the layout the iteration kernels use
+    (the float4 state of the fused path, or planar live / warp of the Sobolev path) and handed out on demand"""
+
+    def __init__(self, grid, canonical, state=None, live=None, warp_planar=None):
+        self.grid, self.canonical, self.state = grid, canonical, state
+        self._live, self._warp_planar = live, warp_planar
+
+    def _shape(self):
+        g = self.grid
+        return (g.nz, g.ny, g.nx) if g.dims == 3 else (g.ny, g.nx)
+
+    def _device(self):
+        return (self.state if self.state is not None else self._live).device
+
+    def live(self):
+        if self._live is None:
+            self._live = torch.empty(self._shape(), dtype=torch.float32, device=self._device())
+            dev.state_unpack(self.state, self.grid, self._live, None, None)
+        return self._live
+
+    def warp_planar(self):
+        if self._warp_planar is None:
+            self._warp_planar = torch.empty((self.grid.dims,) + self._shape(), dtype=torch.float32,
+                                            device=self._device())
+            dev.state_unpack(self.state, self.grid, None, self._warp_planar, None)
+        return self._warp_planar
+
+    def finalize(self, live_out=None, lower_threshold=0.0, statistics=False):
+        """ONE pass for the end of optimize(): writes the final live field into `live_out` (a contiguous float32
+        device tensor, or None for a new one), builds the interleaved warp [z,]y,x,c and -- with `statistics` -- the raw
+        convergence statistics (float64 [16] on the HOST: warp [0:8], |canonical - live| [8:16]).
+        Returns (live, warp_interleaved, raw statistics or None)."""
+        g = self.grid
+        full = dev.full_range(g)
+        if live_out is None or not (live_out.is_cuda and live_out.dtype == torch.float32 and live_out.is_contiguous()):
+            target = torch.empty(self._shape(), dtype=torch.float32, device=self._device())
+        else:
+            target = live_out
+        if self.state is not None:
+            warp = torch.empty(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
+            raw = dev.state_finalize(self.state, self.canonical, full, target, None, warp, lower_threshold, statistics)
+            self._live = target
+        else:
+            target.copy_(self._live)
+            warp = dev.interleave(self._warp_planar)
+            raw = None
+            if statistics:
+                raw = torch.cat([dev.warp_statistics(self._warp_planar, self.canonical, self._live, lower_threshold, full),
+                                 dev.tsdf_difference_statistics(self.canonical, self._live, full)])
+        if live_out is not None and target is not live_out:
+            live_out.copy_(target)
+        return target, warp, (raw.cpu().numpy() if raw is not None else None)
+
+
 class SlavchevaEngine:
     """per-iteration-update optimizer with in-place re-warping of the live field
     (nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:332-408), D = 2 or 3, optionally on a z-slab."""
@@ -470,105 +525,118 @@ class SlavchevaEngine:
                                                                   self.hi)
 
     def _enqueue_iteration(self, i, live_in, live_out, warp_in, warp_out, canonical, grid, records, gbufs, limit):
+        """Sobolev path (planar fields): gradient kernel, zero-preserving separable filter, update + re-warp"""
         gate = self._gate_for(records, i)
         slab = self._slab()
-        if not self.sobolev:
-            if not slab:
-                f = self._fast
-                for band in f.bands:  # interior + boundary band voxels (or one list / the dense walk)
-                    _lib.check(_lib.lib.lsf_slavcheva_iteration(_lib.STAGE_FUSED, f.p_live[i % 2], f.p_canon,
-                                                                f.p_warp[i % 2], f.p_warp[(i + 1) % 2],
-                                                                f.p_live[(i + 1) % 2], None, f.grid_ref, f.params_ref,
-                                                                None if i < self.min_iterations else f.gate_ref(i - 1),
-                                                                f.record_ptrs[i], band.pointer, band.count, band.subset,
-                                                                dev.stream_ptr()), "lsf_slavcheva_iteration")
-            else:
-                # boundary slices first, then the halo exchange on a second stream WHILE the interior runs
-                boundary, interior = self._slab_parts
-                for g, bands in boundary:
-                    for band in bands:
-                        dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None,
-                                                g, self.params, gate, records, i, band)
-                main = torch.cuda.current_stream()
-                boundary_done, halos_done = self._events[i % 2]
-                boundary_done.record(main)
-                with torch.cuda.stream(self._comm_stream):
-                    self._comm_stream.wait_event(boundary_done)
-                    self.comm.exchange_live_and_warp(live_out, warp_out)
-                    halos_done.record(self._comm_stream)
-                for g, bands in interior:
-                    for band in bands:
-                        dev.slavcheva_iteration(_lib.STAGE_FUSED, live_in, canonical, warp_in, warp_out, live_out, None,
-                                                g, self.params, gate, records, i, band)
-                main.wait_event(halos_done)
-        else:
-            g0, t1, t2 = gbufs
-            dev.slavcheva_iteration(_lib.STAGE_GRADIENT, live_in, canonical, warp_in, None, None, g0, grid,
-                                    self.params, gate, records, i)
-            in_plane_grid = grid
-            if slab:
-                # the z pass of the filter reads len(kernel)//2 slices of the (x,y)-filtered field on either
-                # side: exchange the raw gradient's halo once and run the x and y passes on the halo slices too
-                self.comm.exchange_halos([g0])
-                in_plane_grid = dev.make_grid(live_in.shape, 0, grid.nz, grid.z_global_offset)
-            src, dst = g0, t1
-            for axis in _conv_axis_order(grid.dims):
-                dev.convolve_axis(src, dst, g0, grid if axis == 2 else in_plane_grid, axis, self.sobolev_kernel,
-                                  gate)
-                src, dst = dst, (t2 if dst is t1 else t1)
-            dev.slavcheva_update_rewarp(live_in, canonical, src, warp_out, live_out, grid, self.params, gate,
-                                        records, i)
-            self._last_g = src
-            if slab:
-                self.comm.exchange_live_and_warp(live_out, warp_out)
-        if slab and i + 1 < limit and i + 1 >= self.min_iterations:
-            self.comm.reduce_max(records, i)  # the next iteration's gate tests this record: make it global now
+        g0, t1, t2 = gbufs
+        dev.slavcheva_gradient(live_in, canonical, warp_in, g0, grid, self.params, gate, records, i)
+        in_plane_grid = grid
+        if slab:
+            # the z pass of the filter reads len(kernel)//2 slices of the (x,y)-filtered field on either
+            # side: exchange the raw gradient's halo once and run the x and y passes on the halo slices too
+            self.comm.exchange_halos([g0])
+            in_plane_grid = dev.make_grid(live_in.shape, 0, grid.nz, grid.z_global_offset)
+        src, dst = g0, t1
+        for axis in _conv_axis_order(grid.dims):
+            dev.convolve_axis(src, dst, g0, grid if axis == 2 else in_plane_grid, axis, self.sobolev_kernel,
+                              gate)
+            src, dst = dst, (t2 if dst is t1 else t1)
+        dev.slavcheva_update_rewarp(live_in, canonical, src, warp_out, live_out, grid, self.params, gate,
+                                    records, i)
+        self._last_g = src
+        if slab:
+            self.comm.exchange_live_and_warp(live_out, warp_out)
+            if i + 1 < limit and i + 1 >= self.min_iterations:
+                self.comm.reduce_max(records, i)  # the next iteration's gate tests this record: make it global now
+
+    def _enqueue_state_iteration(self, i, states, limit):
+        """fused path: ONE kernel per iteration (and per band list) on the float4 state (live, u, v, w)"""
+        f = self._fast
+        s_in, s_out = f.p_state[i % 2], f.p_state[(i + 1) % 2]
+        gate_ref = None if i < self.min_iterations else f.gate_ref(i - 1)
+        run = _lib.lib.lsf_slavcheva_state_iteration
+        if not self._slab():
+            for band in f.bands:  # interior + boundary band voxels (or one list / the dense walk)
+                _lib.check(run(s_in, f.p_canon, s_out, f.grid_ref, f.params_ref, gate_ref, f.record_ptrs[i],
+                               band.pointer, band.count, band.subset, dev.stream_ptr()),
+                           "lsf_slavcheva_state_iteration")
+            return
+        # z-slab: boundary slices first, then the halo exchange on a second stream WHILE the interior runs
+        boundary, interior = self._slab_parts
+        for grid_ref, bands in boundary:
+            for band in bands:
+                _lib.check(run(s_in, f.p_canon, s_out, grid_ref, f.params_ref, gate_ref, f.record_ptrs[i],
+                               band.pointer, band.count, band.subset, dev.stream_ptr()),
+                           "lsf_slavcheva_state_iteration")
+        main = torch.cuda.current_stream()
+        boundary_done, halos_done = self._events[i % 2]
+        boundary_done.record(main)
+        with torch.cuda.stream(self._comm_stream):
+            self._comm_stream.wait_event(boundary_done)
+            self.comm.exchange_state(states[(i + 1) % 2])
+            halos_done.record(self._comm_stream)
+        for grid_ref, bands in interior:
+            for band in bands:
+                _lib.check(run(s_in, f.p_canon, s_out, grid_ref, f.params_ref, gate_ref, f.record_ptrs[i],
+                               band.pointer, band.count, band.subset, dev.stream_ptr()),
+                           "lsf_slavcheva_state_iteration")
+        main.wait_event(halos_done)
+        if i + 1 < limit and i + 1 >= self.min_iterations:
+            self.comm.reduce_max(f.records, i)  # the next iteration's gate tests this record: make it global now
 
     def optimize(self, live, canonical):
-        """live, canonical: float32 device tensors.  Returns (final live tensor, final warp PLANAR).  The
-        caller's `live` tensor is not modified; the drop-in class copies the result back in place."""
+        """live, canonical: float32 device tensors (z-slab runs: the local slab incl. halos).  Returns a
+        SlavchevaOutcome holding the final fields on the device; the caller's tensors are not modified."""
         if live.shape != canonical.shape:
             raise ValueError("live and canonical fields must have the same shape")
         grid = self._grid(live)
         dims = grid.dims
         n_rec = max(self.max_iterations, self.min_iterations, 1)
-        slab = self.comm is not None and self.comm.active
+        slab = self._slab()
         if slab:
             need = 1 if not self.sobolev else max(1, len(self.sobolev_kernel) // 2)
             if self.comm.layout.halo < need:
                 raise ValueError("slab halo of %d slices is too narrow: this configuration needs >= %d"
                                  % (self.comm.layout.halo, need))
         records = dev.new_records(n_rec, live.device)
-        # Both ping-pong sets start as (live, warp 0): the fused kernel only visits the voxels of the band list and the
-        # rest must already hold their final values (see lsf_slavcheva_iteration); slab halos start out valid too.
-        lives = [live.clone(), live.clone()]
-        warps = [torch.zeros((dims,) + tuple(live.shape), dtype=torch.float32, device=live.device) for _ in range(2)]
-        gbufs = [torch.zeros_like(warps[0]) for _ in range(3)] if self.sobolev else None
         self._last_g = None
-        if not slab and not self.sobolev:  # pre-validated launch arguments of the fused kernel
+        lives = warps = gbufs = states = None
+        if self.sobolev:
+            lives = [live.clone(), live.clone()]
+            warps = [torch.zeros((dims,) + tuple(live.shape), dtype=torch.float32, device=live.device)
+                     for _ in range(2)]
+            gbufs = [torch.zeros_like(warps[0]) for _ in range(3)]
+        else:
+            # Both ping-pong states start as (live, 0): the fused kernel only visits the voxels of the band list and
+            # the rest must already hold their final values (lsf_slavcheva_state_iteration); slab halos start valid.
+            states = dev.state_pack(live, None, grid, copies=2)
             n = dev.n_voxels(grid)
             f = dev.IterationLauncher(grid, records, _lib.GATE_SLAVCHEVA, self.lo, self.hi)
-            f.p_live = [f.pointer(t, n, "live") for t in lives]
-            f.p_warp = [f.pointer(t, n * dims, "warp") for t in warps]
+            f.p_state = [f.pointer(t, 4 * n, "state") for t in states]
             f.p_canon = f.pointer(canonical, n, "canonical")
             f.params_ref = ctypes.byref(self.params)
-            f.bands = dev.band_lists(live, canonical, grid) if self.use_band_list else [dev.BandList.none()]
             self._fast = f
-        if slab and not self.sobolev:
-            L = self.comm.layout
-            h = L.halo
-            lo_b = (L.z_begin, L.z_begin + h) if L.rank > 0 else None
-            hi_b = (L.z_end - h, L.z_end) if L.rank < L.world - 1 else None
-            mid = (lo_b[1] if lo_b else L.z_begin, hi_b[0] if hi_b else L.z_end)
+            if not slab:
+                f.bands = dev.band_lists(live, canonical, grid, bytes_per_voxel=16) if self.use_band_list \
+                    else [dev.BandList.none()]
+            else:
+                L = self.comm.layout
+                h = L.halo
+                lo_b = (L.z_begin, L.z_begin + h) if L.rank > 0 else None
+                hi_b = (L.z_end - h, L.z_end) if L.rank < L.world - 1 else None
+                mid = (lo_b[1] if lo_b else L.z_begin, hi_b[0] if hi_b else L.z_end)
+                f.part_grids = []
 
-            def part(rng):
-                g = dev.make_grid(live.shape, rng[0], rng[1], grid.z_global_offset)
-                return g, (dev.band_lists(live, canonical, g) if self.use_band_list else [None])
-            self._slab_parts = ([part(r) for r in (lo_b, hi_b) if r is not None],
-                                [part(mid)] if mid[1] > mid[0] else [])
-        if slab and not hasattr(self, "_comm_stream"):
-            self._comm_stream = torch.cuda.Stream(device=live.device)
-            self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
+                def part(rng):
+                    g = dev.make_grid(live.shape, rng[0], rng[1], grid.z_global_offset)
+                    f.part_grids.append(g)
+                    return ctypes.byref(g), (dev.band_lists(live, canonical, g, bytes_per_voxel=16)
+                                             if self.use_band_list else [dev.BandList.none()])
+                self._slab_parts = ([part(r) for r in (lo_b, hi_b) if r is not None],
+                                    [part(mid)] if mid[1] > mid[0] else [])
+                if not hasattr(self, "_comm_stream"):
+                    self._comm_stream = torch.cuda.Stream(device=live.device)
+                    self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
         # with min_iterations == 0 the reference never enters its loop (max_warp starts at +inf, :354,:360-362)
         limit = 0 if self.min_iterations == 0 else max(self.max_iterations, self.min_iterations)
         it, n_exec = 0, 0
@@ -576,8 +644,11 @@ class SlavchevaEngine:
         while it < limit:
             batch = min(self.check_interval, limit - it)
             for i in range(it, it + batch):
-                self._enqueue_iteration(i, lives[i % 2], lives[(i + 1) % 2], warps[i % 2], warps[(i + 1) % 2],
-                                        canonical, grid, records, gbufs, limit)
+                if self.sobolev:
+                    self._enqueue_iteration(i, lives[i % 2], lives[(i + 1) % 2], warps[i % 2], warps[(i + 1) % 2],
+                                            canonical, grid, records, gbufs, limit)
+                else:
+                    self._enqueue_state_iteration(i, states, limit)
             if slab:  # global max (idempotent) and, once per record, the energy sums of this batch
                 self.comm.reduce_records(records, it, it + batch)
             it += batch
@@ -600,17 +671,21 @@ class SlavchevaEngine:
                         data_energies=[wd * float(v) for v in dec["data_energy"][:n_exec]],
                         smoothing_energies=[ws * float(v) for v in dec["smoothing_energy"][:n_exec]],
                         level_set_energies=[wl * float(v) for v in dec["level_set_energy"][:n_exec]])
-        final_live, final_warp = lives[n_exec % 2], warps[n_exec % 2]
+        if self.sobolev:
+            outcome = SlavchevaOutcome(grid, canonical, live=lives[n_exec % 2], warp_planar=warps[n_exec % 2])
+        else:
+            outcome = SlavchevaOutcome(grid, canonical, state=states[n_exec % 2])
         # what is needed to (re)produce gradient_field of the last executed iteration on demand
         if n_exec == 0:
-            self._gradient_state = ("zeros", torch.zeros_like(warps[0]))
+            self._gradient_state = ("zeros", torch.zeros((dims,) + tuple(live.shape), dtype=torch.float32,
+                                                         device=live.device))
         elif self.sobolev:
             # g buffers rotate identically every iteration, so the last executed iteration's filtered gradient
             # is in the buffer the (gated, skipped) later launches would have used too
             self._gradient_state = ("ready", self._last_g)
         else:
-            self._gradient_state = ("recompute", lives[(n_exec - 1) % 2], warps[(n_exec - 1) % 2], canonical, grid)
-        return final_live, final_warp
+            self._gradient_state = ("recompute", states[(n_exec - 1) % 2], canonical, grid)
+        return outcome
 
     def gradient_field(self):
         """planar gradient of the last executed iteration (zeroed where the live field snapped, DIRECT only).
@@ -622,13 +697,15 @@ class SlavchevaEngine:
             return None
         if st[0] in ("zeros", "ready"):
             return st[1]
-        _, live_in, warp_in, canonical, grid = st
+        _, state_in, canonical, grid = st
+        live_in = torch.empty(tuple(state_in.shape[:-1]), dtype=torch.float32, device=state_in.device)
+        warp_in = torch.empty((grid.dims,) + tuple(live_in.shape), dtype=torch.float32, device=state_in.device)
+        dev.state_unpack(state_in, grid, live_in, warp_in, None)
         g = torch.empty_like(warp_in)
         scratch_records = dev.new_records(1, live_in.device)
         params = _lib.SlavchevaParams.from_buffer_copy(self.params)
         params.energy_mode = _lib.ENERGY_NONE
-        dev.slavcheva_iteration(_lib.STAGE_GRADIENT, live_in, canonical, warp_in, None, None, g, grid, params, None,
-                                scratch_records, 0)
+        dev.slavcheva_gradient(live_in, canonical, warp_in, g, grid, params, None, scratch_records, 0)
         dev.slavcheva_update_rewarp(live_in, canonical, g, torch.empty_like(warp_in), torch.empty_like(live_in), grid,
                                     params, None, scratch_records, 0)
         self._gradient_state = ("ready", g)

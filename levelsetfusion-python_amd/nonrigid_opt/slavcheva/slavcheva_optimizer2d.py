@@ -12,8 +12,8 @@ import numpy as np
 import torch
 
 from ... import _lib, device as dev
-from ...convergence_report import (ConvergenceReport, build_tsdf_difference_statistics,
-                                   build_warp_delta_statistics)
+from ...convergence_report import (ConvergenceReport, tsdf_difference_statistics_from_raw,
+                                   warp_delta_statistics_from_raw)
 from ...engine import SlavchevaEngine, as_device_field
 from .data_term import DataTermMethod
 from .smoothing_term import SmoothingTermMethod
@@ -114,7 +114,7 @@ class _SlavchevaOptimizerBase:
             self._run_checks(live_field, canonical_field)
         live = as_device_field(live_field)
         canonical = as_device_field(canonical_field)
-        final_live, final_warp = self._engine.optimize(live, canonical)
+        outcome = self._engine.optimize(live, canonical)
         eng_log = self._engine.log
         self.log = OptimizationLog()
         self.log.max_warps = eng_log["max_warps"]
@@ -128,25 +128,29 @@ class _SlavchevaOptimizerBase:
             self.total_data_energy = self.log.data_energies[-1]
             self.total_smoothing_energy = self.log.smoothing_energies[-1]
             self.total_level_set_energy = self.log.level_set_energies[-1]
-        self._final_warp_planar = final_warp
         n = self._engine.iteration_count
         if self.verbose:
             for i in range(n):
                 print("[Iteration %d done], data energy: %f; smoothing energy: %f; level set energy: %f; max warp: %f"
                       % (i, self.log.data_energies[i], self.log.smoothing_energies[i],
                          self.log.level_set_energies[i], self.log.max_warps[i]))
-        if self.enable_convergence_status_logging and (self._engine.comm is None or not self._engine.comm.active):
-            ws = build_warp_delta_statistics(final_warp, canonical, final_live,
-                                             self.maximum_warp_length_lower_threshold,
-                                             self.maximum_warp_length_upper_threshold)
-            ds = build_tsdf_difference_statistics(canonical, final_live)
+        # one pass over the final state: the live field back into the caller's array (in place, like np.copyto at
+        # :230,:328), the warp in the API layout, and the convergence statistics (:393-404)
+        want_report = self.enable_convergence_status_logging and \
+            (self._engine.comm is None or not self._engine.comm.active)
+        final_live, warp, raw = outcome.finalize(live_field if on_device else None,
+                                                 self.maximum_warp_length_lower_threshold, want_report)
+        if want_report:
+            shape = tuple(live.shape)
+            ws = warp_delta_statistics_from_raw(raw[:8], shape, self.maximum_warp_length_lower_threshold,
+                                                self.maximum_warp_length_upper_threshold)
+            ds = tsdf_difference_statistics_from_raw(raw[8:], shape)
             self.log.convergence_report = ConvergenceReport(n, n >= self.max_iterations, ws, ds)
         if on_device:
-            live_field.copy_(final_live)
-            self.warp_field = dev.interleave(final_warp)
+            self.warp_field = warp
         else:
-            np.copyto(live_field, final_live.cpu().numpy())  # in place, like np.copyto at :230,:328
-            self.warp_field = dev.interleave(final_warp).cpu().numpy()
+            np.copyto(live_field, final_live.cpu().numpy())
+            self.warp_field = warp.cpu().numpy()
         return live_field
 
     def get_convergence_report(self):

@@ -142,6 +142,26 @@ class SlabComm:
         dev.halo_copy(live, warp_planar, lo[1], hi[1], h, L.z_begin - h if lo[1] is not None else 0, L.z_end,
                       unpack=True)
 
+    def exchange_state(self, state):
+        """the per-iteration exchange of the fused Slavcheva path: the float4 state [z][y][x][4] keeps the live field
+        and the warp together, so a halo is ONE contiguous run per neighbour and direction -- sent from and received
+        into the tensor itself (RCCL point-to-point), no pack / unpack kernels, no staging buffers"""
+        L = self.layout
+        if not self.active or L.halo == 0:
+            return
+        if self.stage_through_host or not state.is_cuda:
+            return self.exchange_halos([state.view(state.shape[0], state.shape[1], -1)])
+        h = L.halo
+        ops = []
+        if L.rank > 0:
+            ops += [dist.P2POp(dist.isend, state[L.z_begin:L.z_begin + h], L.rank - 1, self.group),
+                    dist.P2POp(dist.irecv, state[L.z_begin - h:L.z_begin], L.rank - 1, self.group)]
+        if L.rank < L.world - 1:
+            ops += [dist.P2POp(dist.isend, state[L.z_end - h:L.z_end], L.rank + 1, self.group),
+                    dist.P2POp(dist.irecv, state[L.z_end:L.z_end + h], L.rank + 1, self.group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
     def reduce_scalar_max(self, value):
         """in-place MAX all-reduce of a small float tensor (slab guards)"""
         if not self.active:

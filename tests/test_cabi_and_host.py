@@ -62,7 +62,7 @@ def test_ctypes_structs_match_header_layout(pkg):
     assert ctypes.sizeof(L.SlavchevaParams) == 56 and L.SlavchevaParams.rate.offset == 8
     text = open(HEADER).read()
     for macro, value in (("LSF_ABI_VERSION", 1), ("LSF_MAX_KERNEL_TAPS", L.MAX_KERNEL_TAPS),
-                         ("LSF_STAGE_GRADIENT", L.STAGE_GRADIENT), ("LSF_SMOOTHING_KILLING", L.SMOOTHING_KILLING),
+                         ("LSF_SMOOTHING_KILLING", L.SMOOTHING_KILLING),
                          ("LSF_DATA_THRESHOLDED_FDM", L.DATA_THRESHOLDED_FDM),
                          ("LSF_ENERGY_VECTORIZED", L.ENERGY_VECTORIZED), ("LSF_GATE_SLAVCHEVA", L.GATE_SLAVCHEVA)):
         assert re.search(r"#define\s+%s\s+%d\b" % (macro, value), text), macro

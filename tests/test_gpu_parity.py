@@ -457,9 +457,9 @@ def test_band_list_matches_numpy(lsf, shape, zr):
 
 
 def test_slavcheva_band_list_is_invisible(lsf):
-    """lsf_slavcheva_iteration with a band list visits only the listed voxels; with both ping-pong sets initialised
-    as the header demands, buffers and records must equal those of the dense walk -- 200-voxel lines, voxels that
-    leave the band by snapping, and the oracle as third opinion"""
+    """lsf_slavcheva_state_iteration with a band list visits only the listed voxels; with both ping-pong states
+    initialised as the header demands, states and records must equal those of the dense walk -- 200-voxel lines, voxels
+    that leave the band by snapping, and the oracle as third opinion"""
     from levelsetfusion_python_amd import _lib, device as dev
     n_it = 9
     shape = (12, 20, 200)
@@ -475,23 +475,23 @@ def test_slavcheva_band_list_is_invisible(lsf):
     outs = []
     for mode in ("dense", "one list", "interior + boundary"):
         c = torch.from_numpy(canon).cuda()
-        lives = [torch.from_numpy(live0).cuda(), torch.from_numpy(live0).cuda()]
-        warps = [torch.zeros((3,) + shape, device="cuda") for _ in range(2)]
+        l0 = torch.from_numpy(live0).cuda()
+        states = dev.state_pack(l0, None, grid, copies=2)
         rec = dev.new_records(n_it, "cuda")
-        bands = [None] if mode == "dense" else dev.band_lists(lives[0], c, grid, split=mode != "one list")
+        bands = [None] if mode == "dense" else dev.band_lists(l0, c, grid, split=mode != "one list")
         if mode == "one list":
             assert len(bands) == 1 and 0 < bands[0].count < live0.size * 0.7
         if mode == "interior + boundary":
             assert [b.subset for b in bands] == [_lib.BAND_INTERIOR, _lib.BAND_BOUNDARY]
         for i in range(n_it):
             for band in bands:
-                dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2],
-                                        lives[(i + 1) % 2], None, grid, eng.params, None, rec, i, band)
-        outs.append([t.cpu().numpy() for t in lives + warps + [rec]])
+                dev.slavcheva_state_iteration(states[i % 2], c, states[(i + 1) % 2], grid, eng.params, None, rec, i,
+                                              band)
+        outs.append([t.cpu().numpy() for t in states + [rec]])
     for other in outs[1:]:
-        for a, b in zip(outs[0][:4], other[:4]):
+        for a, b in zip(outs[0][:2], other[:2]):
             assert np.array_equal(a, b)
-        ra, rb = dev.decode_records(outs[0][4]), dev.decode_records(other[4])
+        ra, rb = dev.decode_records(outs[0][2]), dev.decode_records(other[2])
         assert np.array_equal(ra["max_value"], rb["max_value"]) and np.array_equal(ra["argmax"], rb["argmax"])
         for k in ("data_energy", "smoothing_energy", "level_set_energy"):
             # the energy sums are float64 atomics whose order varies from launch to launch
@@ -501,7 +501,8 @@ def test_slavcheva_band_list_is_invisible(lsf):
                           maximum_warp_length_lower_threshold=0.0)
     live_ref = live0.copy()
     o.optimize(live_ref, canon)
-    assert maxdiff(outs[2][n_it % 2], live_ref) == EXACT
+    assert maxdiff(outs[2][n_it % 2][..., 0], live_ref) == EXACT
+    assert maxdiff(outs[2][n_it % 2][..., 1:], o.warp_field) == EXACT
 
 
 def test_slavcheva_band_list_all_zero_update_reports_first_voxel(lsf):
@@ -515,11 +516,50 @@ def test_slavcheva_band_list_all_zero_update_reports_first_voxel(lsf):
     band = dev.band_list(ones, ones, grid)
     assert band.count == 0
     rec = dev.new_records(1, "cuda")
-    dev.slavcheva_iteration(_lib.STAGE_FUSED, ones, ones, torch.zeros((3,) + shape, device="cuda"),
-                            torch.zeros((3,) + shape, device="cuda"), ones.clone(), None, grid, eng.params, None, rec, 0,
-                            band)
+    states = dev.state_pack(ones, None, grid, copies=2)
+    dev.slavcheva_state_iteration(states[0], ones, states[1], grid, eng.params, None, rec, 0, band)
     dec = dev.decode_records(rec.cpu().numpy())
     assert dec["max_value"][0] == 0.0 and dec["argmax"][0] == (1 + 5) * 8 * 70
+
+
+def test_state_pack_unpack_finalize(lsf):
+    """lsf_state_pack / lsf_state_unpack round trip (2-D and 3-D, ragged extents, z-ranges) and lsf_state_finalize:
+    fields equal the unpacked ones, statistics equal those of the two stand-alone statistics kernels (a20)"""
+    from levelsetfusion_python_amd import device as dev
+    gen = torch.Generator("cuda").manual_seed(11)
+    for shape in ((7, 13, 70), (33, 130), (4, 8, 64)):
+        dims = len(shape)
+        live = (torch.rand(shape, device="cuda", generator=gen) * 2 - 1).contiguous()
+        canon = (torch.rand(shape, device="cuda", generator=gen) * 2 - 1).contiguous()
+        live[torch.rand(shape, device="cuda", generator=gen) < 0.4] = 1.0
+        canon[torch.rand(shape, device="cuda", generator=gen) < 0.6] = -1.0
+        warp = torch.randn((dims,) + shape, device="cuda", generator=gen)
+        grid = dev.make_grid(shape)
+        a, b = dev.state_pack(live, warp, grid, copies=2)
+        assert torch.equal(a, b) and torch.equal(a[..., 0], live)
+        for c in range(dims):
+            assert torch.equal(a[..., 1 + c], warp[c])
+        if dims == 2:
+            assert float(a[..., 3].abs().max()) == 0.0
+        z0 = dev.state_pack(live, None, grid, copies=1)[0]
+        assert float(z0[..., 1:].abs().max()) == 0.0
+        l2, p2, i2 = torch.empty_like(live), torch.empty_like(warp), torch.empty(shape + (dims,), device="cuda")
+        dev.state_unpack(a, grid, l2, p2, i2)
+        assert torch.equal(l2, live) and torch.equal(p2, warp) and torch.equal(i2, dev.interleave(warp))
+        # finalize on a z-range (3-D) / the whole field
+        g = dev.make_grid(shape, 1, shape[0] - 2, 3) if dims == 3 else grid
+        l3 = torch.zeros_like(live)
+        i3 = torch.zeros(shape + (dims,), device="cuda")
+        raw = dev.state_finalize(a, canon, g, l3, None, i3, 0.25, True).cpu().numpy()
+        zs = slice(g.z_begin, g.z_end) if dims == 3 else slice(None)
+        assert torch.equal(l3[zs], live[zs]) and torch.equal(i3[zs], dev.interleave(warp)[zs])
+        if dims == 3:
+            assert float(l3[:1].abs().max()) == 0.0 and float(i3[-2:].abs().max()) == 0.0
+        want_w = dev.warp_statistics(warp, canon, live, 0.25, g).cpu().numpy()
+        want_d = dev.tsdf_difference_statistics(canon, live, g).cpu().numpy()
+        for got, want in ((raw[:8], want_w), (raw[8:], want_d)):
+            assert np.array_equal(got[[0, 1, 2, 5]], want[[0, 1, 2, 5]])      # counts, max / min, arg-max: exact
+            assert np.allclose(got[3:5], want[3:5], rtol=1e-12, atol=0.0)     # float64 sums in a different order
 
 
 # ------------------------------------------------------------ full-size, size-independent properties
@@ -571,19 +611,17 @@ def test_full_size_fixed_point_and_slab_invariance_256(lsf):
                                    smoothing_term_method=lsf.SmoothingTermMethod.KILLING)._engine
     warp_prev = (0.3 * torch.randn((3, n, n, n), device="cuda", generator=torch.Generator("cuda").manual_seed(3)))
     rec = dev.new_records(3, "cuda")
-    full_w, full_l = torch.empty_like(warp_prev), torch.empty_like(lt)
-    dev.slavcheva_iteration(_lib.STAGE_FUSED, lt, ct, warp_prev, full_w, full_l, None, dev.make_grid(lt.shape),
-                            eng.params, None, rec, 0)
+    s_in = dev.state_pack(lt, warp_prev, dev.make_grid(lt.shape), copies=1)[0]
+    full = torch.empty_like(s_in)
+    dev.slavcheva_state_iteration(s_in, ct, full, dev.make_grid(lt.shape), eng.params, None, rec, 0)
     h, half = 2, n // 2
     pieces = []
     for k, (a, b, zb, ze) in enumerate(((0, half + h, 0, half), (half - h, n, h, h + half))):
-        ls, cs, ws = lt[a:b].contiguous(), ct[a:b].contiguous(), warp_prev[:, a:b].contiguous()
-        ow, ol = torch.zeros_like(ws), torch.zeros_like(ls)
-        dev.slavcheva_iteration(_lib.STAGE_FUSED, ls, cs, ws, ow, ol, None, dev.make_grid(ls.shape, zb, ze, a),
-                                eng.params, None, rec, 1 + k)
-        pieces.append((ow[:, zb:ze], ol[zb:ze]))
-    assert torch.equal(torch.cat([p[1] for p in pieces], 0), full_l)
-    assert torch.equal(torch.cat([p[0] for p in pieces], 1), full_w)
+        ss, cs = s_in[a:b].contiguous(), ct[a:b].contiguous()
+        out = torch.zeros_like(ss)
+        dev.slavcheva_state_iteration(ss, cs, out, dev.make_grid(cs.shape, zb, ze, a), eng.params, None, rec, 1 + k)
+        pieces.append(out[zb:ze])
+    assert torch.equal(torch.cat(pieces, 0), full)
     d = dev.decode_records(rec.cpu().numpy())
     assert d["max_value"][0] == max(d["max_value"][1], d["max_value"][2])
     assert d["argmax"][0] == (d["argmax"][1] if d["max_value"][1] >= d["max_value"][2] else d["argmax"][2])

@@ -1,5 +1,5 @@
 """Fused kernel time at 256^3 on three inputs: nothing in the narrow band, the sphere pair (~10 % in band), everything
-in the band -- separates the floor (streaming 24 B/voxel) from the per-band-voxel cost and shows load balance."""
+in the band -- separates the floor (streaming 36 B/voxel) from the per-band-voxel cost and shows load balance."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,21 +22,18 @@ ramp_l = (0.8 * torch.sin(x * 0.05 + 0.1) * torch.cos(y * 0.04 - 0.05) * torch.c
 for name, c, l in (("none in band", ones, ones.clone()), ("sphere pair", c_s, l_s), ("all in band", ramp_c, ramp_l)):
     band = float((~((l.abs() == 1) & (c.abs() == 1))).float().mean())
     for listed in (False, True):
-        lives = [l.clone(), l.clone()]
-        warps = [torch.zeros((3, n, n, n), device="cuda") for _ in range(2)]
+        st = dev.state_pack(l, None, grid, copies=2)
         bands = dev.band_lists(l, c, grid, split=os.environ.get("SPLIT", "1") == "1") if listed else [None]
         for i in range(4):
             for b in bands:
-                dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2],
-                                        lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0, b)
+                dev.slavcheva_state_iteration(st[i % 2], c, st[(i + 1) % 2], grid, eng.params, None, rec, 0, b)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         reps = 20
         for i in range(reps):
             for b in bands:
-                dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2],
-                                        lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0, b)
+                dev.slavcheva_state_iteration(st[i % 2], c, st[(i + 1) % 2], grid, eng.params, None, rec, 0, b)
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps

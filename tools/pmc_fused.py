@@ -1,6 +1,6 @@
-"""launches the fused Slavcheva kernel a few times on the 256^3 sphere pair (band lists) and on an all-in-band pair
-(band lists, then dense walk) -- target for rocprofv3 --pmc passes; dispatch order: 6 x sphere/lists, 6 x all/lists
-(interior + boundary launch each), 6 x all/dense"""
+"""launches the fused Slavcheva state kernel a few times on the 256^3 sphere pair (band lists) and on an all-in-band
+pair (band lists, then dense walk) -- target for rocprofv3 --pmc passes; dispatch order: 6 x sphere/lists,
+6 x all/lists (interior + boundary launch each), 6 x all/dense"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,9 +8,11 @@ import levelsetfusion_python_amd as lsf
 from levelsetfusion_python_amd import _lib, device as dev
 from levelsetfusion_python_amd.synthetic import sphere_pair
 
-n = 256
+n = int(os.environ.get("N", "256"))
 eng = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
                                smoothing_term_method=lsf.SmoothingTermMethod.KILLING)._engine
+if os.environ.get("ENERGY", "1") == "0":
+    eng.params.energy_mode = _lib.ENERGY_NONE
 grid = dev.make_grid((n, n, n))
 rec = dev.new_records(1, "cuda")
 c_s, l_s = sphere_pair(n, 3, "cuda")
@@ -18,11 +20,9 @@ z, y, x = torch.meshgrid(*[torch.arange(n, device="cuda", dtype=torch.float32)] 
 ramp_c = (0.8 * torch.sin(x * 0.05) * torch.cos(y * 0.04) * torch.cos(z * 0.03)).contiguous()
 ramp_l = (0.8 * torch.sin(x * 0.05 + 0.1) * torch.cos(y * 0.04 - 0.05) * torch.cos(z * 0.03 + 0.08)).contiguous()
 for c, l, listed in ((c_s, l_s, True), (ramp_c, ramp_l, True), (ramp_c, ramp_l, False)):
-    bands = dev.band_lists(l, c, grid) if listed else [None]
-    lives = [l.clone(), l.clone()]
-    warps = [torch.zeros((3, n, n, n), device="cuda") for _ in range(2)]
+    bands = dev.band_lists(l, c, grid, bytes_per_voxel=16) if listed else [None]
+    st = dev.state_pack(l, None, grid)
     for i in range(6):
         for b in bands:
-            dev.slavcheva_iteration(_lib.STAGE_FUSED, lives[i % 2], c, warps[i % 2], warps[(i + 1) % 2],
-                                    lives[(i + 1) % 2], None, grid, eng.params, None, rec, 0, b)
+            dev.slavcheva_state_iteration(st[i % 2], c, st[(i + 1) % 2], grid, eng.params, None, rec, 0, b)
 torch.cuda.synchronize()
