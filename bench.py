@@ -14,6 +14,7 @@ every iteration (RCCL point-to-point over xGMI) and all-reduces the iteration re
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -190,6 +191,11 @@ def main():
     executed = 0
     for _ in range(args.warmup):
         executed = step()
+    # Python's cyclic collector walks every object torch has created (~40 ms per full collection, measured with
+    # tools/step_times.py: one 2.5 ms step in ~25 took 40 ms): park the existing objects in the permanent generation,
+    # as a serving loop would; the per-step garbage is still collected.
+    gc.collect()
+    gc.freeze()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):

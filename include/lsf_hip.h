@@ -245,6 +245,12 @@ int lsf_band_list_fill(const float *live, const float *canonical, const lsf_grid
  * destinations does exactly that).  An INTERIOR list requires 16 * nz * ny * nx < 2^32.
  * lsf_state_pack: (live, warp planar or NULL = 0) -> state_a and, if not NULL, state_b, slices [z_begin, z_end).
  * lsf_state_unpack: state -> live and / or planar warp [c][z][y][x] and / or interleaved warp [z][y][x][c]. */
+/* lsf_state_prepare: the start of an optimize() call in one pass over WHOLE arrays (z_begin = 0, z_end = nz): both
+ * ping-pong states = (live, 0) and the counting step of lsf_band_count for the INTERIOR and the BOUNDARY subset at once.
+ * scratch: 2 * lsf_band_scratch_elements(grid) int32; afterwards scratch[0 ..) and scratch[lsf_band_scratch_elements ..)
+ * are the two scratch arrays lsf_band_list_fill expects; counts_out[0..2) (device) = INTERIOR and BOUNDARY totals. */
+int lsf_state_prepare(const float *live, const float *canonical, float *state_a, float *state_b,
+                      const lsf_grid *grid, int32_t *scratch, int64_t *counts_out, void *stream);
 int lsf_state_pack(const float *live, const float *warp_planar, float *state_a, float *state_b,
                    const lsf_grid *grid, void *stream);
 int lsf_state_unpack(const float *state, float *live_out, float *warp_planar_out, float *warp_interleaved_out,

@@ -109,6 +109,7 @@ PROTOTYPES = {
     "lsf_hier_update": (ctypes.c_int, [_vp, _vp, _P(Grid), _f32, _P(Gate), _vp, _vp]),
     "lsf_slavcheva_gradient": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp,
                                               _vp]),
+    "lsf_state_prepare": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp, _vp, _vp]),
     "lsf_state_pack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp]),
     "lsf_state_unpack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp]),
     "lsf_state_finalize_scratch_elements": (ctypes.c_int64, [_P(Grid)]),

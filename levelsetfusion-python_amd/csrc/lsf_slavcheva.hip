@@ -260,27 +260,75 @@ __global__ __launch_bounds__(kBlock) void band_list_kernel(const float* __restri
     }
 }
 
-// exclusive prefix sums of sums[0..n) in place by ONE block (n <= 2^21 chunks; runs once per optimize() call)
-__global__ __launch_bounds__(1024) void band_scan_kernel(int* __restrict__ sums, unsigned n, long long* total) {
+// exclusive prefix sums of sums[0..n) in place, one block per array (blockIdx.x selects the array: arrays are
+// `stride` ints apart, totals consecutive).  Each thread sums a contiguous share, one Hillis-Steele scan over the 1024
+// shares, then the shares are rewritten: two passes over <= 2^21 ints instead of a block-wide scan per 1024 of them.
+__global__ __launch_bounds__(1024) void band_scan_kernel(int* __restrict__ sums_base, unsigned n, unsigned stride,
+                                                         long long* totals) {
     __shared__ int buf[1024];
+    int* __restrict__ sums = sums_base + (size_t)blockIdx.x * stride;
     const unsigned t = threadIdx.x;
-    int carry = 0;
-    for (unsigned base = 0; base < n; base += 1024) {
-        const unsigned i = base + t;
-        const int v = i < n ? sums[i] : 0;
-        buf[t] = v;
+    const unsigned per = (n + 1023u) / 1024u;
+    const unsigned lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
+    int share = 0;
+    for (unsigned i = lo; i < hi; ++i) share += sums[i];
+    buf[t] = share;
+    __syncthreads();
+    for (unsigned off = 1; off < 1024; off <<= 1) {
+        const int add = t >= off ? buf[t - off] : 0;
         __syncthreads();
-        for (unsigned off = 1; off < 1024; off <<= 1) {
-            const int add = t >= off ? buf[t - off] : 0;
-            __syncthreads();
-            buf[t] += add;
-            __syncthreads();
-        }
-        if (i < n) sums[i] = carry + buf[t] - v;
-        carry += buf[1023];
+        buf[t] += add;
         __syncthreads();
     }
-    if (t == 0) *total = carry;
+    int run = buf[t] - share;  // exclusive prefix of this thread's share
+    for (unsigned i = lo; i < hi; ++i) {
+        const int v = sums[i];
+        sums[i] = run;
+        run += v;
+    }
+    if (t == 1023) totals[blockIdx.x] = buf[1023];
+}
+
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
+// start of an optimize() call on the fused path in ONE pass over live and canonical: both ping-pong states = (live, 0)
+// (lsf_state_pack) and the per-chunk counts of the INTERIOR and the BOUNDARY band voxels (lsf_band_count twice)
+__global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __restrict__ live,
+                                                               const float* __restrict__ canonical,
+                                                               vf4* __restrict__ a, vf4* __restrict__ b, unsigned n,
+                                                               Grid g, int dims, int* __restrict__ sums_interior,
+                                                               int* __restrict__ sums_boundary) {
+    __shared__ int part[2][16];  // [subset][pass j * 4 + wave]
+    const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned v = blockIdx.x * kBandChunk + j * kBlock + t;
+        bool in_band = false, interior = false;
+        if (v < n) {
+            const float l = live[v];
+            in_band = !(fabsf(l) == 1.0f && fabsf(canonical[v]) == 1.0f);
+            vf4 o;
+            o.x = l; o.y = 0.0f; o.z = 0.0f; o.w = 0.0f;
+            a[v] = o;
+            b[v] = o;
+            const unsigned zy = fast_div(v, g.div_nx);
+            const int x = (int)(v - zy * (unsigned)g.nx);
+            const int z = (int)fast_div(zy, g.div_ny);
+            const int y = (int)zy - z * g.ny;
+            interior = x > 0 && x < g.nx - 1 && y > 0 && y < g.ny - 1 && (dims == 2 || (z > 0 && z < g.nz - 1));
+        }
+        const unsigned long long mi = __ballot(in_band && interior), mb = __ballot(in_band && !interior);
+        if (lane == 0) {
+            part[0][j * 4 + wave] = __popcll(mi);
+            part[1][j * 4 + wave] = __popcll(mb);
+        }
+    }
+    __syncthreads();
+    if (t < 2) {
+        int sum = 0;
+        for (int k = 0; k < 16; ++k) sum += part[t][k];
+        (t == 0 ? sums_interior : sums_boundary)[blockIdx.x] = sum;
+    }
 }
 
 }  // namespace
@@ -354,7 +402,24 @@ extern "C" int lsf_band_count(const float* live, const float* canonical, const l
     if (chunks > 0)
         hipLaunchKernelGGL(band_list_kernel<false>, dim3(chunks), dim3(kBlock), 0, s, live, canonical, first, n,
                            make_grid(grid), grid->dims, subset, scratch, (int*)nullptr);
-    hipLaunchKernelGGL(band_scan_kernel, dim3(1), dim3(1024), 0, s, scratch, chunks, (long long*)count_out);
+    hipLaunchKernelGGL(band_scan_kernel, dim3(1), dim3(1024), 0, s, scratch, chunks, 0u, (long long*)count_out);
+    return launch_status();
+}
+
+extern "C" int lsf_state_prepare(const float* live, const float* canonical, float* state_a, float* state_b,
+                                 const lsf_grid* grid, int32_t* scratch, int64_t* counts_out, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!live || !canonical || !state_a || !state_b || !scratch || !counts_out) return LSF_ERR_BAD_ARGUMENT;
+    if (grid->z_begin != 0 || grid->z_end != grid->nz) return LSF_ERR_BAD_ARGUMENT;  // whole arrays only
+    unsigned first, n, chunks;
+    band_range(grid, first, n, chunks);
+    hipStream_t s = as_stream(stream);
+    int* sums_interior = scratch;
+    int* sums_boundary = scratch + (chunks + 1);
+    hipLaunchKernelGGL(state_prepare_kernel, dim3(chunks), dim3(kBlock), 0, s, live, canonical,
+                       reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b), n, make_grid(grid), grid->dims,
+                       sums_interior, sums_boundary);
+    hipLaunchKernelGGL(band_scan_kernel, dim3(2), dim3(1024), 0, s, scratch, chunks, chunks + 1, (long long*)counts_out);
     return launch_status();
 }
 

@@ -518,10 +518,13 @@ inline bool range_of(const lsf_grid* grid, long long& first, long long& n) {
     return n > 0;
 }
 
-inline unsigned stream_blocks(long long n) {
+inline unsigned stream_blocks(long long n, long long cap = 8192) {
     const long long want = (n + kBlock - 1) / kBlock;
-    return (unsigned)(want < 8192 ? want : 8192);
+    return (unsigned)(want < cap ? want : cap);
 }
+
+// finalize: 8 blocks per CU keep enough loads in flight; fewer rows for the one-block combine kernel
+inline unsigned finalize_blocks(long long n) { return stream_blocks(n, 2048); }
 
 }  // namespace
 
@@ -553,7 +556,7 @@ extern "C" int64_t lsf_state_finalize_scratch_elements(const lsf_grid* grid) {
     if (check_grid(grid)) return 0;
     long long first, n;
     range_of(grid, first, n);
-    return (int64_t)stream_blocks(n > 0 ? n : 1) * kFinalizeWords;
+    return (int64_t)finalize_blocks(n > 0 ? n : 1) * kFinalizeWords;
 }
 
 extern "C" int lsf_state_finalize(const float* state, const float* canonical, float* live_out,
@@ -563,7 +566,7 @@ extern "C" int lsf_state_finalize(const float* state, const float* canonical, fl
     if (!state || (statistics16 && (!canonical || !scratch))) return LSF_ERR_BAD_ARGUMENT;
     long long first, n;
     if (!range_of(grid, first, n)) return statistics16 ? LSF_ERR_BAD_ARGUMENT : 0;
-    const unsigned blocks = stream_blocks(n);
+    const unsigned blocks = finalize_blocks(n);
     const long long slice = (long long)grid->ny * grid->nx;
     hipLaunchKernelGGL(state_finalize_kernel, dim3(blocks), dim3(kBlock), 0, as_stream(stream),
                        reinterpret_cast<const vf4*>(state), canonical, live_out, warp_planar_out, warp_interleaved_out,

@@ -557,17 +557,17 @@ class SlavchevaEngine:
         run = _lib.lib.lsf_slavcheva_state_iteration
         if not self._slab():
             for band in f.bands:  # interior + boundary band voxels (or one list / the dense walk)
-                _lib.check(run(s_in, f.p_canon, s_out, f.grid_ref, f.params_ref, gate_ref, f.record_ptrs[i],
-                               band.pointer, band.count, band.subset, dev.stream_ptr()),
-                           "lsf_slavcheva_state_iteration")
+                status = run(s_in, f.p_canon, s_out, f.grid_ref, f.params_ref, gate_ref, f.record_ptrs[i],
+                             band.pointer, band.count, band.subset, f.stream)
+                if status:
+                    _lib.check(status, "lsf_slavcheva_state_iteration")
             return
         # z-slab: boundary slices first, then the halo exchange on a second stream WHILE the interior runs
         boundary, interior = self._slab_parts
         for grid_ref, bands in boundary:
             for band in bands:
                 _lib.check(run(s_in, f.p_canon, s_out, grid_ref, f.params_ref, gate_ref, f.record_ptrs[i],
-                               band.pointer, band.count, band.subset, dev.stream_ptr()),
-                           "lsf_slavcheva_state_iteration")
+                               band.pointer, band.count, band.subset, f.stream), "lsf_slavcheva_state_iteration")
         main = torch.cuda.current_stream()
         boundary_done, halos_done = self._events[i % 2]
         boundary_done.record(main)
@@ -578,8 +578,7 @@ class SlavchevaEngine:
         for grid_ref, bands in interior:
             for band in bands:
                 _lib.check(run(s_in, f.p_canon, s_out, grid_ref, f.params_ref, gate_ref, f.record_ptrs[i],
-                               band.pointer, band.count, band.subset, dev.stream_ptr()),
-                           "lsf_slavcheva_state_iteration")
+                               band.pointer, band.count, band.subset, f.stream), "lsf_slavcheva_state_iteration")
         main.wait_event(halos_done)
         if i + 1 < limit and i + 1 >= self.min_iterations:
             self.comm.reduce_max(f.records, i)  # the next iteration's gate tests this record: make it global now
@@ -609,16 +608,22 @@ class SlavchevaEngine:
         else:
             # Both ping-pong states start as (live, 0): the fused kernel only visits the voxels of the band list and
             # the rest must already hold their final values (lsf_slavcheva_state_iteration); slab halos start valid.
-            states = dev.state_pack(live, None, grid, copies=2)
+            fused_prepare = not slab and self.use_band_list and dev.buffer_addressing_ok(grid)
+            if fused_prepare:
+                states, bands = dev.state_prepare(live, canonical, grid)
+            else:
+                states = dev.state_pack(live, None, grid, copies=2)
             n = dev.n_voxels(grid)
             f = dev.IterationLauncher(grid, records, _lib.GATE_SLAVCHEVA, self.lo, self.hi)
             f.p_state = [f.pointer(t, 4 * n, "state") for t in states]
             f.p_canon = f.pointer(canonical, n, "canonical")
             f.params_ref = ctypes.byref(self.params)
+            f.stream = dev.stream_ptr()  # the launch stream of this call (one ctypes object, not one per launch)
             self._fast = f
-            if not slab:
-                f.bands = dev.band_lists(live, canonical, grid, bytes_per_voxel=16) if self.use_band_list \
-                    else [dev.BandList.none()]
+            if fused_prepare:
+                f.bands = bands
+            elif not slab:
+                f.bands = dev.band_lists(live, canonical, grid) if self.use_band_list else [dev.BandList.none()]
             else:
                 L = self.comm.layout
                 h = L.halo
@@ -630,8 +635,8 @@ class SlavchevaEngine:
                 def part(rng):
                     g = dev.make_grid(live.shape, rng[0], rng[1], grid.z_global_offset)
                     f.part_grids.append(g)
-                    return ctypes.byref(g), (dev.band_lists(live, canonical, g, bytes_per_voxel=16)
-                                             if self.use_band_list else [dev.BandList.none()])
+                    return ctypes.byref(g), (dev.band_lists(live, canonical, g) if self.use_band_list
+                                             else [dev.BandList.none()])
                 self._slab_parts = ([part(r) for r in (lo_b, hi_b) if r is not None],
                                     [part(mid)] if mid[1] > mid[0] else [])
                 if not hasattr(self, "_comm_stream"):

@@ -543,6 +543,13 @@ def test_state_pack_unpack_finalize(lsf):
             assert float(a[..., 3].abs().max()) == 0.0
         z0 = dev.state_pack(live, None, grid, copies=1)[0]
         assert float(z0[..., 1:].abs().max()) == 0.0
+        # lsf_state_prepare = lsf_state_pack (two copies, zero warp) + the INTERIOR / BOUNDARY lists of lsf_band_count
+        st, lists = dev.state_prepare(live, canon, grid)
+        assert torch.equal(st[0], z0) and torch.equal(st[1], z0)
+        want_lists = dev.band_lists(live, canon, grid)
+        assert [(bl.subset, bl.count) for bl in lists] == [(bl.subset, bl.count) for bl in want_lists]
+        for got_l, want_l in zip(lists, want_lists):
+            assert torch.equal(got_l.indices[:got_l.count], want_l.indices[:want_l.count])
         l2, p2, i2 = torch.empty_like(live), torch.empty_like(warp), torch.empty(shape + (dims,), device="cuda")
         dev.state_unpack(a, grid, l2, p2, i2)
         assert torch.equal(l2, live) and torch.equal(p2, warp) and torch.equal(i2, dev.interleave(warp))
