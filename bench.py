@@ -33,8 +33,8 @@ HBM_PEAK_GBS = 8000.0                    # MI355X HBM3E spec peak (MI355X_MICROA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=256, help="edge of the per-GPU volume (256 = BASELINE config 4)")
     ap.add_argument("--iterations", type=int, default=50)
     ap.add_argument("--halo", type=int, default=2)

@@ -80,6 +80,10 @@ struct NbhState : TapsBase<D> {
 // (the neighbourhood's lowest corner relative to the wave's first lane), the tap chosen by the instruction's scalar
 // offset (dy, dz) and immediate (dx) -- no per-tap VALU address arithmetic, no OOB selects.  32-bit buffer offsets:
 // 16 * nz * ny * nx < 2^32 (Grid::fast_ok as set by the launcher).
+// (Measured and rejected: taking the ten x -/+ 1 taps from the neighbouring lane's own-x taps by wave-wide DPP shifts,
+// with exec-masked loads only for the lanes at the ends of an x-run -- bit-identical, 27 % fewer bytes through the
+// vector L1, yet 4 % SLOWER on both walks: a mostly masked buffer_load_dwordx4 occupies the address path like a full
+// one, and almost every wave has some lane at a run end.  DESIGN.md section 5.)
 template <int D>
 struct NbhStateFast : TapsBase<D> {
     __device__ inline NbhStateFast(const vf4* __restrict__ s, const Grid& g, int x, int y, int z,

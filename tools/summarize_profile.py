@@ -33,34 +33,46 @@ def counter_means(sub):
 
 
 rows = []
-fused = {}
+fused = {"list": {}, "dense": {}}
 cal = {}
 for run, subs in (("calibration", ("cal_fetch", "cal_write")), ("bench", ("pmc_fetch", "pmc_write"))):
     for sub in subs:
         for (kernel, counter), vals in sorted(counter_means(sub).items()):
-            if "hier_update_kernel" in kernel and run == "calibration":
-                cal[counter] = sum(vals) / len(vals)
-            elif "slavcheva_iteration_kernel" in kernel and run == "bench":
-                fused[counter] = (sum(vals) / len(vals), len(vals))
+            mean = sum(vals) / len(vals)
+            if run == "calibration" and kernel.startswith(("hier_update_kernel", "state_unpack_kernel",
+                                                           "state_pack_kernel")):
+                cal[(kernel.split("<")[0], counter)] = mean
+            elif run == "bench" and "slavcheva_state_kernel" in kernel:
+                # last template argument: 0 dense walk, 1 list, 2 interior list (the bench's band list)
+                walk = "dense" if kernel.rstrip(">").endswith(" 0") else "list"
+                fused[walk][counter] = (mean, len(vals))
             else:
                 continue
-            rows.append((run, kernel, counter, len(vals), sum(vals) / len(vals), min(vals), max(vals)))
+            rows.append((run, kernel, counter, len(vals), mean, min(vals), max(vals)))
 with open(os.path.join(out_dir, tag + "_pmc_hbm_traffic.csv"), "w") as f:
     f.write("run,kernel,counter,dispatches,mean_KiB,min_KiB,max_KiB\n")
     for r in rows:
         f.write('%s,"%s",%s,%d,%.1f,%.1f,%.1f\n' % r)
 
-# calibration launches: hier_update_kernel<3> at 256^3 reads 393216 KiB and writes 196608 KiB (tools/pmc_calibrate.py)
-fetch_corr = 393216.0 / cal["FETCH_SIZE"]
-write_corr = 196608.0 / cal["WRITE_SIZE"]
-hbm = (fused["FETCH_SIZE"][0] * fetch_corr + fused["WRITE_SIZE"][0] * write_corr) * 1024.0
-json.dump(dict(workload="killing", size=256, hbm_bytes_per_launch=int(round(hbm)),
-               fetch_size_KiB=fused["FETCH_SIZE"][0], fetch_correction=round(fetch_corr, 4),
-               write_size_KiB=fused["WRITE_SIZE"][0], write_correction=round(write_corr, 4),
-               dispatches=fused["FETCH_SIZE"][1],
-               source="profiles/%s_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
-                      "calibrated on launches of known traffic)" % tag),
-          open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
+# calibration launches (tools/pmc_calibrate.py), KiB actually moved per launch at 256^3
+KNOWN = {("hier_update_kernel", "FETCH_SIZE"): 393216.0, ("hier_update_kernel", "WRITE_SIZE"): 196608.0,
+         ("state_unpack_kernel", "FETCH_SIZE"): 262144.0, ("state_pack_kernel", "WRITE_SIZE"): 524288.0}
+corr = {k: KNOWN[k] / v for k, v in cal.items() if k in KNOWN}
+# the state kernel moves 16 bytes per lane: corrections of the 16-byte calibration launches
+fetch_corr = corr[("state_unpack_kernel", "FETCH_SIZE")]
+write_corr = corr[("state_pack_kernel", "WRITE_SIZE")]
+result = dict(workload="killing", size=256, fetch_correction=round(fetch_corr, 4), write_correction=round(write_corr, 4),
+              corrections={"%s %s" % k: round(v, 4) for k, v in corr.items()},
+              source="profiles/%s_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                     "calibrated on launches of known traffic with the same bytes per lane)" % tag)
+for walk, key in (("list", "hbm_bytes_per_launch"), ("dense", "dense_hbm_bytes_per_launch")):
+    c = fused[walk]
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        result[key] = int(round((c["FETCH_SIZE"][0] * fetch_corr + c["WRITE_SIZE"][0] * write_corr) * 1024.0))
+        result[walk + "_fetch_size_KiB"] = c["FETCH_SIZE"][0]
+        result[walk + "_write_size_KiB"] = c["WRITE_SIZE"][0]
+        result[walk + "_dispatches"] = c["FETCH_SIZE"][1]
+json.dump(result, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
 
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
 table = list(csv.DictReader(open(stats)))
