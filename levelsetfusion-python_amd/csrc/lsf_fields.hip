@@ -509,6 +509,142 @@ __global__ __launch_bounds__(kBlock) void convolve_x_kernel(const float* __restr
     }
 }
 
+// ---- register-window variants for the common tap counts (3, 5, 7, 9): no LDS, no barrier, compile-time taps --------
+// The tiled kernels above reach ~2 TB/s at 256^3 (load phase, barrier, compute phase in small blocks; taps indexed
+// dynamically).  Here every thread owns its outputs outright:
+//   y / z pass: a thread marches along the filter axis over kMarch outputs of one (x, other) column with a rolling
+//     window of NT doubles; a wave's loads and stores are 256-byte rows (x fastest); the NT - 1 halo rows of a run are
+//     re-read by the neighbouring run (x 1.19 at kMarch = 32, from L2);
+//   x pass: a thread computes 4 consecutive outputs from three aligned float4 loads (previous, own, next quad).
+// Same arithmetic as the tiled kernels: float64 products and sums in tap order, one rounding per pass.
+template <int NT>
+struct TapsN {
+    double k[NT];
+};
+
+constexpr int kMarch = 32;
+
+template <int AXIS, int NT, bool MASK>
+__global__ __launch_bounds__(kBlock) void convolve_march_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                const float* __restrict__ mask_src, Grid g,
+                                                                TapsN<NT> taps, lsf_gate gate) {
+    if (gate_closed(gate)) return;
+    const int lx = threadIdx.x & (kTileX - 1), w = threadIdx.x / kTileX;
+    const int x = blockIdx.x * kTileX + lx;
+    const int len = AXIS == 1 ? g.ny : g.nz;
+    const int stride = AXIS == 1 ? g.nx : g.nx * g.ny;
+    const int n_other = AXIS == 1 ? g.z_end - g.z_begin : g.ny;
+    const int runs = AXIS == 1 ? (g.ny + kMarch - 1) / kMarch : (g.z_end - g.z_begin + kMarch - 1) / kMarch;
+    const int run = blockIdx.y % runs, other = (blockIdx.y / runs) * (kBlock / kTileX) + w;
+    if (x >= g.nx || other >= n_other) return;
+    const int a0 = (AXIS == 1 ? 0 : g.z_begin) + run * kMarch;
+    const int a_end = AXIS == 1 ? g.ny : g.z_end;
+    const int count = min(kMarch, a_end - a0);
+    const int fixed = AXIS == 1 ? (g.z_begin + other) * g.nx * g.ny : other * g.nx;
+    const float* __restrict__ src = in + (long long)blockIdx.z * g.plane + fixed + x;
+    float* __restrict__ dst = out + (long long)blockIdx.z * g.plane + fixed + x;
+    const float* __restrict__ msk = MASK ? mask_src + (long long)blockIdx.z * g.plane + fixed + x : nullptr;
+    constexpr int c = NT / 2, lo = NT - 1 - c;
+    float v[kMarch + NT - 1];  // v[q] = in[a0 - lo + q], zero outside the array (np.convolve's zero padding)
+#pragma unroll
+    for (int q = 0; q < kMarch + NT - 1; ++q) {
+        const int a = a0 - lo + q;
+        const float t = src[min(max(a, 0), len - 1) * stride];  // < plane < 2^31 (check_grid)
+        v[q] = (a >= 0 && a < len && q < count + NT - 1) ? t : 0.0f;
+    }
+    double win[NT];
+#pragma unroll
+    for (int t = 0; t < NT - 1; ++t) win[t] = (double)v[t];
+#pragma unroll
+    for (int m = 0; m < kMarch; ++m) {
+        win[(m + NT - 1) % NT] = (double)v[m + NT - 1];
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc = acc + taps.k[j] * win[(m + NT - 1 - j) % NT];  // = in[a0 + m + c - j]
+        if (m < count) {
+            float r = (float)acc;
+            const int o = (a0 + m) * stride;
+            if (MASK && fabsf(msk[o]) < 1e-6f) r = 0.0f;
+            dst[o] = r;
+        }
+    }
+}
+
+typedef float cvf4 __attribute__((ext_vector_type(4)));
+
+// x pass, nx % 4 == 0, NT <= 9 (reach <= 4): one thread = one aligned quad of outputs
+template <int NT, bool MASK>
+__global__ __launch_bounds__(kBlock) void convolve_x4_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                             const float* __restrict__ mask_src, Grid g,
+                                                             TapsN<NT> taps, long long first_quad, long long n_quads,
+                                                             lsf_gate gate) {
+    if (gate_closed(gate)) return;
+    const long long k = blockIdx.x * (long long)kBlock + threadIdx.x;
+    if (k >= n_quads) return;
+    const long long q = first_quad + k;
+    const unsigned quads_x = (unsigned)g.nx / 4u;
+    const unsigned qx = (unsigned)(q % quads_x);
+    const long long base = (long long)blockIdx.y * g.plane;
+    const cvf4* __restrict__ src = reinterpret_cast<const cvf4*>(in + base);
+    const cvf4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    const cvf4 mid = src[q];
+    const cvf4 left = qx > 0 ? src[q - 1] : zero;
+    const cvf4 right = qx + 1 < quads_x ? src[q + 1] : zero;
+    const float v[12] = {left.x, left.y, left.z, left.w, mid.x, mid.y, mid.z, mid.w, right.x, right.y, right.z, right.w};
+    double d[12];
+#pragma unroll
+    for (int t = 0; t < 12; ++t) d[t] = (double)v[t];
+    constexpr int c = NT / 2;
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc = acc + taps.k[j] * d[4 + i + c - j];
+        r[i] = (float)acc;
+    }
+    if (MASK) {
+        const cvf4 m = reinterpret_cast<const cvf4*>(mask_src + base)[q];
+        if (fabsf(m.x) < 1e-6f) r[0] = 0.0f;
+        if (fabsf(m.y) < 1e-6f) r[1] = 0.0f;
+        if (fabsf(m.z) < 1e-6f) r[2] = 0.0f;
+        if (fabsf(m.w) < 1e-6f) r[3] = 0.0f;
+    }
+    cvf4 o;
+    o.x = r[0]; o.y = r[1]; o.z = r[2]; o.w = r[3];
+    reinterpret_cast<cvf4*>(out + base)[q] = o;
+}
+
+template <int NT>
+static bool launch_window_pass(const float* in, float* out, const float* mask, const Grid& g, int planes, int axis,
+                               const double* taps_host, const lsf_gate& gt, hipStream_t s) {
+    TapsN<NT> taps;
+    for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
+    const int slices = g.z_end - g.z_begin;
+    const unsigned tiles_x = (unsigned)(g.nx + kTileX - 1) / kTileX, waves = kBlock / kTileX;
+    if (axis == 0) {
+        if (g.nx % 4 != 0) return false;
+        const long long quads_per_slice = (long long)g.ny * (g.nx / 4);
+        const long long first = quads_per_slice * g.z_begin, n = quads_per_slice * slices;
+        const dim3 grid((unsigned)((n + kBlock - 1) / kBlock), (unsigned)planes);
+        if (mask) hipLaunchKernelGGL((convolve_x4_kernel<NT, true>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, first, n, gt);
+        else hipLaunchKernelGGL((convolve_x4_kernel<NT, false>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, first, n, gt);
+    } else if (axis == 1) {
+        const unsigned runs = (unsigned)(g.ny + kMarch - 1) / kMarch;
+        const dim3 grid(tiles_x, runs * (((unsigned)slices + waves - 1) / waves), (unsigned)planes);
+        if (grid.y > 65535u) return false;
+        if (mask) hipLaunchKernelGGL((convolve_march_kernel<1, NT, true>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, gt);
+        else hipLaunchKernelGGL((convolve_march_kernel<1, NT, false>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, gt);
+    } else {
+        const unsigned runs = (unsigned)(slices + kMarch - 1) / kMarch;
+        const dim3 grid(tiles_x, runs * (((unsigned)g.ny + waves - 1) / waves), (unsigned)planes);
+        if (grid.y > 65535u) return false;
+        if (mask) hipLaunchKernelGGL((convolve_march_kernel<2, NT, true>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, gt);
+        else hipLaunchKernelGGL((convolve_march_kernel<2, NT, false>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, gt);
+    }
+    return true;
+}
+
 extern "C" int lsf_convolve_axis(const float* in_planar, float* out_planar, const float* zero_mask_source,
                                  const lsf_grid* grid, int32_t planes, int32_t axis, const double* taps_host,
                                  int32_t n_taps, const lsf_gate* gate, void* stream) {
@@ -525,6 +661,15 @@ extern "C" int lsf_convolve_axis(const float* in_planar, float* out_planar, cons
     lsf_gate gt = gate ? *gate : lsf_gate{nullptr, 0, 0.0f, 0.0f};
     const unsigned tiles_x = (unsigned)(g.nx + kTileX - 1) / kTileX;
     hipStream_t s = as_stream(stream);
+    bool done = false;
+    switch (n_taps) {  // register-window kernels for the common tap counts; anything else: the tiled kernels
+        case 3: done = launch_window_pass<3>(in_planar, out_planar, zero_mask_source, g, planes, axis, taps_host, gt, s); break;
+        case 5: done = launch_window_pass<5>(in_planar, out_planar, zero_mask_source, g, planes, axis, taps_host, gt, s); break;
+        case 7: done = launch_window_pass<7>(in_planar, out_planar, zero_mask_source, g, planes, axis, taps_host, gt, s); break;
+        case 9: done = launch_window_pass<9>(in_planar, out_planar, zero_mask_source, g, planes, axis, taps_host, gt, s); break;
+        default: break;
+    }
+    if (done) return launch_status();
     if (axis == 0) {
         const unsigned tiles_y = (unsigned)(g.ny + kConvRows - 1) / kConvRows;
         hipLaunchKernelGGL(convolve_x_kernel, dim3(tiles_x, tiles_y * slices, planes), dim3(kBlock),

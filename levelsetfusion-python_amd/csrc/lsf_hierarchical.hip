@@ -74,14 +74,16 @@ __device__ inline Packed gather_packed(const float4* __restrict__ s, const Grid&
 // double and stored float32, summed in float32, slowest axis first (oracle.laplace_replicate)
 template <int D>
 __device__ inline float laplace_replicate(const float* __restrict__ a, const Grid& g, int x, int y, int z) {
+    // neighbours are read from CLAMPED offsets (a missing neighbour IS the centre in mode='nearest'): unconditional
+    // loads the compiler can issue together, instead of one exec-masked load + wait per neighbour
     const int i = vidx(g, x, y, z);
     const float a0 = a[i];
     const int sy = g.nx, sz = g.nx * g.ny;
     float out;
-    float d2y = second_difference_f64(y > 0 ? a[i - sy] : a0, a0, y < g.ny - 1 ? a[i + sy] : a0);
-    float d2x = second_difference_f64(x > 0 ? a[i - 1] : a0, a0, x < g.nx - 1 ? a[i + 1] : a0);
+    float d2y = second_difference_f64(a[i - (y > 0 ? sy : 0)], a0, a[i + (y < g.ny - 1 ? sy : 0)]);
+    float d2x = second_difference_f64(a[i - (x > 0 ? 1 : 0)], a0, a[i + (x < g.nx - 1 ? 1 : 0)]);
     if (D == 3) {
-        float d2z = second_difference_f64(z > 0 ? a[i - sz] : a0, a0, z < g.nz - 1 ? a[i + sz] : a0);
+        float d2z = second_difference_f64(a[i - (z > 0 ? sz : 0)], a0, a[i + (z < g.nz - 1 ? sz : 0)]);
         out = d2z + d2y;
     } else {
         out = d2y;
