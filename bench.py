@@ -267,8 +267,10 @@ def main():
                config=dict(workload="3D %d^3 KillingFusion (Killing + level-set) SlavchevaOptimizer3d, %d fixed "
                                     "iterations per step, sphere-pair TSDF" % (n, iters),
                            voxels_per_gpu=voxels_per_rank, iterations_per_step=iters,
-                           parallelism=("z-slab x%d, halo %d, %s" % (world, args.halo, args.backend)) if world > 1
-                           else "single GPU"),
+                           parallelism=("z-slab x%d, halo %d, %s" % (
+                               world, args.halo, "RCCL send/recv from the library (lsf_slab_state_iteration)"
+                               if comm.native() is not None else "torch.distributed " + args.backend))
+                           if world > 1 else "single GPU"),
                roofline=roofline)
     if roofline_dense is not None:
         out["roofline_dense_walk"] = roofline_dense
@@ -277,6 +279,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_size, args.cpu_sample_iterations)
         print(json.dumps(out), flush=True)
     if world > 1:
+        comm.close()  # the library's own RCCL communicator, before torch tears its process group down
         dist.destroy_process_group()
 
 

@@ -39,6 +39,8 @@ extern "C" {
 #define LSF_ERR_BAD_ARGUMENT (-1)
 #define LSF_ERR_BAD_DIMS (-2)
 #define LSF_ERR_KERNEL_TOO_LONG (-3)
+#define LSF_ERR_RCCL_UNAVAILABLE (-4) /* librccl.so could not be bound at run time */
+#define LSF_ERR_RCCL_FAILED (-5)      /* an RCCL call returned an error (its text goes to stderr) */
 
 /* extents of one field as stored on this device */
 typedef struct lsf_grid {
@@ -268,6 +270,41 @@ int lsf_slavcheva_state_iteration(const float *state_in, const float *canonical,
                                   const lsf_grid *grid, const lsf_slavcheva_params *params, const lsf_gate *gate,
                                   lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,
                                   int32_t band_subset, void *stream);
+
+/* ---- z-slab runtime of the fused path for multi-GPU runs (new design) -----------------------------
+ * One process per GPU; rank r owns z-slices [z_begin, z_end) of its local array and keeps `halo` slices of its
+ * neighbours on either interior side.  lsf_slab_state_iteration enqueues ONE whole iteration with one host call:
+ *   1. lsf_slavcheva_state_iteration over the boundary parts (the `halo` owned slices next to each neighbour),
+ *   2. the exchange of those slices of state_out with the neighbours -- ncclSend / ncclRecv in one group on the
+ *      communicator's own HIP stream (RCCL over xGMI), each face one contiguous run of halo * ny * nx float4 --
+ *   3. while the interior parts run on `stream`; 4. `stream` then waits for the halos.
+ * RCCL is bound with dlopen (rccl_library_path, else "librccl.so" as already mapped into the process).
+ * Communicator: rank 0 calls lsf_slab_unique_id, the 128 bytes travel to the other ranks by any means (the Python side
+ * broadcasts them with torch.distributed), every rank calls lsf_slab_comm_create on its current device. */
+typedef struct lsf_slab_comm lsf_slab_comm;
+typedef struct lsf_slab_layout {
+    int32_t nz, ny, nx;       /* local array (owned slab + halos) */
+    int32_t z_begin, z_end;   /* owned slices */
+    int32_t halo;
+    int32_t lo_rank, hi_rank; /* neighbour ranks, -1 = none (end of the volume) */
+} lsf_slab_layout;
+typedef struct lsf_slab_part {
+    lsf_grid grid;             /* z-range of this part */
+    const int32_t *band_list[2]; /* NULL = dense walk */
+    int64_t band_count[2];
+    int32_t band_subset[2];
+    int32_t n_lists;           /* 1 or 2 launches (INTERIOR + BOUNDARY band lists) */
+    int32_t reserved;
+} lsf_slab_part;
+int lsf_slab_unique_id(const char *rccl_library_path, uint8_t *id_out128);
+int lsf_slab_comm_create(const char *rccl_library_path, const uint8_t *id128, int32_t rank, int32_t world,
+                         lsf_slab_comm **out);
+int lsf_slab_comm_destroy(lsf_slab_comm *comm);
+int lsf_slab_state_iteration(lsf_slab_comm *comm, const float *state_in, const float *canonical, float *state_out,
+                             const lsf_slab_layout *layout, const lsf_slab_part *boundary_parts, int32_t n_boundary,
+                             const lsf_slab_part *interior_parts, int32_t n_interior,
+                             const lsf_slavcheva_params *params, const lsf_gate *gate, lsf_iteration_record *record,
+                             void *stream);
 
 int lsf_slavcheva_update_rewarp(const float *live, const float *canonical, float *g_planar /* inout */,
                                 float *warp_out_planar, float *live_out, const lsf_grid *grid,

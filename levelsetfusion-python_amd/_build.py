@@ -8,7 +8,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "liblsf_hip.so")
-SOURCES = ["lsf_fields.hip", "lsf_hierarchical.hip", "lsf_slavcheva.hip", "lsf_slavcheva_state.hip", "lsf_tsdf.hip"]
+SOURCES = ["lsf_fields.hip", "lsf_hierarchical.hip", "lsf_slavcheva.hip", "lsf_slavcheva_state.hip", "lsf_slab.hip", "lsf_tsdf.hip"]
 HEADERS = ["lsf_device.h", "lsf_slavcheva_terms.h", os.path.join("..", "..", "include", "lsf_hip.h")]
 # -ffp-contract=off: multiply and add stay separately rounded so that results are bit-identical to the numpy
 # oracle (numpy never fuses); the path is HBM/L1-bound, the lost FMAs do not show.
@@ -49,7 +49,7 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

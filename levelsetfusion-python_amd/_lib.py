@@ -18,7 +18,8 @@ c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_p
 MAX_KERNEL_TAPS = 31
 ABI_VERSION = 1
 
-ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG"}
+ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
+          -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED"}
 
 SMOOTHING_TIKHONOV, SMOOTHING_KILLING = 0, 1
 DATA_BASIC, DATA_THRESHOLDED_FDM = 0, 2
@@ -54,6 +55,17 @@ SLOT_WORDS = ctypes.sizeof(RecordSlot) // 8    # 32
 class Gate(ctypes.Structure):
     _fields_ = [("prev_record", ctypes.c_void_p), ("mode", ctypes.c_int32), ("a", ctypes.c_float),
                 ("b", ctypes.c_float)]
+
+
+class SlabLayoutC(ctypes.Structure):
+    _fields_ = [("nz", ctypes.c_int32), ("ny", ctypes.c_int32), ("nx", ctypes.c_int32), ("z_begin", ctypes.c_int32),
+                ("z_end", ctypes.c_int32), ("halo", ctypes.c_int32), ("lo_rank", ctypes.c_int32),
+                ("hi_rank", ctypes.c_int32)]
+
+
+class SlabPart(ctypes.Structure):
+    _fields_ = [("grid", Grid), ("band_list", ctypes.c_void_p * 2), ("band_count", ctypes.c_int64 * 2),
+                ("band_subset", ctypes.c_int32 * 2), ("n_lists", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class HierParams(ctypes.Structure):
@@ -119,6 +131,11 @@ PROTOTYPES = {
     "lsf_band_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
     "lsf_band_count": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),
     "lsf_band_list_fill": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),
+    "lsf_slab_unique_id": (ctypes.c_int, [ctypes.c_char_p, _vp]),
+    "lsf_slab_comm_create": (ctypes.c_int, [ctypes.c_char_p, _vp, _i32, _i32, _P(_vp)]),
+    "lsf_slab_comm_destroy": (ctypes.c_int, [_vp]),
+    "lsf_slab_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(SlabLayoutC), _P(SlabPart), _i32, _P(SlabPart),
+                                                _i32, _P(SlavchevaParams), _P(Gate), _vp, _vp]),
     "lsf_slavcheva_update_rewarp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),
                                                    _P(Gate), _vp, _vp]),
     "lsf_warp_statistics": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp, _vp]),

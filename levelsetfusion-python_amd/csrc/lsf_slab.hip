@@ -1,0 +1,201 @@
+// z-slab runtime of the fused Slavcheva path for multi-GPU runs (one process per GPU): ONE host call enqueues a whole
+// iteration -- boundary-slice launches, the halo exchange over RCCL (xGMI) on a second HIP stream, the interior
+// launches -- instead of ~10 Python-level calls into torch.distributed (measured on one GPU with self send / recv,
+// tools/slab_nccl_loopback.py: 150 us of host time per iteration through batch_isend_irecv against a 40 us kernel).
+// The reference has no distributed code; this is new design, DESIGN.md section 6.
+//
+// RCCL is bound at run time (dlopen of the librccl.so the process already uses -- PyTorch ships its own copy), so
+// liblsf_hip.so has no link-time dependency on it and single-GPU users never touch it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/lsf_hip.h"
+
+namespace {
+
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi g_rccl;
+
+template <class F>
+bool bind(F& fn, const char* name) {
+    fn = reinterpret_cast<F>(dlsym(g_rccl.handle, name));
+    return fn != nullptr;
+}
+
+int load_rccl(const char* path) {
+    if (g_rccl.handle) return 0;
+    const char* candidates[] = {path, "librccl.so", "librccl.so.1"};
+    for (const char* c : candidates) {
+        if (!c || !c[0]) continue;
+        // the copy already mapped into this process first (same soname), else load it
+        void* h = dlopen(c, RTLD_NOW | RTLD_NOLOAD);
+        if (!h) h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            g_rccl.handle = h;
+            break;
+        }
+    }
+    if (!g_rccl.handle) return LSF_ERR_RCCL_UNAVAILABLE;
+    const bool ok = bind(g_rccl.GetUniqueId, "ncclGetUniqueId") && bind(g_rccl.CommInitRank, "ncclCommInitRank") &&
+                    bind(g_rccl.CommDestroy, "ncclCommDestroy") && bind(g_rccl.GroupStart, "ncclGroupStart") &&
+                    bind(g_rccl.GroupEnd, "ncclGroupEnd") && bind(g_rccl.Send, "ncclSend") &&
+                    bind(g_rccl.Recv, "ncclRecv") && bind(g_rccl.GetErrorString, "ncclGetErrorString");
+    if (!ok) {
+        g_rccl = RcclApi();
+        return LSF_ERR_RCCL_UNAVAILABLE;
+    }
+    return 0;
+}
+
+}  // namespace
+
+struct lsf_slab_comm {
+    ncclComm_t comm;
+    int rank, world;
+    hipStream_t comm_stream;
+    hipEvent_t boundary_done[2], halos_done[2];
+    unsigned parity;
+};
+
+#define LSF_RCCL_CHECK(call)                                                                       \
+    do {                                                                                           \
+        const ncclResult_t r_ = (call);                                                            \
+        if (r_ != ncclSuccess) {                                                                   \
+            fprintf(stderr, "liblsf_hip: %s failed: %s\n", #call, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "?"); \
+            return LSF_ERR_RCCL_FAILED;                                                            \
+        }                                                                                          \
+    } while (0)
+
+#define LSF_HIP_CHECK(call)               \
+    do {                                  \
+        const hipError_t e_ = (call);     \
+        if (e_ != hipSuccess) return (int)e_; \
+    } while (0)
+
+extern "C" int lsf_slab_unique_id(const char* rccl_library_path, uint8_t* id_out128) {
+    if (!id_out128) return LSF_ERR_BAD_ARGUMENT;
+    if (int e = load_rccl(rccl_library_path)) return e;
+    ncclUniqueId id;
+    LSF_RCCL_CHECK(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id_out128, &id, sizeof(id));
+    return 0;
+}
+
+extern "C" int lsf_slab_comm_create(const char* rccl_library_path, const uint8_t* id128, int32_t rank, int32_t world,
+                                    lsf_slab_comm** out) {
+    if (!id128 || !out || world < 1 || rank < 0 || rank >= world) return LSF_ERR_BAD_ARGUMENT;
+    if (int e = load_rccl(rccl_library_path)) return e;
+    lsf_slab_comm* c = new (std::nothrow) lsf_slab_comm();
+    if (!c) return LSF_ERR_BAD_ARGUMENT;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    if (g_rccl.CommInitRank(&c->comm, world, id, rank) != ncclSuccess) {
+        delete c;
+        return LSF_ERR_RCCL_FAILED;
+    }
+    c->rank = rank;
+    c->world = world;
+    c->parity = 0;
+    hipError_t e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
+    for (int k = 0; k < 2 && e == hipSuccess; ++k) {
+        e = hipEventCreateWithFlags(&c->boundary_done[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->halos_done[k], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        g_rccl.CommDestroy(c->comm);
+        delete c;
+        return (int)e;
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" int lsf_slab_comm_destroy(lsf_slab_comm* c) {
+    if (!c) return 0;
+    (void)hipStreamSynchronize(c->comm_stream);
+    for (int k = 0; k < 2; ++k) {
+        (void)hipEventDestroy(c->boundary_done[k]);
+        (void)hipEventDestroy(c->halos_done[k]);
+    }
+    (void)hipStreamDestroy(c->comm_stream);
+    if (g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    delete c;
+    return 0;
+}
+
+// exchange of the state's halo slices with the z-neighbours: each face is one contiguous run of halo * ny * nx float4
+static int exchange_state(lsf_slab_comm* c, float* state, const lsf_slab_layout* L, hipStream_t s) {
+    const size_t slice = (size_t)L->ny * L->nx * 4;  // floats per z-slice of the state
+    const size_t count = slice * (size_t)L->halo;
+    LSF_RCCL_CHECK(g_rccl.GroupStart());
+    if (L->lo_rank >= 0) {
+        LSF_RCCL_CHECK(g_rccl.Send(state + slice * L->z_begin, count, ncclFloat, L->lo_rank, c->comm, s));
+        LSF_RCCL_CHECK(g_rccl.Recv(state + slice * (L->z_begin - L->halo), count, ncclFloat, L->lo_rank, c->comm, s));
+    }
+    if (L->hi_rank >= 0) {
+        LSF_RCCL_CHECK(g_rccl.Send(state + slice * (L->z_end - L->halo), count, ncclFloat, L->hi_rank, c->comm, s));
+        LSF_RCCL_CHECK(g_rccl.Recv(state + slice * L->z_end, count, ncclFloat, L->hi_rank, c->comm, s));
+    }
+    LSF_RCCL_CHECK(g_rccl.GroupEnd());
+    return 0;
+}
+
+static int launch_parts(const float* state_in, const float* canonical, float* state_out, const lsf_slab_part* parts,
+                        int32_t n, const lsf_slavcheva_params* params, const lsf_gate* gate,
+                        lsf_iteration_record* record, void* stream) {
+    for (int32_t k = 0; k < n; ++k) {
+        const lsf_slab_part& p = parts[k];
+        for (int32_t j = 0; j < p.n_lists; ++j)
+            if (int e = lsf_slavcheva_state_iteration(state_in, canonical, state_out, &p.grid, params, gate, record,
+                                                      p.band_list[j], p.band_count[j], p.band_subset[j], stream))
+                return e;
+    }
+    return 0;
+}
+
+extern "C" int lsf_slab_state_iteration(lsf_slab_comm* comm, const float* state_in, const float* canonical,
+                                        float* state_out, const lsf_slab_layout* layout,
+                                        const lsf_slab_part* boundary_parts, int32_t n_boundary,
+                                        const lsf_slab_part* interior_parts, int32_t n_interior,
+                                        const lsf_slavcheva_params* params, const lsf_gate* gate,
+                                        lsf_iteration_record* record, void* stream) {
+    if (!comm || !state_in || !canonical || !state_out || !layout || !params || !record) return LSF_ERR_BAD_ARGUMENT;
+    if ((n_boundary > 0 && !boundary_parts) || (n_interior > 0 && !interior_parts)) return LSF_ERR_BAD_ARGUMENT;
+    if (layout->halo < 1 || layout->z_begin - (layout->lo_rank >= 0 ? layout->halo : 0) < 0 ||
+        layout->z_end + (layout->hi_rank >= 0 ? layout->halo : 0) > layout->nz || layout->z_end - layout->z_begin < layout->halo ||
+        layout->lo_rank >= comm->world || layout->hi_rank >= comm->world)
+        return LSF_ERR_BAD_ARGUMENT;
+    hipStream_t main = reinterpret_cast<hipStream_t>(stream);
+    const unsigned k = comm->parity++ & 1u;
+    // 1. the slices the neighbours are waiting for
+    if (int e = launch_parts(state_in, canonical, state_out, boundary_parts, n_boundary, params, gate, record, stream))
+        return e;
+    // 2. their exchange on the communication stream, while ...
+    LSF_HIP_CHECK(hipEventRecord(comm->boundary_done[k], main));
+    LSF_HIP_CHECK(hipStreamWaitEvent(comm->comm_stream, comm->boundary_done[k], 0));
+    if (int e = exchange_state(comm, state_out, layout, comm->comm_stream)) return e;
+    LSF_HIP_CHECK(hipEventRecord(comm->halos_done[k], comm->comm_stream));
+    // 3. ... the interior runs on the launch stream
+    if (int e = launch_parts(state_in, canonical, state_out, interior_parts, n_interior, params, gate, record, stream))
+        return e;
+    // 4. the next iteration reads the halos
+    LSF_HIP_CHECK(hipStreamWaitEvent(main, comm->halos_done[k], 0));
+    return 0;
+}

@@ -562,7 +562,17 @@ class SlavchevaEngine:
                 if status:
                     _lib.check(status, "lsf_slavcheva_state_iteration")
             return
-        # z-slab: boundary slices first, then the halo exchange on a second stream WHILE the interior runs
+        if f.native is not None:  # the whole iteration in one host call (lsf_slab.hip): RCCL on the library's stream
+            status = _lib.lib.lsf_slab_state_iteration(f.native, s_in, f.p_canon, s_out, f.layout_ref, f.boundary_parts,
+                                                       f.n_boundary, f.interior_parts, f.n_interior,
+                                                       f.params_ref, gate_ref, f.record_ptrs[i], f.stream)
+            if status:
+                _lib.check(status, "lsf_slab_state_iteration")
+            if i + 1 < limit and i + 1 >= self.min_iterations:
+                self.comm.reduce_max(f.records, i)
+            return
+        # torch.distributed transport (gloo tests, fallback): boundary slices first, then the halo exchange on a second
+        # stream WHILE the interior runs
         boundary, interior = self._slab_parts
         for grid_ref, bands in boundary:
             for band in bands:
@@ -619,6 +629,7 @@ class SlavchevaEngine:
             f.p_canon = f.pointer(canonical, n, "canonical")
             f.params_ref = ctypes.byref(self.params)
             f.stream = dev.stream_ptr()  # the launch stream of this call (one ctypes object, not one per launch)
+            f.native = None
             self._fast = f
             if fused_prepare:
                 f.bands = bands
@@ -637,8 +648,49 @@ class SlavchevaEngine:
                     f.part_grids.append(g)
                     return ctypes.byref(g), (dev.band_lists(live, canonical, g) if self.use_band_list
                                              else [dev.BandList.none()])
-                self._slab_parts = ([part(r) for r in (lo_b, hi_b) if r is not None],
-                                    [part(mid)] if mid[1] > mid[0] else [])
+
+                def merged_boundary():
+                    # both boundary ranges in ONE launch per subset: a band list is just ascending voxel indices, so
+                    # the lower range's list followed by the upper range's is a list again (the launch's z-range only
+                    # places the "all updates are zero" arg-max candidate) -- the boundary phase sits on the critical
+                    # path of every iteration (boundary -> exchange -> next iteration)
+                    pieces = [dev.band_lists(live, canonical, dev.make_grid(live.shape, r[0], r[1], grid.z_global_offset))
+                              for r in (lo_b, hi_b)]
+                    merged = []
+                    for subset in (_lib.BAND_INTERIOR, _lib.BAND_BOUNDARY, _lib.BAND_ALL):
+                        same = [b for piece in pieces for b in piece if b.subset == subset and b.count > 0]
+                        if same:
+                            idx = torch.cat([b.indices[:b.count] for b in same])
+                            merged.append(dev.BandList(idx, idx.numel(), subset))
+                    if not merged:
+                        merged = [pieces[0][-1]]  # nothing in the band: one empty list still reports the zero update
+                    g = dev.make_grid(live.shape, lo_b[0], hi_b[1], grid.z_global_offset)
+                    f.part_grids.append(g)
+                    return ctypes.byref(g), merged
+                if self.use_band_list and lo_b is not None and hi_b is not None:
+                    boundary_parts = [merged_boundary()]
+                else:
+                    boundary_parts = [part(r) for r in (lo_b, hi_b) if r is not None]
+                self._slab_parts = (boundary_parts, [part(mid)] if mid[1] > mid[0] else [])
+                f.native = self.comm.native()
+                if f.native is not None:
+                    def pack(parts, grids):
+                        arr = (_lib.SlabPart * max(len(parts), 1))()
+                        for k, ((_, bands), g) in enumerate(zip(parts, grids)):
+                            arr[k].grid = g
+                            arr[k].n_lists = len(bands)
+                            for j, band in enumerate(bands):
+                                arr[k].band_list[j] = band.pointer.value or None
+                                arr[k].band_count[j] = band.count
+                                arr[k].band_subset[j] = band.subset
+                        return arr
+                    nb = len(self._slab_parts[0])
+                    f.n_boundary, f.n_interior = nb, len(self._slab_parts[1])
+                    f.boundary_parts = pack(self._slab_parts[0], f.part_grids[:nb])
+                    f.interior_parts = pack(self._slab_parts[1], f.part_grids[nb:])
+                    _, _, lo_rank, hi_rank = self.comm.native_identity()
+                    f.layout = _lib.SlabLayoutC(grid.nz, grid.ny, grid.nx, L.z_begin, L.z_end, h, lo_rank, hi_rank)
+                    f.layout_ref = ctypes.byref(f.layout)
                 if not hasattr(self, "_comm_stream"):
                     self._comm_stream = torch.cuda.Stream(device=live.device)
                     self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]

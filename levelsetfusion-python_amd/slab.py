@@ -10,6 +10,10 @@ the (at most two) neighbours, and the iteration record (max update, energies) is
 
 The reference has no distributed code at all; this module is new design, see DESIGN.md section 6.
 """
+import ctypes
+import os
+import warnings
+
 import torch
 import torch.distributed as dist
 
@@ -59,6 +63,53 @@ class SlabComm:
     @property
     def active(self):
         return self.layout.world > 1
+
+    # ---- native transport: the library's own RCCL communicator (lsf_slab.hip) -------------------------------------
+    def native_identity(self):
+        """(rank, world, lower neighbour, upper neighbour) inside the native communicator; -1 = no neighbour"""
+        L = self.layout
+        return L.rank, L.world, (L.rank - 1 if L.rank > 0 else -1), (L.rank + 1 if L.rank < L.world - 1 else -1)
+
+    def native(self):
+        """handle of the library-side communicator (created on first use: rank 0 draws the RCCL unique id, the bytes
+        travel over torch.distributed), or None when the transport is torch.distributed -- CPU / gloo runs,
+        LSF_SLAB_TRANSPORT=torch, or RCCL could not be bound"""
+        if hasattr(self, "_native"):
+            return self._native
+        self._native = None
+        if not self.active or self.stage_through_host or not dist.is_initialized() \
+                or os.environ.get("LSF_SLAB_TRANSPORT", "rccl") == "torch":
+            return None
+        from . import _lib
+        rank, world, _, _ = self.native_identity()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = path.encode() if os.path.exists(path) else None
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        try:
+            if rank == 0:
+                host = (ctypes.c_uint8 * 128)()
+                _lib.check(_lib.lib.lsf_slab_unique_id(path, ctypes.cast(host, ctypes.c_void_p)), "lsf_slab_unique_id")
+                uid.copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
+            if dist.get_world_size(self.group) > 1:
+                src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+                dist.broadcast(uid, src=src, group=self.group)
+            host = (ctypes.c_uint8 * 128)(*uid.cpu().tolist())
+            handle = ctypes.c_void_p()
+            _lib.check(_lib.lib.lsf_slab_comm_create(path, ctypes.cast(host, ctypes.c_void_p), rank, world,
+                                                     ctypes.byref(handle)), "lsf_slab_comm_create")
+            self._native = handle
+        except Exception as exc:  # noqa: BLE001 -- any failure here only costs speed: the torch transport still works
+            warnings.warn("native RCCL slab transport unavailable (%s); using torch.distributed point-to-point" % exc)
+            self._native = None
+        return self._native
+
+    def close(self):
+        """release the native communicator (before torch.distributed.destroy_process_group)"""
+        handle = getattr(self, "_native", None)
+        if handle is not None:
+            from . import _lib
+            _lib.lib.lsf_slab_comm_destroy(handle)
+        self._native = None
 
     def _z_view(self, t, a, b):
         # scalar field [z,y,x] or planar vector field [c,z,y,x]

@@ -171,3 +171,21 @@ def test_halo_copy_kernel_matches_slicing():
     only = torch.zeros_like(lo)
     dev.halo_copy(live, warp, None, only, h, 0, z_hi, unpack=False)
     assert torch.equal(only, hi)
+
+
+def test_native_rccl_transport_equals_torch_transport(tmp_path):
+    """the library's own RCCL transport (lsf_slab_state_iteration: boundary launches, ncclSend / ncclRecv on the comm
+    stream, interior launches in ONE host call) against the torch.distributed transport, both over real RCCL on one GPU
+    (a world of one rank that is its own neighbour, see slab_loopback_worker.py): bit-identical fields and records"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    out = os.path.join(str(tmp_path), "loopback.npz")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "slab_loopback_worker.py")
+    proc = subprocess.run([sys.executable, worker, out, str(_free_port())], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
+    r = np.load(out)
+    assert str(r["used_rccl"]) == "rccl", "the native RCCL transport was not used: " + proc.stderr[-1000:]
+    assert str(r["used_torch"]) == "torch"
+    assert bool(r["live_equal"]) and bool(r["warp_equal"]) and bool(r["max_equal"]) and bool(r["data_close"])
+    assert float(r["moved"]) > 1e-3  # the optimisation did something

@@ -1,0 +1,72 @@
+"""Host-side cost per iteration of the N > 1 enqueue path over the REAL transport API (torch.distributed "nccl" = RCCL)
+on ONE GPU: a world of size 1 whose rank plays the middle slab of three and sends both halo faces to ITSELF (RCCL
+allows self send / recv inside a group).  The received data are meaningless; what is exercised and timed is the exact
+call sequence of SlabComm.exchange_state / reduce_* on device tensors.  Tiny volume => wall time per iteration = host."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29571")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import levelsetfusion_python_amd as lsf
+from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
+from levelsetfusion_python_amd.synthetic import sphere_pair
+
+
+class SelfComm(SlabComm):
+    """middle rank of three; both neighbours are this very rank"""
+    def native_identity(self):
+        return 0, 1, 0, 0
+
+    def exchange_state(self, state):
+        if os.environ.get("NO_EXCHANGE") == "1":
+            return
+        L = self.layout
+        h = L.halo
+        ops = [dist.P2POp(dist.isend, state[L.z_begin:L.z_begin + h], 0, self.group),
+               dist.P2POp(dist.irecv, state[L.z_begin - h:L.z_begin], 0, self.group),
+               dist.P2POp(dist.isend, state[L.z_end - h:L.z_end], 0, self.group),
+               dist.P2POp(dist.irecv, state[L.z_end:L.z_end + h], 0, self.group)]
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+iters = 200
+layout = SlabLayout(3 * n, 1, 3, 2)
+comm = SelfComm(layout)
+assert comm.active and not comm.stage_through_host
+sl = layout.local_slice()
+canonical, live0 = sphere_pair(n, 3, "cuda", (sl.start, sl.stop))
+print("transport:", "native RCCL (lsf_slab_state_iteration)" if comm.native() is not None else "torch.distributed",
+      flush=True)
+from levelsetfusion_python_amd.engine import SlavchevaEngine
+_orig = SlavchevaEngine._enqueue_state_iteration
+_host = [0.0, 0]
+def _timed(self, *a, **k):
+    t = time.perf_counter()
+    _orig(self, *a, **k)
+    _host[0] += time.perf_counter() - t
+    _host[1] += 1
+SlavchevaEngine._enqueue_state_iteration = _timed
+for fixed in (True, False):
+    kw = dict(maximum_warp_length_lower_threshold=0.0, max_iterations=iters, min_iterations=iters if fixed else 1)
+    opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING, check_interval=50,
+                                   comm=comm, **kw)
+    for rep in range(3):
+        live = live0.clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        opt.optimize(live, canonical)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print("%s: %d iterations, %.1f us per iteration (whole optimize %.2f ms)"
+              % ("fixed count (no per-iteration all-reduce)" if fixed else "gated (MAX all-reduce per iteration)",
+                 len(opt.log.max_warps), dt / max(len(opt.log.max_warps), 1) * 1e6, dt * 1e3), flush=True)
+        print("    host time inside the enqueue call: %.1f us per iteration" % (_host[0] / max(_host[1], 1) * 1e6))
+        _host[0], _host[1] = 0.0, 0
+comm.close()
+dist.destroy_process_group()
