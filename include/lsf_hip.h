@@ -343,6 +343,13 @@ typedef struct lsf_tsdf_params {
 int lsf_tsdf_generate_nearest(const uint16_t *depth_image, float *field, const lsf_grid *grid,
                               const lsf_tsdf_params *params, void *stream);
 
+/* the two bilinear 2-D variants: replaces tsdf/generation.py:78-128 (generate_2d_tsdf_field_from_depth_image_bilinear_
+ * image_space, method 1: blend the depth of the two pixels around the projection, one TSDF value) and :18-75
+ * (…_bilinear_tsdf_space, method 2 = FilteringMethod.BILINEAR_VOXEL_SPACE: a TSDF value per pixel, then blend); grid
+ * dims 2 only, out-of-image taps read 1 as in utils/sampling.py:35-55. */
+int lsf_tsdf_generate_bilinear(const uint16_t *depth_image, float *field, const lsf_grid *grid,
+                               const lsf_tsdf_params *params, int32_t method, void *stream);
+
 /* EWA filters: replaces tsdf/ewa.py:230-353 (generate_tsdf_2d_ewa_image, method 3), :358-481 (…_ewa_tsdf, method 4),
  * :485-624 (…_ewa_tsdf_inclusive, method 5) for grid dims 2, and :59-184 (generate_tsdf_3d_ewa_image, method 3) for
  * grid dims 3 -- there field[a][b][c] has world x on array axis 0 and the depth axis on array axis 2 (the reference's

@@ -141,6 +141,7 @@ PROTOTYPES = {
     "lsf_warp_statistics": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp, _vp]),
     "lsf_tsdf_difference_statistics": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp, _vp]),
     "lsf_tsdf_generate_nearest": (ctypes.c_int, [_vp, _vp, _P(Grid), _P(TsdfParams), _vp]),
+    "lsf_tsdf_generate_bilinear": (ctypes.c_int, [_vp, _vp, _P(Grid), _P(TsdfParams), _i32, _vp]),
     "lsf_tsdf_generate_ewa": (ctypes.c_int, [_vp, _vp, _P(Grid), _P(TsdfParams), _P(EwaParams), _vp]),
 }
 

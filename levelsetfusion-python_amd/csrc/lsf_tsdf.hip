@@ -19,6 +19,10 @@ struct TsdfParams {
     float default_value;
 };
 
+__device__ inline double tsdf_value(double sd, double half) {
+    return sd < -half ? -1.0 : (sd > half ? 1.0 : sd / half);
+}
+
 template <typename P>
 __device__ inline long long project(P f, float pc, P z, P c) {
     P v = ((f * (P)pc) / z + c) + (P)0.5;
@@ -56,6 +60,50 @@ __global__ __launch_bounds__(kBlock) void tsdf_nearest_kernel(const unsigned sho
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The two bilinear 2-D variants (tsdf/generation.py:18-75 "bilinear TSDF space", :78-128 "bilinear image space";
+// utils/sampling.py:110-175).  image_y_coordinate is an integer, so the reference's y ratio is exactly 0 and both
+// reduce to a blend of the taps (floor x, row) and (floor x + 1, row) along x:
+//   image space: blend the raw depth values (out-of-image tap = 1 depth unit, utils/sampling.py:35-55), skip voxels
+//                whose projection leaves the image and non-positive depths, then one TSDF value;
+//   TSDF space:  a TSDF value per tap (out-of-image tap = 1.0), then blend.
+// dtypes as numpy >= 2 evaluates the reference: ratio and 1 - ratio in the intrinsic matrix's dtype, products and sum
+// in float64, result stored float32 (oracle.tsdf_bilinear).
+template <typename P, int MODE>
+__global__ __launch_bounds__(kBlock) void tsdf_bilinear_kernel(const unsigned short* __restrict__ depth,
+                                                               float* __restrict__ field, Grid g, TsdfParams p) {
+    for_each_voxel(g, [&](int x, int y, int z) {
+        const int i = vidx(g, x, y, z);
+        float result = p.default_value;
+        const float xv = (float)((double)(x + p.off[0]) * p.voxel_size);
+        const float zv = (float)((double)(y + p.off[2]) * p.voxel_size);
+        const float pcx = ((p.e[0] * xv + p.e[1] * 0.0f) + p.e[2] * zv) + p.e[3] * 1.0f;
+        const float pcz = ((p.e[8] * xv + p.e[9] * 0.0f) + p.e[10] * zv) + p.e[11] * 1.0f;
+        if (pcz > 0.0f) {
+            const P ix = ((P)p.fx * (P)pcx) / (P)pcz + (P)p.cx;
+            const bool inside = ix >= (P)0 && ix < (P)p.width;
+            if (MODE == 2 || inside) {
+                const P fl = floor(ix);
+                const P ratio = ix - fl, inverse = (P)1 - ratio;
+                // saturate: a wild projection is out of the image anyway
+                const long long bx = fl > (P)-2147483000.0 && fl < (P)2147483000.0 ? (long long)fl : -2;
+                const unsigned short* row = depth + (long long)p.image_y * p.width;
+                const bool in0 = bx >= 0 && bx < p.width, in1 = bx + 1 >= 0 && bx + 1 < p.width;
+                const double d0 = in0 ? (double)row[bx] : 1.0, d1 = in1 ? (double)row[bx + 1] : 1.0;
+                if (MODE == 1) {
+                    const double d = (d0 * (double)inverse + d1 * (double)ratio) * p.depth_unit_ratio;
+                    if (d > 0.0) result = (float)tsdf_value(d - (double)pcz, p.half_width);
+                } else {
+                    const double t0 = in0 ? tsdf_value(d0 * p.depth_unit_ratio - (double)pcz, p.half_width) : 1.0;
+                    const double t1 = in1 ? tsdf_value(d1 * p.depth_unit_ratio - (double)pcz, p.half_width) : 1.0;
+                    result = (float)(t0 * (double)inverse + t1 * (double)ratio);
+                }
+            }
+        }
+        field[i] = result;
+    });
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // EWA filters (tsdf/ewa.py:59-184 3-D image space; :230-353, :358-481, :485-624 2-D image space / voxel space /
 // voxel space inclusive; math_utils/elliptical_gaussians.py:27-62,145-158).  Per voxel: project a spherical Gaussian
 // through the projection Jacobian into an image-space ellipse (+ unit pixel Gaussian), then average depth (image
@@ -68,10 +116,6 @@ struct EwaParams {
     float k[9];        // intrinsic matrix, row-major
     int method;        // 3 image space, 4 voxel space, 5 voxel space inclusive (FilteringMethod values)
 };
-
-__device__ inline double tsdf_value(double sd, double half) {
-    return sd < -half ? -1.0 : (sd > half ? 1.0 : sd / half);
-}
 
 template <int D>
 __global__ __launch_bounds__(kBlock) void tsdf_ewa_kernel(const unsigned short* __restrict__ depth,
@@ -206,6 +250,30 @@ extern "C" int lsf_tsdf_generate_ewa(const uint16_t* depth_image, float* field, 
         hipLaunchKernelGGL(tsdf_ewa_kernel<2>, dim3(blocks), dim3(kBlock), 0, as_stream(stream), d, field, g, p, q);
     else
         hipLaunchKernelGGL(tsdf_ewa_kernel<3>, dim3(blocks), dim3(kBlock), 0, as_stream(stream), d, field, g, p, q);
+    return launch_status();
+}
+
+extern "C" int lsf_tsdf_generate_bilinear(const uint16_t* depth_image, float* field, const lsf_grid* grid,
+                                          const lsf_tsdf_params* params, int32_t method, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!depth_image || !field || !params || grid->dims != 2 || (method != 1 && method != 2)) return LSF_ERR_BAD_ARGUMENT;
+    if (params->image_width <= 0 || params->image_height <= 0 || !(params->narrow_band_half_width > 0.0) ||
+        params->image_y_coordinate < 0 || params->image_y_coordinate >= params->image_height)
+        return LSF_ERR_BAD_ARGUMENT;
+    Grid g = make_grid(grid);
+    Tiling t = make_tiling(g);
+    if (t.total == 0) return 0;
+    const TsdfParams p = convert_params(params);
+    const unsigned blocks = launch_blocks(t.total);
+    hipStream_t s = as_stream(stream);
+    const unsigned short* d = reinterpret_cast<const unsigned short*>(depth_image);
+    if (params->intrinsics_are_f32) {
+        if (method == 1) hipLaunchKernelGGL((tsdf_bilinear_kernel<float, 1>), dim3(blocks), dim3(kBlock), 0, s, d, field, g, p);
+        else hipLaunchKernelGGL((tsdf_bilinear_kernel<float, 2>), dim3(blocks), dim3(kBlock), 0, s, d, field, g, p);
+    } else {
+        if (method == 1) hipLaunchKernelGGL((tsdf_bilinear_kernel<double, 1>), dim3(blocks), dim3(kBlock), 0, s, d, field, g, p);
+        else hipLaunchKernelGGL((tsdf_bilinear_kernel<double, 2>), dim3(blocks), dim3(kBlock), 0, s, d, field, g, p);
+    }
     return launch_status();
 }
 

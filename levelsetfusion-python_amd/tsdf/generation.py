@@ -38,7 +38,8 @@ class DepthCamera:
 
 
 def _generate(depth_image, camera, field_shape, image_y_coordinate, camera_extrinsic_matrix, default_value,
-              voxel_size, array_offset, narrow_band_width_voxels, ewa_method=None, gaussian_covariance_scale=1.0):
+              voxel_size, array_offset, narrow_band_width_voxels, ewa_method=None, gaussian_covariance_scale=1.0,
+              bilinear_method=None):
     dev.require_gpu()
     P = np.asarray(camera.intrinsics.intrinsic_matrix)
     if isinstance(depth_image, torch.Tensor):
@@ -68,6 +69,12 @@ def _generate(depth_image, camera, field_shape, image_y_coordinate, camera_extri
     params.intrinsics_are_f32 = int(P.dtype == np.float32)
     grid = dev.make_grid(field_shape)
     field = torch.empty(tuple(field_shape), dtype=torch.float32, device="cuda")
+    if bilinear_method is not None:
+        _lib.check(_lib.lib.lsf_tsdf_generate_bilinear(ctypes.c_void_p(depth.data_ptr()),
+                                                       ctypes.c_void_p(field.data_ptr()), ctypes.byref(grid),
+                                                       ctypes.byref(params), int(bilinear_method.value),
+                                                       dev.stream_ptr()), "lsf_tsdf_generate_bilinear")
+        return field
     if ewa_method is None:
         _lib.check(_lib.lib.lsf_tsdf_generate_nearest(ctypes.c_void_p(depth.data_ptr()),
                                                       ctypes.c_void_p(field.data_ptr()), ctypes.byref(grid),
@@ -101,6 +108,33 @@ def generate_2d_tsdf_field_from_depth_image_no_interpolation(depth_image, camera
     return f if as_tensor else f.cpu().numpy()
 
 
+def generate_2d_tsdf_field_from_depth_image_bilinear_image_space(depth_image, camera, image_y_coordinate,
+                                                                 camera_extrinsic_matrix=None, field_size=128,
+                                                                 default_value=1, voxel_size=0.004,
+                                                                 array_offset=np.array([-64, -64, 64]),
+                                                                 narrow_band_width_voxels=20,
+                                                                 back_cutoff_voxels=np.inf, as_tensor=False):
+    """depth blended between the two pixels around the voxel's projection, then one TSDF value
+    (tsdf/generation.py:78-128)"""
+    f = _generate(depth_image, camera, (field_size, field_size), image_y_coordinate, camera_extrinsic_matrix,
+                  default_value, voxel_size, array_offset, narrow_band_width_voxels,
+                  bilinear_method=FilteringMethod.BILINEAR_IMAGE_SPACE)
+    return f if as_tensor else f.cpu().numpy()
+
+
+def generate_2d_tsdf_field_from_depth_image_bilinear_tsdf_space(depth_image, camera, image_y_coordinate,
+                                                                camera_extrinsic_matrix=None, field_size=128,
+                                                                default_value=1, voxel_size=0.004,
+                                                                array_offset=np.array([-64, -64, 64]),
+                                                                narrow_band_width_voxels=20,
+                                                                back_cutoff_voxels=np.inf, as_tensor=False):
+    """a TSDF value per pixel around the voxel's projection, then blended (tsdf/generation.py:18-75)"""
+    f = _generate(depth_image, camera, (field_size, field_size), image_y_coordinate, camera_extrinsic_matrix,
+                  default_value, voxel_size, array_offset, narrow_band_width_voxels,
+                  bilinear_method=FilteringMethod.BILINEAR_VOXEL_SPACE)
+    return f if as_tensor else f.cpu().numpy()
+
+
 def generate_2d_tsdf_field_from_depth_image(depth_image, camera, image_y_coordinate, camera_extrinsic_matrix=None,
                                             field_size=128, default_value=1, voxel_size=0.004,
                                             array_offset=np.array([-64, -64, 64]), narrow_band_width_voxels=20,
@@ -115,8 +149,11 @@ def generate_2d_tsdf_field_from_depth_image(depth_image, camera, image_y_coordin
                       default_value, voxel_size, array_offset, narrow_band_width_voxels, interpolation_method,
                       smoothing_coefficient)
         return f if as_tensor else f.cpu().numpy()
-    if interpolation_method != FilteringMethod.NONE:
-        raise NotImplementedError("%s is not built (nearest-pixel and EWA filters only)" % interpolation_method)
+    if interpolation_method in (FilteringMethod.BILINEAR_IMAGE_SPACE, FilteringMethod.BILINEAR_VOXEL_SPACE):
+        f = _generate(depth_image, camera, (field_size, field_size), image_y_coordinate, camera_extrinsic_matrix,
+                      default_value, voxel_size, array_offset, narrow_band_width_voxels,
+                      bilinear_method=interpolation_method)
+        return f if as_tensor else f.cpu().numpy()
     return generate_2d_tsdf_field_from_depth_image_no_interpolation(
         depth_image, camera, image_y_coordinate, camera_extrinsic_matrix, field_size, default_value, voxel_size,
         array_offset, narrow_band_width_voxels, back_cutoff_voxels, as_tensor)

@@ -770,6 +770,64 @@ def tsdf_nearest(depth_image, intrinsic_matrix, depth_unit_ratio, field_shape, i
     return field
 
 
+def tsdf_bilinear(depth_image, intrinsic_matrix, depth_unit_ratio, field_size, image_y_coordinate, tsdf_space,
+                  camera_extrinsic_matrix=None, default_value=1, voxel_size=0.004, array_offset=(-64, -64, 64),
+                  narrow_band_width_voxels=20):
+    """the two bilinear 2-D generators: tsdf/generation.py:78-128 (image space, tsdf_space=False) and :18-75 (TSDF
+    space, tsdf_space=True) with utils/sampling.py:110-175.  image_y_coordinate is an integer, so the y ratio is
+    exactly 0 and only the taps (floor x, row), (floor x + 1, row) carry weight; out-of-image taps read 1 (one raw
+    depth unit / TSDF value 1.0).  dtypes as numpy >= 2 evaluates the reference: projection, ratio and 1 - ratio in the
+    intrinsic matrix's dtype, the blend and the signed distance in float64, result stored float32."""
+    P = np.asarray(intrinsic_matrix)
+    ptype = np.float32 if P.dtype == np.float32 else np.float64
+    E = np.eye(4, dtype=F32) if camera_extrinsic_matrix is None else np.asarray(camera_extrinsic_matrix, dtype=F32)
+    shape = (field_size, field_size)
+    field = np.full(shape, default_value, dtype=F32)
+    half = narrow_band_width_voxels / 2 * voxel_size
+    off = [int(o) for o in array_offset]
+    yy, xx = np.meshgrid(np.arange(field_size, dtype=np.int64), np.arange(field_size, dtype=np.int64), indexing="ij")
+    xv = ((xx + off[0]) * voxel_size).astype(F32)
+    yv = np.zeros(shape, dtype=F32)
+    zv = ((yy + off[2]) * voxel_size).astype(F32)
+    one = F32(1.0)
+
+    def row(i):
+        return ((((E[i, 0] * xv).astype(F32) + (E[i, 1] * yv).astype(F32)).astype(F32)
+                 + (E[i, 2] * zv).astype(F32)).astype(F32) + (E[i, 3] * one)).astype(F32)
+
+    pcx, pcz = row(0), row(2)
+    ok = pcz > 0
+    safe_z = np.where(ok, pcz, one).astype(ptype)
+    h, w = depth_image.shape
+    with np.errstate(invalid="ignore", over="ignore"):
+        ix = (((P[0, 0].astype(ptype) * pcx.astype(ptype)).astype(ptype) / safe_z).astype(ptype)
+              + P[0, 2].astype(ptype)).astype(ptype)
+        fl = np.floor(ix)
+        ratio = (ix - fl).astype(ptype)
+        inverse = (ptype(1.0) - ratio).astype(ptype)
+        bx = np.where(np.abs(fl) < 2.0e9, fl, -2.0).astype(np.int64)
+    in0, in1 = (bx >= 0) & (bx < w), (bx + 1 >= 0) & (bx + 1 < w)
+    image_row = depth_image[int(image_y_coordinate)].astype(np.float64)
+    d0 = np.where(in0, image_row[np.clip(bx, 0, w - 1)], 1.0)
+    d1 = np.where(in1, image_row[np.clip(bx + 1, 0, w - 1)], 1.0)
+    pz = pcz.astype(np.float64)
+
+    def tsdf_of(sd):
+        return np.where(sd < -half, -1.0, np.where(sd > half, 1.0, sd / half))
+
+    if tsdf_space:
+        t0 = np.where(in0, tsdf_of(d0 * depth_unit_ratio - pz), 1.0)
+        t1 = np.where(in1, tsdf_of(d1 * depth_unit_ratio - pz), 1.0)
+        value = t0 * inverse.astype(np.float64) + t1 * ratio.astype(np.float64)
+    else:
+        ok &= (ix >= 0) & (ix < w)
+        depth = (d0 * inverse.astype(np.float64) + d1 * ratio.astype(np.float64)) * depth_unit_ratio
+        ok &= depth > 0.0
+        value = tsdf_of(depth - pz)
+    field[ok] = value[ok].astype(F32)
+    return field
+
+
 def synthetic_depth_image(shift_px=0.0, nearer_m=0.0, width=640, height=480):
     """SURVEY 8(d) 'depth->TSDF' input: a plane at ~1 m with a sinusoidal bump, uint16 millimetres"""
     v, u = np.meshgrid(np.arange(height, dtype=np.float64), np.arange(width, dtype=np.float64), indexing="ij")

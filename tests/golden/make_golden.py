@@ -364,6 +364,20 @@ def tsdf():
     out["d0.row240.n32.default0"] = gen_mod.generate_2d_tsdf_field_from_depth_image(
         d0, cam, 240, field_size=32, default_value=0, array_offset=np.array([-16, -16, 234]),
         narrow_band_width_voxels=10)
+    # the two bilinear 2-D generators (tsdf/generation.py:18-128): float32 and float64 intrinsics, a row band whose
+    # right-most voxels project past the image border (offset +150 voxels in x), default value 0
+    for tag, d in (("d0", d0), ("d1", d1)):
+        for name, fn in (("bilinear_image", gen_mod.generate_2d_tsdf_field_from_depth_image_bilinear_image_space),
+                         ("bilinear_tsdf", gen_mod.generate_2d_tsdf_field_from_depth_image_bilinear_tsdf_space)):
+            out["%s.%s.row240.n32" % (tag, name)] = fn(d, cam, 240, field_size=32,
+                                                       array_offset=np.array([-16, -16, 234]))
+    for name, fn in (("bilinear_image", gen_mod.generate_2d_tsdf_field_from_depth_image_bilinear_image_space),
+                     ("bilinear_tsdf", gen_mod.generate_2d_tsdf_field_from_depth_image_bilinear_tsdf_space)):
+        out["d0.%s.row200.n32.k64" % name] = fn(d0, cam64, 200, field_size=32, array_offset=np.array([-16, -16, 234]))
+        out["d0.%s.row240.n32.border" % name] = fn(d0, cam, 240, field_size=32, default_value=0,
+                                                   array_offset=np.array([90, -16, 234]), narrow_band_width_voxels=10)
+        out["d0.%s.row240.n32.extrinsic" % name] = fn(d0, cam, 240, camera_extrinsic_matrix=E, field_size=32,
+                                                      array_offset=np.array([-16, -16, 234]))
     np.savez_compressed(os.path.join(HERE, "ref_tsdf.npz"), **out)
     print("ref_tsdf.npz:", len(out), "arrays")
 

@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import lsf_oracle as O
-from tests.test_oracle_golden import _tsdf_cases, maxdiff
+from tests.test_oracle_golden import _tsdf_bilinear_cases, _tsdf_cases, maxdiff
 
 pytestmark = pytest.mark.gpu
 
@@ -37,6 +37,33 @@ def test_tsdf_nearest_matches_oracle_and_reference(gen, ref_tsdf):
         assert maxdiff(got, ref_tsdf[key]) <= (2.5e-6 if "extrinsic" in key else 0.0), key
 
 
+def test_tsdf_bilinear_matches_oracle_and_reference(gen, ref_tsdf):
+    """the two bilinear 2-D generators (tsdf/generation.py:18-128) through the dispatcher and by name: bit-identical to
+    the oracle, and to the reference's own outputs (general extrinsics: within the matvec-order tolerance)"""
+    for key, depth, K, tsdf_space, row, kw in _tsdf_bilinear_cases(ref_tsdf):
+        cam = gen.DepthCamera(intrinsic_matrix=K, depth_unit_ratio=0.001)
+        common = dict(camera_extrinsic_matrix=kw.get("camera_extrinsic_matrix"), field_size=32,
+                      default_value=kw.get("default_value", 1), array_offset=np.array(kw["array_offset"]),
+                      narrow_band_width_voxels=kw.get("narrow_band_width_voxels", 20))
+        method = gen.FilteringMethod.BILINEAR_VOXEL_SPACE if tsdf_space else gen.FilteringMethod.BILINEAR_IMAGE_SPACE
+        got = gen.generate_2d_tsdf_field_from_depth_image(depth, cam, row, interpolation_method=method, **common)
+        named = (gen.generate_2d_tsdf_field_from_depth_image_bilinear_tsdf_space if tsdf_space
+                 else gen.generate_2d_tsdf_field_from_depth_image_bilinear_image_space)(depth, cam, row, **common)
+        assert got.dtype == np.float32 and got.shape == (32, 32) and np.array_equal(got, named)
+        assert maxdiff(got, O.tsdf_bilinear(depth, K, 0.001, 32, row, tsdf_space, **kw)) == 0.0, key
+        assert maxdiff(got, ref_tsdf[key]) <= (2.5e-6 if "extrinsic" in key else 0.0), key
+    # a larger slice, both modes, against the oracle
+    d = O.synthetic_depth_image(shift_px=1.0)
+    K = ref_tsdf["intrinsics"]
+    cam = gen.DepthCamera(intrinsic_matrix=K, depth_unit_ratio=0.001)
+    for tsdf_space in (False, True):
+        method = gen.FilteringMethod.BILINEAR_VOXEL_SPACE if tsdf_space else gen.FilteringMethod.BILINEAR_IMAGE_SPACE
+        got = gen.generate_2d_tsdf_field_from_depth_image(d, cam, 100, field_size=200, interpolation_method=method,
+                                                          array_offset=np.array([-100, -100, 150]))
+        want = O.tsdf_bilinear(d, K, 0.001, 200, 100, tsdf_space, array_offset=(-100, -100, 150))
+        assert maxdiff(got, want) == 0.0 and int((np.abs(want) < 1).sum()) > 2000
+
+
 def test_tsdf_larger_volume_and_edge_cases(gen):
     K = np.array([[700., 0., 320.], [0., 700., 240.], [0., 0., 1.]], dtype=np.float32)
     depth = O.synthetic_depth_image()
@@ -52,9 +79,6 @@ def test_tsdf_larger_volume_and_edge_cases(gen):
     assert np.all(outside == 1.0)
     with pytest.raises(ValueError):
         gen.generate_3d_tsdf_field_from_depth_image(depth.astype(np.float32), gen.DepthCamera(intrinsic_matrix=K))
-    with pytest.raises(NotImplementedError):
-        gen.generate_2d_tsdf_field_from_depth_image(depth, gen.DepthCamera(intrinsic_matrix=K), 240,
-                                                    interpolation_method=gen.FilteringMethod.BILINEAR_VOXEL_SPACE)
     with pytest.raises(ValueError):
         gen.generate_2d_tsdf_field_from_depth_image(depth, gen.DepthCamera(intrinsic_matrix=K), 240,
                                                     interpolation_method="NONE")
@@ -110,6 +134,3 @@ def test_tsdf_ewa_matches_oracle_and_reference(gen, ref_ewa):
                                                       interpolation_method=gen.FilteringMethod.EWA_VOXEL_SPACE,
                                                       smoothing_coefficient=0.5)
     assert maxdiff(got, ref_ewa[key]) <= 4e-6
-    with pytest.raises(NotImplementedError):
-        gen.generate_2d_tsdf_field_from_depth_image(depth, cam, 200,
-                                                    interpolation_method=gen.FilteringMethod.BILINEAR_IMAGE_SPACE)

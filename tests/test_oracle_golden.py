@@ -333,6 +333,34 @@ def test_tsdf_nearest_matches_reference(ref_tsdf):
     assert n_band > 3000
 
 
+def _tsdf_bilinear_cases(G):
+    """(key, depth, intrinsics, tsdf_space, row, kwargs of oracle.tsdf_bilinear) for every bilinear fixture"""
+    K, E = G["intrinsics"], G["extrinsic"]
+    d0, d1 = O.synthetic_depth_image(), O.synthetic_depth_image(shift_px=2.0, nearer_m=0.008)
+    cases = []
+    for key in sorted(k for k in G.files if "bilinear" in k):
+        parts = key.split(".")
+        kw = dict(array_offset=(-16, -16, 234))
+        if "border" in key:  # the right-most voxels project past the image border
+            kw = dict(array_offset=(90, -16, 234), default_value=0, narrow_band_width_voxels=10)
+        if "extrinsic" in key:
+            kw["camera_extrinsic_matrix"] = E
+        cases.append((key, d0 if parts[0] == "d0" else d1, K.astype(np.float64) if "k64" in key else K,
+                      parts[1] == "bilinear_tsdf", int(parts[2][3:]), kw))
+    assert len(cases) == 10
+    return cases
+
+
+def test_tsdf_bilinear_matches_reference(ref_tsdf):
+    """tsdf/generation.py:18-128 (bilinear image space / TSDF space) run by the reference itself"""
+    for key, depth, K, tsdf_space, row, kw in _tsdf_bilinear_cases(ref_tsdf):
+        got = O.tsdf_bilinear(depth, K, 0.001, 32, row, tsdf_space, **kw)
+        assert maxdiff(got, ref_tsdf[key]) <= (2.5e-6 if "extrinsic" in key else 0.0), key
+        assert int((np.abs(ref_tsdf[key]) < 1).sum()) > 150, key
+    border = ref_tsdf["d0.bilinear_image.row240.n32.border"]
+    assert int((border == 0).sum()) > 100  # voxels whose projection left the image kept the default value
+
+
 # ------------------------------------------------------------------------------------ a21 EWA TSDF generation
 def _banded_image(rows, band):
     img = np.full((480, 640), np.iinfo(np.uint16).max, dtype=np.uint16)
