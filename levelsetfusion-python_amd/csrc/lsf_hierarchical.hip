@@ -72,18 +72,34 @@ __device__ inline Packed gather_packed(const float4* __restrict__ s, const Grid&
 
 // scipy.ndimage.laplace(mode='nearest') of one plane at (x,y,z): per-axis second differences evaluated in
 // double and stored float32, summed in float32, slowest axis first (oracle.laplace_replicate)
-template <int D>
-__device__ inline float laplace_replicate(const float* __restrict__ a, const Grid& g, int x, int y, int z) {
+// ENERGY: also adds this plane's share of the reference's "tikhonov energy" printout to *energy -- the sum over the
+// axes of np.gradient(previous gradient)^2 (hierarchical_optimizer2d.py:204-210; central differences inside, one-sided
+// at the border: the clamped neighbour is the centre there)
+template <int D, bool ENERGY>
+__device__ inline float laplace_replicate(const float* __restrict__ a, const Grid& g, int x, int y, int z,
+                                          double* energy) {
     // neighbours are read from CLAMPED offsets (a missing neighbour IS the centre in mode='nearest'): unconditional
     // loads the compiler can issue together, instead of one exec-masked load + wait per neighbour
     const int i = vidx(g, x, y, z);
     const float a0 = a[i];
     const int sy = g.nx, sz = g.nx * g.ny;
     float out;
-    float d2y = second_difference_f64(a[i - (y > 0 ? sy : 0)], a0, a[i + (y < g.ny - 1 ? sy : 0)]);
-    float d2x = second_difference_f64(a[i - (x > 0 ? 1 : 0)], a0, a[i + (x < g.nx - 1 ? 1 : 0)]);
+    const float ym = a[i - (y > 0 ? sy : 0)], yp = a[i + (y < g.ny - 1 ? sy : 0)];
+    const float xm = a[i - (x > 0 ? 1 : 0)], xp = a[i + (x < g.nx - 1 ? 1 : 0)];
+    float d2y = second_difference_f64(ym, a0, yp);
+    float d2x = second_difference_f64(xm, a0, xp);
+    if (ENERGY) {
+        const float gy = (y > 0 && y < g.ny - 1) ? (yp - ym) * 0.5f : (g.ny > 1 ? yp - ym : 0.0f);
+        const float gx = (x > 0 && x < g.nx - 1) ? (xp - xm) * 0.5f : (g.nx > 1 ? xp - xm : 0.0f);
+        *energy += (double)(gy * gy) + (double)(gx * gx);
+    }
     if (D == 3) {
-        float d2z = second_difference_f64(a[i - (z > 0 ? sz : 0)], a0, a[i + (z < g.nz - 1 ? sz : 0)]);
+        const float zm = a[i - (z > 0 ? sz : 0)], zp = a[i + (z < g.nz - 1 ? sz : 0)];
+        float d2z = second_difference_f64(zm, a0, zp);
+        if (ENERGY) {
+            const float gz = (z > 0 && z < g.nz - 1) ? (zp - zm) * 0.5f : (g.nz > 1 ? zp - zm : 0.0f);
+            *energy += (double)(gz * gz);
+        }
         out = d2z + d2y;
     } else {
         out = d2y;
@@ -101,7 +117,7 @@ __global__ __launch_bounds__(kBlock) void hier_iteration_kernel(const float4* __
                                                                 lsf_iteration_record* record) {
     if (gate_closed(gate)) return;
     unsigned long long best = 0ull;
-    double sums[1] = {0.0};
+    double sums[2] = {0.0, 0.0};  // data energy sum(diff^2); tikhonov energy sum |np.gradient(previous gradient)|^2
     for_each_voxel(g, [&](int x, int y, int z) {
         const int i = vidx(g, x, y, z);
         float w[3];
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(kBlock) void hier_iteration_kernel(const float4* __
         for (int c = 0; c < D; ++c) {
             float gd = diff * live_grad[c];
             if (TIK) {
-                float lap = laplace_replicate<D>(g_prev + c * g.plane, g, x, y, z);
+                float lap = laplace_replicate<D, ENERGY>(g_prev + c * g.plane, g, x, y, z, &sums[1]);
                 gv[c] = amp * gd - strength * lap;
             } else {
                 gv[c] = amp * gd;
@@ -134,8 +150,9 @@ __global__ __launch_bounds__(kBlock) void hier_iteration_kernel(const float4* __
         if (ENERGY) sums[0] += (double)diff * (double)diff;
     });
     if (UPDATE || ENERGY) {
-        double* dst[1] = {ENERGY ? &record_slot(record)->data_energy : nullptr};
-        block_reduce_commit<1>(best, sums, UPDATE ? record_max(record) : nullptr, dst);
+        double* dst[2] = {ENERGY ? &record_slot(record)->data_energy : nullptr,
+                          ENERGY && TIK ? &record_slot(record)->smoothing_energy : nullptr};
+        block_reduce_commit<2>(best, sums, UPDATE ? record_max(record) : nullptr, dst);
     }
 }
 

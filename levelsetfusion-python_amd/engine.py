@@ -50,8 +50,9 @@ def _conv_axis_order(dims):
 
 
 class LevelResult:
-    def __init__(self, iteration_count, max_updates, argmax, data_energies, voxel_count=0):
+    def __init__(self, iteration_count, max_updates, argmax, data_energies, voxel_count=0, tikhonov_energies=()):
         self.voxel_count = voxel_count
+        self.tikhonov_energies = list(tikhonov_energies)  # sum |np.gradient(previous gradient)|^2 per iteration
         self.iteration_count = iteration_count
         self.max_updates = max_updates
         self.argmax = argmax
@@ -254,7 +255,8 @@ class HierarchicalEngine:
         n_vox = dev.n_voxels(lv.grid) if slab_layout is None else slab_layout.nz_global * lv.grid.ny * lv.grid.nx
         res = LevelResult(n_exec, [float(v) for v in dec["max_value"][:n_exec]],
                           [int(v) for v in dec["argmax"][:n_exec]],
-                          [float(v) for v in dec["data_energy"][:n_exec]], n_vox)
+                          [float(v) for v in dec["data_energy"][:n_exec]], n_vox,
+                          [float(v) for v in dec["smoothing_energy"][:n_exec]])
         res.iteration_limit_reached = n_exec >= self.maximum_iteration_count
         self.level_results.append(res)
         self.last_gradient = self._final_gradient(lv, n_exec)

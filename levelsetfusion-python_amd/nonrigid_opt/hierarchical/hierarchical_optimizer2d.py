@@ -47,7 +47,8 @@ class _HierarchicalOptimizerBase:
             tikhonov_term_enabled, gradient_kernel_enabled, maximum_chunk_size, rate, maximum_iteration_count,
             maximum_warp_update_threshold, data_term_amplifier, tikhonov_strength,
             None if kernel is None else np.asarray(kernel, dtype=np.float64),
-            compute_energy=bool(getattr(self.verbosity_parameters, "print_iteration_data_energy", False)),
+            compute_energy=bool(getattr(self.verbosity_parameters, "print_iteration_data_energy", False)
+                                or getattr(self.verbosity_parameters, "print_iteration_tikhonov_energy", False)),
             check_interval=check_interval,
             collect_reports=self.logging_parameters.collect_per_level_convergence_reports, comm=comm,
             collect_iteration_data=self.logging_parameters.collect_per_level_iteration_data,
@@ -120,6 +121,9 @@ class _HierarchicalOptimizerBase:
                     line += " max upd. l.: %f" % r.max_updates[it]
                 if vp.print_iteration_data_energy:
                     line += " norm. data energy: %f" % (1000000.0 * r.data_energies[it] / max(r.voxel_count, 1))
+                if vp.print_iteration_tikhonov_energy and self._engine.tikhonov_term_enabled:  # :204-210,:237-238
+                    line += " norm. tikhonov energy: %f" % (1000000.0 * 0.5 * r.tikhonov_energies[it]
+                                                            / max(r.voxel_count, 1))
                 print(line)
             print("[LEVEL %d COMPLETED]" % level)
 

@@ -319,6 +319,10 @@ class HierarchicalOracle:
         self.maximum_iteration_count = maximum_iteration_count
         self.per_level_iteration_counts = []
         self.per_level_max_updates = []
+        # float64 sums behind the reference's optional printouts (hierarchical_optimizer2d.py:204-210,233-238):
+        # normalised data energy = 1e6 * sum / N, normalised tikhonov energy = 1e6 * 0.5 * sum / N
+        self.per_level_data_energy_sums = []
+        self.per_level_tikhonov_energy_sums = []
         self.iteration_hook = None  # f(level, iteration, warp, gradient, max_update)
 
     def iteration(self, canonical, live, live_grads, warp, g_prev):
@@ -328,7 +332,11 @@ class HierarchicalOracle:
         diff = (resampled - canonical).astype(F32)
         comps = [(diff * warp_field_replacement(g, warp, 0.0)).astype(F32) for g in live_grads]
         data_gradient = np.stack(comps, axis=-1)
+        self._tikhonov_energy_sum = 0.0
         if self.tikhonov_term_enabled:
+            for c in range(g_prev.shape[-1]):  # np.gradient of every component of the previous gradient, squared
+                for d_axis in gradient(np.ascontiguousarray(g_prev[..., c])):
+                    self._tikhonov_energy_sum += float((d_axis.astype(F32) ** 2).astype(np.float64).sum())
             tik = np.stack([laplace_replicate(g_prev[..., c]) for c in range(g_prev.shape[-1])], axis=-1)
             g = (F32(self.data_term_amplifier) * data_gradient - F32(self.tikhonov_strength) * tik).astype(F32)
         else:
@@ -344,15 +352,19 @@ class HierarchicalOracle:
         g = np.zeros_like(warp)
         max_update = float(np.finfo(np.float32).max)
         it = 0
-        maxes = []
+        maxes, data_sums, tik_sums = [], [], []
         while not (max_update < self.maximum_warp_update_threshold or it >= self.maximum_iteration_count):
-            g, max_update, _ = self.iteration(canonical, live, live_grads, warp, g)
+            g, max_update, diff = self.iteration(canonical, live, live_grads, warp, g)
             maxes.append(max_update)
+            data_sums.append(float((diff.astype(np.float64) ** 2).sum()))
+            tik_sums.append(self._tikhonov_energy_sum)
             if self.iteration_hook is not None:
                 self.iteration_hook(level, it, warp, g, max_update)
             it += 1
         self.per_level_iteration_counts.append(it)
         self.per_level_max_updates.append(maxes)
+        self.per_level_data_energy_sums.append(data_sums)
+        self.per_level_tikhonov_energy_sums.append(tik_sums)
         return warp
 
     def optimize(self, canonical_field, live_field):
@@ -366,6 +378,8 @@ class HierarchicalOracle:
         grad_pyrs = [pyramid(g, self.maximum_chunk_size, lin) for g in grads]
         self.per_level_iteration_counts = []
         self.per_level_max_updates = []
+        self.per_level_data_energy_sums = []
+        self.per_level_tikhonov_energy_sums = []
         warp = None
         n_levels = len(canonical_pyr)
         for level in range(n_levels):

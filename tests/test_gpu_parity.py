@@ -522,6 +522,33 @@ def test_slavcheva_band_list_all_zero_update_reports_first_voxel(lsf):
     assert dec["max_value"][0] == 0.0 and dec["argmax"][0] == (1 + 5) * 8 * 70
 
 
+def test_hierarchical_energy_printouts(lsf, capsys):
+    """VerbosityParameters(print_iteration_data_energy, print_iteration_tikhonov_energy): the sums behind the reference's
+    per-iteration printouts (hierarchical_optimizer2d.py:204-210, 233-238) are accumulated by the iteration kernel; 2-D
+    (graph-replayed levels) and 3-D against the oracle's float64 sums, and the printed line format"""
+    for d, n in ((2, 64), (3, 32)):
+        canon, live = O.sphere_pair(n, d)
+        kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=8, rate=0.1,
+                  maximum_iteration_count=6, maximum_warp_update_threshold=0.0, tikhonov_strength=0.05)
+        cls = lsf.HierarchicalOptimizer2d if d == 2 else lsf.HierarchicalOptimizer3d
+        vp = cls.VerbosityParameters(print_max_warp_update=True, print_iteration_data_energy=True,
+                                     print_iteration_tikhonov_energy=True)
+        opt = cls(verbosity_parameters=vp, **kw)
+        warp = opt.optimize(canon, live)
+        o = O.HierarchicalOracle(**kw)
+        assert maxdiff(warp, o.optimize(canon, live)) == EXACT
+        results = opt._engine.level_results
+        assert len(results) == len(o.per_level_data_energy_sums)
+        for r, want_data, want_tik in zip(results, o.per_level_data_energy_sums, o.per_level_tikhonov_energy_sums):
+            assert np.allclose(r.data_energies, want_data, rtol=1e-9, atol=0.0)
+            assert np.allclose(r.tikhonov_energies, want_tik, rtol=1e-6, atol=1e-30)
+            assert r.tikhonov_energies[0] == 0.0 and r.tikhonov_energies[-1] > 0.0  # zero previous gradient at level start
+        printed = capsys.readouterr().out
+        last = results[-1]
+        want = " norm. tikhonov energy: %f" % (1000000.0 * 0.5 * last.tikhonov_energies[-1] / last.voxel_count)
+        assert want in printed and " norm. data energy: " in printed and " max upd. l.: " in printed
+
+
 def test_state_pack_unpack_finalize(lsf):
     """lsf_state_pack / lsf_state_unpack round trip (2-D and 3-D, ragged extents, z-ranges) and lsf_state_finalize:
     fields equal the unpacked ones, statistics equal those of the two stand-alone statistics kernels (a20)"""
