@@ -49,6 +49,10 @@ typedef struct lsf_grid {
     int32_t z_begin, z_end;  /* slices processed by the launch, 0 <= z_begin <= z_end <= nz */
     int32_t z_global_offset; /* global z of local slice 0 (for reported voxel indices) */
     int32_t reserved;
+    /* lsf_slavcheva_state_iteration only: energies are accumulated for slices in [energy_z_begin, energy_z_end) --
+     * a z-slab launch that recomputes halo slices must not count them twice.
+     * energy_z_end <= energy_z_begin (e.g. both 0): every slice of the launch counts. */
+    int32_t energy_z_begin, energy_z_end;
 } lsf_grid;
 
 /* per-iteration reduction record written by the iteration kernels (one record per iteration).
@@ -278,6 +282,10 @@ int lsf_slavcheva_state_iteration(const float *state_in, const float *canonical,
  *   2. the exchange of those slices of state_out with the neighbours -- ncclSend / ncclRecv in one group on the
  *      communicator's own HIP stream (RCCL over xGMI), each face one contiguous run of halo * ny * nx float4 --
  *   3. while the interior parts run on `stream`; 4. `stream` then waits for the halos.
+ * Exchange groups: with a halo of k slices the faces need to travel only every k-th iteration when the iterations in
+ * between recompute the neighbours' slices they still have valid inputs for (iteration j of a group runs over the owned
+ * range widened by k - 1 - j slices, energies limited to the owned range by lsf_grid::energy_z_*; each iteration
+ * consumes one slice of validity while every warp update stays below one voxel).  Those iterations pass exchange = 0.
  * RCCL is bound with dlopen (rccl_library_path, else "librccl.so" as already mapped into the process).
  * Communicator: rank 0 calls lsf_slab_unique_id, the 128 bytes travel to the other ranks by any means (the Python side
  * broadcasts them with torch.distributed), every rank calls lsf_slab_comm_create on its current device. */
@@ -304,6 +312,7 @@ int lsf_slab_state_iteration(lsf_slab_comm *comm, const float *state_in, const f
                              const lsf_slab_layout *layout, const lsf_slab_part *boundary_parts, int32_t n_boundary,
                              const lsf_slab_part *interior_parts, int32_t n_interior,
                              const lsf_slavcheva_params *params, const lsf_gate *gate, lsf_iteration_record *record,
+                             int32_t exchange /* 0: launches only (an iteration inside an exchange group) */,
                              void *stream);
 
 int lsf_slavcheva_update_rewarp(const float *live, const float *canonical, float *g_planar /* inout */,

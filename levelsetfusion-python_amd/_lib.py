@@ -30,7 +30,7 @@ GATE_HIERARCHICAL, GATE_SLAVCHEVA = 0, 1
 class Grid(ctypes.Structure):
     _fields_ = [("dims", ctypes.c_int32), ("nz", ctypes.c_int32), ("ny", ctypes.c_int32), ("nx", ctypes.c_int32),
                 ("z_begin", ctypes.c_int32), ("z_end", ctypes.c_int32), ("z_global_offset", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("reserved", ctypes.c_int32), ("energy_z_begin", ctypes.c_int32), ("energy_z_end", ctypes.c_int32)]
 
 
 BAND_ALL, BAND_INTERIOR, BAND_BOUNDARY = 0, 1, 2
@@ -135,7 +135,7 @@ PROTOTYPES = {
     "lsf_slab_comm_create": (ctypes.c_int, [ctypes.c_char_p, _vp, _i32, _i32, _P(_vp)]),
     "lsf_slab_comm_destroy": (ctypes.c_int, [_vp]),
     "lsf_slab_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(SlabLayoutC), _P(SlabPart), _i32, _P(SlabPart),
-                                                _i32, _P(SlavchevaParams), _P(Gate), _vp, _vp]),
+                                                _i32, _P(SlavchevaParams), _P(Gate), _vp, _i32, _vp]),
     "lsf_slavcheva_update_rewarp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),
                                                    _P(Gate), _vp, _vp]),
     "lsf_warp_statistics": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp, _vp]),

@@ -120,14 +120,17 @@ __global__ __launch_bounds__(kBlock) void hier_iteration_kernel(const float4* __
     double sums[2] = {0.0, 0.0};  // data energy sum(diff^2); tikhonov energy sum |np.gradient(previous gradient)|^2
     for_each_voxel(g, [&](int x, int y, int z) {
         const int i = vidx(g, x, y, z);
+        // streamed once per iteration (warp, canonical, the gradient written): non-temporal, so that they do not push
+        // the REUSED lines -- the packed field's z + 1 slice and the previous gradient's z -/+ 1 slices, needed again
+        // one slice later -- out of the 4 MB L2 (a 256^2 slice of everything is 4.3 MB)
         float w[3];
-        w[0] = warp[i];
-        w[1] = warp[g.plane + i];
-        w[2] = D == 3 ? warp[2 * g.plane + i] : 0.0f;
+        w[0] = __builtin_nontemporal_load(warp + i);
+        w[1] = __builtin_nontemporal_load(warp + g.plane + i);
+        w[2] = D == 3 ? __builtin_nontemporal_load(warp + 2 * g.plane + i) : 0.0f;
         const float px = (float)x + w[0], py = (float)y + w[1];
         const float pz = D == 3 ? (float)(z + g.z_global_offset) + w[2] : 0.0f;
         const Packed s = gather_packed<D>(packed, g, px, py, pz);
-        const float diff = s.l - canonical[i];
+        const float diff = s.l - __builtin_nontemporal_load(canonical + i);
         const float live_grad[3] = {s.gx, s.gy, s.gz};
         float gv[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -139,11 +142,11 @@ __global__ __launch_bounds__(kBlock) void hier_iteration_kernel(const float4* __
             } else {
                 gv[c] = amp * gd;
             }
-            if (g_out) g_out[c * g.plane + i] = gv[c];
+            if (g_out) __builtin_nontemporal_store(gv[c], g_out + c * g.plane + i);
         }
         if (UPDATE) {
 #pragma unroll
-            for (int c = 0; c < D; ++c) warp[c * g.plane + i] = w[c] - rate * gv[c];
+            for (int c = 0; c < D; ++c) __builtin_nontemporal_store(w[c] - rate * gv[c], warp + c * g.plane + i);
             unsigned long long p = pack_max(vec_length<D>(gv), linear_index(g, x, y, z));
             best = p > best ? p : best;
         }

@@ -175,7 +175,13 @@ extern "C" int lsf_slab_state_iteration(lsf_slab_comm* comm, const float* state_
                                         const lsf_slab_part* boundary_parts, int32_t n_boundary,
                                         const lsf_slab_part* interior_parts, int32_t n_interior,
                                         const lsf_slavcheva_params* params, const lsf_gate* gate,
-                                        lsf_iteration_record* record, void* stream) {
+                                        lsf_iteration_record* record, int32_t exchange, void* stream) {
+    if (!exchange) {  // an iteration inside an exchange group: plain launches, nothing on the wire
+        if (!state_in || !canonical || !state_out || !params || !record) return LSF_ERR_BAD_ARGUMENT;
+        if (int e = launch_parts(state_in, canonical, state_out, boundary_parts, n_boundary, params, gate, record, stream))
+            return e;
+        return launch_parts(state_in, canonical, state_out, interior_parts, n_interior, params, gate, record, stream);
+    }
     if (!comm || !state_in || !canonical || !state_out || !layout || !params || !record) return LSF_ERR_BAD_ARGUMENT;
     if ((n_boundary > 0 && !boundary_parts) || (n_interior > 0 && !interior_parts)) return LSF_ERR_BAD_ARGUMENT;
     if (layout->halo < 1 || layout->z_begin - (layout->lo_rank >= 0 ? layout->halo : 0) < 0 ||

@@ -197,9 +197,11 @@ __global__ __launch_bounds__(kBlock) void slavcheva_state_kernel(const vf4* __re
                 const NbhState<D> n(state_in, g, x, y, z, sc);
                 band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
             }
-            en[0] += e[0];
-            en[1] += e[1];
-            en[2] += e[2];
+            if (z >= g.e_begin && z < g.e_end) {  // a slab's recomputed halo slices belong to the neighbour's sums
+                en[0] += e[0];
+                en[1] += e[1];
+                en[2] += e[2];
+            }
         }
         // warp = -g * rate, its length for the arg-max, truncation-aware re-warp of the live field (a18 + a3)
         float wv[3] = {0.0f, 0.0f, 0.0f};

@@ -564,36 +564,127 @@ class SlavchevaEngine:
                 if status:
                     _lib.check(status, "lsf_slavcheva_state_iteration")
             return
+        # z-slab: what this iteration launches and whether the faces travel afterwards is planned in _plan_slab
+        k = f.exchange_interval
+        j = i % k
+        exchange = j == k - 1 and i + 1 < limit
+        boundary, interior = (f.exchange_parts if exchange else f.widened_parts[0 if j == k - 1 else k - 1 - j])
         if f.native is not None:  # the whole iteration in one host call (lsf_slab.hip): RCCL on the library's stream
-            status = _lib.lib.lsf_slab_state_iteration(f.native, s_in, f.p_canon, s_out, f.layout_ref, f.boundary_parts,
-                                                       f.n_boundary, f.interior_parts, f.n_interior,
-                                                       f.params_ref, gate_ref, f.record_ptrs[i], f.stream)
+            status = _lib.lib.lsf_slab_state_iteration(f.native, s_in, f.p_canon, s_out, f.layout_ref, boundary.array,
+                                                       boundary.n, interior.array, interior.n, f.params_ref, gate_ref,
+                                                       f.record_ptrs[i], int(exchange), f.stream)
             if status:
                 _lib.check(status, "lsf_slab_state_iteration")
-            if i + 1 < limit and i + 1 >= self.min_iterations:
-                self.comm.reduce_max(f.records, i)
-            return
-        # torch.distributed transport (gloo tests, fallback): boundary slices first, then the halo exchange on a second
-        # stream WHILE the interior runs
-        boundary, interior = self._slab_parts
-        for grid_ref, bands in boundary:
-            for band in bands:
-                _lib.check(run(s_in, f.p_canon, s_out, grid_ref, f.params_ref, gate_ref, f.record_ptrs[i],
-                               band.pointer, band.count, band.subset, f.stream), "lsf_slavcheva_state_iteration")
-        main = torch.cuda.current_stream()
-        boundary_done, halos_done = self._events[i % 2]
-        boundary_done.record(main)
-        with torch.cuda.stream(self._comm_stream):
-            self._comm_stream.wait_event(boundary_done)
-            self.comm.exchange_state(states[(i + 1) % 2])
-            halos_done.record(self._comm_stream)
-        for grid_ref, bands in interior:
-            for band in bands:
-                _lib.check(run(s_in, f.p_canon, s_out, grid_ref, f.params_ref, gate_ref, f.record_ptrs[i],
-                               band.pointer, band.count, band.subset, f.stream), "lsf_slavcheva_state_iteration")
-        main.wait_event(halos_done)
+        else:
+            # torch.distributed transport (gloo tests, fallback): boundary slices first, then the halo exchange on a
+            # second stream WHILE the interior runs
+            for grid_ref, bands in boundary.launches:
+                for band in bands:
+                    _lib.check(run(s_in, f.p_canon, s_out, grid_ref, f.params_ref, gate_ref, f.record_ptrs[i],
+                                   band.pointer, band.count, band.subset, f.stream), "lsf_slavcheva_state_iteration")
+            if exchange:
+                main = torch.cuda.current_stream()
+                boundary_done, halos_done = self._events[i % 2]
+                boundary_done.record(main)
+                with torch.cuda.stream(self._comm_stream):
+                    self._comm_stream.wait_event(boundary_done)
+                    self.comm.exchange_state(states[(i + 1) % 2])
+                    halos_done.record(self._comm_stream)
+            for grid_ref, bands in interior.launches:
+                for band in bands:
+                    _lib.check(run(s_in, f.p_canon, s_out, grid_ref, f.params_ref, gate_ref, f.record_ptrs[i],
+                                   band.pointer, band.count, band.subset, f.stream), "lsf_slavcheva_state_iteration")
+            if exchange:
+                main.wait_event(halos_done)
         if i + 1 < limit and i + 1 >= self.min_iterations:
             self.comm.reduce_max(f.records, i)  # the next iteration's gate tests this record: make it global now
+
+    class _Parts:
+        """the launches of one phase of a slab iteration: (grid, band lists) pairs, also as a ctypes lsf_slab_part array"""
+
+        def __init__(self, launches):
+            self.launches = [(ctypes.byref(g), bands) for g, bands in launches]
+            self._grids = [g for g, _ in launches]
+            self.n = len(launches)
+            self.array = (_lib.SlabPart * max(self.n, 1))()
+            for k, (g, bands) in enumerate(launches):
+                self.array[k].grid = g
+                self.array[k].n_lists = len(bands)
+                for j, band in enumerate(bands):
+                    self.array[k].band_list[j] = band.pointer.value or None
+                    self.array[k].band_count[j] = band.count
+                    self.array[k].band_subset[j] = band.subset
+
+    def _plan_slab(self, f, live, grid, bands, limit):
+        """Launch plan of a z-slab rank (fused path).  ONE band list of the whole local array (owned slices + halos) is
+        cut by z -- it is sorted, so every z-range is a contiguous run of it.
+        Exchange groups: with a halo of h slices and a fixed iteration count the faces travel only every h-th iteration
+        (an RCCL send / recv costs ~50 us of latency whatever its size, a 256^3 iteration 40 us): iteration j of a group
+        runs over the owned range WIDENED by h - 1 - j slices on every interior side -- it recomputes what the
+        neighbour computes for those slices, bit for bit, from inputs that are still valid: every iteration consumes
+        one slice of validity (stencils reach 1 slice, the re-warp gather floor(|w_z|) + 1 = 1 while updates stay
+        below one voxel; the guard in optimize() enforces that) -- and only the last iteration of a group splits into
+        boundary slices -> exchange || interior.  Energies count owned slices only (lsf_grid::energy_z_*).  Gated runs
+        (the stop test can fire) exchange and reduce every iteration."""
+        L = self.comm.layout
+        h = L.halo
+        lo, hi = L.rank > 0, L.rank < L.world - 1
+        _, _, lo_rank, hi_rank = self.comm.native_identity()
+        lo, hi = lo or lo_rank >= 0, hi or hi_rank >= 0
+        own = L.z_end - L.z_begin
+        if own < 2 * h:
+            raise ValueError("a slab of %d slices is too thin for a %d-slice halo" % (own, h))
+        fixed = self.min_iterations >= limit
+        f.exchange_interval = h if fixed else 1
+        slice_voxels = grid.ny * grid.nx
+        listed = bands[0].indices is not None
+        if listed:  # positions of the z cuts inside every list: one searchsorted per list, one host read
+            zs = sorted({z for e in range(h) for z in (L.z_begin - e, L.z_end + e)} | {L.z_begin + h, L.z_end - h})
+            zs = [z for z in zs if 0 <= z <= grid.nz]
+            keys = torch.tensor([z * slice_voxels for z in zs], dtype=torch.int32, device=live.device)
+            cuts = torch.stack([torch.searchsorted(b.indices[:b.count], keys) if b.count else torch.zeros_like(keys,
+                               dtype=torch.int64) for b in bands]).cpu().tolist()
+            cut = [dict(zip(zs, c)) for c in cuts]
+
+        def grid_of(z0, z1):
+            g = dev.make_grid(live.shape, z0, z1, grid.z_global_offset)
+            g.energy_z_begin, g.energy_z_end = L.z_begin, L.z_end
+            return g
+
+        def lists_of(ranges):
+            """the band lists covering the z-ranges (ascending, disjoint): views of the global lists, concatenated when
+            there is more than one range; at least one (possibly empty) list so that the launch still reports"""
+            if not listed:
+                return None
+            out = []
+            for b, c in zip(bands, cut):
+                pieces = [b.indices[c[z0]:c[z1]] for z0, z1 in ranges if c[z1] > c[z0]]
+                if pieces:
+                    idx = pieces[0] if len(pieces) == 1 else torch.cat(pieces)
+                    out.append(dev.BandList(idx, idx.numel(), b.subset))
+            return out or [dev.BandList(bands[0].indices[:1], 0, bands[0].subset)]
+
+        def parts(ranges):
+            ranges = [r for r in ranges if r[1] > r[0]]
+            if not ranges:
+                return SlavchevaEngine._Parts([])
+            if listed:  # one launch per subset over all ranges
+                return SlavchevaEngine._Parts([(grid_of(ranges[0][0], ranges[-1][1]), lists_of(ranges))])
+            return SlavchevaEngine._Parts([(grid_of(z0, z1), [dev.BandList.none()]) for z0, z1 in ranges])
+
+        empty = SlavchevaEngine._Parts([])
+        f.widened_parts = [(empty, parts([(L.z_begin - (e if lo else 0), L.z_end + (e if hi else 0))]))
+                           for e in range(f.exchange_interval)]
+        z_lo, z_hi = L.z_begin + (h if lo else 0), L.z_end - (h if hi else 0)
+        f.exchange_parts = (parts(([(L.z_begin, z_lo)] if lo else []) + ([(z_hi, L.z_end)] if hi else [])),
+                            parts([(z_lo, z_hi)]))
+        f.native = self.comm.native()
+        if f.native is not None:
+            f.layout = _lib.SlabLayoutC(grid.nz, grid.ny, grid.nx, L.z_begin, L.z_end, h, lo_rank, hi_rank)
+            f.layout_ref = ctypes.byref(f.layout)
+        elif not hasattr(self, "_comm_stream"):
+            self._comm_stream = torch.cuda.Stream(device=live.device)
+            self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
 
     def optimize(self, live, canonical):
         """live, canonical: float32 device tensors (z-slab runs: the local slab incl. halos).  Returns a
@@ -620,11 +711,13 @@ class SlavchevaEngine:
         else:
             # Both ping-pong states start as (live, 0): the fused kernel only visits the voxels of the band list and
             # the rest must already hold their final values (lsf_slavcheva_state_iteration); slab halos start valid.
-            fused_prepare = not slab and self.use_band_list and dev.buffer_addressing_ok(grid)
-            if fused_prepare:
-                states, bands = dev.state_prepare(live, canonical, grid)
+            whole = dev.full_range(grid)
+            fused_prepare = self.use_band_list and dev.buffer_addressing_ok(grid)
+            if fused_prepare:  # one pass: both states + the INTERIOR / BOUNDARY band lists of the WHOLE local array
+                states, bands = dev.state_prepare(live, canonical, whole)
             else:
                 states = dev.state_pack(live, None, grid, copies=2)
+                bands = dev.band_lists(live, canonical, whole) if self.use_band_list else [dev.BandList.none()]
             n = dev.n_voxels(grid)
             f = dev.IterationLauncher(grid, records, _lib.GATE_SLAVCHEVA, self.lo, self.hi)
             f.p_state = [f.pointer(t, 4 * n, "state") for t in states]
@@ -632,70 +725,11 @@ class SlavchevaEngine:
             f.params_ref = ctypes.byref(self.params)
             f.stream = dev.stream_ptr()  # the launch stream of this call (one ctypes object, not one per launch)
             f.native = None
+            f.bands = bands
             self._fast = f
-            if fused_prepare:
-                f.bands = bands
-            elif not slab:
-                f.bands = dev.band_lists(live, canonical, grid) if self.use_band_list else [dev.BandList.none()]
-            else:
-                L = self.comm.layout
-                h = L.halo
-                lo_b = (L.z_begin, L.z_begin + h) if L.rank > 0 else None
-                hi_b = (L.z_end - h, L.z_end) if L.rank < L.world - 1 else None
-                mid = (lo_b[1] if lo_b else L.z_begin, hi_b[0] if hi_b else L.z_end)
-                f.part_grids = []
-
-                def part(rng):
-                    g = dev.make_grid(live.shape, rng[0], rng[1], grid.z_global_offset)
-                    f.part_grids.append(g)
-                    return ctypes.byref(g), (dev.band_lists(live, canonical, g) if self.use_band_list
-                                             else [dev.BandList.none()])
-
-                def merged_boundary():
-                    # both boundary ranges in ONE launch per subset: a band list is just ascending voxel indices, so
-                    # the lower range's list followed by the upper range's is a list again (the launch's z-range only
-                    # places the "all updates are zero" arg-max candidate) -- the boundary phase sits on the critical
-                    # path of every iteration (boundary -> exchange -> next iteration)
-                    pieces = [dev.band_lists(live, canonical, dev.make_grid(live.shape, r[0], r[1], grid.z_global_offset))
-                              for r in (lo_b, hi_b)]
-                    merged = []
-                    for subset in (_lib.BAND_INTERIOR, _lib.BAND_BOUNDARY, _lib.BAND_ALL):
-                        same = [b for piece in pieces for b in piece if b.subset == subset and b.count > 0]
-                        if same:
-                            idx = torch.cat([b.indices[:b.count] for b in same])
-                            merged.append(dev.BandList(idx, idx.numel(), subset))
-                    if not merged:
-                        merged = [pieces[0][-1]]  # nothing in the band: one empty list still reports the zero update
-                    g = dev.make_grid(live.shape, lo_b[0], hi_b[1], grid.z_global_offset)
-                    f.part_grids.append(g)
-                    return ctypes.byref(g), merged
-                if self.use_band_list and lo_b is not None and hi_b is not None:
-                    boundary_parts = [merged_boundary()]
-                else:
-                    boundary_parts = [part(r) for r in (lo_b, hi_b) if r is not None]
-                self._slab_parts = (boundary_parts, [part(mid)] if mid[1] > mid[0] else [])
-                f.native = self.comm.native()
-                if f.native is not None:
-                    def pack(parts, grids):
-                        arr = (_lib.SlabPart * max(len(parts), 1))()
-                        for k, ((_, bands), g) in enumerate(zip(parts, grids)):
-                            arr[k].grid = g
-                            arr[k].n_lists = len(bands)
-                            for j, band in enumerate(bands):
-                                arr[k].band_list[j] = band.pointer.value or None
-                                arr[k].band_count[j] = band.count
-                                arr[k].band_subset[j] = band.subset
-                        return arr
-                    nb = len(self._slab_parts[0])
-                    f.n_boundary, f.n_interior = nb, len(self._slab_parts[1])
-                    f.boundary_parts = pack(self._slab_parts[0], f.part_grids[:nb])
-                    f.interior_parts = pack(self._slab_parts[1], f.part_grids[nb:])
-                    _, _, lo_rank, hi_rank = self.comm.native_identity()
-                    f.layout = _lib.SlabLayoutC(grid.nz, grid.ny, grid.nx, L.z_begin, L.z_end, h, lo_rank, hi_rank)
-                    f.layout_ref = ctypes.byref(f.layout)
-                if not hasattr(self, "_comm_stream"):
-                    self._comm_stream = torch.cuda.Stream(device=live.device)
-                    self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
+            if slab:
+                self._plan_slab(f, live, grid, bands, 0 if self.min_iterations == 0
+                                else max(self.max_iterations, self.min_iterations))
         # with min_iterations == 0 the reference never enters its loop (max_warp starts at +inf, :354,:360-362)
         limit = 0 if self.min_iterations == 0 else max(self.max_iterations, self.min_iterations)
         it, n_exec = 0, 0
@@ -716,9 +750,17 @@ class SlavchevaEngine:
             if n_exec < it:
                 break
             m = dec["max_value"][n_exec - 1]
-            if slab and not (m < self.comm.layout.halo):
-                raise RuntimeError("warp update of %.3f voxels reaches past the %d-slice slab halo; re-run with a "
-                                   "wider halo" % (float(m), self.comm.layout.halo))
+            reach = self.comm.layout.halo if slab else 0
+            if slab and not self.sobolev and self._fast.exchange_interval > 1:
+                reach = 1  # inside an exchange group every iteration may consume one slice of validity only
+            if slab and not (dec["max_value"][:n_exec].max() < reach):
+                raise RuntimeError("warp update of %.3f voxels reaches past the slab halo (%d slices, %s); re-run with "
+                                   "a wider halo%s" % (float(dec["max_value"][:n_exec].max()), self.comm.layout.halo,
+                                                       "exchanged every %d iterations" % self._fast.exchange_interval
+                                                       if reach == 1 and self.comm.layout.halo > 1 else
+                                                       "exchanged every iteration",
+                                                       " or min_iterations < max_iterations" if reach == 1 and
+                                                       self.comm.layout.halo > 1 else ""))
             if n_exec >= self.min_iterations and not (np.float32(self.lo) < m < np.float32(self.hi)):
                 break
         self.iteration_count = n_exec

@@ -35,7 +35,7 @@ class SelfComm(SlabComm):
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 iters = 200
-layout = SlabLayout(3 * n, 1, 3, 2)
+layout = SlabLayout(3 * n, 1, 3, int(os.environ.get("HALO", "4")))
 comm = SelfComm(layout)
 assert comm.active and not comm.stage_through_host
 sl = layout.local_slice()
