@@ -304,6 +304,16 @@ typedef struct lsf_slab_part {
     int32_t n_lists;           /* 1 or 2 launches (INTERIOR + BOUNDARY band lists) */
     int32_t reserved;
 } lsf_slab_part;
+/* compact faces (optional): only the band voxels of the boundary slices travel -- every other voxel of a slab face
+ * never changes.  [0] = lower side, [1] = upper side.  send_list: ascending local voxel indices of the band voxels in the
+ * `halo` owned slices next to that neighbour; recv_list: the same for this rank's halo slices on that side (the
+ * neighbour's send list, shifted: both ranks derive the lists from identical initial data, the caller verifies that the
+ * counts agree before the first exchange); send_msg / recv_msg: device buffers of 4 * count floats. */
+typedef struct lsf_slab_faces {
+    const int32_t *send_list[2], *recv_list[2];
+    float *send_msg[2], *recv_msg[2];
+    int64_t send_count[2], recv_count[2];
+} lsf_slab_faces;
 int lsf_slab_unique_id(const char *rccl_library_path, uint8_t *id_out128);
 int lsf_slab_comm_create(const char *rccl_library_path, const uint8_t *id128, int32_t rank, int32_t world,
                          lsf_slab_comm **out);
@@ -313,7 +323,7 @@ int lsf_slab_state_iteration(lsf_slab_comm *comm, const float *state_in, const f
                              const lsf_slab_part *interior_parts, int32_t n_interior,
                              const lsf_slavcheva_params *params, const lsf_gate *gate, lsf_iteration_record *record,
                              int32_t exchange /* 0: launches only (an iteration inside an exchange group) */,
-                             void *stream);
+                             const lsf_slab_faces *faces /* NULL: whole slices travel */, void *stream);
 
 int lsf_slavcheva_update_rewarp(const float *live, const float *canonical, float *g_planar /* inout */,
                                 float *warp_out_planar, float *live_out, const lsf_grid *grid,

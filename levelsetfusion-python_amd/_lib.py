@@ -68,6 +68,12 @@ class SlabPart(ctypes.Structure):
                 ("band_subset", ctypes.c_int32 * 2), ("n_lists", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class SlabFaces(ctypes.Structure):
+    _fields_ = [("send_list", ctypes.c_void_p * 2), ("recv_list", ctypes.c_void_p * 2),
+                ("send_msg", ctypes.c_void_p * 2), ("recv_msg", ctypes.c_void_p * 2),
+                ("send_count", ctypes.c_int64 * 2), ("recv_count", ctypes.c_int64 * 2)]
+
+
 class HierParams(ctypes.Structure):
     _fields_ = [("data_term_amplifier", ctypes.c_float), ("tikhonov_strength", ctypes.c_float),
                 ("rate", ctypes.c_float), ("tikhonov_enabled", ctypes.c_int32), ("apply_update", ctypes.c_int32),
@@ -135,7 +141,7 @@ PROTOTYPES = {
     "lsf_slab_comm_create": (ctypes.c_int, [ctypes.c_char_p, _vp, _i32, _i32, _P(_vp)]),
     "lsf_slab_comm_destroy": (ctypes.c_int, [_vp]),
     "lsf_slab_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(SlabLayoutC), _P(SlabPart), _i32, _P(SlabPart),
-                                                _i32, _P(SlavchevaParams), _P(Gate), _vp, _i32, _vp]),
+                                                _i32, _P(SlavchevaParams), _P(Gate), _vp, _i32, _P(SlabFaces), _vp]),
     "lsf_slavcheva_update_rewarp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),
                                                    _P(Gate), _vp, _vp]),
     "lsf_warp_statistics": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp, _vp]),

@@ -140,19 +140,67 @@ extern "C" int lsf_slab_comm_destroy(lsf_slab_comm* c) {
     return 0;
 }
 
+typedef float vf4 __attribute__((ext_vector_type(4)));
+
+// compact faces: only the band voxels of the boundary / halo slices travel (everything else never changes)
+__global__ __launch_bounds__(256) void face_gather_kernel(const vf4* __restrict__ state, const int* __restrict__ list_a,
+                                                          unsigned n_a, vf4* __restrict__ msg_a,
+                                                          const int* __restrict__ list_b, unsigned n_b,
+                                                          vf4* __restrict__ msg_b) {
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_a) msg_a[k] = state[list_a[k]];
+    else if (k - n_a < n_b) msg_b[k - n_a] = state[list_b[k - n_a]];
+}
+
+__global__ __launch_bounds__(256) void face_scatter_kernel(vf4* __restrict__ state, const int* __restrict__ list_a,
+                                                           unsigned n_a, const vf4* __restrict__ msg_a,
+                                                           const int* __restrict__ list_b, unsigned n_b,
+                                                           const vf4* __restrict__ msg_b) {
+    const unsigned k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n_a) state[list_a[k]] = msg_a[k];
+    else if (k - n_a < n_b) state[list_b[k - n_a]] = msg_b[k - n_a];
+}
+
+// Send order: lower boundary -> lower neighbour, upper halo <- upper neighbour, upper boundary -> upper neighbour, lower
+// halo <- lower neighbour.  Between distinct peers the order inside a group is irrelevant; when a rank is its own
+// neighbour (the one-GPU loop-back of a z-periodic stack) sends and receives pair up in order, and this order pairs the
+// lower boundary with the upper halo -- the same voxels of a periodic stack -- so counts match and the physics is right.
+static int exchange_compact(lsf_slab_comm* c, float* state, const lsf_slab_layout* L, const lsf_slab_faces* F,
+                            hipStream_t s) {
+    const bool lo = L->lo_rank >= 0, hi = L->hi_rank >= 0;
+    const unsigned n_slo = lo ? (unsigned)F->send_count[0] : 0u, n_shi = hi ? (unsigned)F->send_count[1] : 0u;
+    const unsigned n_rlo = lo ? (unsigned)F->recv_count[0] : 0u, n_rhi = hi ? (unsigned)F->recv_count[1] : 0u;
+    if (n_slo + n_shi > 0)
+        hipLaunchKernelGGL(face_gather_kernel, dim3((n_slo + n_shi + 255) / 256), dim3(256), 0, s,
+                           reinterpret_cast<const vf4*>(state), F->send_list[0], n_slo,
+                           reinterpret_cast<vf4*>(F->send_msg[0]), F->send_list[1], n_shi,
+                           reinterpret_cast<vf4*>(F->send_msg[1]));
+    LSF_RCCL_CHECK(g_rccl.GroupStart());
+    if (lo && n_slo) LSF_RCCL_CHECK(g_rccl.Send(F->send_msg[0], (size_t)n_slo * 4, ncclFloat, L->lo_rank, c->comm, s));
+    if (hi && n_rhi) LSF_RCCL_CHECK(g_rccl.Recv(F->recv_msg[1], (size_t)n_rhi * 4, ncclFloat, L->hi_rank, c->comm, s));
+    if (hi && n_shi) LSF_RCCL_CHECK(g_rccl.Send(F->send_msg[1], (size_t)n_shi * 4, ncclFloat, L->hi_rank, c->comm, s));
+    if (lo && n_rlo) LSF_RCCL_CHECK(g_rccl.Recv(F->recv_msg[0], (size_t)n_rlo * 4, ncclFloat, L->lo_rank, c->comm, s));
+    LSF_RCCL_CHECK(g_rccl.GroupEnd());
+    if (n_rlo + n_rhi > 0)
+        hipLaunchKernelGGL(face_scatter_kernel, dim3((n_rlo + n_rhi + 255) / 256), dim3(256), 0, s,
+                           reinterpret_cast<vf4*>(state), F->recv_list[0], n_rlo,
+                           reinterpret_cast<const vf4*>(F->recv_msg[0]), F->recv_list[1], n_rhi,
+                           reinterpret_cast<const vf4*>(F->recv_msg[1]));
+    return (int)hipGetLastError();
+}
+
 // exchange of the state's halo slices with the z-neighbours: each face is one contiguous run of halo * ny * nx float4
 static int exchange_state(lsf_slab_comm* c, float* state, const lsf_slab_layout* L, hipStream_t s) {
     const size_t slice = (size_t)L->ny * L->nx * 4;  // floats per z-slice of the state
     const size_t count = slice * (size_t)L->halo;
     LSF_RCCL_CHECK(g_rccl.GroupStart());
-    if (L->lo_rank >= 0) {
-        LSF_RCCL_CHECK(g_rccl.Send(state + slice * L->z_begin, count, ncclFloat, L->lo_rank, c->comm, s));
-        LSF_RCCL_CHECK(g_rccl.Recv(state + slice * (L->z_begin - L->halo), count, ncclFloat, L->lo_rank, c->comm, s));
-    }
-    if (L->hi_rank >= 0) {
+    // same order as exchange_compact (see there)
+    if (L->lo_rank >= 0) LSF_RCCL_CHECK(g_rccl.Send(state + slice * L->z_begin, count, ncclFloat, L->lo_rank, c->comm, s));
+    if (L->hi_rank >= 0) LSF_RCCL_CHECK(g_rccl.Recv(state + slice * L->z_end, count, ncclFloat, L->hi_rank, c->comm, s));
+    if (L->hi_rank >= 0)
         LSF_RCCL_CHECK(g_rccl.Send(state + slice * (L->z_end - L->halo), count, ncclFloat, L->hi_rank, c->comm, s));
-        LSF_RCCL_CHECK(g_rccl.Recv(state + slice * L->z_end, count, ncclFloat, L->hi_rank, c->comm, s));
-    }
+    if (L->lo_rank >= 0)
+        LSF_RCCL_CHECK(g_rccl.Recv(state + slice * (L->z_begin - L->halo), count, ncclFloat, L->lo_rank, c->comm, s));
     LSF_RCCL_CHECK(g_rccl.GroupEnd());
     return 0;
 }
@@ -175,7 +223,8 @@ extern "C" int lsf_slab_state_iteration(lsf_slab_comm* comm, const float* state_
                                         const lsf_slab_part* boundary_parts, int32_t n_boundary,
                                         const lsf_slab_part* interior_parts, int32_t n_interior,
                                         const lsf_slavcheva_params* params, const lsf_gate* gate,
-                                        lsf_iteration_record* record, int32_t exchange, void* stream) {
+                                        lsf_iteration_record* record, int32_t exchange, const lsf_slab_faces* faces,
+                                        void* stream) {
     if (!exchange) {  // an iteration inside an exchange group: plain launches, nothing on the wire
         if (!state_in || !canonical || !state_out || !params || !record) return LSF_ERR_BAD_ARGUMENT;
         if (int e = launch_parts(state_in, canonical, state_out, boundary_parts, n_boundary, params, gate, record, stream))
@@ -196,7 +245,9 @@ extern "C" int lsf_slab_state_iteration(lsf_slab_comm* comm, const float* state_
     // 2. their exchange on the communication stream, while ...
     LSF_HIP_CHECK(hipEventRecord(comm->boundary_done[k], main));
     LSF_HIP_CHECK(hipStreamWaitEvent(comm->comm_stream, comm->boundary_done[k], 0));
-    if (int e = exchange_state(comm, state_out, layout, comm->comm_stream)) return e;
+    if (int e = faces ? exchange_compact(comm, state_out, layout, faces, comm->comm_stream)
+                      : exchange_state(comm, state_out, layout, comm->comm_stream))
+        return e;
     LSF_HIP_CHECK(hipEventRecord(comm->halos_done[k], comm->comm_stream));
     // 3. ... the interior runs on the launch stream
     if (int e = launch_parts(state_in, canonical, state_out, interior_parts, n_interior, params, gate, record, stream))

@@ -6,6 +6,7 @@ the C ABI (device.py -> liblsf_hip.so).  The host loop only enqueues launches an
 iterations, reads back the tiny iteration records to learn whether the device-side convergence gate has closed.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -572,7 +573,7 @@ class SlavchevaEngine:
         if f.native is not None:  # the whole iteration in one host call (lsf_slab.hip): RCCL on the library's stream
             status = _lib.lib.lsf_slab_state_iteration(f.native, s_in, f.p_canon, s_out, f.layout_ref, boundary.array,
                                                        boundary.n, interior.array, interior.n, f.params_ref, gate_ref,
-                                                       f.record_ptrs[i], int(exchange), f.stream)
+                                                       f.record_ptrs[i], int(exchange), f.faces_ref, f.stream)
             if status:
                 _lib.check(status, "lsf_slab_state_iteration")
         else:
@@ -598,6 +599,52 @@ class SlavchevaEngine:
                 main.wait_event(halos_done)
         if i + 1 < limit and i + 1 >= self.min_iterations:
             self.comm.reduce_max(f.records, i)  # the next iteration's gate tests this record: make it global now
+
+    def _plan_compact_faces(self, f, live, bands, cut, lo, hi, lo_rank, hi_rank):
+        """Only the band voxels of a face travel: every other voxel of the boundary slices never changes (and both ranks
+        hold it already).  The sender gathers state[its boundary band voxels], the receiver scatters into its halo band
+        voxels -- the same physical voxels in the same ascending order, because both ranks cut their lists out of
+        identical initial data; the counts are cross-checked with the neighbours once, and whole slices travel if any
+        rank disagrees (a caller that hands inconsistent halos)."""
+        L = self.comm.layout
+        h = L.halo
+
+        def union(z0, z1):
+            pieces = [b.indices[c[z0]:c[z1]] for b, c in zip(bands, cut) if c[z1] > c[z0]]
+            if not pieces:
+                return torch.zeros(1, dtype=torch.int32, device=live.device), 0
+            idx = pieces[0] if len(pieces) == 1 else torch.sort(torch.cat(pieces)).values
+            return idx.contiguous(), idx.numel()
+        none = (torch.zeros(1, dtype=torch.int32, device=live.device), 0)
+        send = [union(L.z_begin, L.z_begin + h) if lo else none, union(L.z_end - h, L.z_end) if hi else none]
+        recv = [union(L.z_begin - h, L.z_begin) if lo else none, union(L.z_end, L.z_end + h) if hi else none]
+        mine = torch.tensor([send[0][1], send[1][1], recv[0][1], recv[1][1]], dtype=torch.int64, device=live.device)
+        rows = [torch.zeros_like(mine) for _ in range(torch.distributed.get_world_size(self.comm.group))]
+        torch.distributed.all_gather(rows, mine, group=self.comm.group)
+        rows = [r.tolist() for r in rows]
+        ok = True
+        if lo:  # my lower boundary lands in the lower neighbour's UPPER halo; its upper boundary in my lower halo
+            ok &= rows[lo_rank][3] == send[0][1] and rows[lo_rank][1] == recv[0][1]
+        if hi:
+            ok &= rows[hi_rank][2] == send[1][1] and rows[hi_rank][0] == recv[1][1]
+        flag = torch.tensor([int(ok)], dtype=torch.int32, device=live.device)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=self.comm.group)
+        if int(flag.item()) == 0:
+            import warnings
+            warnings.warn("slab halos are not consistent with the neighbours' slabs (band voxel counts differ): whole "
+                          "slices are exchanged")
+            return
+        faces = _lib.SlabFaces()
+        f.face_tensors = []
+        for side in range(2):
+            for name, (idx, count) in (("send", send[side]), ("recv", recv[side])):
+                msg = torch.empty(max(count, 1) * 4, dtype=torch.float32, device=live.device)
+                f.face_tensors += [idx, msg]
+                getattr(faces, name + "_list")[side] = idx.data_ptr()
+                getattr(faces, name + "_msg")[side] = msg.data_ptr()
+                getattr(faces, name + "_count")[side] = count
+        f.faces = faces
+        f.faces_ref = ctypes.byref(faces)
 
     class _Parts:
         """the launches of one phase of a slab iteration: (grid, band lists) pairs, also as a ctypes lsf_slab_part array"""
@@ -639,7 +686,7 @@ class SlavchevaEngine:
         slice_voxels = grid.ny * grid.nx
         listed = bands[0].indices is not None
         if listed:  # positions of the z cuts inside every list: one searchsorted per list, one host read
-            zs = sorted({z for e in range(h) for z in (L.z_begin - e, L.z_end + e)} | {L.z_begin + h, L.z_end - h})
+            zs = sorted({z for e in range(h + 1) for z in (L.z_begin - e, L.z_end + e)} | {L.z_begin + h, L.z_end - h})
             zs = [z for z in zs if 0 <= z <= grid.nz]
             keys = torch.tensor([z * slice_voxels for z in zs], dtype=torch.int32, device=live.device)
             cuts = torch.stack([torch.searchsorted(b.indices[:b.count], keys) if b.count else torch.zeros_like(keys,
@@ -679,9 +726,12 @@ class SlavchevaEngine:
         f.exchange_parts = (parts(([(L.z_begin, z_lo)] if lo else []) + ([(z_hi, L.z_end)] if hi else [])),
                             parts([(z_lo, z_hi)]))
         f.native = self.comm.native()
+        f.faces_ref = None
         if f.native is not None:
             f.layout = _lib.SlabLayoutC(grid.nz, grid.ny, grid.nx, L.z_begin, L.z_end, h, lo_rank, hi_rank)
             f.layout_ref = ctypes.byref(f.layout)
+            if listed and os.environ.get("LSF_SLAB_FACES", "compact") != "full":
+                self._plan_compact_faces(f, live, bands, cut, lo, hi, lo_rank, hi_rank)
         elif not hasattr(self, "_comm_stream"):
             self._comm_stream = torch.cuda.Stream(device=live.device)
             self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]

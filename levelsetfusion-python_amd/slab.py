@@ -203,13 +203,17 @@ class SlabComm:
         if self.stage_through_host or not state.is_cuda:
             return self.exchange_halos([state.view(state.shape[0], state.shape[1], -1)])
         h = L.halo
+        _, _, lo, hi = self.native_identity()
+        # order as in lsf_slab.hip: irrelevant between distinct peers, and the right pairing (lower boundary -> upper
+        # halo) when a rank is its own neighbour in the one-GPU loop-back of a z-periodic stack
         ops = []
-        if L.rank > 0:
-            ops += [dist.P2POp(dist.isend, state[L.z_begin:L.z_begin + h], L.rank - 1, self.group),
-                    dist.P2POp(dist.irecv, state[L.z_begin - h:L.z_begin], L.rank - 1, self.group)]
-        if L.rank < L.world - 1:
-            ops += [dist.P2POp(dist.isend, state[L.z_end - h:L.z_end], L.rank + 1, self.group),
-                    dist.P2POp(dist.irecv, state[L.z_end:L.z_end + h], L.rank + 1, self.group)]
+        if lo >= 0:
+            ops.append(dist.P2POp(dist.isend, state[L.z_begin:L.z_begin + h], lo, self.group))
+        if hi >= 0:
+            ops.append(dist.P2POp(dist.irecv, state[L.z_end:L.z_end + h], hi, self.group))
+            ops.append(dist.P2POp(dist.isend, state[L.z_end - h:L.z_end], hi, self.group))
+        if lo >= 0:
+            ops.append(dist.P2POp(dist.irecv, state[L.z_begin - h:L.z_begin], lo, self.group))
         for req in dist.batch_isend_irecv(ops):
             req.wait()
 

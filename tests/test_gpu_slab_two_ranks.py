@@ -177,8 +177,9 @@ def test_halo_copy_kernel_matches_slicing():
 
 def test_native_rccl_transport_equals_torch_transport(tmp_path):
     """the library's own RCCL transport (lsf_slab_state_iteration: boundary launches, ncclSend / ncclRecv on the comm
-    stream, interior launches in ONE host call) against the torch.distributed transport, both over real RCCL on one GPU
-    (a world of one rank that is its own neighbour, see slab_loopback_worker.py): bit-identical fields and records"""
+    stream, interior launches in ONE host call; compact band-voxel faces and whole-slice faces; exchange groups) against
+    the torch.distributed transport, all over real RCCL on one GPU (a world of one rank that is its own neighbour, see
+    slab_loopback_worker.py): bit-identical fields and records, and the middle slab of the whole volume within 2e-5"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import subprocess
@@ -187,7 +188,12 @@ def test_native_rccl_transport_equals_torch_transport(tmp_path):
     proc = subprocess.run([sys.executable, worker, out, str(_free_port())], capture_output=True, text=True, timeout=300)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-2000:]
     r = np.load(out)
-    assert str(r["used_rccl"]) == "rccl", "the native RCCL transport was not used: " + proc.stderr[-1000:]
+    assert str(r["used_rccl"]) == "rccl:compact", "native RCCL transport with compact faces was not used: " + \
+        str(r["used_rccl"]) + proc.stderr[-1000:]
     assert str(r["used_torch"]) == "torch"
+    # compact faces == whole-slice faces == torch.distributed transport, bit for bit
     assert bool(r["live_equal"]) and bool(r["warp_equal"]) and bool(r["max_equal"]) and bool(r["data_close"])
+    # ... and == the middle slab of the whole (z-periodic) volume computed by one process
+    assert float(r["whole_live_diff"]) <= 2e-5 and float(r["whole_warp_diff"]) <= 2e-5, \
+        (float(r["whole_live_diff"]), float(r["whole_warp_diff"]))
     assert float(r["moved"]) > 1e-3  # the optimisation did something

@@ -20,18 +20,6 @@ class SelfComm(SlabComm):
     def native_identity(self):
         return 0, 1, 0, 0
 
-    def exchange_state(self, state):
-        if os.environ.get("NO_EXCHANGE") == "1":
-            return
-        L = self.layout
-        h = L.halo
-        ops = [dist.P2POp(dist.isend, state[L.z_begin:L.z_begin + h], 0, self.group),
-               dist.P2POp(dist.irecv, state[L.z_begin - h:L.z_begin], 0, self.group),
-               dist.P2POp(dist.isend, state[L.z_end - h:L.z_end], 0, self.group),
-               dist.P2POp(dist.irecv, state[L.z_end:L.z_end + h], 0, self.group)]
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 iters = 200
