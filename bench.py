@@ -112,6 +112,8 @@ def extra_workload(args, device):
             ", %d iterations per level"
     for _ in range(args.warmup):
         step()
+    gc.collect()
+    gc.freeze()  # as in main(): keep torch's objects out of the cyclic collector's full passes
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     updates = 0

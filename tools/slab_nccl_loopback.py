@@ -22,7 +22,7 @@ class SelfComm(SlabComm):
 
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-iters = 200
+iters = int(os.environ.get("ITERS", "200"))
 layout = SlabLayout(3 * n, 1, 3, int(os.environ.get("HALO", "4")))
 comm = SelfComm(layout)
 assert comm.active and not comm.stage_through_host
