@@ -153,6 +153,12 @@ int lsf_convolve_axis(const float *in_planar, float *out_planar, const float *ze
                       const lsf_grid *grid, int32_t planes, int32_t axis, const double *taps_host,
                       int32_t n_taps, const lsf_gate *gate, void *stream);
 
+/* the same zero-preserving pass (zero_mask_source required, 3 / 5 / 7 / 9 taps) at the voxels of a band list only */
+int lsf_convolve_axis_listed(const float *in_planar, float *out_planar, const float *zero_mask_source,
+                             const lsf_grid *grid, int32_t planes, int32_t axis, const double *taps_host,
+                             int32_t n_taps, const lsf_gate *gate, const int32_t *band_list, int64_t band_count,
+                             void *stream);
+
 /* ---- hierarchical optimizer iteration ---------------------------------------------------------------
  * replaces one pass of the loop body nonrigid_opt/hierarchical/hierarchical_optimizer2d.py:184-225:
  *   resample live and its gradients under `warp` (a1,a2), data term (a7), Tikhonov = Laplacian of the
@@ -213,9 +219,14 @@ typedef struct lsf_slavcheva_params {
     int32_t reserved;
 } lsf_slavcheva_params;
 
+/* band_list (may be NULL = every voxel of the z-range; LSF_BAND_ALL lists only): the SobolevFusion path on a band list --
+ * gradient, the masked filter passes (lsf_convolve_axis_listed) and the update touch listed voxels only; the caller
+ * zero-initialises the gradient / filter buffers and initialises BOTH ping-pong (live, warp) sets with (live, 0): a
+ * zero-preserving filter cannot move gradient out of the band, so every other voxel keeps those values. */
 int lsf_slavcheva_gradient(const float *live, const float *canonical, const float *warp_prev_planar,
                            float *g_out_planar, const lsf_grid *grid, const lsf_slavcheva_params *params,
-                           const lsf_gate *gate, lsf_iteration_record *record, void *stream);
+                           const lsf_gate *gate, lsf_iteration_record *record, const int32_t *band_list,
+                           int64_t band_count, void *stream);
 
 /* Band lists for lsf_slavcheva_state_iteration: only listed voxels are visited.  This is exact, not an approximation:
  * a voxel outside the narrow-band union (|live| == |canonical| == 1, the test of slavcheva_optimizer2d.py:251-252 /
@@ -328,7 +339,8 @@ int lsf_slab_state_iteration(lsf_slab_comm *comm, const float *state_in, const f
 int lsf_slavcheva_update_rewarp(const float *live, const float *canonical, float *g_planar /* inout */,
                                 float *warp_out_planar, float *live_out, const lsf_grid *grid,
                                 const lsf_slavcheva_params *params, const lsf_gate *gate,
-                                lsf_iteration_record *record, void *stream);
+                                lsf_iteration_record *record, const int32_t *band_list /* may be NULL */,
+                                int64_t band_count, void *stream);
 
 /* ---- a20: convergence statistics ---------------------------------------------------------------------
  * replaces cpp.build_warp_delta_statistics_2d / build_tsdf_difference_statistics_2d

@@ -126,7 +126,9 @@ PROTOTYPES = {
     "lsf_hier_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(HierParams), _P(Gate), _vp, _vp]),
     "lsf_hier_update": (ctypes.c_int, [_vp, _vp, _P(Grid), _f32, _P(Gate), _vp, _vp]),
     "lsf_slavcheva_gradient": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp,
-                                              _vp]),
+                                              _vp, _i64, _vp]),
+    "lsf_convolve_axis_listed": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _i32, _i32, _P(ctypes.c_double), _i32,
+                                                _P(Gate), _vp, _i64, _vp]),
     "lsf_state_prepare": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp, _vp, _vp]),
     "lsf_state_pack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp]),
     "lsf_state_unpack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp]),
@@ -143,7 +145,7 @@ PROTOTYPES = {
     "lsf_slab_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(SlabLayoutC), _P(SlabPart), _i32, _P(SlabPart),
                                                 _i32, _P(SlavchevaParams), _P(Gate), _vp, _i32, _P(SlabFaces), _vp]),
     "lsf_slavcheva_update_rewarp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),
-                                                   _P(Gate), _vp, _vp]),
+                                                   _P(Gate), _vp, _vp, _i64, _vp]),
     "lsf_warp_statistics": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp, _vp]),
     "lsf_tsdf_difference_statistics": (ctypes.c_int, [_vp, _vp, _P(Grid), _vp, _vp]),
     "lsf_tsdf_generate_nearest": (ctypes.c_int, [_vp, _vp, _P(Grid), _P(TsdfParams), _vp]),

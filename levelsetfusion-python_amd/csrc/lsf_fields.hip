@@ -615,6 +615,53 @@ __global__ __launch_bounds__(kBlock) void convolve_x4_kernel(const float* __rest
     reinterpret_cast<cvf4*>(out + base)[q] = o;
 }
 
+// one zero-preserving pass at LISTED voxels only (SobolevFusion on a band list): the gradient is zero outside the
+// narrow band, a masked pass leaves zeros where its mask source is zero (math_utils/convolution.py:118-127), so only
+// band voxels can hold non-zero output -- everything else stays at the zeros the caller initialised.  One thread per
+// (listed voxel, plane); NT taps read along the axis from the planar field (zero padding outside the array).
+template <int NT>
+__global__ __launch_bounds__(kBlock) void convolve_list_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                               const float* __restrict__ mask_src, Grid g,
+                                                               TapsN<NT> taps, int axis, const int* __restrict__ list,
+                                                               unsigned count, lsf_gate gate) {
+    if (gate_closed(gate)) return;
+    const unsigned k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    const unsigned i = (unsigned)list[k];
+    const long long base = (long long)blockIdx.y * g.plane;
+    if (fabsf(mask_src[base + i]) < 1e-6f) {
+        out[base + i] = 0.0f;
+        return;
+    }
+    const unsigned zy = fast_div(i, g.div_nx);
+    const int x = (int)(i - zy * (unsigned)g.nx);
+    const int z = (int)fast_div(zy, g.div_ny);
+    const int y = (int)zy - z * g.ny;
+    const int a = axis == 0 ? x : (axis == 1 ? y : z);
+    const int len = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz);
+    const int stride = axis == 0 ? 1 : (axis == 1 ? g.nx : g.nx * g.ny);
+    constexpr int c = NT / 2;
+    const float* __restrict__ src = in + base + i;
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {  // out[a] = sum_j k[j] * in[a + c - j], zero outside [0, len)
+        const int d = c - j, q = a + d;
+        const float v = src[(q >= 0 && q < len) ? d * stride : 0];
+        acc = acc + taps.k[j] * ((q >= 0 && q < len) ? (double)v : 0.0);
+    }
+    out[base + i] = (float)acc;
+}
+
+template <int NT>
+static void launch_list_pass(const float* in, float* out, const float* mask, const Grid& g, int planes, int axis,
+                             const double* taps_host, const int* list, unsigned count, const lsf_gate& gt,
+                             hipStream_t s) {
+    TapsN<NT> taps;
+    for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
+    hipLaunchKernelGGL((convolve_list_kernel<NT>), dim3((count + kBlock - 1) / kBlock, (unsigned)planes), dim3(kBlock), 0,
+                       s, in, out, mask, g, taps, axis, list, count, gt);
+}
+
 template <int NT>
 static bool launch_window_pass(const float* in, float* out, const float* mask, const Grid& g, int planes, int axis,
                                const double* taps_host, const lsf_gate& gt, hipStream_t s) {
@@ -643,6 +690,30 @@ static bool launch_window_pass(const float* in, float* out, const float* mask, c
         else hipLaunchKernelGGL((convolve_march_kernel<2, NT, false>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, gt);
     }
     return true;
+}
+
+extern "C" int lsf_convolve_axis_listed(const float* in_planar, float* out_planar, const float* zero_mask_source,
+                                        const lsf_grid* grid, int32_t planes, int32_t axis, const double* taps_host,
+                                        int32_t n_taps, const lsf_gate* gate, const int32_t* band_list,
+                                        int64_t band_count, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!in_planar || !out_planar || in_planar == out_planar || !taps_host || !zero_mask_source || !band_list ||
+        band_count < 0 || band_count > 0x7fffffffll)
+        return LSF_ERR_BAD_ARGUMENT;
+    if (n_taps != 3 && n_taps != 5 && n_taps != 7 && n_taps != 9) return LSF_ERR_KERNEL_TOO_LONG;
+    if (axis < 0 || axis >= grid->dims || planes < 1 || planes > 4) return LSF_ERR_BAD_ARGUMENT;
+    if (band_count == 0) return 0;
+    const Grid g = make_grid(grid);
+    const lsf_gate gt = gate ? *gate : lsf_gate{nullptr, 0, 0.0f, 0.0f};
+    hipStream_t s = as_stream(stream);
+    const unsigned n = (unsigned)band_count;
+    switch (n_taps) {
+        case 3: launch_list_pass<3>(in_planar, out_planar, zero_mask_source, g, planes, axis, taps_host, band_list, n, gt, s); break;
+        case 5: launch_list_pass<5>(in_planar, out_planar, zero_mask_source, g, planes, axis, taps_host, band_list, n, gt, s); break;
+        case 7: launch_list_pass<7>(in_planar, out_planar, zero_mask_source, g, planes, axis, taps_host, band_list, n, gt, s); break;
+        default: launch_list_pass<9>(in_planar, out_planar, zero_mask_source, g, planes, axis, taps_host, band_list, n, gt, s); break;
+    }
+    return launch_status();
 }
 
 extern "C" int lsf_convolve_axis(const float* in_planar, float* out_planar, const float* zero_mask_source,

@@ -106,10 +106,13 @@ __device__ inline unsigned long long update_and_rewarp(const float* __restrict__
 template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
 __global__ __launch_bounds__(kBlock) void slavcheva_gradient_kernel(
     const float* __restrict__ live, const float* __restrict__ canonical, const float* __restrict__ warp_prev,
-    float* __restrict__ g_out, Grid g, Params p, lsf_gate gate, lsf_iteration_record* record) {
+    float* __restrict__ g_out, Grid g, Params p, lsf_gate gate, lsf_iteration_record* record,
+    const int* __restrict__ band_list, unsigned band_count) {
     if (gate_closed(gate)) return;
     double en[3] = {0.0, 0.0, 0.0};
-    for_each_voxel(g, [&](int x, int y, int z) {
+    // band_list != nullptr: only the listed voxels (ALL band voxels of the z-range); everywhere else the gradient is
+    // zero and the caller's zero-initialised g_out already says so
+    for_each_listed_voxel(g, band_list, band_count, [&](int x, int y, int z) {
         const int i = vidx(g, x, y, z);
         float gv[3];
         double e[3] = {0.0, 0.0, 0.0};
@@ -133,16 +136,22 @@ __global__ __launch_bounds__(kBlock) void slavcheva_update_rewarp_kernel(const f
                                                                          float* __restrict__ warp_out,
                                                                          float* __restrict__ live_out, Grid g,
                                                                          Params p, lsf_gate gate,
-                                                                         lsf_iteration_record* record) {
+                                                                         lsf_iteration_record* record,
+                                                                         const int* __restrict__ band_list,
+                                                                         unsigned band_count) {
     if (gate_closed(gate)) return;
     unsigned long long best = 0ull;
-    for_each_voxel(g, [&](int x, int y, int z) {
+    for_each_listed_voxel(g, band_list, band_count, [&](int x, int y, int z) {
         const int i = vidx(g, x, y, z);
         float gv[3] = {gfield[i], gfield[g.plane + i], D == 3 ? gfield[2 * g.plane + i] : 0.0f};
         unsigned long long q = update_and_rewarp<D>(live, g, p, x, y, z, i, gv, warp_out, live_out,
                                                     p.zero_gradient_on_snap ? gfield : nullptr);
         best = q > best ? q : best;
     });
+    if (band_list && blockIdx.x == 0 && threadIdx.x == 0) {  // the unlisted voxels: zero update, smallest index
+        const unsigned long long q = pack_max(0.0f, linear_index(g, 0, 0, g.z_begin));
+        best = q > best ? q : best;
+    }
     const double sums[1] = {0.0};
     double* dst[1] = {nullptr};
     block_reduce_commit<0>(best, sums, record_max(record), dst);
@@ -170,12 +179,15 @@ struct LaunchArgs {
     Params p;
     lsf_gate gate;
     lsf_iteration_record* record;
+    const int* band_list;
+    unsigned band_count;
 };
 
 template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
 void launch_one(const LaunchArgs& a) {
     hipLaunchKernelGGL((slavcheva_gradient_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY>), dim3(a.blocks), dim3(kBlock), 0,
-                       a.s, a.live, a.canonical, a.warp_prev, a.g_out, a.g, a.p, a.gate, a.record);
+                       a.s, a.live, a.canonical, a.warp_prev, a.g_out, a.g, a.p, a.gate, a.record, a.band_list,
+                       a.band_count);
 }
 
 template <int D, int SMOOTH, bool LEVELSET, int DATA>
@@ -339,16 +351,18 @@ static inline bool band_subset_ok(int32_t subset) {
 
 extern "C" int lsf_slavcheva_gradient(const float* live, const float* canonical, const float* warp_prev_planar,
                                       float* g_out_planar, const lsf_grid* grid, const lsf_slavcheva_params* params,
-                                      const lsf_gate* gate, lsf_iteration_record* record, void* stream) {
+                                      const lsf_gate* gate, lsf_iteration_record* record, const int32_t* band_list,
+                                      int64_t band_count, void* stream) {
     if (int e = check_grid(grid)) return e;
     if (!live || !canonical || !warp_prev_planar || !params || !record || !g_out_planar ||
-        g_out_planar == warp_prev_planar)
+        g_out_planar == warp_prev_planar || (band_list && (band_count < 0 || band_count > 0x7fffffffll)))
         return LSF_ERR_BAD_ARGUMENT;
     Grid g = make_grid(grid);
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
-    LaunchArgs a{launch_blocks(t.total), as_stream(stream), live, canonical, warp_prev_planar, g_out_planar, g,
-                 make_params(params), gate_or_open(gate), record};
+    LaunchArgs a{band_list ? band_list_blocks((unsigned)band_count) : launch_blocks(t.total), as_stream(stream), live,
+                 canonical, warp_prev_planar, g_out_planar, g, make_params(params), gate_or_open(gate), record, band_list,
+                 (unsigned)band_count};
     if (grid->dims == 2) pick_terms<2>(params, a);
     else pick_terms<3>(params, a);
     return launch_status();
@@ -357,22 +371,25 @@ extern "C" int lsf_slavcheva_gradient(const float* live, const float* canonical,
 extern "C" int lsf_slavcheva_update_rewarp(const float* live, const float* canonical, float* g_planar,
                                            float* warp_out_planar, float* live_out, const lsf_grid* grid,
                                            const lsf_slavcheva_params* params, const lsf_gate* gate,
-                                           lsf_iteration_record* record, void* stream) {
+                                           lsf_iteration_record* record, const int32_t* band_list, int64_t band_count,
+                                           void* stream) {
     (void)canonical;
     if (int e = check_grid(grid)) return e;
-    if (!live || !g_planar || !warp_out_planar || !live_out || live_out == live || !params || !record)
+    if (!live || !g_planar || !warp_out_planar || !live_out || live_out == live || !params || !record ||
+        (band_list && (band_count < 0 || band_count > 0x7fffffffll)))
         return LSF_ERR_BAD_ARGUMENT;
     Grid g = make_grid(grid);
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
     Params p = make_params(params);
     lsf_gate gt = gate_or_open(gate);
+    const unsigned blocks = band_list ? band_list_blocks((unsigned)band_count) : launch_blocks(t.total);
     if (grid->dims == 2)
-        hipLaunchKernelGGL(slavcheva_update_rewarp_kernel<2>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream), live,
-                           g_planar, warp_out_planar, live_out, g, p, gt, record);
+        hipLaunchKernelGGL(slavcheva_update_rewarp_kernel<2>, dim3(blocks), dim3(kBlock), 0, as_stream(stream), live,
+                           g_planar, warp_out_planar, live_out, g, p, gt, record, band_list, (unsigned)band_count);
     else
-        hipLaunchKernelGGL(slavcheva_update_rewarp_kernel<3>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream), live,
-                           g_planar, warp_out_planar, live_out, g, p, gt, record);
+        hipLaunchKernelGGL(slavcheva_update_rewarp_kernel<3>, dim3(blocks), dim3(kBlock), 0, as_stream(stream), live,
+                           g_planar, warp_out_planar, live_out, g, p, gt, record, band_list, (unsigned)band_count);
     return launch_status();
 }
 

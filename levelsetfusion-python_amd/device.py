@@ -227,7 +227,11 @@ def upsample2x_linear(coarse, channels=1):
 
 
 # ---------------------------------------------------------------------------------------------- a9/a10
-def convolve_axis(src, dst, zero_mask_source, grid, axis, taps, gate=None):
+LISTED_TAP_COUNTS = (3, 5, 7, 9)  # lsf_convolve_axis_listed
+
+
+def convolve_axis(src, dst, zero_mask_source, grid, axis, taps, gate=None, band=None):
+    """one pass of the separable filter; band: an LSF_BAND_ALL list -- the zero-preserving pass at its voxels only"""
     taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float64))
     if taps.ndim != 1 or not (1 <= taps.size <= _lib.MAX_KERNEL_TAPS):
         raise ValueError("kernel must be 1-D with 1..%d taps" % _lib.MAX_KERNEL_TAPS)
@@ -237,6 +241,13 @@ def convolve_axis(src, dst, zero_mask_source, grid, axis, taps, gate=None):
         raise ValueError("cannot convolve a field of extent %d with a %d-tap kernel" % (length, taps.size))
     planes = src.shape[0]
     n = n_voxels(grid) * planes
+    if band is not None:
+        check(lib.lsf_convolve_axis_listed(_ptr(src, n, "conv src"), _ptr(dst, n, "conv dst"),
+                                           _ptr(zero_mask_source, n, "zero mask"), ctypes.byref(grid), planes, axis,
+                                           taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), taps.size,
+                                           _gate_ref(gate), band.pointer, band.count, stream_ptr()),
+              "lsf_convolve_axis_listed")
+        return
     check(lib.lsf_convolve_axis(_ptr(src, n, "conv src"), _ptr(dst, n, "conv dst"),
                                 _ptr(zero_mask_source, n, "zero mask", allow_none=True), ctypes.byref(grid),
                                 planes, axis, taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), taps.size,
@@ -328,13 +339,16 @@ def band_list(live, canonical, grid=None, subset=_lib.BAND_ALL):
     return BandList(indices, count, subset)
 
 
-def slavcheva_gradient(live, canonical, warp_prev, g_out, grid, params, gate, records, index):
-    """gradient + energies of one iteration on planar fields (the Sobolev path; lsf_slavcheva_gradient)"""
+def slavcheva_gradient(live, canonical, warp_prev, g_out, grid, params, gate, records, index, band=None):
+    """gradient + energies of one iteration on planar fields (the Sobolev path; lsf_slavcheva_gradient); band: an
+    LSF_BAND_ALL list -- only its voxels are visited (g_out must hold zeros elsewhere)"""
     n = n_voxels(grid)
     nd = n * grid.dims
     check(lib.lsf_slavcheva_gradient(_ptr(live, n, "live"), _ptr(canonical, n, "canonical"),
                                      _ptr(warp_prev, nd, "warp_prev"), _ptr(g_out, nd, "g_out"), ctypes.byref(grid),
-                                     ctypes.byref(params), _gate_ref(gate), _record_ptr(records, index), stream_ptr()),
+                                     ctypes.byref(params), _gate_ref(gate), _record_ptr(records, index),
+                                     band.pointer if band is not None else ctypes.c_void_p(0),
+                                     band.count if band is not None else 0, stream_ptr()),
           "lsf_slavcheva_gradient")
 
 
@@ -426,13 +440,15 @@ def slavcheva_state_iteration(state_in, canonical, state_out, grid, params, gate
           "lsf_slavcheva_state_iteration")
 
 
-def slavcheva_update_rewarp(live, canonical, g, warp_out, live_out, grid, params, gate, records, index):
+def slavcheva_update_rewarp(live, canonical, g, warp_out, live_out, grid, params, gate, records, index, band=None):
     n = n_voxels(grid)
     nd = n * grid.dims
     check(lib.lsf_slavcheva_update_rewarp(_ptr(live, n, "live"), _ptr(canonical, n, "canonical"), _ptr(g, nd, "g"),
                                           _ptr(warp_out, nd, "warp_out"), _ptr(live_out, n, "live_out"),
                                           ctypes.byref(grid), ctypes.byref(params), _gate_ref(gate),
-                                          _record_ptr(records, index), stream_ptr()),
+                                          _record_ptr(records, index),
+                                          band.pointer if band is not None else ctypes.c_void_p(0),
+                                          band.count if band is not None else 0, stream_ptr()),
           "lsf_slavcheva_update_rewarp")
 
 

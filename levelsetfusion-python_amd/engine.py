@@ -532,7 +532,8 @@ class SlavchevaEngine:
         gate = self._gate_for(records, i)
         slab = self._slab()
         g0, t1, t2 = gbufs
-        dev.slavcheva_gradient(live_in, canonical, warp_in, g0, grid, self.params, gate, records, i)
+        band = self._sobolev_band  # None: every voxel
+        dev.slavcheva_gradient(live_in, canonical, warp_in, g0, grid, self.params, gate, records, i, band)
         in_plane_grid = grid
         if slab:
             # the z pass of the filter reads len(kernel)//2 slices of the (x,y)-filtered field on either
@@ -542,10 +543,10 @@ class SlavchevaEngine:
         src, dst = g0, t1
         for axis in _conv_axis_order(grid.dims):
             dev.convolve_axis(src, dst, g0, grid if axis == 2 else in_plane_grid, axis, self.sobolev_kernel,
-                              gate)
+                              gate, band)
             src, dst = dst, (t2 if dst is t1 else t1)
         dev.slavcheva_update_rewarp(live_in, canonical, src, warp_out, live_out, grid, self.params, gate,
-                                    records, i)
+                                    records, i, band)
         self._last_g = src
         if slab:
             self.comm.exchange_live_and_warp(live_out, warp_out)
@@ -758,6 +759,13 @@ class SlavchevaEngine:
             warps = [torch.zeros((dims,) + tuple(live.shape), dtype=torch.float32, device=live.device)
                      for _ in range(2)]
             gbufs = [torch.zeros_like(warps[0]) for _ in range(3)]
+            # Band list: the gradient is zero outside the narrow band and the zero-preserving filter keeps it there
+            # (math_utils/convolution.py:118-127), so gradient, filter passes and update visit band voxels only; the
+            # zero-initialised g buffers and the two (live, 0) sets hold everything else.  z-slab runs stay dense (the
+            # x / y passes also run on the halo slices there).
+            self._sobolev_band = None
+            if self.use_band_list and not slab and len(self.sobolev_kernel) in dev.LISTED_TAP_COUNTS:
+                self._sobolev_band = dev.band_list(live, canonical, grid, _lib.BAND_ALL)
         else:
             # Both ping-pong states start as (live, 0): the fused kernel only visits the voxels of the band list and
             # the rest must already hold their final values (lsf_slavcheva_state_iteration); slab halos start valid.
