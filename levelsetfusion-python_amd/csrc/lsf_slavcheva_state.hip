@@ -170,6 +170,62 @@ __device__ inline float state_gather(const vf4* __restrict__ s, const Grid& g, f
 }
 
 // WALK: the dense tile walk over every voxel, a band list (ALL or BOUNDARY subset), an INTERIOR band list
+// The re-warp gather out of the neighbourhood that is already in registers (3-D, wave-uniform): while a warp update
+// stays inside (-1, 1) per axis its 2^3-voxel cell lies inside the 3^3 neighbourhood of the voxel, seven of the eight
+// taps are among the 19 loaded ones (at most two non-zero offsets) and only the cell's far corner has to be fetched --
+// one dword load instead of eight 16-byte-strided ones (a fifth of this kernel's vector-L1 traffic), paid for with
+// ~40 selects.  Same taps, same lerp order (z, y, x) as state_gather: bit-identical.
+// Returns false (for the whole wave) when some lane's cell leaves the neighbourhood.
+template <int D>
+__device__ inline bool gather_from_taps(const TapsBase<D>& n, const vf4* __restrict__ s, const Grid& g, int i, int x,
+                                        int y, int z, const float (&wv)[3], float& value) {
+    if (D != 3) return false;
+    const AxisTaps ax = axis_taps((float)x + wv[0], g.nx, 0), ay = axis_taps((float)y + wv[1], g.ny, 0);
+    const AxisTaps az = axis_taps((float)(z + g.z_global_offset) + wv[2], g.nz, g.z_global_offset);
+    const int lox = ax.c0 - x, loy = ay.c0 - y, loz = az.c0 - z;  // -1 or 0 when the cell is inside the neighbourhood
+    const bool near = ax.v0 && ax.v1 && ay.v0 && ay.v1 && az.v0 && az.v1 && (unsigned)(lox + 1) < 2u &&
+                      (unsigned)(loy + 1) < 2u && (unsigned)(loz + 1) < 2u;
+    if (!__all(near)) return false;
+    const int sx = lox < 0 ? -1 : 1, sy = loy < 0 ? -g.nx : g.nx, sz = loz < 0 ? -(g.nx * g.ny) : g.nx * g.ny;
+    const float corner = reinterpret_cast<const float*>(s)[(long long)(i + sx + sy + sz) * 4];
+    float L[3][3][3];
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx)
+                L[dz][dy][dx] = (dx != 1 && dy != 1 && dz != 1) ? corner : n.t[dz][dy][dx].x;
+    float X[3][3][2], Y[3][2][2], Z[2][2][2];
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int ox = 0; ox < 2; ++ox) X[dz][dy][ox] = lox < 0 ? L[dz][dy][ox] : L[dz][dy][ox + 1];
+#pragma unroll
+    for (int dz = 0; dz < 3; ++dz)
+#pragma unroll
+        for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+            for (int ox = 0; ox < 2; ++ox) Y[dz][oy][ox] = loy < 0 ? X[dz][oy][ox] : X[dz][oy + 1][ox];
+#pragma unroll
+    for (int oz = 0; oz < 2; ++oz)
+#pragma unroll
+        for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+            for (int ox = 0; ox < 2; ++ox) Z[oz][oy][ox] = loz < 0 ? Y[oz][oy][ox] : Y[oz + 1][oy][ox];
+    float c[2][2];
+#pragma unroll
+    for (int ox = 0; ox < 2; ++ox)
+#pragma unroll
+        for (int oy = 0; oy < 2; ++oy) c[ox][oy] = Z[0][oy][ox] * az.i + Z[1][oy][ox] * az.r;
+    const float i0 = c[0][0] * ay.i + c[0][1] * ay.r;
+    const float i1 = c[1][0] * ay.i + c[1][1] * ay.r;
+    value = i0 * ax.i + i1 * ax.r;
+    return true;
+}
+
 constexpr int kWalkDense = 0, kWalkList = 1, kWalkListInterior = 2;
 
 template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, int WALK>
@@ -187,12 +243,18 @@ __global__ __launch_bounds__(kBlock) void slavcheva_state_kernel(const vf4* __re
         float gv[3] = {0.0f, 0.0f, 0.0f};
         // outside the narrow-band union (tsdf_set_routines.py:19-52; the `continue` of slavcheva_optimizer2d.py:251-252)
         const bool in_band = !(fabsf(l) == 1.0f && fabsf(cn) == 1.0f);
+        float v_taps = 0.0f;
+        bool have_v_taps = false;
         if (in_band) {
             double e[3] = {0.0, 0.0, 0.0};
             const bool interior = x > 0 && x < g.nx - 1 && y > 0 && y < g.ny - 1 && (D == 2 || (z > 0 && z < g.nz - 1));
             if (WALK == kWalkListInterior || (g.fast_ok && __all(interior))) {
                 const NbhStateFast<D> n(state_in, g, x, y, z, sc);
                 band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
+                float w_now[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int c = 0; c < D; ++c) w_now[c] = (-gv[c]) * p.rate;
+                have_v_taps = gather_from_taps<D>(n, state_in, g, i, x, y, z, w_now, v_taps);
             } else {
                 const NbhState<D> n(state_in, g, x, y, z, sc);
                 band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
@@ -211,6 +273,8 @@ __global__ __launch_bounds__(kBlock) void slavcheva_state_kernel(const vf4* __re
         float v;
         if (wv[0] == 0.0f && wv[1] == 0.0f && wv[2] == 0.0f) {
             v = l;  // zero displacement: every lerp is a*1 + b*0 = a exactly, the gather returns live[p] bit for bit
+        } else if (have_v_taps) {
+            v = v_taps;
         } else {
             const float px = (float)x + wv[0], py = (float)y + wv[1];
             const float pz = D == 3 ? (float)(z + g.z_global_offset) + wv[2] : 0.0f;
