@@ -452,6 +452,23 @@ class SlavchevaOutcome:
         device tensor, or None for a new one), builds the interleaved warp [z,]y,x,c and -- with `statistics` -- the raw
         convergence statistics (float64 [16] on the HOST: warp [0:8], |canonical - live| [8:16]).
         Returns (live, warp_interleaved, raw statistics or None)."""
+        early = getattr(self, "_early", None)
+        if early is not None and early[0][0] is live_out and \
+                early[0][1:] == (float(lower_threshold), bool(statistics)):
+            # already enqueued by optimize() behind the last iteration (fixed iteration counts): nothing left to launch
+            _, target, warp, raw = early
+            self._early = None
+            if live_out is not None and target is not live_out:
+                live_out.copy_(target)
+            return target, warp, (raw.cpu().numpy() if raw is not None else None)
+        return self._finalize_now(live_out, lower_threshold, statistics, to_host=True)
+
+    def enqueue_finalize(self, live_out, lower_threshold, statistics):
+        """launch the finalize pass now (no host synchronisation); finalize() with the same arguments collects it"""
+        target, warp, raw = self._finalize_now(live_out, lower_threshold, statistics, to_host=False)
+        self._early = ((live_out, float(lower_threshold), bool(statistics)), target, warp, raw)
+
+    def _finalize_now(self, live_out, lower_threshold, statistics, to_host):
         g = self.grid
         full = dev.full_range(g)
         if live_out is None or not (live_out.is_cuda and live_out.dtype == torch.float32 and live_out.is_contiguous()):
@@ -469,6 +486,8 @@ class SlavchevaOutcome:
             if statistics:
                 raw = torch.cat([dev.warp_statistics(self._warp_planar, self.canonical, self._live, lower_threshold, full),
                                  dev.tsdf_difference_statistics(self.canonical, self._live, full)])
+        if not to_host:
+            return target, warp, raw
         if live_out is not None and target is not live_out:
             live_out.copy_(target)
         return target, warp, (raw.cpu().numpy() if raw is not None else None)
@@ -737,9 +756,12 @@ class SlavchevaEngine:
             self._comm_stream = torch.cuda.Stream(device=live.device)
             self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
 
-    def optimize(self, live, canonical):
+    def optimize(self, live, canonical, finalize=None):
         """live, canonical: float32 device tensors (z-slab runs: the local slab incl. halos).  Returns a
-        SlavchevaOutcome holding the final fields on the device; the caller's tensors are not modified."""
+        SlavchevaOutcome holding the final fields on the device; the caller's tensors are not modified.
+        finalize = (live_out, lower_threshold, statistics): the arguments the caller is going to pass to
+        outcome.finalize() -- with a fixed iteration count (no stop test can fire) the finalize pass is then enqueued
+        right behind the last iteration and the records and statistics are read with ONE host synchronisation."""
         if live.shape != canonical.shape:
             raise ValueError("live and canonical fields must have the same shape")
         grid = self._grid(live)
@@ -792,6 +814,7 @@ class SlavchevaEngine:
         limit = 0 if self.min_iterations == 0 else max(self.max_iterations, self.min_iterations)
         it, n_exec = 0, 0
         dec = None
+        early = None
         while it < limit:
             batch = min(self.check_interval, limit - it)
             for i in range(it, it + batch):
@@ -803,6 +826,10 @@ class SlavchevaEngine:
             if slab:  # global max (idempotent) and, once per record, the energy sums of this batch
                 self.comm.reduce_records(records, it, it + batch)
             it += batch
+            if finalize is not None and not self.sobolev and it == limit and self.min_iterations >= limit:
+                # every launch runs ungated, so the final state is states[limit % 2]: finalize before looking
+                early = SlavchevaOutcome(grid, canonical, state=states[limit % 2])
+                early.enqueue_finalize(*finalize)
             dec = dev.decode_records(records[:it].cpu().numpy())
             n_exec = int(dec["executed"].sum())
             if n_exec < it:
@@ -832,6 +859,8 @@ class SlavchevaEngine:
                         level_set_energies=[wl * float(v) for v in dec["level_set_energy"][:n_exec]])
         if self.sobolev:
             outcome = SlavchevaOutcome(grid, canonical, live=lives[n_exec % 2], warp_planar=warps[n_exec % 2])
+        elif early is not None and n_exec == limit:
+            outcome = early
         else:
             outcome = SlavchevaOutcome(grid, canonical, state=states[n_exec % 2])
         # what is needed to (re)produce gradient_field of the last executed iteration on demand

@@ -114,7 +114,12 @@ class _SlavchevaOptimizerBase:
             self._run_checks(live_field, canonical_field)
         live = as_device_field(live_field)
         canonical = as_device_field(canonical_field)
-        outcome = self._engine.optimize(live, canonical)
+        # one pass over the final state: the live field back into the caller's array (in place, like np.copyto at
+        # :230,:328), the warp in the API layout, and the convergence statistics (:393-404)
+        want_report = self.enable_convergence_status_logging and \
+            (self._engine.comm is None or not self._engine.comm.active)
+        finalize_args = (live_field if on_device else None, self.maximum_warp_length_lower_threshold, want_report)
+        outcome = self._engine.optimize(live, canonical, finalize=finalize_args)
         eng_log = self._engine.log
         self.log = OptimizationLog()
         self.log.max_warps = eng_log["max_warps"]
@@ -134,12 +139,7 @@ class _SlavchevaOptimizerBase:
                 print("[Iteration %d done], data energy: %f; smoothing energy: %f; level set energy: %f; max warp: %f"
                       % (i, self.log.data_energies[i], self.log.smoothing_energies[i],
                          self.log.level_set_energies[i], self.log.max_warps[i]))
-        # one pass over the final state: the live field back into the caller's array (in place, like np.copyto at
-        # :230,:328), the warp in the API layout, and the convergence statistics (:393-404)
-        want_report = self.enable_convergence_status_logging and \
-            (self._engine.comm is None or not self._engine.comm.active)
-        final_live, warp, raw = outcome.finalize(live_field if on_device else None,
-                                                 self.maximum_warp_length_lower_threshold, want_report)
+        final_live, warp, raw = outcome.finalize(*finalize_args)
         if want_report:
             shape = tuple(live.shape)
             ws = warp_delta_statistics_from_raw(raw[:8], shape, self.maximum_warp_length_lower_threshold,
