@@ -660,3 +660,38 @@ def test_full_size_fixed_point_and_slab_invariance_256(lsf):
     assert d["max_value"][0] == max(d["max_value"][1], d["max_value"][2])
     assert d["argmax"][0] == (d["argmax"][1] if d["max_value"][1] >= d["max_value"][2] else d["argmax"][2])
     assert np.isclose(d["data_energy"][0], d["data_energy"][1] + d["data_energy"][2], rtol=1e-10)
+
+
+def test_full_size_config2_hierarchical_2d_512(lsf):
+    """BASELINE config 2 at full size: 2-D 512 x 512 circle pair, HierarchicalOptimizer2d with a 3-level pyramid
+    (maximum_chunk_size 4: 128 / 256 / 512), Tikhonov smoothing, no gradient kernel -- bit-identical to the oracle;
+    levels run through the HIP-graph replay path"""
+    canon, live = O.sphere_pair(512, 2)
+    kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=4, rate=0.1,
+              maximum_iteration_count=10, maximum_warp_update_threshold=0.0, tikhonov_strength=0.2)
+    opt = lsf.HierarchicalOptimizer2d(**kw)
+    warp = opt.optimize(canon, live)
+    o = O.HierarchicalOracle(**kw)
+    want = o.optimize(canon, live)
+    assert warp.shape == (512, 512, 2) and opt.get_per_level_iteration_counts() == [10, 10, 10]
+    assert maxdiff(warp, want) == EXACT
+    for mine, theirs in zip(opt.get_per_level_maximum_updates(), o.per_level_max_updates):
+        assert np.array_equal(np.float32(mine), np.float32(theirs))
+    assert float(np.abs(want).max()) > 0.05  # the optimisation moved
+
+
+def test_full_size_config3_hierarchical_3d_128_with_sobolev_kernel(lsf):
+    """BASELINE config 3 at full size: 3-D 128^3 sphere pair, HierarchicalOptimizer3d, chunk 8 (4 levels 16 ... 128),
+    Tikhonov + the 7-tap Sobolev gradient kernel (register-window filter passes) -- bit-identical to the oracle"""
+    n = 128
+    canon, live = O.sphere_pair(n, 3)
+    k7 = lsf.generate_1d_sobolev_kernel(7, 0.1)
+    kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=True, maximum_chunk_size=8, rate=0.1,
+              maximum_iteration_count=2, maximum_warp_update_threshold=0.0, tikhonov_strength=0.05, kernel=k7)
+    opt = lsf.HierarchicalOptimizer3d(**kw)
+    warp = opt.optimize(torch.from_numpy(canon).cuda(), torch.from_numpy(live).cuda())
+    o = O.HierarchicalOracle(**kw)
+    want = o.optimize(canon, live)
+    assert tuple(warp.shape) == (n, n, n, 3) and opt.get_per_level_iteration_counts() == [2, 2, 2, 2]
+    assert maxdiff(warp.cpu().numpy(), want) == EXACT
+    assert float(np.abs(want).max()) > 1e-3
