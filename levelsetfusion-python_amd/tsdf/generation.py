@@ -1,7 +1,7 @@
 """TSDF generation from depth images on the GPU -- the input stage of the optimizers
 (reference: tsdf/generation.py:130-235, 356-437; camera model calib/camera.py:69-311 reduced to what is consumed:
-a 3x3 intrinsic matrix and the depth unit ratio).  Nearest-pixel lookup (FilteringMethod.NONE) here, the EWA filters in
-tsdf/ewa.py of this package; the two bilinear variants are not built and raise NotImplementedError."""
+a 3x3 intrinsic matrix and the depth unit ratio).  Nearest-pixel lookup (FilteringMethod.NONE) and the two bilinear 2-D
+variants (tsdf/generation.py:18-128) here, the EWA filters in tsdf/ewa.py of this package."""
 import ctypes
 from enum import Enum
 
