@@ -50,6 +50,21 @@ def _conv_axis_order(dims):
     return [1, 0] if dims == 2 else [0, 1, 2]
 
 
+def _combine_statistics(rows, has_min):
+    """per-rank raw statistics (the 8 doubles of lsf_warp_statistics / lsf_tsdf_difference_statistics over disjoint
+    z-ranges, arg-max as GLOBAL voxel index) -> the statistics of the union"""
+    rows = [np.asarray(r, dtype=np.float64) for r in rows]
+    out = np.zeros(8)
+    sums = (0, 3, 4) if has_min else (0, 1, 3, 4)
+    for k in sums:
+        out[k] = sum(r[k] for r in rows)
+    if has_min:
+        out[1] = min(r[1] for r in rows)
+    best = max(rows, key=lambda r: (r[2], -r[5] if r[5] >= 0 else -np.inf))
+    out[2], out[5] = best[2], best[5]
+    return out
+
+
 class LevelResult:
     def __init__(self, iteration_count, max_updates, argmax, data_energies, voxel_count=0, tikhonov_energies=()):
         self.voxel_count = voxel_count
@@ -104,6 +119,12 @@ class HierarchicalEngine:
     def _slab(self):
         return self.comm is not None and self.comm.active
 
+    def _slab_comm_of(self, layout):
+        for c in getattr(self, "_level_comms", []) or [self.comm]:
+            if c is not None and c.layout is layout:
+                return c
+        return self.comm
+
     def build_pyramids(self, canonical, live):
         """canonical / live pyramids, coarsest first; live is packed with its full-resolution np.gradient
         BEFORE restriction (gradients are averaged, not recomputed: hierarchical_optimizer2d.py:126-131).
@@ -157,6 +178,7 @@ class HierarchicalEngine:
         canon_levels.reverse()
         packed_levels.reverse()
         comms.reverse()
+        self._level_comms = comms
         return canon_levels, packed_levels, comms
 
     def optimize(self, canonical, live):
@@ -272,6 +294,25 @@ class HierarchicalEngine:
                                            build_warp_delta_statistics(g_final, lv.canonical, resampled, thr,
                                                                        float("inf")),
                                            build_tsdf_difference_statistics(lv.canonical, resampled))
+        elif self.collect_reports:
+            # z-slab: the same statistics over the OWNED slices (global voxel indices through z_global_offset), then
+            # combined over the ranks -- counts and sums add, minima / maxima compare, the arg-max of the larger
+            # maximum wins (smallest index on a tie, as np.argmax over the whole volume)
+            from .convergence_report import (ConvergenceReport, tsdf_difference_statistics_from_raw,
+                                             warp_delta_statistics_from_raw)
+            L = slab_layout
+            whole = dev.make_grid(lv.canonical.shape, 0, L.nz_local, L.z_global_offset)
+            resampled = dev.warp_field(lv.packed[..., 0].contiguous(), lv.warp, 1.0, whole)
+            g_final = self.last_gradient if self.last_gradient is not None else torch.zeros_like(lv.warp)
+            raw = torch.stack([dev.warp_statistics(g_final, lv.canonical, resampled, thr, lv.grid),
+                               dev.tsdf_difference_statistics(lv.canonical, resampled, lv.grid)])
+            rows = self._slab_comm_of(L).gather_rows(raw)
+            shape = (L.nz_global,) + tuple(lv.canonical.shape[1:])
+            res.report = ConvergenceReport(
+                n_exec, res.iteration_limit_reached,
+                warp_delta_statistics_from_raw(_combine_statistics([r[0] for r in rows], has_min=False), shape, thr,
+                                               float("inf")),
+                tsdf_difference_statistics_from_raw(_combine_statistics([r[1] for r in rows], has_min=True), shape))
 
     OPEN_RECORD = 0x7F800000FFFFFFFF  # packed max = +inf: "previous iteration has not converged" for the gate
 

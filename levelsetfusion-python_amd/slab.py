@@ -217,6 +217,16 @@ class SlabComm:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
 
+    def gather_rows(self, value):
+        """every rank's copy of a small float64 device tensor, as a list of host arrays in rank order"""
+        if not self.active:
+            return [value.cpu().numpy()]
+        world = dist.get_world_size(self.group)
+        mine = value.cpu() if (self.stage_through_host and value.is_cuda) else value
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine.contiguous(), group=self.group)
+        return [r.cpu().numpy() for r in rows]
+
     def reduce_scalar_max(self, value):
         """in-place MAX all-reduce of a small float tensor (slab guards)"""
         if not self.active:

@@ -88,6 +88,13 @@ def test_two_slab_ranks_equal_whole_volume(tmp_path, config):
         assert np.allclose(p["level_set"], ref.log.level_set_energies, rtol=1e-10)
 
 
+def _report_row(r):
+    w, d = r.warp_delta_statistics, r.tsdf_difference_statistics
+    return [r.iteration_count, float(r.iteration_limit_reached), w.ratio_above_min_threshold, w.length_max,
+            w.length_mean, w.length_standard_deviation, *w.longest_warp_location, d.difference_min, d.difference_max,
+            d.difference_mean, d.difference_standard_deviation, *d.biggest_difference_location]
+
+
 def _hier_worker(rank, world, port, n, nz, halo, kwargs, out_dir):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
@@ -100,11 +107,15 @@ def _hier_worker(rank, world, port, n, nz, halo, kwargs, out_dir):
     layout = SlabLayout(nz, rank, world, halo)
     sl = layout.local_slice()
     canonical, live = sphere_pair(n, 3, "cuda", (sl.start, sl.stop))
-    opt = lsf.HierarchicalOptimizer3d(comm=SlabComm(layout), **kwargs)
+    opt = lsf.HierarchicalOptimizer3d(
+        comm=SlabComm(layout),
+        logging_parameters=lsf.HierarchicalOptimizer3d.LoggingParameters(collect_per_level_convergence_reports=True),
+        **kwargs)
     warp = opt.optimize(canonical, live)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), warp=warp.cpu().numpy(),
              counts=np.int64(opt.get_per_level_iteration_counts()),
-             last_max=np.float32([m[-1] for m in opt.get_per_level_maximum_updates()]))
+             last_max=np.float32([m[-1] for m in opt.get_per_level_maximum_updates()]),
+             reports=np.float64([_report_row(r) for r in opt.get_per_level_convergence_reports()]))
     dist.destroy_process_group()
 
 
@@ -137,13 +148,19 @@ def test_two_slab_ranks_hierarchical_equal_whole_volume(tmp_path, config):
         kwargs["maximum_warp_update_threshold"] = float(0.5 * (trajectory[11] + trajectory[12]))
     mp.spawn(_hier_worker, args=(world, _free_port(), n, nz, halo, kwargs, str(tmp_path)), nprocs=world, join=True)
     canonical, live = sphere_pair(n, 3, "cuda", (0, nz))
-    ref = lsf.HierarchicalOptimizer3d(**kwargs)
+    ref = lsf.HierarchicalOptimizer3d(
+        logging_parameters=lsf.HierarchicalOptimizer3d.LoggingParameters(collect_per_level_convergence_reports=True),
+        **kwargs)
     warp = ref.optimize(canonical, live).cpu().numpy()
+    want_reports = np.float64([_report_row(r) for r in ref.get_per_level_convergence_reports()])
     parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     assert np.array_equal(np.concatenate([p["warp"] for p in parts], 0), warp)
     for p in parts:
         assert list(p["counts"]) == ref.get_per_level_iteration_counts()
         assert np.array_equal(p["last_max"], np.float32([m[-1] for m in ref.get_per_level_maximum_updates()]))
+        # per-level convergence reports: the slab ranks combine their statistics into those of the whole volume
+        assert p["reports"].shape == want_reports.shape and want_reports.shape[1] == 16
+        assert np.allclose(p["reports"], want_reports, rtol=1e-9, atol=1e-12), (p["reports"], want_reports)
     if config == "data_threshold":
         assert any(1 < c < 40 for c in ref.get_per_level_iteration_counts())
 
