@@ -189,15 +189,25 @@ __device__ inline void killing_gradient(const NB& n, const typename NB::Field (&
         gs[i] = g;
     }
     if (want_energy) {
-        double e = 0.0;
+        // sum_ic J_ic^2 + lambda * sum_ic J_ic J_ci  =  |J|_F^2 + lambda * (sum_i J_ii^2 + 2 sum_{i<c} J_ic J_ci),
+        // J_ic = d w_i / d c, in float64 with fused multiply-adds: energies are sums the tests compare to 1e-9, not bit
+        // for bit (their accumulation order varies with the launch anyway), and the float64 energy math was 16 % of this
+        // kernel's time in the term-by-term form
+        double j[3][3];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int c = 0; c < D; ++c) j[i][c] = (double)first[c][i];
+        double frob = 0.0, diag = 0.0, off = 0.0;
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
             for (int c = 0; c < D; ++c) {
-                const double jic = (double)first[c][i], jci = (double)first[i][c];
-                e += jic * jic + p.lambda64 * jic * jci;
+                frob = fma(j[i][c], j[i][c], frob);
+                if (c == i) diag = fma(j[i][i], j[i][i], diag);
+                if (c > i) off = fma(j[i][c], j[c][i], off);
             }
-        energy = e;
+        energy = fma(p.lambda64, diag + (off + off), frob);
     }
 }
 
