@@ -264,8 +264,12 @@ int lsf_band_list_fill(const float *live, const float *canonical, const lsf_grid
  * lsf_state_unpack: state -> live and / or planar warp [c][z][y][x] and / or interleaved warp [z][y][x][c]. */
 /* lsf_state_prepare: the start of an optimize() call in one pass over WHOLE arrays (z_begin = 0, z_end = nz): both
  * ping-pong states = (live, 0) and the counting step of lsf_band_count for the INTERIOR and the BOUNDARY subset at once.
- * scratch: 2 * lsf_band_scratch_elements(grid) int32; afterwards scratch[0 ..) and scratch[lsf_band_scratch_elements ..)
- * are the two scratch arrays lsf_band_list_fill expects; counts_out[0..2) (device) = INTERIOR and BOUNDARY totals. */
+ * scratch: lsf_state_prepare_scratch_elements(grid) int32 (8-byte aligned); counts_out[0..2) (device) = INTERIOR and
+ * BOUNDARY totals.  lsf_band_list_fill_prepared then writes one subset's list from the ballots the prepare pass kept
+ * in scratch (16 bytes per 64 voxels) -- live and canonical are not read again. */
+int64_t lsf_state_prepare_scratch_elements(const lsf_grid *grid);
+int lsf_band_list_fill_prepared(const lsf_grid *grid, int32_t subset, const int32_t *scratch, int32_t *list,
+                                void *stream);
 int lsf_state_prepare(const float *live, const float *canonical, float *state_a, float *state_b,
                       const lsf_grid *grid, int32_t *scratch, int64_t *counts_out, void *stream);
 int lsf_state_pack(const float *live, const float *warp_planar, float *state_a, float *state_b,

@@ -129,6 +129,8 @@ PROTOTYPES = {
                                               _vp, _i64, _vp]),
     "lsf_convolve_axis_listed": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _i32, _i32, _P(ctypes.c_double), _i32,
                                                 _P(Gate), _vp, _i64, _vp]),
+    "lsf_state_prepare_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
+    "lsf_band_list_fill_prepared": (ctypes.c_int, [_P(Grid), _i32, _vp, _vp, _vp]),
     "lsf_state_prepare": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp, _vp, _vp]),
     "lsf_state_pack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp]),
     "lsf_state_unpack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp]),

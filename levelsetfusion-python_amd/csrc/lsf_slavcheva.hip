@@ -309,7 +309,8 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
                                                                const float* __restrict__ canonical,
                                                                vf4* __restrict__ a, vf4* __restrict__ b, unsigned n,
                                                                Grid g, int dims, int* __restrict__ sums_interior,
-                                                               int* __restrict__ sums_boundary) {
+                                                               int* __restrict__ sums_boundary,
+                                                               unsigned long long* __restrict__ masks) {
     __shared__ int part[2][16];  // [subset][pass j * 4 + wave]
     const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
 #pragma unroll
@@ -333,6 +334,9 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
         if (lane == 0) {
             part[0][j * 4 + wave] = __popcll(mi);
             part[1][j * 4 + wave] = __popcll(mb);
+            // the ballots themselves: the fill step reads these 16 bytes per 64 voxels instead of live and canonical again
+            masks[((size_t)blockIdx.x * 16 + j * 4 + wave) * 2 + 0] = mi;
+            masks[((size_t)blockIdx.x * 16 + j * 4 + wave) * 2 + 1] = mb;
         }
     }
     __syncthreads();
@@ -340,6 +344,24 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
         int sum = 0;
         for (int k = 0; k < 16; ++k) sum += part[t][k];
         (t == 0 ? sums_interior : sums_boundary)[blockIdx.x] = sum;
+    }
+}
+
+// ordered fill of one subset's list from the ballots lsf_state_prepare kept (which = 0 INTERIOR, 1 BOUNDARY)
+__global__ __launch_bounds__(kBlock) void band_fill_from_masks_kernel(const unsigned long long* __restrict__ masks,
+                                                                      const int* __restrict__ block_sums, int which,
+                                                                      int* __restrict__ list) {
+    const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
+    int at = block_sums[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) {
+            const unsigned long long m = masks[((size_t)blockIdx.x * 16 + j * 4 + wv) * 2 + which];
+            if (wv == wave && ((m >> lane) & 1ull))
+                list[at + __popcll(m & ((1ull << lane) - 1ull))] = (int)(blockIdx.x * kBandChunk + j * kBlock + t);
+            at += __popcll(m);
+        }
     }
 }
 
@@ -423,6 +445,34 @@ extern "C" int lsf_band_count(const float* live, const float* canonical, const l
     return launch_status();
 }
 
+// scratch of lsf_state_prepare: [chunks + 1] INTERIOR sums, [chunks + 1] BOUNDARY sums, then (8-byte aligned) the two
+// ballots of every 64-voxel group: 32 uint64 per 1024-voxel chunk
+static inline unsigned long long* prepare_masks(int32_t* scratch, unsigned chunks) {
+    return reinterpret_cast<unsigned long long*>(scratch + 2 * (size_t)(chunks + 1) + (2 * (chunks + 1)) % 2);
+}
+
+extern "C" int64_t lsf_state_prepare_scratch_elements(const lsf_grid* grid) {
+    if (check_grid(grid)) return 0;
+    unsigned first, n, chunks;
+    band_range(grid, first, n, chunks);
+    return 2 * (int64_t)(chunks + 1) + 64 * (int64_t)chunks + 2;
+}
+
+extern "C" int lsf_band_list_fill_prepared(const lsf_grid* grid, int32_t subset, const int32_t* scratch, int32_t* list,
+                                           void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!scratch || !list || (subset != LSF_BAND_INTERIOR && subset != LSF_BAND_BOUNDARY) || grid->z_begin != 0 ||
+        grid->z_end != grid->nz)
+        return LSF_ERR_BAD_ARGUMENT;
+    unsigned first, n, chunks;
+    if (!band_range(grid, first, n, chunks)) return 0;
+    const int which = subset == LSF_BAND_INTERIOR ? 0 : 1;
+    hipLaunchKernelGGL(band_fill_from_masks_kernel, dim3(chunks), dim3(kBlock), 0, as_stream(stream),
+                       prepare_masks(const_cast<int32_t*>(scratch), chunks), scratch + which * (size_t)(chunks + 1), which,
+                       list);
+    return launch_status();
+}
+
 extern "C" int lsf_state_prepare(const float* live, const float* canonical, float* state_a, float* state_b,
                                  const lsf_grid* grid, int32_t* scratch, int64_t* counts_out, void* stream) {
     if (int e = check_grid(grid)) return e;
@@ -435,7 +485,7 @@ extern "C" int lsf_state_prepare(const float* live, const float* canonical, floa
     int* sums_boundary = scratch + (chunks + 1);
     hipLaunchKernelGGL(state_prepare_kernel, dim3(chunks), dim3(kBlock), 0, s, live, canonical,
                        reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b), n, make_grid(grid), grid->dims,
-                       sums_interior, sums_boundary);
+                       sums_interior, sums_boundary, prepare_masks(scratch, chunks));
     hipLaunchKernelGGL(band_scan_kernel, dim3(2), dim3(1024), 0, s, scratch, chunks, chunks + 1, (long long*)counts_out);
     return launch_status();
 }

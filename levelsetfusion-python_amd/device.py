@@ -354,17 +354,17 @@ def slavcheva_gradient(live, canonical, warp_prev, g_out, grid, params, gate, re
 
 def state_prepare(live, canonical, grid=None):
     """start of a fused optimize() call on whole arrays, one pass over live and canonical (lsf_state_prepare): the two
-    ping-pong states (live, 0) and the INTERIOR + BOUNDARY band lists (empty lists dropped, but never both).
-    Returns (states, band lists)."""
+    ping-pong states (live, 0) and the INTERIOR + BOUNDARY band lists (empty lists dropped, but never both).  The lists
+    are filled from the ballots the pass keeps (lsf_band_list_fill_prepared).  Returns (states, band lists)."""
     grid = grid or make_grid(live.shape)
     n = n_voxels(grid)
     states = [torch.empty(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device) for _ in range(2)]
-    n_scratch = int(lib.lsf_band_scratch_elements(ctypes.byref(grid)))
-    scratch = torch.empty((2, n_scratch), dtype=torch.int32, device=live.device)
+    n_scratch = int(lib.lsf_state_prepare_scratch_elements(ctypes.byref(grid)))
+    scratch = torch.empty(n_scratch, dtype=torch.int32, device=live.device)
     totals = torch.empty(2, dtype=torch.int64, device=live.device)
-    p_live, p_canon = _ptr(live, n, "live"), _ptr(canonical, n, "canonical")
-    check(lib.lsf_state_prepare(p_live, p_canon, _ptr(states[0], 4 * n, "state"), _ptr(states[1], 4 * n, "state"),
-                                ctypes.byref(grid), ctypes.c_void_p(scratch.data_ptr()),
+    p_scratch = ctypes.c_void_p(scratch.data_ptr())
+    check(lib.lsf_state_prepare(_ptr(live, n, "live"), _ptr(canonical, n, "canonical"), _ptr(states[0], 4 * n, "state"),
+                                _ptr(states[1], 4 * n, "state"), ctypes.byref(grid), p_scratch,
                                 ctypes.c_void_p(totals.data_ptr()), stream_ptr()), "lsf_state_prepare")
     counts = [int(c) for c in totals.cpu()]
     lists = []
@@ -373,9 +373,9 @@ def state_prepare(live, canonical, grid=None):
             continue
         indices = torch.empty(max(count, 1), dtype=torch.int32, device=live.device)
         if count:
-            check(lib.lsf_band_list_fill(p_live, p_canon, ctypes.byref(grid), subset,
-                                         ctypes.c_void_p(scratch[k].data_ptr()), ctypes.c_void_p(indices.data_ptr()),
-                                         stream_ptr()), "lsf_band_list_fill")
+            check(lib.lsf_band_list_fill_prepared(ctypes.byref(grid), subset, p_scratch,
+                                                  ctypes.c_void_p(indices.data_ptr()), stream_ptr()),
+                  "lsf_band_list_fill_prepared")
         lists.append(BandList(indices, count, subset))
     return states, lists
 
