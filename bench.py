@@ -8,10 +8,11 @@ section 8(d), fp32.  One *step* = one optimize(live, canonical) call = 50 launch
 over one 256^3 pair (+ the convergence-statistics reductions the reference also runs per call).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns a 256^3 z-slab of a
-256 x 256 x (256 N) volume with a 4-slice halo; every 4th iteration the band voxels of the 4 boundary slices of the
+256 x 256 x (256 N) volume with an 8-slice halo; every 8th iteration the band voxels of the 8 boundary slices of the
 state (live field + warp) travel to the z-neighbours (RCCL send / recv over xGMI, issued by the library:
-lsf_slab_state_iteration) while the interior is computed; the iterations in between recompute the neighbours' slices
-they still have valid inputs for; the iteration records are all-reduced once per step.
+lsf_slab_state_iteration) while the interior -- and the halo-independent part of the next iteration -- is computed; the
+iterations in between recompute the neighbours' slices they still have valid inputs for; the iteration records are
+all-reduced once per step.
 
 Prints ONE JSON line on rank 0.
 """
@@ -39,7 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=256, help="edge of the per-GPU volume (256 = BASELINE config 4)")
     ap.add_argument("--iterations", type=int, default=50)
-    ap.add_argument("--halo", type=int, default=4,
+    ap.add_argument("--halo", type=int, default=8,
                     help="halo slices per interior slab face = iterations per exchange group: the faces travel every "
                          "--halo iterations, the iterations in between recompute the neighbours' slices (exact while "
                          "every warp update stays below one voxel; the engine raises otherwise)")

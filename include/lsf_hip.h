@@ -304,6 +304,11 @@ int lsf_slavcheva_state_iteration(const float *state_in, const float *canonical,
  * RCCL is bound with dlopen (rccl_library_path, else "librccl.so" as already mapped into the process).
  * Communicator: rank 0 calls lsf_slab_unique_id, the 128 bytes travel to the other ranks by any means (the Python side
  * broadcasts them with torch.distributed), every rank calls lsf_slab_comm_create on its current device. */
+#define LSF_SLAB_LAUNCH 0            /* launches only (boundary parts, then interior parts): inside an exchange group */
+#define LSF_SLAB_EXCHANGE 1          /* boundary parts -> exchange || interior parts -> the stream waits for the halos */
+#define LSF_SLAB_EXCHANGE_DEFERRED 2 /* the same, but the wait is left to the next call, which must be a RESUME */
+#define LSF_SLAB_RESUME 3            /* "boundary" parts = what does not read the halos (runs while the previous call's
+                                        exchange is in flight), wait for that exchange, then the "interior" parts */
 typedef struct lsf_slab_comm lsf_slab_comm;
 typedef struct lsf_slab_layout {
     int32_t nz, ny, nx;       /* local array (owned slab + halos) */
@@ -337,7 +342,7 @@ int lsf_slab_state_iteration(lsf_slab_comm *comm, const float *state_in, const f
                              const lsf_slab_layout *layout, const lsf_slab_part *boundary_parts, int32_t n_boundary,
                              const lsf_slab_part *interior_parts, int32_t n_interior,
                              const lsf_slavcheva_params *params, const lsf_gate *gate, lsf_iteration_record *record,
-                             int32_t exchange /* 0: launches only (an iteration inside an exchange group) */,
+                             int32_t exchange /* LSF_SLAB_* */,
                              const lsf_slab_faces *faces /* NULL: whole slices travel */, void *stream);
 
 int lsf_slavcheva_update_rewarp(const float *live, const float *canonical, float *g_planar /* inout */,

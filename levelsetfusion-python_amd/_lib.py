@@ -57,6 +57,9 @@ class Gate(ctypes.Structure):
                 ("b", ctypes.c_float)]
 
 
+SLAB_LAUNCH, SLAB_EXCHANGE, SLAB_EXCHANGE_DEFERRED, SLAB_RESUME = 0, 1, 2, 3
+
+
 class SlabLayoutC(ctypes.Structure):
     _fields_ = [("nz", ctypes.c_int32), ("ny", ctypes.c_int32), ("nx", ctypes.c_int32), ("z_begin", ctypes.c_int32),
                 ("z_end", ctypes.c_int32), ("halo", ctypes.c_int32), ("lo_rank", ctypes.c_int32),

@@ -71,6 +71,7 @@ struct lsf_slab_comm {
     hipStream_t comm_stream;
     hipEvent_t boundary_done[2], halos_done[2];
     unsigned parity;
+    int pending;  // index of the halos_done event a LSF_SLAB_EXCHANGE_DEFERRED call left for the next call, or -1
 };
 
 #define LSF_RCCL_CHECK(call)                                                                       \
@@ -113,6 +114,7 @@ extern "C" int lsf_slab_comm_create(const char* rccl_library_path, const uint8_t
     c->rank = rank;
     c->world = world;
     c->parity = 0;
+    c->pending = -1;
     hipError_t e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
         e = hipEventCreateWithFlags(&c->boundary_done[k], hipEventDisableTiming);
@@ -225,12 +227,22 @@ extern "C" int lsf_slab_state_iteration(lsf_slab_comm* comm, const float* state_
                                         const lsf_slavcheva_params* params, const lsf_gate* gate,
                                         lsf_iteration_record* record, int32_t exchange, const lsf_slab_faces* faces,
                                         void* stream) {
-    if (!exchange) {  // an iteration inside an exchange group: plain launches, nothing on the wire
+    if (exchange == LSF_SLAB_LAUNCH || exchange == LSF_SLAB_RESUME) {
+        // an iteration inside an exchange group: plain launches, nothing on the wire.  RESUME: the first part does not
+        // touch the halos (the owned slices at least one slice away from them) and runs while the previous call's
+        // exchange is still in flight; the launch stream waits for that exchange only before the second part
         if (!state_in || !canonical || !state_out || !params || !record) return LSF_ERR_BAD_ARGUMENT;
         if (int e = launch_parts(state_in, canonical, state_out, boundary_parts, n_boundary, params, gate, record, stream))
             return e;
+        if (exchange == LSF_SLAB_RESUME) {
+            if (!comm) return LSF_ERR_BAD_ARGUMENT;
+            if (comm->pending >= 0)
+                LSF_HIP_CHECK(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), comm->halos_done[comm->pending], 0));
+            comm->pending = -1;
+        }
         return launch_parts(state_in, canonical, state_out, interior_parts, n_interior, params, gate, record, stream);
     }
+    if (exchange != LSF_SLAB_EXCHANGE && exchange != LSF_SLAB_EXCHANGE_DEFERRED) return LSF_ERR_BAD_ARGUMENT;
     if (!comm || !state_in || !canonical || !state_out || !layout || !params || !record) return LSF_ERR_BAD_ARGUMENT;
     if ((n_boundary > 0 && !boundary_parts) || (n_interior > 0 && !interior_parts)) return LSF_ERR_BAD_ARGUMENT;
     if (layout->halo < 1 || layout->z_begin - (layout->lo_rank >= 0 ? layout->halo : 0) < 0 ||
@@ -252,7 +264,12 @@ extern "C" int lsf_slab_state_iteration(lsf_slab_comm* comm, const float* state_
     // 3. ... the interior runs on the launch stream
     if (int e = launch_parts(state_in, canonical, state_out, interior_parts, n_interior, params, gate, record, stream))
         return e;
-    // 4. the next iteration reads the halos
+    // 4. the next iteration reads the halos: wait now, or leave that to the next call (LSF_SLAB_RESUME), which first
+    //    launches what does not depend on them
+    if (exchange == LSF_SLAB_EXCHANGE_DEFERRED) {
+        comm->pending = (int)k;
+        return 0;
+    }
     LSF_HIP_CHECK(hipStreamWaitEvent(main, comm->halos_done[k], 0));
     return 0;
 }

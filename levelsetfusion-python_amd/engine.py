@@ -630,34 +630,46 @@ class SlavchevaEngine:
         k = f.exchange_interval
         j = i % k
         exchange = j == k - 1 and i + 1 < limit
-        boundary, interior = (f.exchange_parts if exchange else f.widened_parts[0 if j == k - 1 else k - 1 - j])
+        resume = k > 1 and j == 0 and i > 0   # the iteration before this one left its exchange in flight
+        if exchange:
+            mode, (boundary, interior) = (_lib.SLAB_EXCHANGE_DEFERRED if k > 1 else _lib.SLAB_EXCHANGE), f.exchange_parts
+        elif resume:
+            mode, (boundary, interior) = _lib.SLAB_RESUME, f.resume_parts
+        else:
+            mode, (boundary, interior) = _lib.SLAB_LAUNCH, f.widened_parts[0 if j == k - 1 else k - 1 - j]
         if f.native is not None:  # the whole iteration in one host call (lsf_slab.hip): RCCL on the library's stream
             status = _lib.lib.lsf_slab_state_iteration(f.native, s_in, f.p_canon, s_out, f.layout_ref, boundary.array,
                                                        boundary.n, interior.array, interior.n, f.params_ref, gate_ref,
-                                                       f.record_ptrs[i], int(exchange), f.faces_ref, f.stream)
+                                                       f.record_ptrs[i], mode, f.faces_ref, f.stream)
             if status:
                 _lib.check(status, "lsf_slab_state_iteration")
         else:
-            # torch.distributed transport (gloo tests, fallback): boundary slices first, then the halo exchange on a
-            # second stream WHILE the interior runs
+            # torch.distributed transport (gloo tests, fallback), the same schedule: boundary slices first, then the halo
+            # exchange on a second stream WHILE the interior runs -- and, in an exchange group, while the next
+            # iteration's halo-independent part runs
+            main = torch.cuda.current_stream()
             for grid_ref, bands in boundary.launches:
                 for band in bands:
                     _lib.check(run(s_in, f.p_canon, s_out, grid_ref, f.params_ref, gate_ref, f.record_ptrs[i],
                                    band.pointer, band.count, band.subset, f.stream), "lsf_slavcheva_state_iteration")
             if exchange:
-                main = torch.cuda.current_stream()
                 boundary_done, halos_done = self._events[i % 2]
                 boundary_done.record(main)
                 with torch.cuda.stream(self._comm_stream):
                     self._comm_stream.wait_event(boundary_done)
                     self.comm.exchange_state(states[(i + 1) % 2])
                     halos_done.record(self._comm_stream)
+                self._pending_halos = halos_done
+            if resume and self._pending_halos is not None:
+                main.wait_event(self._pending_halos)
+                self._pending_halos = None
             for grid_ref, bands in interior.launches:
                 for band in bands:
                     _lib.check(run(s_in, f.p_canon, s_out, grid_ref, f.params_ref, gate_ref, f.record_ptrs[i],
                                    band.pointer, band.count, band.subset, f.stream), "lsf_slavcheva_state_iteration")
-            if exchange:
-                main.wait_event(halos_done)
+            if exchange and k == 1:
+                main.wait_event(self._pending_halos)
+                self._pending_halos = None
         if i + 1 < limit and i + 1 >= self.min_iterations:
             self.comm.reduce_max(f.records, i)  # the next iteration's gate tests this record: make it global now
 
@@ -747,7 +759,8 @@ class SlavchevaEngine:
         slice_voxels = grid.ny * grid.nx
         listed = bands[0].indices is not None
         if listed:  # positions of the z cuts inside every list: one searchsorted per list, one host read
-            zs = sorted({z for e in range(h + 1) for z in (L.z_begin - e, L.z_end + e)} | {L.z_begin + h, L.z_end - h})
+            zs = sorted({z for e in range(h + 1) for z in (L.z_begin - e, L.z_end + e)} |
+                        {L.z_begin + h, L.z_end - h, L.z_begin + 1, L.z_end - 1})
             zs = [z for z in zs if 0 <= z <= grid.nz]
             keys = torch.tensor([z * slice_voxels for z in zs], dtype=torch.int32, device=live.device)
             cuts = torch.stack([torch.searchsorted(b.indices[:b.count], keys) if b.count else torch.zeros_like(keys,
@@ -786,6 +799,13 @@ class SlavchevaEngine:
         z_lo, z_hi = L.z_begin + (h if lo else 0), L.z_end - (h if hi else 0)
         f.exchange_parts = (parts(([(L.z_begin, z_lo)] if lo else []) + ([(z_hi, L.z_end)] if hi else [])),
                             parts([(z_lo, z_hi)]))
+        # first iteration of a group, while the previous group's exchange may still be in flight: the owned slices that
+        # do not touch a halo slice first, the rest (the widened range's outer slices) after the halos have arrived
+        e = f.exchange_interval - 1
+        in_lo, in_hi = L.z_begin + (1 if lo else 0), L.z_end - (1 if hi else 0)
+        f.resume_parts = (parts([(in_lo, in_hi)]),
+                          parts(([(L.z_begin - e, in_lo)] if lo else []) + ([(in_hi, L.z_end + e)] if hi else [])))
+        self._pending_halos = None
         f.native = self.comm.native()
         f.faces_ref = None
         if f.native is not None:
