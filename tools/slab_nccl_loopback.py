@@ -56,5 +56,14 @@ for fixed in (True, False):
                  len(opt.log.max_warps), dt / max(len(opt.log.max_warps), 1) * 1e6, dt * 1e3), flush=True)
         print("    host time inside the enqueue call: %.1f us per iteration" % (_host[0] / max(_host[1], 1) * 1e6))
         _host[0], _host[1] = 0.0, 0
+if os.environ.get("LB_PROFILE") == "1":
+    import cProfile, pstats
+    live = live0.clone()
+    pr = cProfile.Profile()
+    pr.enable()
+    opt.optimize(live, canonical)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(22)
 comm.close()
 dist.destroy_process_group()
