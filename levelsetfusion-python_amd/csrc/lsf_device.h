@@ -268,15 +268,16 @@ __device__ inline void for_each_listed_voxel(const Grid& g, const int* __restric
 }
 
 // grid size for a list walk: <= 8 * kBlocksPerXcd-ish persistent blocks, every block the same number of units
-__host__ inline unsigned band_list_blocks(unsigned count) {
+__host__ inline unsigned band_list_blocks(unsigned count, unsigned default_per_xcd = 256u) {
     const unsigned units = (count + kBlock - 1) / kBlock;
     if (units <= kXcds) return units < 1 ? 1 : units;
     const unsigned per_xcd = (units + kXcds - 1) / kXcds;
-    static const unsigned cap = [] {
+    static const unsigned override_cap = [] {
         const char* e = getenv("LSF_LIST_BLOCKS_PER_XCD");  // measurement knob, see blocks_per_xcd()
         const int n = e ? atoi(e) : 0;
-        return n > 0 ? (unsigned)n : 256u;
+        return n > 0 ? (unsigned)n : 0u;
     }();
+    const unsigned cap = override_cap ? override_cap : default_per_xcd;
     const unsigned rounds = (per_xcd + cap - 1) / cap;
     return kXcds * ((per_xcd + rounds - 1) / rounds);
 }
