@@ -60,7 +60,7 @@ typedef struct lsf_grid {
  * with the smallest index wins an unsigned 64-bit max, which reproduces numpy's first-arg-max tie break
  * (hierarchical_optimizer2d.py:223-225, slavcheva_optimizer2d.py:213-215).  0 = iteration not executed.
  *
- * A record is kept as LSF_RECORD_SLOTS partial records 256 bytes apart; a block accumulates into slot
+ * A record is kept as LSF_RECORD_SLOTS partial records 4 KiB apart (different memory channels); a block accumulates into slot
  * (block id mod 8), i.e. the slot of its XCD.  The record's VALUE is the max over the slots' max_packed and the sum
  * over the slots' energies -- the gate below, and the host when it decodes records, combine them that way.  (Atomics
  * of ~2000 blocks on one address serialise at ~12 ns each: 0.10 -> 0.055 ms for the band-list kernel at 256^3.) */
@@ -70,11 +70,12 @@ typedef struct lsf_record_slot {
     double data_energy;      /* Slavcheva: sum over band of 0.5*diff^2 ; hierarchical: sum diff^2 */
     double smoothing_energy; /* un-weighted */
     double level_set_energy; /* un-weighted */
-    uint64_t pad[28];
-} lsf_record_slot; /* 256 bytes */
+    uint64_t pad[508];
+} lsf_record_slot; /* 4096 bytes: the slots of a record land in different L2 / memory channels (256 bytes apart, the
+                      eight atomics streams of a launch's ~1000 blocks shared one: 0.0368 -> 0.0353 ms at 256^3) */
 typedef struct lsf_iteration_record {
     lsf_record_slot slot[LSF_RECORD_SLOTS];
-} lsf_iteration_record; /* 2048 bytes */
+} lsf_iteration_record; /* 32 KiB */
 
 /* Device-side convergence gate.  The reference tests its stop condition on the host after every iteration
  * (hierarchical_optimizer2d.py:169-171, slavcheva_optimizer2d.py:360-362); here every kernel of iteration i

@@ -40,7 +40,7 @@ RECORD_SLOTS = 8
 class RecordSlot(ctypes.Structure):
     _fields_ = [("max_packed", ctypes.c_uint64), ("data_energy", ctypes.c_double),
                 ("smoothing_energy", ctypes.c_double), ("level_set_energy", ctypes.c_double),
-                ("pad", ctypes.c_uint64 * 28)]
+                ("pad", ctypes.c_uint64 * 508)]
 
 
 class IterationRecord(ctypes.Structure):
@@ -48,8 +48,8 @@ class IterationRecord(ctypes.Structure):
     _fields_ = [("slot", RecordSlot * RECORD_SLOTS)]
 
 
-RECORD_BYTES = ctypes.sizeof(IterationRecord)  # 2048
-SLOT_WORDS = ctypes.sizeof(RecordSlot) // 8    # 32
+RECORD_BYTES = ctypes.sizeof(IterationRecord)  # 32768
+SLOT_WORDS = ctypes.sizeof(RecordSlot) // 8    # 512
 
 
 class Gate(ctypes.Structure):

@@ -86,7 +86,7 @@ def _gate_ref(gate):
 
 
 def slot_view(records):
-    """[n, RECORD_WORDS] (tensor or array) -> [n, slots, 32]: word 0 = packed max, words 1..3 = energies"""
+    """[n, RECORD_WORDS] (tensor or array) -> [n, slots, SLOT_WORDS]: word 0 = packed max, words 1..3 = energies"""
     return records.reshape(records.shape[0], _lib.RECORD_SLOTS, _lib.SLOT_WORDS)
 
 
@@ -96,10 +96,21 @@ def set_record_max(records, index, packed):
     records[index, 0] = packed
 
 
+USED_SLOT_WORDS = 4  # packed max + three energies; the rest of a slot is padding (slots sit 4 KiB apart)
+
+
+def records_to_host(records):
+    """device records [n, RECORD_WORDS] -> numpy int64 [n, slots, 4]: only the used words cross PCIe"""
+    return slot_view(records)[:, :, :USED_SLOT_WORDS].contiguous().cpu().numpy()
+
+
 def decode_records(records_host):
-    """records_host: numpy int64 [n, RECORD_WORDS] -> dict of arrays (max value, linear arg-max index, energies,
-    executed); combines the slots of every record: max of the packed maxima, sum of the energies"""
-    raw = slot_view(np.ascontiguousarray(records_host))
+    """records_host: numpy int64 [n, slots, >= 4] (records_to_host) or [n, RECORD_WORDS] -> dict of arrays (max value,
+    linear arg-max index, energies, executed); combines the slots of every record: max of the packed maxima, sum of the
+    energies"""
+    raw = np.ascontiguousarray(records_host)
+    if raw.ndim == 2:
+        raw = slot_view(raw)
     packed = np.ascontiguousarray(raw[:, :, 0]).view(np.uint64).max(axis=1)
     energies = np.ascontiguousarray(raw[:, :, 1:4]).view(np.float64).sum(axis=1)
     executed = packed != 0

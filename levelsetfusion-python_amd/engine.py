@@ -370,7 +370,7 @@ class HierarchicalEngine:
             if slab:
                 comm.reduce_records(records, it, it + batch)
             it += batch
-            dec = dev.decode_records(records[:it].cpu().numpy())  # the only host sync of the batch
+            dec = dev.decode_records(dev.records_to_host(records[:it]))  # the only host sync of the batch
             n_exec = int(dec["executed"].sum())
             if slab:
                 # the gather follows the cumulative warp: it must stay inside the halo of the static packed field
@@ -382,7 +382,7 @@ class HierarchicalEngine:
             if n_exec < it or dec["max_value"][n_exec - 1] < np.float32(thr):
                 break
         if dec is None:  # maximum_iteration_count == 0: the reference's loop body never runs
-            dec = dev.decode_records(records[:1].cpu().numpy())
+            dec = dev.decode_records(dev.records_to_host(records[:1]))
         if self.collect_iteration_data:
             self.iteration_data.append(snapshots[:n_exec])  # snapshots of gated (not executed) launches are dropped
         self._finish_level(lv, n_exec, dec, L)
@@ -431,7 +431,7 @@ class HierarchicalEngine:
         parts = []
         while done + K <= max_it and not converged:
             graph.replay()
-            dec = dev.decode_records(lv.records[:K].cpu().numpy())  # host sync once per K iterations
+            dec = dev.decode_records(dev.records_to_host(lv.records[:K]))  # host sync once per K iterations
             k_exec = int(dec["executed"].sum())
             parts.append({k: v[:k_exec].copy() for k, v in dec.items()})
             n_exec += k_exec
@@ -445,7 +445,7 @@ class HierarchicalEngine:
             rem.records[0].copy_(lv.records[K - 1])
             for t in range(rest):
                 self._enqueue(rem, t + 1, t, (done + t) % 2)
-            dec = dev.decode_records(rem.records[1:rest + 1].cpu().numpy())
+            dec = dev.decode_records(dev.records_to_host(rem.records[1:rest + 1]))
             k_exec = int(dec["executed"].sum())
             parts.append({k: v[:k_exec].copy() for k, v in dec.items()})
             n_exec += k_exec
@@ -892,7 +892,7 @@ class SlavchevaEngine:
                 # every launch runs ungated, so the final state is states[limit % 2]: finalize before looking
                 early = SlavchevaOutcome(grid, canonical, state=states[limit % 2])
                 early.enqueue_finalize(*finalize)
-            dec = dev.decode_records(records[:it].cpu().numpy())
+            dec = dev.decode_records(dev.records_to_host(records[:it]))
             n_exec = int(dec["executed"].sum())
             if n_exec < it:
                 break
@@ -913,7 +913,7 @@ class SlavchevaEngine:
         self.iteration_count = n_exec
         wd, ws, wl = self.weights
         if dec is None:
-            dec = dev.decode_records(records[:1].cpu().numpy())
+            dec = dev.decode_records(dev.records_to_host(records[:1]))
         self.log = dict(max_warps=[float(v) for v in dec["max_value"][:n_exec]],
                         max_warp_indices=[int(v) for v in dec["argmax"][:n_exec]],
                         data_energies=[wd * float(v) for v in dec["data_energy"][:n_exec]],

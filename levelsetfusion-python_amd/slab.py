@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 
 # lsf_iteration_record (include/lsf_hip.h): 8 partial slots of 32 int64 words; word 0 = packed max, 1..3 = energies
-RECORD_SLOTS, SLOT_WORDS = 8, 32
+RECORD_SLOTS, SLOT_WORDS = 8, 512
 
 
 def _slot_view(records):

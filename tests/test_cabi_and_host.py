@@ -55,7 +55,7 @@ def test_ctypes_structs_match_header_layout(pkg):
     L = pkg._lib
     assert ctypes.sizeof(L.Grid) == 40 and L.Grid.energy_z_begin.offset == 32
     assert ctypes.sizeof(L.SlabLayoutC) == 32 and ctypes.sizeof(L.SlabPart) == 40 + 16 + 16 + 8 + 8
-    assert ctypes.sizeof(L.IterationRecord) == 2048 == L.RECORD_BYTES and ctypes.sizeof(L.RecordSlot) == 256
+    assert ctypes.sizeof(L.IterationRecord) == 32768 == L.RECORD_BYTES and ctypes.sizeof(L.RecordSlot) == 4096
     from levelsetfusion_python_amd import slab
     assert (slab.RECORD_SLOTS, slab.SLOT_WORDS) == (L.RECORD_SLOTS, L.SLOT_WORDS)
     assert ctypes.sizeof(L.Gate) == 24 and L.Gate.mode.offset == 8 and L.Gate.a.offset == 12
