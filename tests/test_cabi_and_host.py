@@ -87,6 +87,34 @@ def test_argument_errors_are_reported_not_launched(pkg):
         pkg._lib.check(-2, "x")
 
 
+def test_slab_runtime_argument_errors(pkg):
+    """the z-slab runtime (lsf_slab.hip) validates on the host before touching a device or RCCL"""
+    L = pkg._lib
+    layout = L.SlabLayoutC(16, 8, 8, 4, 12, 2, 0, 0)
+    params = L.SlavchevaParams()
+    grid = L.Grid(3, 16, 8, 8, 4, 12, 0, 0)
+    # no communicator / null state for an exchanging call
+    assert L.lib.lsf_slab_state_iteration(None, 1, 1, 2, ctypes.byref(layout), None, 0, None, 0, ctypes.byref(params),
+                                          None, 1, L.SLAB_EXCHANGE, None, None) == -1
+    # unknown mode
+    assert L.lib.lsf_slab_state_iteration(None, 1, 1, 2, ctypes.byref(layout), None, 0, None, 0, ctypes.byref(params),
+                                          None, 1, 7, None, None) == -1
+    # launches only, but no record
+    assert L.lib.lsf_slab_state_iteration(None, 1, 1, 2, ctypes.byref(layout), None, 0, None, 0, ctypes.byref(params),
+                                          None, None, L.SLAB_LAUNCH, None, None) == -1
+    # RESUME needs the communicator that holds the pending exchange
+    assert L.lib.lsf_slab_state_iteration(None, 1, 1, 2, ctypes.byref(layout), None, 0, None, 0, ctypes.byref(params),
+                                          None, 1, L.SLAB_RESUME, None, None) == -1
+    handle = ctypes.c_void_p()
+    ident = (ctypes.c_uint8 * 128)()
+    assert L.lib.lsf_slab_comm_create(None, None, 0, 1, ctypes.byref(handle)) == -1              # no id
+    assert L.lib.lsf_slab_comm_create(None, ctypes.cast(ident, ctypes.c_void_p), 3, 2, ctypes.byref(handle)) == -1  # rank
+    assert L.lib.lsf_slab_unique_id(None, None) == -1
+    assert L.lib.lsf_slab_comm_destroy(None) == 0
+    assert L.lib.lsf_state_prepare_scratch_elements(ctypes.byref(grid)) == 2 * 2 + 64 * 1 + 2  # one 1024-voxel chunk
+    assert L.lib.lsf_band_list_fill_prepared(ctypes.byref(grid), L.BAND_INTERIOR, 1, 1, None) == -1  # not a whole array
+
+
 def test_no_cpu_fallback(pkg):
     import torch
     if torch.cuda.is_available():
