@@ -265,8 +265,9 @@ int lsf_band_list_fill(const float *live, const float *canonical, const lsf_grid
  * lsf_state_unpack: state -> live and / or planar warp [c][z][y][x] and / or interleaved warp [z][y][x][c]. */
 /* lsf_state_prepare: the start of an optimize() call in one pass over WHOLE arrays (z_begin = 0, z_end = nz): both
  * ping-pong states = (live, 0) and the counting step of lsf_band_count for the INTERIOR and the BOUNDARY subset at once.
- * scratch: lsf_state_prepare_scratch_elements(grid) int32 (8-byte aligned); counts_out[0..2) (device) = INTERIOR and
- * BOUNDARY totals.  lsf_band_list_fill_prepared then writes one subset's list from the ballots the prepare pass kept
+ * scratch: lsf_state_prepare_scratch_elements(grid) int32 (8-byte aligned); counts_out[0..4) (device) = INTERIOR and
+ * BOUNDARY totals, then the number of voxels OUTSIDE the band with live = -canonical and the first of them (-1: none)
+ * -- what lsf_state_finalize_listed needs to know about the voxels no list holds.  lsf_band_list_fill_prepared then writes one subset's list from the ballots the prepare pass kept
  * in scratch (16 bytes per 64 voxels) -- live and canonical are not read again. */
 int64_t lsf_state_prepare_scratch_elements(const lsf_grid *grid);
 int lsf_band_list_fill_prepared(const lsf_grid *grid, int32_t subset, const int32_t *scratch, int32_t *list,
@@ -286,6 +287,14 @@ int64_t lsf_state_finalize_scratch_elements(const lsf_grid *grid);
 int lsf_state_finalize(const float *state, const float *canonical, float *live_out, float *warp_planar_out,
                        float *warp_interleaved_out, const lsf_grid *grid, float lower_threshold,
                        double *statistics16, double *scratch, void *stream);
+/* lsf_state_finalize for whole arrays whose band lists are at hand: only the listed voxels are visited -- live_out must
+ * already hold the INPUT live field and warp_interleaved_out zeros (nothing else can have changed); the statistics
+ * take the unlisted voxels from lsf_state_prepare's counts_out[2..4): opposite_count of them have
+ * |canonical - live| = 2, the first one at voxel first_opposite (-1: none), the others 0.  scratch as lsf_state_finalize. */
+int lsf_state_finalize_listed(const float *state, const float *canonical, float *live_out, float *warp_interleaved_out,
+                              const lsf_grid *grid, const int32_t *const *band_lists, const int64_t *band_counts,
+                              int32_t n_lists, int64_t opposite_count, int64_t first_opposite, float lower_threshold,
+                              double *statistics16, double *scratch, void *stream);
 int lsf_slavcheva_state_iteration(const float *state_in, const float *canonical, float *state_out,
                                   const lsf_grid *grid, const lsf_slavcheva_params *params, const lsf_gate *gate,
                                   lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,

@@ -310,16 +310,20 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
                                                                vf4* __restrict__ a, vf4* __restrict__ b, unsigned n,
                                                                Grid g, int dims, int* __restrict__ sums_interior,
                                                                int* __restrict__ sums_boundary,
-                                                               unsigned long long* __restrict__ masks) {
-    __shared__ int part[2][16];  // [subset][pass j * 4 + wave]
+                                                               unsigned long long* __restrict__ masks,
+                                                               int* __restrict__ opposite) {
+    __shared__ int part[4][16];  // [INTERIOR count, BOUNDARY count, opposite count, first opposite][pass j * 4 + wave]
     const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const unsigned v = blockIdx.x * kBandChunk + j * kBlock + t;
-        bool in_band = false, interior = false;
+        bool in_band = false, interior = false, opposed = false;
         if (v < n) {
-            const float l = live[v];
-            in_band = !(fabsf(l) == 1.0f && fabsf(canonical[v]) == 1.0f);
+            const float l = live[v], cn = canonical[v];
+            in_band = !(fabsf(l) == 1.0f && fabsf(cn) == 1.0f);
+            // outside the band |canonical - live| is 0 or -- live = -canonical -- exactly 2, now and for ever: what the
+            // end-of-call statistics need to know about the voxels no list holds (lsf_state_finalize_listed)
+            opposed = !in_band && l != cn;
             vf4 o;
             o.x = l; o.y = 0.0f; o.z = 0.0f; o.w = 0.0f;
             a[v] = o;
@@ -331,9 +335,13 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
             interior = x > 0 && x < g.nx - 1 && y > 0 && y < g.ny - 1 && (dims == 2 || (z > 0 && z < g.nz - 1));
         }
         const unsigned long long mi = __ballot(in_band && interior), mb = __ballot(in_band && !interior);
+        const unsigned long long mo = __ballot(opposed);
         if (lane == 0) {
             part[0][j * 4 + wave] = __popcll(mi);
             part[1][j * 4 + wave] = __popcll(mb);
+            part[2][j * 4 + wave] = __popcll(mo);
+            part[3][j * 4 + wave] = mo ? (int)(blockIdx.x * kBandChunk + j * kBlock + wave * kWave) + __ffsll((long long)mo) - 1
+                                       : 0x7fffffff;
             // the ballots themselves: the fill step reads these 16 bytes per 64 voxels instead of live and canonical again
             masks[((size_t)blockIdx.x * 16 + j * 4 + wave) * 2 + 0] = mi;
             masks[((size_t)blockIdx.x * 16 + j * 4 + wave) * 2 + 1] = mb;
@@ -344,6 +352,44 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
         int sum = 0;
         for (int k = 0; k < 16; ++k) sum += part[t][k];
         (t == 0 ? sums_interior : sums_boundary)[blockIdx.x] = sum;
+    } else if (t == 2) {
+        int sum = 0, first = 0x7fffffff;
+        for (int k = 0; k < 16; ++k) {
+            sum += part[2][k];
+            first = min(first, part[3][k]);
+        }
+        opposite[2 * blockIdx.x] = sum;
+        opposite[2 * blockIdx.x + 1] = first;
+    }
+}
+
+// totals[2] = number of unlisted voxels with live = -canonical, totals[3] = the first of them (or -1)
+__global__ __launch_bounds__(1024) void prepare_opposite_kernel(const int* __restrict__ opposite, unsigned chunks,
+                                                                long long* __restrict__ totals) {
+    __shared__ long long s_sum[1024 / kWave];
+    __shared__ int s_first[1024 / kWave];
+    long long sum = 0;
+    int first = 0x7fffffff;
+    for (unsigned c = threadIdx.x; c < chunks; c += 1024) {
+        sum += opposite[2 * c];
+        first = min(first, opposite[2 * c + 1]);
+    }
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        sum += (long long)shfl_down_u64((unsigned long long)sum, d);
+        first = min(first, __shfl_down(first, d, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        s_sum[threadIdx.x / kWave] = sum;
+        s_first[threadIdx.x / kWave] = first;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 1024 / kWave; ++k) {
+            sum += s_sum[k];
+            first = min(first, s_first[k]);
+        }
+        totals[2] = sum;
+        totals[3] = first == 0x7fffffff ? -1 : first;
     }
 }
 
@@ -446,16 +492,21 @@ extern "C" int lsf_band_count(const float* live, const float* canonical, const l
 }
 
 // scratch of lsf_state_prepare: [chunks + 1] INTERIOR sums, [chunks + 1] BOUNDARY sums, then (8-byte aligned) the two
-// ballots of every 64-voxel group: 32 uint64 per 1024-voxel chunk
+// ballots of every 64-voxel group: 32 uint64 per 1024-voxel chunk, then per chunk (count, first) of the unlisted voxels
+// with live = -canonical
 static inline unsigned long long* prepare_masks(int32_t* scratch, unsigned chunks) {
     return reinterpret_cast<unsigned long long*>(scratch + 2 * (size_t)(chunks + 1) + (2 * (chunks + 1)) % 2);
+}
+
+static inline int* prepare_opposite(int32_t* scratch, unsigned chunks) {
+    return reinterpret_cast<int*>(prepare_masks(scratch, chunks) + (size_t)chunks * 32);
 }
 
 extern "C" int64_t lsf_state_prepare_scratch_elements(const lsf_grid* grid) {
     if (check_grid(grid)) return 0;
     unsigned first, n, chunks;
     band_range(grid, first, n, chunks);
-    return 2 * (int64_t)(chunks + 1) + 64 * (int64_t)chunks + 2;
+    return 2 * (int64_t)(chunks + 1) + 64 * (int64_t)chunks + 2 + 2 * (int64_t)chunks;
 }
 
 extern "C" int lsf_band_list_fill_prepared(const lsf_grid* grid, int32_t subset, const int32_t* scratch, int32_t* list,
@@ -485,8 +536,10 @@ extern "C" int lsf_state_prepare(const float* live, const float* canonical, floa
     int* sums_boundary = scratch + (chunks + 1);
     hipLaunchKernelGGL(state_prepare_kernel, dim3(chunks), dim3(kBlock), 0, s, live, canonical,
                        reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b), n, make_grid(grid), grid->dims,
-                       sums_interior, sums_boundary, prepare_masks(scratch, chunks));
+                       sums_interior, sums_boundary, prepare_masks(scratch, chunks), prepare_opposite(scratch, chunks));
     hipLaunchKernelGGL(band_scan_kernel, dim3(2), dim3(1024), 0, s, scratch, chunks, chunks + 1, (long long*)counts_out);
+    hipLaunchKernelGGL(prepare_opposite_kernel, dim3(1), dim3(1024), 0, s, prepare_opposite(scratch, chunks), chunks,
+                       (long long*)counts_out);
     return launch_status();
 }
 

@@ -385,6 +385,67 @@ __global__ __launch_bounds__(kBlock) void state_unpack_kernel(const vf4* __restr
 // made the two separate statistics kernels take 0.35 ms at 256^3 for 0.13 GB of reads); a one-block kernel combines.
 constexpr int kFinalizeWords = 12;  // per block: packed warp max, packed diff max, diff min, 4 warp sums, 2 diff sums
 
+struct FinalizeAccumulator {
+    unsigned long long best_w = 0ull, best_d = 0ull;
+    double sums[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // band count, above lo, sum len, sum len^2, sum d, sum d^2
+    double mn = __longlong_as_double(0x7ff0000000000000ll);
+
+    __device__ inline void add(const vf4& v, float cn, unsigned lin, int dims, float lo) {
+        if (!(fabsf(v.x) == 1.0f && fabsf(cn) == 1.0f)) {
+            const float wv[3] = {v.y, v.z, v.w};
+            const float len = dims == 3 ? vec_length<3>(wv) : vec_length<2>(wv);
+            const unsigned long long p = pack_max(len, lin);
+            best_w = p > best_w ? p : best_w;
+            sums[0] += 1.0;
+            sums[1] += len > lo ? 1.0 : 0.0;
+            sums[2] += (double)len;
+            sums[3] += (double)len * (double)len;
+        }
+        const double d = fabs((double)cn - (double)v.x);
+        const unsigned long long q = pack_max((float)d, lin);
+        best_d = q > best_d ? q : best_d;
+        sums[4] += d;
+        sums[5] += d * d;
+        mn = fmin(mn, d);
+    }
+
+    // block reduction -> one scratch row (no same-address atomics)
+    __device__ inline void store_row(double* __restrict__ row) {
+        __shared__ unsigned long long s_w[kBlock / kWave], s_d[kBlock / kWave];
+        __shared__ double s_mn[kBlock / kWave], s_sum[6][kBlock / kWave];
+        const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+        best_w = wave_max_u64(best_w);
+        best_d = wave_max_u64(best_d);
+        for (int dl = kWave / 2; dl > 0; dl >>= 1) mn = fmin(mn, shfl_down_f64(mn, dl));
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sums[j] = wave_sum_f64(sums[j]);
+        if (lane == 0) {
+            s_w[wave] = best_w; s_d[wave] = best_d; s_mn[wave] = mn;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) s_sum[j][wave] = sums[j];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long w = 0ull, d = 0ull;
+            double m = s_mn[0];
+            for (int k = 0; k < kBlock / kWave; ++k) {
+                w = s_w[k] > w ? s_w[k] : w;
+                d = s_d[k] > d ? s_d[k] : d;
+                m = fmin(m, s_mn[k]);
+            }
+            row[0] = __longlong_as_double((long long)w);
+            row[1] = __longlong_as_double((long long)d);
+            row[2] = m;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                double t = 0.0;
+                for (int k = 0; k < kBlock / kWave; ++k) t += s_sum[j][k];
+                row[3 + j] = t;
+            }
+        }
+    }
+};
+
 __global__ __launch_bounds__(kBlock) void state_finalize_kernel(const vf4* __restrict__ s,
                                                                 const float* __restrict__ canonical,
                                                                 float* __restrict__ live, float* __restrict__ planar,
@@ -392,9 +453,7 @@ __global__ __launch_bounds__(kBlock) void state_finalize_kernel(const vf4* __res
                                                                 long long n, long long plane, int dims,
                                                                 long long index_offset, float lo,
                                                                 double* __restrict__ scratch) {
-    unsigned long long best_w = 0ull, best_d = 0ull;
-    double sums[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // band count, above lo, sum len, sum len^2, sum d, sum d^2
-    double mn = __longlong_as_double(0x7ff0000000000000ll);
+    FinalizeAccumulator acc;
     for (long long k = blockIdx.x * (long long)kBlock + threadIdx.x; k < n; k += (long long)gridDim.x * kBlock) {
         const long long i = first + k;
         const vf4 v = s[i];
@@ -409,67 +468,44 @@ __global__ __launch_bounds__(kBlock) void state_finalize_kernel(const vf4* __res
             interleaved[i * dims + 1] = v.z;
             if (dims == 3) interleaved[i * dims + 2] = v.w;
         }
-        if (scratch) {
-            const float cn = canonical[i];
-            const unsigned lin = (unsigned)(i + index_offset);
-            if (!(fabsf(v.x) == 1.0f && fabsf(cn) == 1.0f)) {
-                const float wv[3] = {v.y, v.z, v.w};
-                const float len = dims == 3 ? vec_length<3>(wv) : vec_length<2>(wv);
-                const unsigned long long p = pack_max(len, lin);
-                best_w = p > best_w ? p : best_w;
-                sums[0] += 1.0;
-                sums[1] += len > lo ? 1.0 : 0.0;
-                sums[2] += (double)len;
-                sums[3] += (double)len * (double)len;
-            }
-            const double d = fabs((double)cn - (double)v.x);
-            const unsigned long long q = pack_max((float)d, lin);
-            best_d = q > best_d ? q : best_d;
-            sums[4] += d;
-            sums[5] += d * d;
-            mn = fmin(mn, d);
-        }
+        if (scratch) acc.add(v, canonical[i], (unsigned)(i + index_offset), dims, lo);
     }
-    if (!scratch) return;
-    __shared__ unsigned long long s_w[kBlock / kWave], s_d[kBlock / kWave];
-    __shared__ double s_mn[kBlock / kWave], s_sum[6][kBlock / kWave];
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    best_w = wave_max_u64(best_w);
-    best_d = wave_max_u64(best_d);
-    for (int dl = kWave / 2; dl > 0; dl >>= 1) mn = fmin(mn, shfl_down_f64(mn, dl));
-#pragma unroll
-    for (int j = 0; j < 6; ++j) sums[j] = wave_sum_f64(sums[j]);
-    if (lane == 0) {
-        s_w[wave] = best_w; s_d[wave] = best_d; s_mn[wave] = mn;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) s_sum[j][wave] = sums[j];
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double* row = scratch + (long long)blockIdx.x * kFinalizeWords;
-        unsigned long long w = 0ull, d = 0ull;
-        double m = s_mn[0];
-        for (int k = 0; k < kBlock / kWave; ++k) {
-            w = s_w[k] > w ? s_w[k] : w;
-            d = s_d[k] > d ? s_d[k] : d;
-            m = fmin(m, s_mn[k]);
+    if (scratch) acc.store_row(scratch + (long long)blockIdx.x * kFinalizeWords);
+}
+
+// the same for the voxels of a band list only: everything else still holds (live, 0) -- the caller's live field is
+// already right there, its warp is zero-filled, and what those voxels contribute to the statistics was counted by
+// lsf_state_prepare (|canonical - live| is 0 or exactly 2 outside the band, for ever)
+__global__ __launch_bounds__(kBlock) void state_finalize_list_kernel(const vf4* __restrict__ s,
+                                                                     const float* __restrict__ canonical,
+                                                                     float* __restrict__ live,
+                                                                     float* __restrict__ interleaved,
+                                                                     const int* __restrict__ list, unsigned count,
+                                                                     int dims, long long index_offset, float lo,
+                                                                     double* __restrict__ scratch) {
+    FinalizeAccumulator acc;
+    for (unsigned k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
+        const long long i = list[k];
+        const vf4 v = s[i];
+        if (live) live[i] = v.x;
+        if (interleaved) {
+            interleaved[i * dims] = v.y;
+            interleaved[i * dims + 1] = v.z;
+            if (dims == 3) interleaved[i * dims + 2] = v.w;
         }
-        row[0] = __longlong_as_double((long long)w);
-        row[1] = __longlong_as_double((long long)d);
-        row[2] = m;
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            double t = 0.0;
-            for (int k = 0; k < kBlock / kWave; ++k) t += s_sum[j][k];
-            row[3 + j] = t;
-        }
+        if (scratch) acc.add(v, canonical[i], (unsigned)(i + index_offset), dims, lo);
     }
+    if (scratch) acc.store_row(scratch + (long long)blockIdx.x * kFinalizeWords);
 }
 
 // one block: rows -> out16 = the 8-double layouts of lsf_warp_statistics and lsf_tsdf_difference_statistics
+// unlisted: the voxels no row covers (list variant): `opposite` of them have |canonical - live| = 2 (the first one at
+// linear index `first_opposite`), the rest 0; first_voxel = linear index of the array's first voxel
 __global__ __launch_bounds__(kBlock) void state_finalize_combine_kernel(const double* __restrict__ scratch,
                                                                         unsigned rows, double voxels,
-                                                                        double* __restrict__ out16) {
+                                                                        double* __restrict__ out16, double unlisted,
+                                                                        double opposite, long long first_opposite,
+                                                                        long long first_voxel) {
     unsigned long long best_w = 0ull, best_d = 0ull;
     double sums[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     double mn = __longlong_as_double(0x7ff0000000000000ll);
@@ -507,6 +543,16 @@ __global__ __launch_bounds__(kBlock) void state_finalize_combine_kernel(const do
 #pragma unroll
         for (int j = 0; j < 6; ++j) t[j] += s_sum[j][k];
     }
+    if (unlisted > opposite) m = fmin(m, 0.0);
+    if (opposite > 0.0) {
+        m = fmin(m, 2.0);
+        const unsigned long long q = pack_max(2.0f, (unsigned)first_opposite);
+        d = q > d ? q : d;
+        t[4] += 2.0 * opposite;
+        t[5] += 4.0 * opposite;
+    }
+    // the maximum is 0: every voxel ties and the first one of the array wins, listed or not
+    if (unlisted > 0.0 && (d >> 32) == 0ull) d = pack_max(0.0f, (unsigned)first_voxel);
     // warp: [count_band, count_above_lo, max_len, sum_len, sum_len^2, argmax, 0, 0]
     out16[0] = t[0]; out16[1] = t[1];
     out16[2] = w ? (double)unpack_max_value(w) : 0.0;
@@ -644,7 +690,40 @@ extern "C" int lsf_state_finalize(const float* state, const float* canonical, fl
                        lower_threshold, statistics16 ? scratch : (double*)nullptr);
     if (statistics16)
         hipLaunchKernelGGL(state_finalize_combine_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), scratch, blocks,
-                           (double)n, statistics16);
+                           (double)n, statistics16, 0.0, 0.0, 0ll, 0ll);
+    return launch_status();
+}
+
+extern "C" int lsf_state_finalize_listed(const float* state, const float* canonical, float* live_out,
+                                         float* warp_interleaved_out, const lsf_grid* grid,
+                                         const int32_t* const* band_lists, const int64_t* band_counts, int32_t n_lists,
+                                         int64_t opposite_count, int64_t first_opposite, float lower_threshold,
+                                         double* statistics16, double* scratch, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!state || n_lists < 0 || n_lists > 2 || (n_lists && (!band_lists || !band_counts)) ||
+        (statistics16 && (!canonical || !scratch)) || grid->z_begin != 0 || grid->z_end != grid->nz)
+        return LSF_ERR_BAD_ARGUMENT;
+    long long first, n;
+    if (!range_of(grid, first, n)) return statistics16 ? LSF_ERR_BAD_ARGUMENT : 0;
+    unsigned rows = 0;
+    long long listed = 0;
+    for (int32_t k = 0; k < n_lists; ++k) {
+        if (band_counts[k] < 0 || band_counts[k] > 0x7fffffffll || (band_counts[k] && !band_lists[k])) return LSF_ERR_BAD_ARGUMENT;
+        if (band_counts[k] == 0) continue;
+        const unsigned blocks = finalize_blocks(band_counts[k]);
+        hipLaunchKernelGGL(state_finalize_list_kernel, dim3(blocks), dim3(kBlock), 0, as_stream(stream),
+                           reinterpret_cast<const vf4*>(state), canonical, live_out, warp_interleaved_out, band_lists[k],
+                           (unsigned)band_counts[k], grid->dims, (long long)grid->ny * grid->nx * grid->z_global_offset,
+                           lower_threshold, statistics16 ? scratch + (long long)rows * kFinalizeWords : (double*)nullptr);
+        rows += blocks;
+        listed += band_counts[k];
+    }
+    if (statistics16) {
+        const long long first_voxel = (long long)grid->ny * grid->nx * grid->z_global_offset;
+        hipLaunchKernelGGL(state_finalize_combine_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), scratch, rows,
+                           (double)n, statistics16, (double)(n - listed), (double)opposite_count,
+                           (long long)first_opposite + first_voxel, first_voxel);
+    }
     return launch_status();
 }
 

@@ -366,20 +366,21 @@ def slavcheva_gradient(live, canonical, warp_prev, g_out, grid, params, gate, re
 def state_prepare(live, canonical, grid=None):
     """start of a fused optimize() call on whole arrays, one pass over live and canonical (lsf_state_prepare): the two
     ping-pong states (live, 0) and the INTERIOR + BOUNDARY band lists (empty lists dropped, but never both).  The lists
-    are filled from the ballots the pass keeps (lsf_band_list_fill_prepared).  Returns (states, band lists)."""
+    are filled from the ballots the pass keeps (lsf_band_list_fill_prepared).  Returns (states, band lists, (number of
+    voxels outside the band with live = -canonical, the first of them or -1)) -- the last for state_finalize_listed."""
     grid = grid or make_grid(live.shape)
     n = n_voxels(grid)
     states = [torch.empty(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device) for _ in range(2)]
     n_scratch = int(lib.lsf_state_prepare_scratch_elements(ctypes.byref(grid)))
     scratch = torch.empty(n_scratch, dtype=torch.int32, device=live.device)
-    totals = torch.empty(2, dtype=torch.int64, device=live.device)
+    totals = torch.empty(4, dtype=torch.int64, device=live.device)
     p_scratch = ctypes.c_void_p(scratch.data_ptr())
     check(lib.lsf_state_prepare(_ptr(live, n, "live"), _ptr(canonical, n, "canonical"), _ptr(states[0], 4 * n, "state"),
                                 _ptr(states[1], 4 * n, "state"), ctypes.byref(grid), p_scratch,
                                 ctypes.c_void_p(totals.data_ptr()), stream_ptr()), "lsf_state_prepare")
     counts = [int(c) for c in totals.cpu()]
     lists = []
-    for k, (subset, count) in enumerate(zip((_lib.BAND_INTERIOR, _lib.BAND_BOUNDARY), counts)):
+    for k, (subset, count) in enumerate(zip((_lib.BAND_INTERIOR, _lib.BAND_BOUNDARY), counts[:2])):
         if count == 0 and not (k == 1 and not lists):
             continue
         indices = torch.empty(max(count, 1), dtype=torch.int32, device=live.device)
@@ -388,7 +389,7 @@ def state_prepare(live, canonical, grid=None):
                                                   ctypes.c_void_p(indices.data_ptr()), stream_ptr()),
                   "lsf_band_list_fill_prepared")
         lists.append(BandList(indices, count, subset))
-    return states, lists
+    return states, lists, (counts[2], counts[3])
 
 
 def state_pack(live, warp_planar=None, grid=None, copies=2):
@@ -430,6 +431,33 @@ def state_finalize(state, canonical, grid, live_out=None, warp_planar_out=None, 
                                  _ptr(stats, 16, "statistics", dtype=torch.float64, allow_none=True),
                                  _ptr(scratch, scratch.numel() if scratch is not None else 0, "scratch",
                                       dtype=torch.float64, allow_none=True), stream_ptr()), "lsf_state_finalize")
+    return stats
+
+
+def state_finalize_listed(state, canonical, grid, bands, unlisted, live_out=None, warp_interleaved_out=None,
+                          lower_threshold=0.0, statistics=False):
+    """state_finalize of whole arrays that visits the voxels of `bands` only (lsf_state_finalize_listed): live_out must
+    hold the input live field and warp_interleaved_out zeros already; `unlisted` as state_prepare returned it"""
+    n = n_voxels(grid)
+    bands = [b for b in bands if b.count]
+    stats = scratch = None
+    if statistics:
+        stats = torch.empty(16, dtype=torch.float64, device=state.device)
+        scratch = torch.empty(int(lib.lsf_state_finalize_scratch_elements(ctypes.byref(grid))) * max(len(bands), 1),
+                              dtype=torch.float64, device=state.device)
+    pointers = (ctypes.c_void_p * 2)(*[b.pointer for b in bands])
+    counts = (ctypes.c_int64 * 2)(*[b.count for b in bands])
+    check(lib.lsf_state_finalize_listed(_ptr(state, 4 * n, "state"),
+                                        _ptr(canonical, n, "canonical", allow_none=not statistics),
+                                        _ptr(live_out, n, "live_out", allow_none=True),
+                                        _ptr(warp_interleaved_out, n * grid.dims, "warp_interleaved_out",
+                                             allow_none=True),
+                                        ctypes.byref(grid), pointers, counts, len(bands), int(unlisted[0]),
+                                        int(unlisted[1]), float(lower_threshold),
+                                        _ptr(stats, 16, "statistics", dtype=torch.float64, allow_none=True),
+                                        _ptr(scratch, scratch.numel() if scratch is not None else 0, "scratch",
+                                             dtype=torch.float64, allow_none=True), stream_ptr()),
+          "lsf_state_finalize_listed")
     return stats
 
 

@@ -464,9 +464,11 @@ class SlavchevaOutcome:
     """final fields of one SlavchevaEngine.optimize() call, left on the device in the layout the iteration kernels use
     (the float4 state of the fused path, or planar live / warp of the Sobolev path) and handed out on demand"""
 
-    def __init__(self, grid, canonical, state=None, live=None, warp_planar=None):
+    def __init__(self, grid, canonical, state=None, live=None, warp_planar=None, listed=None):
         self.grid, self.canonical, self.state = grid, canonical, state
         self._live, self._warp_planar = live, warp_planar
+        # (input live field, band lists, state_prepare's unlisted counts): finalize then visits the band voxels only
+        self._listed = listed
 
     def _shape(self):
         g = self.grid
@@ -516,7 +518,16 @@ class SlavchevaOutcome:
             target = torch.empty(self._shape(), dtype=torch.float32, device=self._device())
         else:
             target = live_out
-        if self.state is not None:
+        if self.state is not None and self._listed is not None:
+            # outside the band lists nothing ever moves: the input live field and a zero warp are already final there
+            live0, bands, unlisted = self._listed
+            if target is not live0:
+                target.copy_(live0)
+            warp = torch.zeros(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
+            raw = dev.state_finalize_listed(self.state, self.canonical, full, bands, unlisted, target, warp,
+                                            lower_threshold, statistics)
+            self._live = target
+        elif self.state is not None:
             warp = torch.empty(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
             raw = dev.state_finalize(self.state, self.canonical, full, target, None, warp, lower_threshold, statistics)
             self._live = target
@@ -855,8 +866,11 @@ class SlavchevaEngine:
             # the rest must already hold their final values (lsf_slavcheva_state_iteration); slab halos start valid.
             whole = dev.full_range(grid)
             fused_prepare = self.use_band_list and dev.buffer_addressing_ok(grid)
+            listed = None
             if fused_prepare:  # one pass: both states + the INTERIOR / BOUNDARY band lists of the WHOLE local array
-                states, bands = dev.state_prepare(live, canonical, whole)
+                states, bands, unlisted = dev.state_prepare(live, canonical, whole)
+                if not slab:
+                    listed = (live, bands, unlisted)
             else:
                 states = dev.state_pack(live, None, grid, copies=2)
                 bands = dev.band_lists(live, canonical, whole) if self.use_band_list else [dev.BandList.none()]
@@ -890,7 +904,7 @@ class SlavchevaEngine:
             it += batch
             if finalize is not None and not self.sobolev and it == limit and self.min_iterations >= limit:
                 # every launch runs ungated, so the final state is states[limit % 2]: finalize before looking
-                early = SlavchevaOutcome(grid, canonical, state=states[limit % 2])
+                early = SlavchevaOutcome(grid, canonical, state=states[limit % 2], listed=listed)
                 early.enqueue_finalize(*finalize)
             dec = dev.decode_records(dev.records_to_host(records[:it]))
             n_exec = int(dec["executed"].sum())
@@ -924,7 +938,7 @@ class SlavchevaEngine:
         elif early is not None and n_exec == limit:
             outcome = early
         else:
-            outcome = SlavchevaOutcome(grid, canonical, state=states[n_exec % 2])
+            outcome = SlavchevaOutcome(grid, canonical, state=states[n_exec % 2], listed=listed)
         # what is needed to (re)produce gradient_field of the last executed iteration on demand
         if n_exec == 0:
             self._gradient_state = ("zeros", torch.zeros((dims,) + tuple(live.shape), dtype=torch.float32,

@@ -571,8 +571,11 @@ def test_state_pack_unpack_finalize(lsf):
         z0 = dev.state_pack(live, None, grid, copies=1)[0]
         assert float(z0[..., 1:].abs().max()) == 0.0
         # lsf_state_prepare = lsf_state_pack (two copies, zero warp) + the INTERIOR / BOUNDARY lists of lsf_band_count
-        st, lists = dev.state_prepare(live, canon, grid)
+        st, lists, unlisted = dev.state_prepare(live, canon, grid)
         assert torch.equal(st[0], z0) and torch.equal(st[1], z0)
+        outside = (live.abs() == 1) & (canon.abs() == 1) & (live != canon)
+        assert unlisted[0] == int(outside.sum())
+        assert unlisted[1] == (int(outside.flatten().nonzero()[0]) if unlisted[0] else -1)
         want_lists = dev.band_lists(live, canon, grid)
         assert [(bl.subset, bl.count) for bl in lists] == [(bl.subset, bl.count) for bl in want_lists]
         for got_l, want_l in zip(lists, want_lists):
@@ -594,6 +597,66 @@ def test_state_pack_unpack_finalize(lsf):
         for got, want in ((raw[:8], want_w), (raw[8:], want_d)):
             assert np.array_equal(got[[0, 1, 2, 5]], want[[0, 1, 2, 5]])      # counts, max / min, arg-max: exact
             assert np.allclose(got[3:5], want[3:5], rtol=1e-12, atol=0.0)     # float64 sums in a different order
+
+
+def test_state_finalize_listed_equals_dense_finalize(lsf):
+    """lsf_state_finalize_listed (band voxels only + lsf_state_prepare's counts of the rest) against lsf_state_finalize
+    over every voxel: fields bit-identical, counts / extrema / arg-max exact, float64 sums to rounding.  Cases: a band
+    with both kinds of outside voxels, no outside voxel with live = -canonical, an empty band, identical fields."""
+    from levelsetfusion_python_amd import device as dev
+    gen = torch.Generator("cuda").manual_seed(5)
+
+    def fields(shape, case):
+        live = (torch.rand(shape, device="cuda", generator=gen) * 2 - 1).contiguous()
+        canon = (torch.rand(shape, device="cuda", generator=gen) * 2 - 1).contiguous()
+        if case == "identical":
+            live[torch.rand(shape, device="cuda", generator=gen) < 0.5] = 1.0
+            return live, live.clone()
+        if case == "empty band":
+            live = torch.where(live > 0, 1.0, -1.0).contiguous()
+            canon = torch.where(canon > 0, 1.0, -1.0).contiguous()
+            return live, canon
+        far = torch.rand(shape, device="cuda", generator=gen) < 0.6
+        sign = torch.where(torch.rand(shape, device="cuda", generator=gen) < 0.5, 1.0, -1.0)
+        live[far], canon[far] = sign[far], sign[far]
+        if case == "both":
+            flip = far & (torch.rand(shape, device="cuda", generator=gen) < 0.3)
+            flip.view(-1)[:3] = False  # the first opposite voxel is not the first voxel
+            canon[flip] = -canon[flip]
+        return live, canon
+
+    for shape in ((9, 21, 67), (45, 131)):
+        dims = len(shape)
+        for case in ("both", "no opposite", "empty band", "identical"):
+            live, canon = fields(shape, case)
+            grid = dev.make_grid(shape)
+            st, lists, unlisted = dev.state_prepare(live, canon, grid)
+            state = st[0]
+            flat = state.view(-1, 4)
+            for bl in lists:  # move the listed voxels the way iterations would: new live values (some to +-1), a warp
+                if bl.count == 0:
+                    continue
+                idx = bl.indices[:bl.count].long()
+                vals = torch.randn((bl.count, 4), device="cuda", generator=gen)
+                vals[:, 0] = vals[:, 0].clamp(-1, 1)
+                if dims == 2:
+                    vals[:, 3] = 0
+                if case == "identical":
+                    vals[:, 0] = canon.view(-1)[idx]
+                flat[idx] = vals
+            l_d, w_d = torch.empty_like(live), torch.empty(shape + (dims,), device="cuda")
+            raw_d = dev.state_finalize(state, canon, grid, l_d, None, w_d, 0.3, True).cpu().numpy()
+            l_l, w_l = live.clone(), torch.zeros(shape + (dims,), device="cuda")
+            raw_l = dev.state_finalize_listed(state, canon, grid, lists, unlisted, l_l, w_l, 0.3, True).cpu().numpy()
+            assert torch.equal(l_l, l_d) and torch.equal(w_l, w_d), (shape, case)
+            for got, want in ((raw_l[:8], raw_d[:8]), (raw_l[8:], raw_d[8:])):
+                assert np.array_equal(got[[0, 1, 2, 5]], want[[0, 1, 2, 5]]), (shape, case, got, want)
+                assert np.allclose(got[3:5], want[3:5], rtol=1e-12, atol=0.0), (shape, case, got, want)
+                assert np.array_equal(got[6:], want[6:]), (shape, case, got, want)
+            # fields only
+            l_l, w_l = live.clone(), torch.zeros(shape + (dims,), device="cuda")
+            assert dev.state_finalize_listed(state, canon, grid, lists, unlisted, l_l, w_l) is None
+            assert torch.equal(l_l, l_d) and torch.equal(w_l, w_d)
 
 
 # ------------------------------------------------------------ full-size, size-independent properties
