@@ -140,8 +140,6 @@ class HierarchicalEngine:
             canon_levels.reverse()
             packed_levels.reverse()
             return canon_levels, packed_levels, [None] * n_levels
-        if self.linear_resampling:
-            raise NotImplementedError("ResamplingStrategy.LINEAR is not available for z-slab runs")
         # z-slab: every level keeps `halo` neighbour slices; a level's owned slices are the restriction of the finer
         # level's owned slices (slab boundaries are multiples of 2^levels), its halos come from one exchange per level
         L0 = self.comm.layout
@@ -164,8 +162,12 @@ class HierarchicalEngine:
             Lc = SlabLayout(Lf.nz_global // 2, Lf.rank, Lf.world, Lf.halo)
             cc = SlabComm(Lc, fine_comm.group)
             own_f = Lf.owned_local()
-            c_own = dev.restrict_mean(canon_levels[-1][own_f].contiguous(), 1)
-            p_own = dev.restrict_mean(packed_levels[-1][own_f].contiguous(), 4)
+            if self.linear_resampling:
+                c_own = self._restrict_linear_owned(canon_levels[-1], Lf, 1)
+                p_own = self._restrict_linear_owned(packed_levels[-1], Lf, 4)
+            else:
+                c_own = dev.restrict_mean(canon_levels[-1][own_f].contiguous(), 1)
+                p_own = dev.restrict_mean(packed_levels[-1][own_f].contiguous(), 4)
             c_loc = torch.zeros((Lc.nz_local,) + tuple(c_own.shape[1:]), dtype=torch.float32, device=live.device)
             p_loc = torch.zeros((Lc.nz_local,) + tuple(p_own.shape[1:]), dtype=torch.float32, device=live.device)
             c_loc[Lc.owned_local()] = c_own
@@ -180,6 +182,18 @@ class HierarchicalEngine:
         comms.reverse()
         self._level_comms = comms
         return canon_levels, packed_levels, comms
+
+    @staticmethod
+    def _restrict_linear_owned(fine, layout, channels):
+        """LINEAR restriction (4x4x4 windows, math_utils/resampling.py:90-109) of a slab's owned slices: the window of a
+        coarse slice reaches one fine slice past the owned range -- the neighbour's slice from the halo, or the edge
+        slice again where the volume ends (the kernel's clamp).  Two slices are put on either side so that the window
+        origin stays even; the outer one and the two extra coarse slices it produces are never looked at."""
+        own = layout.owned_local()
+        below = fine[own.start - 1:own.start] if layout.halo_lo >= 1 else fine[own.start:own.start + 1]
+        above = fine[own.stop:own.stop + 1] if layout.halo_hi >= 1 else fine[own.stop - 1:own.stop]
+        padded = torch.cat([below, below, fine[own], above, above], 0).contiguous()
+        return dev.downsample2x_linear(padded, channels)[1:-1].contiguous()
 
     def optimize(self, canonical, live):
         """canonical, live: float32 device tensors [z,]y,x (z-slab runs: the local slab incl. halos).
@@ -197,6 +211,10 @@ class HierarchicalEngine:
             self.optimize_level(canon_l, packed_l, warp, comm_l)
             if level != len(canon_levels) - 1:
                 if self.linear_resampling:
+                    if comm_l is not None:
+                        # the lerp of a slab's first / last fine slices reads the neighbour's adjacent coarse slice;
+                        # iterations never touch the warp's halo slices (the warp is only read voxel by voxel)
+                        comm_l.exchange_halos([warp], width=1)
                     fine = torch.stack([dev.upsample2x_linear(warp[c].contiguous()) for c in range(dims)])
                 else:
                     fine = dev.prolong_repeat(warp)

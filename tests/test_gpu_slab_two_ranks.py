@@ -119,18 +119,24 @@ def _hier_worker(rank, world, port, n, nz, halo, kwargs, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("config", ["tikhonov_fixed", "tikhonov_kernel_fixed", "data_threshold"])
+@pytest.mark.parametrize("config", ["tikhonov_fixed", "tikhonov_kernel_fixed", "data_threshold", "linear_halo4",
+                                    "linear_halo2"])
 def test_two_slab_ranks_hierarchical_equal_whole_volume(tmp_path, config):
-    """HierarchicalOptimizer3d on two z-slabs (per-level halos, gradient halo exchange, global gate) == whole volume"""
+    """HierarchicalOptimizer3d on two z-slabs (per-level halos, gradient halo exchange, global gate) == whole volume;
+    linear_*: ResamplingStrategy.LINEAR (windows of the restriction and the prolongation reach into the halos)"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
     import levelsetfusion_python_amd as lsf
     from levelsetfusion_python_amd.synthetic import sphere_pair
-    n, world, halo = 64, 2, 4
+    n, world, halo = 64, 2, (2 if config == "linear_halo2" else 4)
     nz = n * world
     kwargs = dict(maximum_chunk_size=4, rate=0.1, tikhonov_strength=0.05, check_interval=3)
-    if config == "tikhonov_fixed":
+    if config.startswith("linear"):
+        kwargs.update(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_iteration_count=5,
+                      maximum_warp_update_threshold=0.0,
+                      resampling_strategy=lsf.HierarchicalOptimizer3d.ResamplingStrategy.LINEAR)
+    elif config == "tikhonov_fixed":
         kwargs.update(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_iteration_count=5,
                       maximum_warp_update_threshold=0.0)
     elif config == "tikhonov_kernel_fixed":
@@ -154,7 +160,9 @@ def test_two_slab_ranks_hierarchical_equal_whole_volume(tmp_path, config):
     warp = ref.optimize(canonical, live).cpu().numpy()
     want_reports = np.float64([_report_row(r) for r in ref.get_per_level_convergence_reports()])
     parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
-    assert np.array_equal(np.concatenate([p["warp"] for p in parts], 0), warp)
+    got = np.concatenate([p["warp"] for p in parts], 0)
+    per_slice = np.abs(got - warp).reshape(nz, -1).max(1)
+    assert np.array_equal(got, warp), [(z, float(d)) for z, d in enumerate(per_slice) if d > 0]
     for p in parts:
         assert list(p["counts"]) == ref.get_per_level_iteration_counts()
         assert np.array_equal(p["last_max"], np.float32([m[-1] for m in ref.get_per_level_maximum_updates()]))
