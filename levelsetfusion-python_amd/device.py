@@ -108,14 +108,15 @@ def decode_records(records_host):
     """records_host: numpy int64 [n, slots, >= 4] (records_to_host) or [n, RECORD_WORDS] -> dict of arrays (max value,
     linear arg-max index, energies, executed); combines the slots of every record: max of the packed maxima, sum of the
     energies"""
-    raw = np.ascontiguousarray(records_host)
+    raw = records_host
     if raw.ndim == 2:
-        raw = slot_view(raw)
-    packed = np.ascontiguousarray(raw[:, :, 0]).view(np.uint64).max(axis=1)
+        raw = slot_view(np.ascontiguousarray(raw))
+    words = raw.view(np.uint64)  # same item size: no copy, strides kept
+    packed = words[:, :, 0].max(axis=1)
     energies = np.ascontiguousarray(raw[:, :, 1:4]).view(np.float64).sum(axis=1)
     executed = packed != 0
     max_value = (packed >> np.uint64(32)).astype(np.uint32).view(np.float32)
-    index = (~packed.astype(np.uint32)).astype(np.int64) & 0xFFFFFFFF
+    index = (~packed.astype(np.uint32)).astype(np.int64)
     return dict(executed=executed, max_value=max_value, argmax=index, data_energy=energies[:, 0],
                 smoothing_energy=energies[:, 1], level_set_energy=energies[:, 2])
 
@@ -363,33 +364,53 @@ def slavcheva_gradient(live, canonical, warp_prev, g_out, grid, params, gate, re
           "lsf_slavcheva_gradient")
 
 
-def state_prepare(live, canonical, grid=None):
+class StatePrepare:
     """start of a fused optimize() call on whole arrays, one pass over live and canonical (lsf_state_prepare): the two
-    ping-pong states (live, 0) and the INTERIOR + BOUNDARY band lists (empty lists dropped, but never both).  The lists
-    are filled from the ballots the pass keeps (lsf_band_list_fill_prepared).  Returns (states, band lists, (number of
-    voxels outside the band with live = -canonical, the first of them or -1)) -- the last for state_finalize_listed."""
-    grid = grid or make_grid(live.shape)
-    n = n_voxels(grid)
-    states = [torch.empty(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device) for _ in range(2)]
-    n_scratch = int(lib.lsf_state_prepare_scratch_elements(ctypes.byref(grid)))
-    scratch = torch.empty(n_scratch, dtype=torch.int32, device=live.device)
-    totals = torch.empty(4, dtype=torch.int64, device=live.device)
-    p_scratch = ctypes.c_void_p(scratch.data_ptr())
-    check(lib.lsf_state_prepare(_ptr(live, n, "live"), _ptr(canonical, n, "canonical"), _ptr(states[0], 4 * n, "state"),
-                                _ptr(states[1], 4 * n, "state"), ctypes.byref(grid), p_scratch,
-                                ctypes.c_void_p(totals.data_ptr()), stream_ptr()), "lsf_state_prepare")
-    counts = [int(c) for c in totals.cpu()]
-    lists = []
-    for k, (subset, count) in enumerate(zip((_lib.BAND_INTERIOR, _lib.BAND_BOUNDARY), counts[:2])):
-        if count == 0 and not (k == 1 and not lists):
-            continue
-        indices = torch.empty(max(count, 1), dtype=torch.int32, device=live.device)
-        if count:
-            check(lib.lsf_band_list_fill_prepared(ctypes.byref(grid), subset, p_scratch,
-                                                  ctypes.c_void_p(indices.data_ptr()), stream_ptr()),
-                  "lsf_band_list_fill_prepared")
-        lists.append(BandList(indices, count, subset))
-    return states, lists, (counts[2], counts[3])
+    ping-pong states (live, 0) -- `states`, valid in stream order as soon as this object exists -- and, from collect(),
+    the INTERIOR + BOUNDARY band lists, filled from the ballots the pass keeps (lsf_band_list_fill_prepared).  The
+    constructor only launches: whatever the host has to set up for the iterations fits between it and collect(), which
+    is where the host waits for the list sizes."""
+
+    def __init__(self, live, canonical, grid=None):
+        self.grid = grid = grid or make_grid(live.shape)
+        n = n_voxels(grid)
+        self.states = [torch.empty(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device) for _ in range(2)]
+        n_scratch = int(lib.lsf_state_prepare_scratch_elements(ctypes.byref(grid)))
+        self._scratch = torch.empty(n_scratch, dtype=torch.int32, device=live.device)
+        totals = torch.empty(4, dtype=torch.int64, device=live.device)
+        check(lib.lsf_state_prepare(_ptr(live, n, "live"), _ptr(canonical, n, "canonical"),
+                                    _ptr(self.states[0], 4 * n, "state"), _ptr(self.states[1], 4 * n, "state"),
+                                    ctypes.byref(grid), ctypes.c_void_p(self._scratch.data_ptr()),
+                                    ctypes.c_void_p(totals.data_ptr()), stream_ptr()), "lsf_state_prepare")
+        self._totals_host = torch.empty(4, dtype=torch.int64, pin_memory=True)
+        self._totals_host.copy_(totals, non_blocking=True)
+        self._copied = torch.cuda.Event()
+        self._copied.record()
+
+    def collect(self):
+        """(band lists -- empty lists dropped, but never both --, (number of voxels outside the band with
+        live = -canonical, the first of them or -1)); the second is what state_finalize_listed needs"""
+        self._copied.synchronize()
+        counts = self._totals_host.tolist()
+        p_scratch = ctypes.c_void_p(self._scratch.data_ptr())
+        lists = []
+        for k, (subset, count) in enumerate(zip((_lib.BAND_INTERIOR, _lib.BAND_BOUNDARY), counts[:2])):
+            if count == 0 and not (k == 1 and not lists):
+                continue
+            indices = torch.empty(max(count, 1), dtype=torch.int32, device=self._scratch.device)
+            if count:
+                check(lib.lsf_band_list_fill_prepared(ctypes.byref(self.grid), subset, p_scratch,
+                                                      ctypes.c_void_p(indices.data_ptr()), stream_ptr()),
+                      "lsf_band_list_fill_prepared")
+            lists.append(BandList(indices, count, subset))
+        return lists, (counts[2], counts[3])
+
+
+def state_prepare(live, canonical, grid=None):
+    """StatePrepare in one call: (states, band lists, unlisted counts)"""
+    prepared = StatePrepare(live, canonical, grid)
+    lists, unlisted = prepared.collect()
+    return prepared.states, lists, unlisted
 
 
 def state_pack(live, warp_planar=None, grid=None, copies=2):

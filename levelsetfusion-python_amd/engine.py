@@ -521,12 +521,22 @@ class SlavchevaOutcome:
             self._early = None
             if live_out is not None and target is not live_out:
                 live_out.copy_(target)
-            return target, warp, (raw.cpu().numpy() if raw is not None else None)
+            if raw is not None:
+                host, done = raw
+                done.synchronize()
+                raw = host.numpy()
+            return target, warp, raw
         return self._finalize_now(live_out, lower_threshold, statistics, to_host=True)
 
     def enqueue_finalize(self, live_out, lower_threshold, statistics):
         """launch the finalize pass now (no host synchronisation); finalize() with the same arguments collects it"""
         target, warp, raw = self._finalize_now(live_out, lower_threshold, statistics, to_host=False)
+        if raw is not None:  # on its way to the host behind the pass: the caller's next synchronising read covers it
+            host = torch.empty(raw.shape, dtype=raw.dtype, pin_memory=True)
+            host.copy_(raw, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            raw = (host, done)
         self._early = ((live_out, float(lower_threshold), bool(statistics)), target, warp, raw)
 
     def _finalize_now(self, live_out, lower_threshold, statistics, to_host):
@@ -864,6 +874,12 @@ class SlavchevaEngine:
             if self.comm.layout.halo < need:
                 raise ValueError("slab halo of %d slices is too narrow: this configuration needs >= %d"
                                  % (self.comm.layout.halo, need))
+        prepared = None
+        fused_prepare = not self.sobolev and self.use_band_list and dev.buffer_addressing_ok(grid)
+        if fused_prepare:
+            # one pass: both states + the INTERIOR / BOUNDARY band lists of the WHOLE local array.  Launched first: the
+            # host sets up records and launch arguments while it runs, and only then waits for the list sizes
+            prepared = dev.StatePrepare(live, canonical, dev.full_range(grid))
         records = dev.new_records(n_rec, live.device)
         self._last_g = None
         lives = warps = gbufs = states = None
@@ -883,15 +899,8 @@ class SlavchevaEngine:
             # Both ping-pong states start as (live, 0): the fused kernel only visits the voxels of the band list and
             # the rest must already hold their final values (lsf_slavcheva_state_iteration); slab halos start valid.
             whole = dev.full_range(grid)
-            fused_prepare = self.use_band_list and dev.buffer_addressing_ok(grid)
             listed = None
-            if fused_prepare:  # one pass: both states + the INTERIOR / BOUNDARY band lists of the WHOLE local array
-                states, bands, unlisted = dev.state_prepare(live, canonical, whole)
-                if not slab:
-                    listed = (live, bands, unlisted)
-            else:
-                states = dev.state_pack(live, None, grid, copies=2)
-                bands = dev.band_lists(live, canonical, whole) if self.use_band_list else [dev.BandList.none()]
+            states = prepared.states if fused_prepare else dev.state_pack(live, None, grid, copies=2)
             n = dev.n_voxels(grid)
             f = dev.IterationLauncher(grid, records, _lib.GATE_SLAVCHEVA, self.lo, self.hi)
             f.p_state = [f.pointer(t, 4 * n, "state") for t in states]
@@ -899,6 +908,12 @@ class SlavchevaEngine:
             f.params_ref = ctypes.byref(self.params)
             f.stream = dev.stream_ptr()  # the launch stream of this call (one ctypes object, not one per launch)
             f.native = None
+            if fused_prepare:
+                bands, unlisted = prepared.collect()
+                if not slab:
+                    listed = (live, bands, unlisted)
+            else:
+                bands = dev.band_lists(live, canonical, whole) if self.use_band_list else [dev.BandList.none()]
             f.bands = bands
             self._fast = f
             if slab:
@@ -946,11 +961,11 @@ class SlavchevaEngine:
         wd, ws, wl = self.weights
         if dec is None:
             dec = dev.decode_records(dev.records_to_host(records[:1]))
-        self.log = dict(max_warps=[float(v) for v in dec["max_value"][:n_exec]],
-                        max_warp_indices=[int(v) for v in dec["argmax"][:n_exec]],
-                        data_energies=[wd * float(v) for v in dec["data_energy"][:n_exec]],
-                        smoothing_energies=[ws * float(v) for v in dec["smoothing_energy"][:n_exec]],
-                        level_set_energies=[wl * float(v) for v in dec["level_set_energy"][:n_exec]])
+        self.log = dict(max_warps=dec["max_value"][:n_exec].tolist(),
+                        max_warp_indices=dec["argmax"][:n_exec].tolist(),
+                        data_energies=(wd * dec["data_energy"][:n_exec]).tolist(),
+                        smoothing_energies=(ws * dec["smoothing_energy"][:n_exec]).tolist(),
+                        level_set_energies=(wl * dec["level_set_energy"][:n_exec]).tolist())
         if self.sobolev:
             outcome = SlavchevaOutcome(grid, canonical, live=lives[n_exec % 2], warp_planar=warps[n_exec % 2])
         elif early is not None and n_exec == limit:

@@ -126,9 +126,11 @@ class _SlavchevaOptimizerBase:
         self.log.data_energies = eng_log["data_energies"]
         self.log.smoothing_energies = eng_log["smoothing_energies"]
         self.log.level_set_energies = eng_log["level_set_energies"]
-        self.log.max_warp_locations = [tuple(int(i) for i in np.unravel_index(k, tuple(live.shape))[::-1])
-                                       for k in eng_log["max_warp_indices"]] \
-            if (self._engine.comm is None or not self._engine.comm.active) else eng_log["max_warp_indices"]
+        if self._engine.comm is None or not self._engine.comm.active:
+            coords = np.unravel_index(np.asarray(eng_log["max_warp_indices"], dtype=np.int64), tuple(live.shape))
+            self.log.max_warp_locations = list(zip(*(c.tolist() for c in coords[::-1])))
+        else:
+            self.log.max_warp_locations = eng_log["max_warp_indices"]
         if self.log.max_warps:
             self.total_data_energy = self.log.data_energies[-1]
             self.total_smoothing_energy = self.log.smoothing_energies[-1]

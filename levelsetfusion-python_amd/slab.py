@@ -85,10 +85,19 @@ class SlabComm:
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         path = path.encode() if os.path.exists(path) else None
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        # every rank draws an id (only rank 0's is used): that binds RCCL, and the ranks agree on the outcome BEFORE
+        # anyone enters the collective communicator set-up -- a rank that cannot bind must not leave the others waiting
+        host = (ctypes.c_uint8 * 128)()
+        bound = torch.tensor([int(_lib.lib.lsf_slab_unique_id(path, ctypes.cast(host, ctypes.c_void_p)) == 0)],
+                             dtype=torch.int32, device="cuda")
+        if dist.get_world_size(self.group) > 1:
+            dist.all_reduce(bound, op=dist.ReduceOp.MIN, group=self.group)
+        if int(bound.item()) == 0:
+            warnings.warn("native RCCL slab transport unavailable (RCCL could not be bound on every rank); using "
+                          "torch.distributed point-to-point")
+            return None
         try:
             if rank == 0:
-                host = (ctypes.c_uint8 * 128)()
-                _lib.check(_lib.lib.lsf_slab_unique_id(path, ctypes.cast(host, ctypes.c_void_p)), "lsf_slab_unique_id")
                 uid.copy_(torch.frombuffer(bytearray(host), dtype=torch.uint8))
             if dist.get_world_size(self.group) > 1:
                 src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
