@@ -272,33 +272,81 @@ __global__ __launch_bounds__(kBlock) void band_list_kernel(const float* __restri
     }
 }
 
-// exclusive prefix sums of sums[0..n) in place, one block per array (blockIdx.x selects the array: arrays are
-// `stride` ints apart, totals consecutive).  Each thread sums a contiguous share, one Hillis-Steele scan over the 1024
-// shares, then the shares are rewritten: two passes over <= 2^21 ints instead of a block-wide scan per 1024 of them.
-__global__ __launch_bounds__(1024) void band_scan_kernel(int* __restrict__ sums_base, unsigned n, unsigned stride,
-                                                         long long* totals) {
-    __shared__ int buf[1024];
-    int* __restrict__ sums = sums_base + (size_t)blockIdx.x * stride;
-    const unsigned t = threadIdx.x;
-    const unsigned per = (n + 1023u) / 1024u;
-    const unsigned lo = t * per < n ? t * per : n, hi = lo + per < n ? lo + per : n;
-    int share = 0;
-    for (unsigned i = lo; i < hi; ++i) share += sums[i];
-    buf[t] = share;
+// totals[2] = number of unlisted voxels with live = -canonical, totals[3] = the first of them (or -1); one block
+__device__ inline void reduce_opposite(const int* __restrict__ opposite, unsigned chunks, long long* __restrict__ totals) {
+    __shared__ long long s_sum[1024 / kWave];
+    __shared__ int s_first[1024 / kWave];
+    long long sum = 0;
+    int first = 0x7fffffff;
+    for (unsigned c = threadIdx.x; c < chunks; c += 1024) {
+        sum += opposite[2 * c];
+        first = min(first, opposite[2 * c + 1]);
+    }
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        sum += (long long)shfl_down_u64((unsigned long long)sum, d);
+        first = min(first, __shfl_down(first, d, kWave));
+    }
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        s_sum[threadIdx.x / kWave] = sum;
+        s_first[threadIdx.x / kWave] = first;
+    }
     __syncthreads();
-    for (unsigned off = 1; off < 1024; off <<= 1) {
-        const int add = t >= off ? buf[t - off] : 0;
-        __syncthreads();
-        buf[t] += add;
-        __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 1024 / kWave; ++k) {
+            sum += s_sum[k];
+            first = min(first, s_first[k]);
+        }
+        totals[2] = sum;
+        totals[3] = first == 0x7fffffff ? -1 : first;
     }
-    int run = buf[t] - share;  // exclusive prefix of this thread's share
-    for (unsigned i = lo; i < hi; ++i) {
-        const int v = sums[i];
-        sums[i] = run;
-        run += v;
+}
+
+// exclusive prefix sums of sums[0..n) in place, one block per array (blockIdx.x selects the array: arrays are
+// `stride` ints apart, totals consecutive).  Tiles of 4096 ints: four consecutive ints per thread, a shuffle scan per
+// wave, the sixteen wave totals through LDS, the running total carried from tile to tile.  A block past the arrays
+// (`opposite` given) reduces lsf_state_prepare's per-chunk counts of the unlisted voxels instead.
+__global__ __launch_bounds__(1024) void band_scan_kernel(int* __restrict__ sums_base, unsigned n, unsigned stride,
+                                                         unsigned arrays, long long* totals,
+                                                         const int* __restrict__ opposite) {
+    if (blockIdx.x >= arrays) {
+        reduce_opposite(opposite, n, totals);
+        return;
     }
-    if (t == 1023) totals[blockIdx.x] = buf[1023];
+    __shared__ int wave_total[1024 / kWave];
+    int* __restrict__ sums = sums_base + (size_t)blockIdx.x * stride;
+    const unsigned t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+    int carry = 0;
+    for (unsigned base = 0; base < n; base += 4096u) {
+        const unsigned i = base + 4u * t;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = i + k < n ? sums[i + k] : 0;
+        const int mine = v[0] + v[1] + v[2] + v[3];
+        int inclusive = mine;
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int up = __shfl_up(inclusive, d, kWave);
+            if ((int)lane >= d) inclusive += up;
+        }
+        if (lane == kWave - 1) wave_total[wave] = inclusive;
+        __syncthreads();
+        int before = 0, tile = 0;
+#pragma unroll
+        for (int w = 0; w < 1024 / kWave; ++w) {
+            const int x = wave_total[w];
+            before += w < (int)wave ? x : 0;
+            tile += x;
+        }
+        int run = carry + before + inclusive - mine;  // exclusive prefix of this thread's four
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i + k < n) sums[i + k] = run;
+            run += v[k];
+        }
+        carry += tile;
+        __syncthreads();  // wave_total is rewritten by the next tile
+    }
+    if (t == 0) totals[blockIdx.x] = carry;
 }
 
 typedef float vf4 __attribute__((ext_vector_type(4)));
@@ -363,35 +411,6 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
     }
 }
 
-// totals[2] = number of unlisted voxels with live = -canonical, totals[3] = the first of them (or -1)
-__global__ __launch_bounds__(1024) void prepare_opposite_kernel(const int* __restrict__ opposite, unsigned chunks,
-                                                                long long* __restrict__ totals) {
-    __shared__ long long s_sum[1024 / kWave];
-    __shared__ int s_first[1024 / kWave];
-    long long sum = 0;
-    int first = 0x7fffffff;
-    for (unsigned c = threadIdx.x; c < chunks; c += 1024) {
-        sum += opposite[2 * c];
-        first = min(first, opposite[2 * c + 1]);
-    }
-    for (int d = kWave / 2; d > 0; d >>= 1) {
-        sum += (long long)shfl_down_u64((unsigned long long)sum, d);
-        first = min(first, __shfl_down(first, d, kWave));
-    }
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        s_sum[threadIdx.x / kWave] = sum;
-        s_first[threadIdx.x / kWave] = first;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < 1024 / kWave; ++k) {
-            sum += s_sum[k];
-            first = min(first, s_first[k]);
-        }
-        totals[2] = sum;
-        totals[3] = first == 0x7fffffff ? -1 : first;
-    }
-}
 
 // ordered fill of one subset's list from the ballots lsf_state_prepare kept (which = 0 INTERIOR, 1 BOUNDARY)
 __global__ __launch_bounds__(kBlock) void band_fill_from_masks_kernel(const unsigned long long* __restrict__ masks,
@@ -487,7 +506,8 @@ extern "C" int lsf_band_count(const float* live, const float* canonical, const l
     if (chunks > 0)
         hipLaunchKernelGGL(band_list_kernel<false>, dim3(chunks), dim3(kBlock), 0, s, live, canonical, first, n,
                            make_grid(grid), grid->dims, subset, scratch, (int*)nullptr);
-    hipLaunchKernelGGL(band_scan_kernel, dim3(1), dim3(1024), 0, s, scratch, chunks, 0u, (long long*)count_out);
+    hipLaunchKernelGGL(band_scan_kernel, dim3(1), dim3(1024), 0, s, scratch, chunks, 0u, 1u, (long long*)count_out,
+                       (const int*)nullptr);
     return launch_status();
 }
 
@@ -537,9 +557,8 @@ extern "C" int lsf_state_prepare(const float* live, const float* canonical, floa
     hipLaunchKernelGGL(state_prepare_kernel, dim3(chunks), dim3(kBlock), 0, s, live, canonical,
                        reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b), n, make_grid(grid), grid->dims,
                        sums_interior, sums_boundary, prepare_masks(scratch, chunks), prepare_opposite(scratch, chunks));
-    hipLaunchKernelGGL(band_scan_kernel, dim3(2), dim3(1024), 0, s, scratch, chunks, chunks + 1, (long long*)counts_out);
-    hipLaunchKernelGGL(prepare_opposite_kernel, dim3(1), dim3(1024), 0, s, prepare_opposite(scratch, chunks), chunks,
-                       (long long*)counts_out);
+    hipLaunchKernelGGL(band_scan_kernel, dim3(3), dim3(1024), 0, s, scratch, chunks, chunks + 1, 2u, (long long*)counts_out,
+                       (const int*)prepare_opposite(scratch, chunks));
     return launch_status();
 }
 
