@@ -168,17 +168,38 @@ def main():
 
     n, iters = args.size, args.iterations
     layout = SlabLayout(n * world, rank, world, args.halo if world > 1 else 0)
-    comm = SlabComm(layout) if world > 1 else None
     sl = layout.local_slice()
     canonical, live0 = sphere_pair(n, 3, device, (sl.start, sl.stop))
-    opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT,
-                                   level_set_term_enabled=True,
-                                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
-                                   gradient_descent_rate=0.1, data_term_weight=1.0, smoothing_term_weight=0.2,
-                                   isomorphic_enforcement_factor=0.1, level_set_term_weight=0.2,
-                                   maximum_warp_length_lower_threshold=0.0, max_iterations=iters,
-                                   min_iterations=iters, check_interval=iters, comm=comm)
+
+    def make_optimizer():
+        comm = SlabComm(layout) if world > 1 else None
+        return comm, lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT,
+                                              level_set_term_enabled=True,
+                                              smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
+                                              gradient_descent_rate=0.1, data_term_weight=1.0,
+                                              smoothing_term_weight=0.2, isomorphic_enforcement_factor=0.1,
+                                              level_set_term_weight=0.2, maximum_warp_length_lower_threshold=0.0,
+                                              max_iterations=iters, min_iterations=iters, check_interval=iters,
+                                              comm=comm)
+
+    comm, opt = make_optimizer()
     live = torch.empty_like(live0)
+    if world > 1 and comm.native() is not None:
+        # one call through the library's RCCL transport before anything is timed; if ANY rank's call reports an error
+        # every rank switches to the torch.distributed transport together (same schedule, more host work per iteration)
+        failed = torch.zeros(1, dtype=torch.int32, device="cpu" if args.backend == "gloo" else device)
+        try:
+            live.copy_(live0)
+            opt.optimize(live, canonical)
+            torch.cuda.synchronize()
+        except RuntimeError as exc:
+            sys.stderr.write("rank %d: native slab transport failed (%s)\n" % (rank, exc))
+            failed += 1
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if int(failed.item()):
+            comm.close()
+            os.environ["LSF_SLAB_TRANSPORT"] = "torch"
+            comm, opt = make_optimizer()
 
     def step():
         live.copy_(live0)  # a fresh pair every step (optimize() warps live in place)
