@@ -154,6 +154,12 @@ int lsf_convolve_axis(const float *in_planar, float *out_planar, const float *ze
                       const lsf_grid *grid, int32_t planes, int32_t axis, const double *taps_host,
                       int32_t n_taps, const lsf_gate *gate, void *stream);
 
+/* the three passes of a 3-D filter (x, then y, then z: convolution.py:94-105) in one launch, without a zero mask: the
+ * result equals three lsf_convolve_axis calls bit for bit.  Whole arrays (z_begin = 0, z_end = nz), nx % 4 == 0,
+ * 3 / 5 / 7 / 9 taps; LSF_ERR_BAD_DIMS / LSF_ERR_KERNEL_TOO_LONG otherwise (the caller then runs the single passes). */
+int lsf_convolve_xyz(const float *in_planar, float *out_planar, const lsf_grid *grid, int32_t planes,
+                     const double *taps_host, int32_t n_taps, const lsf_gate *gate, void *stream);
+
 /* the same zero-preserving pass (zero_mask_source required, 3 / 5 / 7 / 9 taps) at the voxels of a band list only */
 int lsf_convolve_axis_listed(const float *in_planar, float *out_planar, const float *zero_mask_source,
                              const lsf_grid *grid, int32_t planes, int32_t axis, const double *taps_host,

@@ -692,6 +692,160 @@ static bool launch_window_pass(const float* in, float* out, const float* mask, c
     return true;
 }
 
+// ---- all three passes of a 3-D separable filter in ONE launch (x, then y, then z: math_utils/convolution.py:94-105) ----
+// A block owns a column of kXyzRows rows x 64 x-positions and marches through kXyzChunk output slices (+ NT - 1 slices of
+// run-in).  Per slice: the raw tile with its x / y reach goes through LDS, the x pass writes its float32-rounded
+// results back to LDS, the y pass reads them into registers -- and the z pass never leaves the
+// registers: each thread keeps the last NT (x, y)-filtered values of its four columns.  One read of the input and one
+// write of the output instead of three each; the run-in slices are re-read by the neighbouring chunk (x 1.19 at 32).
+// Same arithmetic as the single passes: float64 products and sums in tap order, one float32 rounding per pass, zeros
+// outside the array.
+constexpr int kXyzRows = 16;
+constexpr int kXyzChunk = 32;
+constexpr int kXyzCols = kTileX + 8;  // the tile's columns plus one aligned quad on either side (reach <= 4)
+
+template <int NT>
+__global__ __launch_bounds__(kBlock, 5) void convolve_xyz_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              Grid g, TapsN<NT> taps, unsigned chunks_z,
+                                                              int chunk, lsf_gate gate) {
+    if (gate_closed(gate)) return;
+    constexpr int R = NT / 2;                   // odd NT: reach R on either side, out[o] = sum_j k[j] * in[o + R - j]
+    constexpr int kStaged = kXyzRows + 2 * R;   // rows of the raw tile and of the x pass
+    constexpr int kQuads = kStaged * (kXyzCols / 4);
+    constexpr int kLoads = (kQuads + kBlock - 1) / kBlock;
+    __shared__ __attribute__((aligned(16))) float raw[kStaged][kXyzCols];  // float32 in LDS: its bandwidth, not the conversions, is the scarcer one
+    __shared__ float xs[kStaged][kTileX];
+    const int t = threadIdx.x, lx = t & (kTileX - 1), wy = t / kTileX;
+    const int x0 = blockIdx.x * kTileX;
+    const int y0 = (int)(blockIdx.y / chunks_z) * kXyzRows;
+    const int z0 = (int)(blockIdx.y % chunks_z) * chunk;
+    const int count = min(chunk, g.nz - z0);
+    const float* __restrict__ src = in + (long long)blockIdx.z * g.plane;
+    float* __restrict__ dst = out + (long long)blockIdx.z * g.plane;
+
+    // this thread's share of a slice's raw tile: quads q = t + 256 m -> (row, quad column)
+    int q_row[kLoads], q_col[kLoads], q_off[kLoads];  // offsets inside a slice: < 2^31 (check_grid)
+    bool q_ok[kLoads];
+#pragma unroll
+    for (int m = 0; m < kLoads; ++m) {
+        const int q = t + m * kBlock;
+        q_row[m] = q / (kXyzCols / 4);
+        q_col[m] = (q % (kXyzCols / 4)) * 4;
+        const int gx = x0 - 4 + q_col[m], gy = y0 - R + q_row[m];
+        q_ok[m] = q < kQuads && gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny;  // nx % 4 == 0: quads are in or out whole
+        q_off[m] = gy * g.nx + gx;
+    }
+    const cvf4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const long long slice = (long long)g.nx * g.ny;
+    auto fetch = [&](int p, cvf4 (&v)[kLoads]) {
+#pragma unroll
+        for (int m = 0; m < kLoads; ++m)
+            v[m] = (q_ok[m] && p >= 0 && p < g.nz) ? *reinterpret_cast<const cvf4*>(src + p * slice + q_off[m]) : zero4;
+    };
+
+    float win[4][NT];  // win[k][i]: (x, y)-filtered value of column k at slice p - (NT - 1) + i
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) win[k][i] = 0.0f;
+
+    const int p_first = z0 - R, p_last = z0 + count - 1 + R;
+    cvf4 next[kLoads];
+    fetch(p_first, next);
+    for (int p = p_first; p <= p_last; ++p) {
+        const bool inside = p >= 0 && p < g.nz;  // uniform
+        float value[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (inside) {
+#pragma unroll
+            for (int m = 0; m < kLoads; ++m) {
+                if (t + m * kBlock < kQuads) {
+                    *reinterpret_cast<cvf4*>(&raw[q_row[m]][q_col[m]]) = next[m];
+                }
+            }
+        }
+        __syncthreads();  // raw complete; every wave is done with the previous slice's xs
+        fetch(p + 1 <= p_last ? p + 1 : -1, next);  // in flight while this slice is filtered
+        if (inside) {
+#pragma unroll
+            for (int m = 0; m < (kStaged + 3) / 4; ++m) {  // x pass: rows wy, wy + 4, ...
+                const int r = wy + 4 * m;
+                if (r < kStaged) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc = acc + taps.k[j] * (double)raw[r][lx + 4 + R - j];
+                    xs[r][lx] = (float)acc;
+                }
+            }
+        }
+        __syncthreads();  // xs complete; every wave is done with raw
+        if (inside) {
+            double d[4 + 2 * R];  // y pass: four consecutive rows share their taps
+#pragma unroll
+            for (int i = 0; i < 4 + 2 * R; ++i) d[i] = (double)xs[4 * wy + i][lx];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc = acc + taps.k[j] * d[k + 2 * R - j];
+                value[k] = (float)acc;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int i = 0; i + 1 < NT; ++i) win[k][i] = win[k][i + 1];
+            win[k][NT - 1] = value[k];
+        }
+        const int po = p - R;  // the output slice whose NT taps are now in the window
+        if (po >= z0 && x0 + lx < g.nx) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int y = y0 + 4 * wy + k;
+                if (y < g.ny) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc = acc + taps.k[j] * (double)win[k][2 * R - j];
+                    dst[((long long)po * g.ny + y) * g.nx + x0 + lx] = (float)acc;
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+static void launch_xyz(const float* in, float* out, const Grid& g, int planes, const double* taps_host,
+                       const lsf_gate& gt, hipStream_t s) {
+    TapsN<NT> taps;
+    for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
+    const unsigned tiles_x = (unsigned)(g.nx + kTileX - 1) / kTileX, tiles_y = (unsigned)(g.ny + kXyzRows - 1) / kXyzRows;
+    const int chunk = kXyzChunk;
+    const unsigned chunks_z = (unsigned)(g.nz + chunk - 1) / chunk;
+    hipLaunchKernelGGL((convolve_xyz_kernel<NT>), dim3(tiles_x, tiles_y * chunks_z, (unsigned)planes), dim3(kBlock), 0, s,
+                       in, out, g, taps, chunks_z, chunk, gt);
+}
+
+extern "C" int lsf_convolve_xyz(const float* in_planar, float* out_planar, const lsf_grid* grid, int32_t planes,
+                                const double* taps_host, int32_t n_taps, const lsf_gate* gate, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!in_planar || !out_planar || in_planar == out_planar || !taps_host || planes < 1 || planes > 4)
+        return LSF_ERR_BAD_ARGUMENT;
+    if (grid->dims != 3 || grid->nx % 4 != 0 || grid->z_begin != 0 || grid->z_end != grid->nz) return LSF_ERR_BAD_DIMS;
+    if (n_taps != 3 && n_taps != 5 && n_taps != 7 && n_taps != 9) return LSF_ERR_KERNEL_TOO_LONG;
+    const Grid g = make_grid(grid);
+    const unsigned long long blocks_y = (unsigned long long)((g.ny + kXyzRows - 1) / kXyzRows) *
+                                        (unsigned long long)((g.nz + kXyzChunk - 1) / kXyzChunk);
+    if (blocks_y > 65535ull) return LSF_ERR_BAD_DIMS;
+    const lsf_gate gt = gate ? *gate : lsf_gate{nullptr, 0, 0.0f, 0.0f};
+    hipStream_t s = as_stream(stream);
+    switch (n_taps) {
+        case 3: launch_xyz<3>(in_planar, out_planar, g, planes, taps_host, gt, s); break;
+        case 5: launch_xyz<5>(in_planar, out_planar, g, planes, taps_host, gt, s); break;
+        case 7: launch_xyz<7>(in_planar, out_planar, g, planes, taps_host, gt, s); break;
+        default: launch_xyz<9>(in_planar, out_planar, g, planes, taps_host, gt, s); break;
+    }
+    return launch_status();
+}
+
 extern "C" int lsf_convolve_axis_listed(const float* in_planar, float* out_planar, const float* zero_mask_source,
                                         const lsf_grid* grid, int32_t planes, int32_t axis, const double* taps_host,
                                         int32_t n_taps, const lsf_gate* gate, const int32_t* band_list,

@@ -266,6 +266,30 @@ def convolve_axis(src, dst, zero_mask_source, grid, axis, taps, gate=None, band=
                                 _gate_ref(gate), stream_ptr()), "lsf_convolve_axis")
 
 
+XYZ_TAP_COUNTS = (3, 5, 7, 9)
+
+
+def convolve_xyz_ok(grid, taps):
+    """can lsf_convolve_xyz run this 3-D filter (whole array, nx % 4 == 0, 3 / 5 / 7 / 9 taps that fit every axis)?"""
+    n = len(taps)
+    return (grid.dims == 3 and n in XYZ_TAP_COUNTS and grid.nx % 4 == 0 and grid.z_begin == 0
+            and grid.z_end == grid.nz and min(grid.nx, grid.ny, grid.nz) >= n
+            and ((grid.ny + 15) // 16) * ((grid.nz + 31) // 32) <= 65535)
+
+
+def convolve_xyz(src, dst, grid, taps, gate=None):
+    """the x, y and z passes of convolve_axis (no zero mask) in one launch (lsf_convolve_xyz): same result, one read
+    and one write of the field instead of three"""
+    taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float64))
+    if not convolve_xyz_ok(grid, taps):
+        raise ValueError("lsf_convolve_xyz cannot run this grid / kernel; use three convolve_axis passes")
+    planes = src.shape[0]
+    n = n_voxels(grid) * planes
+    check(lib.lsf_convolve_xyz(_ptr(src, n, "conv src"), _ptr(dst, n, "conv dst"), ctypes.byref(grid), planes,
+                               taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), taps.size, _gate_ref(gate),
+                               stream_ptr()), "lsf_convolve_xyz")
+
+
 # ------------------------------------------------------------------------------------- optimizer kernels
 def hier_iteration(packed, canonical, warp, g_prev, g_out, grid, params, gate, records, index):
     n = n_voxels(grid)

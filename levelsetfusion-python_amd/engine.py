@@ -113,6 +113,10 @@ class HierarchicalEngine:
         self.compute_energy = compute_energy
         self.check_interval = max(1, int(check_interval))
         self.level_results = []
+        # 3-D levels from 2^23 voxels up: lsf_convolve_xyz instead of three passes (0.21 against 0.25 ms at 256^3, 1.29
+        # against 1.9 ms at 512^3; below that its 64 x 16-column blocks are too few to fill the GPU: 0.045 / 0.035 ms at 128^3)
+        self.fused_filter = os.environ.get("LSF_FUSED_FILTER", "1") != "0"
+        self.fused_filter_min_voxels = 1 << 23
         self.last_gradient = None  # planar gradient of the finest level after the last iteration
 
     # ------------------------------------------------------------------------------------------------
@@ -272,6 +276,10 @@ class HierarchicalEngine:
                 comm.exchange_halos([lv.S[0]], width=len(self.gradient_kernel) // 2)
             axes = _conv_axis_order(lv.dims)
             src = lv.S[0]
+            if (not slab and self.fused_filter and dev.n_voxels(lv.grid) >= self.fused_filter_min_voxels
+                    and dev.convolve_xyz_ok(lv.grid, self.gradient_kernel)):
+                dev.convolve_xyz(src, out, lv.grid, self.gradient_kernel, gate)  # x, y, z in one launch
+                axes = ()
             for k, axis in enumerate(axes):
                 dst = out if k == len(axes) - 1 else lv.S[(k + 1) % 2]
                 dev.convolve_axis(src, dst, None, lv.grid if axis == 2 else lv.full_grid, axis, self.gradient_kernel,

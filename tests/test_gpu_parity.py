@@ -599,6 +599,33 @@ def test_state_pack_unpack_finalize(lsf):
             assert np.allclose(got[3:5], want[3:5], rtol=1e-12, atol=0.0)     # float64 sums in a different order
 
 
+def test_fused_xyz_filter_equals_three_passes(lsf):
+    """lsf_convolve_xyz (x, y and z pass in one launch) == three lsf_convolve_axis passes, bit for bit: ragged
+    extents (tiles, rows and z chunks that end early), every supported tap count, a closed gate leaves dst alone"""
+    from levelsetfusion_python_amd import device as dev
+    gen = torch.Generator("cuda").manual_seed(3)
+    for shape in ((37, 35, 72), (64, 64, 64), (9, 10, 12), (70, 18, 132)):
+        grid = dev.make_grid(shape)
+        src = torch.randn((3,) + shape, device="cuda", generator=gen)
+        src[:, :, :, : shape[2] // 3] = 0.0  # exact zeros as in a gradient that vanishes outside a band
+        for n_taps in (3, 5, 7, 9):
+            taps = lsf.generate_1d_sobolev_kernel(n_taps, 0.1) if n_taps in (3, 7) else \
+                np.linspace(-0.2, 1.0, n_taps).astype(np.float32)
+            assert dev.convolve_xyz_ok(grid, taps)
+            a, b = torch.empty_like(src), torch.empty_like(src)
+            dev.convolve_axis(src, a, None, grid, 0, taps)
+            dev.convolve_axis(a, b, None, grid, 1, taps)
+            dev.convolve_axis(b, a, None, grid, 2, taps)
+            fused = torch.full_like(src, 7.0)
+            dev.convolve_xyz(src, fused, grid, taps)
+            assert torch.equal(fused, a), (shape, n_taps, float((fused - a).abs().max()))
+    assert not dev.convolve_xyz_ok(dev.make_grid((16, 16, 18)), np.ones(7))   # nx % 4
+    assert not dev.convolve_xyz_ok(dev.make_grid((16, 16, 16)), np.ones(4))   # even tap count
+    assert not dev.convolve_xyz_ok(dev.make_grid((4, 16, 16)), np.ones(7))    # shorter than the kernel
+    with pytest.raises(ValueError):
+        dev.convolve_xyz(src, fused, dev.make_grid((16, 16)), np.ones(7))
+
+
 def test_state_finalize_listed_equals_dense_finalize(lsf):
     """lsf_state_finalize_listed (band voxels only + lsf_state_prepare's counts of the rest) against lsf_state_finalize
     over every voxel: fields bit-identical, counts / extrema / arg-max exact, float64 sums to rounding.  Cases: a band
@@ -758,3 +785,9 @@ def test_full_size_config3_hierarchical_3d_128_with_sobolev_kernel(lsf):
     assert tuple(warp.shape) == (n, n, n, 3) and opt.get_per_level_iteration_counts() == [2, 2, 2, 2]
     assert maxdiff(warp.cpu().numpy(), want) == EXACT
     assert float(np.abs(want).max()) > 1e-3
+    # the same with the three filter passes of every level in one launch (lsf_convolve_xyz; by default only levels of
+    # 2^23 voxels and more take it)
+    fused = lsf.HierarchicalOptimizer3d(**kw)
+    fused._engine.fused_filter_min_voxels = 0
+    warp_fused = fused.optimize(torch.from_numpy(canon).cuda(), torch.from_numpy(live).cuda())
+    assert torch.equal(warp_fused, warp)
