@@ -707,8 +707,9 @@ extern "C" int lsf_state_finalize_listed(const float* state, const float* canoni
     if (!range_of(grid, first, n)) return statistics16 ? LSF_ERR_BAD_ARGUMENT : 0;
     unsigned rows = 0;
     long long listed = 0;
-    for (int32_t k = 0; k < n_lists; ++k) {
+    for (int32_t k = 0; k < n_lists; ++k)  // everything is checked before anything is launched
         if (band_counts[k] < 0 || band_counts[k] > 0x7fffffffll || (band_counts[k] && !band_lists[k])) return LSF_ERR_BAD_ARGUMENT;
+    for (int32_t k = 0; k < n_lists; ++k) {
         if (band_counts[k] == 0) continue;
         const unsigned blocks = finalize_blocks(band_counts[k]);
         hipLaunchKernelGGL(state_finalize_list_kernel, dim3(blocks), dim3(kBlock), 0, as_stream(stream),

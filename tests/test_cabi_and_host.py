@@ -83,6 +83,23 @@ def test_argument_errors_are_reported_not_launched(pkg):
     taps = (ctypes.c_double * 40)()
     assert L.lib.lsf_convolve_axis(1, 2, None, ctypes.byref(ok), 3, 0, taps, 33, None, None) == -3
     assert L.lib.lsf_convolve_axis(1, 1, None, ctypes.byref(ok), 3, 0, taps, 7, None, None) == -1  # in place
+    # the one-launch 3-D filter: whole arrays, nx % 4 == 0, 3 / 5 / 7 / 9 taps -- anything else is refused, not launched
+    assert L.lib.lsf_convolve_xyz(1, 2, ctypes.byref(ok), 3, taps, 4, None, None) == -3
+    assert L.lib.lsf_convolve_xyz(1, 1, ctypes.byref(ok), 3, taps, 7, None, None) == -1           # in place
+    assert L.lib.lsf_convolve_xyz(1, 2, ctypes.byref(L.Grid(3, 4, 8, 6, 0, 4, 0, 0)), 3, taps, 7, None, None) == -2
+    assert L.lib.lsf_convolve_xyz(1, 2, ctypes.byref(L.Grid(3, 4, 8, 8, 1, 4, 0, 0)), 3, taps, 7, None, None) == -2
+    assert L.lib.lsf_convolve_xyz(1, 2, ctypes.byref(L.Grid(2, 1, 8, 8, 0, 1, 0, 0)), 2, taps, 7, None, None) == -2
+    # the band-only finalize: whole arrays, at most two lists, statistics need canonical + scratch
+    lists = (ctypes.c_void_p * 2)(1, 1)
+    counts = (ctypes.c_int64 * 2)(5, -1)
+    assert L.lib.lsf_state_finalize_listed(1, 1, 1, 1, ctypes.byref(ok), lists, counts, 3, 0, -1, 0.0, None, None,
+                                           None) == -1                                            # three lists
+    assert L.lib.lsf_state_finalize_listed(1, 1, 1, 1, ctypes.byref(ok), lists, counts, 2, 0, -1, 0.0, None, None,
+                                           None) == -1                                            # negative count
+    assert L.lib.lsf_state_finalize_listed(1, None, 1, 1, ctypes.byref(ok), lists, counts, 1, 0, -1, 0.0, 1, 1,
+                                           None) == -1                                            # statistics, no canonical
+    assert L.lib.lsf_state_finalize_listed(1, 1, 1, 1, ctypes.byref(L.Grid(3, 4, 8, 8, 1, 4, 0, 0)), lists, counts, 1,
+                                           0, -1, 0.0, None, None, None) == -1                    # not a whole array
     with pytest.raises(pkg._lib.LsfHipError):
         pkg._lib.check(-2, "x")
 
