@@ -156,9 +156,12 @@ int lsf_convolve_axis(const float *in_planar, float *out_planar, const float *ze
 
 /* the three passes of a 3-D filter (x, then y, then z: convolution.py:94-105) in one launch, without a zero mask: the
  * result equals three lsf_convolve_axis calls bit for bit.  Whole arrays (z_begin = 0, z_end = nz), nx % 4 == 0,
- * 3 / 5 / 7 / 9 taps; LSF_ERR_BAD_DIMS / LSF_ERR_KERNEL_TOO_LONG otherwise (the caller then runs the single passes). */
-int lsf_convolve_xyz(const float *in_planar, float *out_planar, const lsf_grid *grid, int32_t planes,
-                     const double *taps_host, int32_t n_taps, const lsf_gate *gate, void *stream);
+ * 3 / 5 / 7 / 9 taps; LSF_ERR_BAD_DIMS / LSF_ERR_KERNEL_TOO_LONG otherwise (the caller then runs the single passes).
+ * warp_planar (may be NULL): the filtered field also moves the warp, warp -= rate * out, component by component -- the
+ * hierarchical optimizer's update (hierarchical_optimizer2d.py:220-221) without another pass over out; the caller
+ * then calls lsf_hier_update with warp_planar = NULL for the record's maximum. */
+int lsf_convolve_xyz(const float *in_planar, float *out_planar, float *warp_planar, float rate, const lsf_grid *grid,
+                     int32_t planes, const double *taps_host, int32_t n_taps, const lsf_gate *gate, void *stream);
 
 /* the same zero-preserving pass (zero_mask_source required, 3 / 5 / 7 / 9 taps) at the voxels of a band list only */
 int lsf_convolve_axis_listed(const float *in_planar, float *out_planar, const float *zero_mask_source,
@@ -189,7 +192,8 @@ int lsf_hier_iteration(const float *packed_live4, const float *canonical, float 
                        const lsf_hier_params *params, const lsf_gate *gate, lsf_iteration_record *record,
                        void *stream);
 
-/* warp -= rate*g ; the record's max_packed = max |g|   (hierarchical_optimizer2d.py:220-225) */
+/* warp -= rate*g ; the record's max_packed = max |g|   (hierarchical_optimizer2d.py:220-225).  warp_planar may be
+ * NULL: only the maximum (the warp was moved by lsf_convolve_xyz already). */
 int lsf_hier_update(const float *g_planar, float *warp_planar, const lsf_grid *grid, float rate,
                     const lsf_gate *gate, lsf_iteration_record *record, void *stream);
 

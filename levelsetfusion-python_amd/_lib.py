@@ -126,7 +126,8 @@ PROTOTYPES = {
     "lsf_downsample2x_linear": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp]),
     "lsf_convolve_axis": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _i32, _i32, _P(ctypes.c_double), _i32,
                                          _P(Gate), _vp]),
-    "lsf_convolve_xyz": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _P(ctypes.c_double), _i32, _P(Gate), _vp]),
+    "lsf_convolve_xyz": (ctypes.c_int, [_vp, _vp, _vp, _f32, _P(Grid), _i32, _P(ctypes.c_double), _i32, _P(Gate),
+                                        _vp]),
     "lsf_hier_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(HierParams), _P(Gate), _vp, _vp]),
     "lsf_hier_update": (ctypes.c_int, [_vp, _vp, _P(Grid), _f32, _P(Gate), _vp, _vp]),
     "lsf_slavcheva_gradient": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp,

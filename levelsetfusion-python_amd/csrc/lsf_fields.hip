@@ -706,8 +706,9 @@ constexpr int kXyzCols = kTileX + 8;  // the tile's columns plus one aligned qua
 
 template <int NT>
 __global__ __launch_bounds__(kBlock, 5) void convolve_xyz_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                              Grid g, TapsN<NT> taps, unsigned chunks_z,
-                                                              int chunk, lsf_gate gate) {
+                                                              float* __restrict__ warp, float rate, Grid g,
+                                                              TapsN<NT> taps, unsigned chunks_z, int chunk,
+                                                              lsf_gate gate) {
     if (gate_closed(gate)) return;
     constexpr int R = NT / 2;                   // odd NT: reach R on either side, out[o] = sum_j k[j] * in[o + R - j]
     constexpr int kStaged = kXyzRows + 2 * R;   // rows of the raw tile and of the x pass
@@ -722,6 +723,7 @@ __global__ __launch_bounds__(kBlock, 5) void convolve_xyz_kernel(const float* __
     const int count = min(chunk, g.nz - z0);
     const float* __restrict__ src = in + (long long)blockIdx.z * g.plane;
     float* __restrict__ dst = out + (long long)blockIdx.z * g.plane;
+    float* __restrict__ moved = warp ? warp + (long long)blockIdx.z * g.plane : nullptr;
 
     // this thread's share of a slice's raw tile: quads q = t + 256 m -> (row, quad column)
     int q_row[kLoads], q_col[kLoads], q_off[kLoads];  // offsets inside a slice: < 2^31 (check_grid)
@@ -805,7 +807,10 @@ __global__ __launch_bounds__(kBlock, 5) void convolve_xyz_kernel(const float* __
                     double acc = 0.0;
 #pragma unroll
                     for (int j = 0; j < NT; ++j) acc = acc + taps.k[j] * (double)win[k][2 * R - j];
-                    dst[((long long)po * g.ny + y) * g.nx + x0 + lx] = (float)acc;
+                    const long long o = ((long long)po * g.ny + y) * g.nx + x0 + lx;
+                    const float r = (float)acc;
+                    dst[o] = r;
+                    if (moved) moved[o] = moved[o] - rate * r;  // lsf_hier_update's component-wise half (a11)
                 }
             }
         }
@@ -813,21 +818,23 @@ __global__ __launch_bounds__(kBlock, 5) void convolve_xyz_kernel(const float* __
 }
 
 template <int NT>
-static void launch_xyz(const float* in, float* out, const Grid& g, int planes, const double* taps_host,
-                       const lsf_gate& gt, hipStream_t s) {
+static void launch_xyz(const float* in, float* out, float* warp, float rate, const Grid& g, int planes,
+                       const double* taps_host, const lsf_gate& gt, hipStream_t s) {
     TapsN<NT> taps;
     for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
     const unsigned tiles_x = (unsigned)(g.nx + kTileX - 1) / kTileX, tiles_y = (unsigned)(g.ny + kXyzRows - 1) / kXyzRows;
     const int chunk = kXyzChunk;
     const unsigned chunks_z = (unsigned)(g.nz + chunk - 1) / chunk;
     hipLaunchKernelGGL((convolve_xyz_kernel<NT>), dim3(tiles_x, tiles_y * chunks_z, (unsigned)planes), dim3(kBlock), 0, s,
-                       in, out, g, taps, chunks_z, chunk, gt);
+                       in, out, warp, rate, g, taps, chunks_z, chunk, gt);
 }
 
-extern "C" int lsf_convolve_xyz(const float* in_planar, float* out_planar, const lsf_grid* grid, int32_t planes,
-                                const double* taps_host, int32_t n_taps, const lsf_gate* gate, void* stream) {
+extern "C" int lsf_convolve_xyz(const float* in_planar, float* out_planar, float* warp_planar, float rate,
+                                const lsf_grid* grid, int32_t planes, const double* taps_host, int32_t n_taps,
+                                const lsf_gate* gate, void* stream) {
     if (int e = check_grid(grid)) return e;
-    if (!in_planar || !out_planar || in_planar == out_planar || !taps_host || planes < 1 || planes > 4)
+    if (!in_planar || !out_planar || in_planar == out_planar || !taps_host || planes < 1 || planes > 4 ||
+        warp_planar == in_planar || (warp_planar && warp_planar == out_planar))
         return LSF_ERR_BAD_ARGUMENT;
     if (grid->dims != 3 || grid->nx % 4 != 0 || grid->z_begin != 0 || grid->z_end != grid->nz) return LSF_ERR_BAD_DIMS;
     if (n_taps != 3 && n_taps != 5 && n_taps != 7 && n_taps != 9) return LSF_ERR_KERNEL_TOO_LONG;
@@ -838,10 +845,10 @@ extern "C" int lsf_convolve_xyz(const float* in_planar, float* out_planar, const
     const lsf_gate gt = gate ? *gate : lsf_gate{nullptr, 0, 0.0f, 0.0f};
     hipStream_t s = as_stream(stream);
     switch (n_taps) {
-        case 3: launch_xyz<3>(in_planar, out_planar, g, planes, taps_host, gt, s); break;
-        case 5: launch_xyz<5>(in_planar, out_planar, g, planes, taps_host, gt, s); break;
-        case 7: launch_xyz<7>(in_planar, out_planar, g, planes, taps_host, gt, s); break;
-        default: launch_xyz<9>(in_planar, out_planar, g, planes, taps_host, gt, s); break;
+        case 3: launch_xyz<3>(in_planar, out_planar, warp_planar, rate, g, planes, taps_host, gt, s); break;
+        case 5: launch_xyz<5>(in_planar, out_planar, warp_planar, rate, g, planes, taps_host, gt, s); break;
+        case 7: launch_xyz<7>(in_planar, out_planar, warp_planar, rate, g, planes, taps_host, gt, s); break;
+        default: launch_xyz<9>(in_planar, out_planar, warp_planar, rate, g, planes, taps_host, gt, s); break;
     }
     return launch_status();
 }

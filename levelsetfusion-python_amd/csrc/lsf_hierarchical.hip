@@ -159,7 +159,8 @@ __global__ __launch_bounds__(kBlock) void hier_iteration_kernel(const float4* __
     }
 }
 
-template <int D>
+// MOVE = false: only the record's maximum (the filter kernel has already moved the warp: lsf_convolve_xyz)
+template <int D, bool MOVE>
 __global__ __launch_bounds__(kBlock) void hier_update_kernel(const float* __restrict__ gfield,
                                                              float* __restrict__ warp, Grid g, float rate,
                                                              lsf_gate gate, lsf_iteration_record* record) {
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(kBlock) void hier_update_kernel(const float* __rest
 #pragma unroll
         for (int c = 0; c < D; ++c) {
             gv[c] = gfield[c * g.plane + i];
-            warp[c * g.plane + i] = warp[c * g.plane + i] - rate * gv[c];
+            if (MOVE) warp[c * g.plane + i] = warp[c * g.plane + i] - rate * gv[c];
         }
         unsigned long long p = pack_max(vec_length<D>(gv), linear_index(g, x, y, z));
         best = p > best ? p : best;
@@ -236,16 +237,20 @@ extern "C" int lsf_hier_iteration(const float* packed_live4, const float* canoni
 extern "C" int lsf_hier_update(const float* g_planar, float* warp_planar, const lsf_grid* grid, float rate,
                                const lsf_gate* gate, lsf_iteration_record* record, void* stream) {
     if (int e = check_grid(grid)) return e;
-    if (!g_planar || !warp_planar || !record) return LSF_ERR_BAD_ARGUMENT;
+    if (!g_planar || !record) return LSF_ERR_BAD_ARGUMENT;
     Grid g = make_grid(grid);
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
     lsf_gate gt = gate_or_open(gate);
-    if (grid->dims == 2)
-        hipLaunchKernelGGL(hier_update_kernel<2>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream), g_planar,
-                           warp_planar, g, rate, gt, record);
+    const dim3 blocks(launch_blocks(t.total));
+    hipStream_t s = as_stream(stream);
+    if (grid->dims == 2 && warp_planar)
+        hipLaunchKernelGGL((hier_update_kernel<2, true>), blocks, dim3(kBlock), 0, s, g_planar, warp_planar, g, rate, gt, record);
+    else if (grid->dims == 2)
+        hipLaunchKernelGGL((hier_update_kernel<2, false>), blocks, dim3(kBlock), 0, s, g_planar, warp_planar, g, rate, gt, record);
+    else if (warp_planar)
+        hipLaunchKernelGGL((hier_update_kernel<3, true>), blocks, dim3(kBlock), 0, s, g_planar, warp_planar, g, rate, gt, record);
     else
-        hipLaunchKernelGGL(hier_update_kernel<3>, dim3(launch_blocks(t.total)), dim3(kBlock), 0, as_stream(stream), g_planar,
-                           warp_planar, g, rate, gt, record);
+        hipLaunchKernelGGL((hier_update_kernel<3, false>), blocks, dim3(kBlock), 0, s, g_planar, warp_planar, g, rate, gt, record);
     return launch_status();
 }

@@ -277,15 +277,16 @@ def convolve_xyz_ok(grid, taps):
             and ((grid.ny + 15) // 16) * ((grid.nz + 31) // 32) <= 65535)
 
 
-def convolve_xyz(src, dst, grid, taps, gate=None):
+def convolve_xyz(src, dst, grid, taps, gate=None, warp=None, rate=0.0):
     """the x, y and z passes of convolve_axis (no zero mask) in one launch (lsf_convolve_xyz): same result, one read
-    and one write of the field instead of three"""
+    and one write of the field instead of three; warp: also warp -= rate * dst (the hierarchical update)"""
     taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float64))
     if not convolve_xyz_ok(grid, taps):
         raise ValueError("lsf_convolve_xyz cannot run this grid / kernel; use three convolve_axis passes")
     planes = src.shape[0]
     n = n_voxels(grid) * planes
-    check(lib.lsf_convolve_xyz(_ptr(src, n, "conv src"), _ptr(dst, n, "conv dst"), ctypes.byref(grid), planes,
+    check(lib.lsf_convolve_xyz(_ptr(src, n, "conv src"), _ptr(dst, n, "conv dst"),
+                               _ptr(warp, n, "warp", allow_none=True), float(rate), ctypes.byref(grid), planes,
                                taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), taps.size, _gate_ref(gate),
                                stream_ptr()), "lsf_convolve_xyz")
 
@@ -302,8 +303,9 @@ def hier_iteration(packed, canonical, warp, g_prev, g_out, grid, params, gate, r
 
 
 def hier_update(g, warp, grid, rate, gate, records, index):
+    """warp -= rate * g and record[index].max = max |g|; warp None: the maximum only (convolve_xyz moved the warp)"""
     n = n_voxels(grid) * grid.dims
-    check(lib.lsf_hier_update(_ptr(g, n, "g"), _ptr(warp, n, "warp"), ctypes.byref(grid), float(rate),
+    check(lib.lsf_hier_update(_ptr(g, n, "g"), _ptr(warp, n, "warp", allow_none=True), ctypes.byref(grid), float(rate),
                               _gate_ref(gate), _record_ptr(records, index), stream_ptr()), "lsf_hier_update")
 
 

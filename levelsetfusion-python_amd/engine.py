@@ -276,16 +276,18 @@ class HierarchicalEngine:
                 comm.exchange_halos([lv.S[0]], width=len(self.gradient_kernel) // 2)
             axes = _conv_axis_order(lv.dims)
             src = lv.S[0]
+            moved = False
             if (not slab and self.fused_filter and dev.n_voxels(lv.grid) >= self.fused_filter_min_voxels
                     and dev.convolve_xyz_ok(lv.grid, self.gradient_kernel)):
-                dev.convolve_xyz(src, out, lv.grid, self.gradient_kernel, gate)  # x, y, z in one launch
-                axes = ()
+                # x, y, z in one launch, which also moves the warp by its filtered gradient, component by component
+                dev.convolve_xyz(src, out, lv.grid, self.gradient_kernel, gate, lv.warp, self.rate)
+                axes, moved = (), True
             for k, axis in enumerate(axes):
                 dst = out if k == len(axes) - 1 else lv.S[(k + 1) % 2]
                 dev.convolve_axis(src, dst, None, lv.grid if axis == 2 else lv.full_grid, axis, self.gradient_kernel,
                                   gate)
                 src = dst
-            dev.hier_update(out, lv.warp, lv.grid, self.rate, gate, lv.records, rec_idx)
+            dev.hier_update(out, None if moved else lv.warp, lv.grid, self.rate, gate, lv.records, rec_idx)
         elif tik:
             _lib.check(lib_hier(lv.p_packed, lv.p_canon, lv.p_warp, lv.p_F[parity], lv.p_F[1 - parity], f.grid_ref,
                                 lv.params_ref, gate_ref, f.record_ptrs[rec_idx], dev.stream_ptr()),

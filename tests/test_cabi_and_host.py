@@ -84,11 +84,13 @@ def test_argument_errors_are_reported_not_launched(pkg):
     assert L.lib.lsf_convolve_axis(1, 2, None, ctypes.byref(ok), 3, 0, taps, 33, None, None) == -3
     assert L.lib.lsf_convolve_axis(1, 1, None, ctypes.byref(ok), 3, 0, taps, 7, None, None) == -1  # in place
     # the one-launch 3-D filter: whole arrays, nx % 4 == 0, 3 / 5 / 7 / 9 taps -- anything else is refused, not launched
-    assert L.lib.lsf_convolve_xyz(1, 2, ctypes.byref(ok), 3, taps, 4, None, None) == -3
-    assert L.lib.lsf_convolve_xyz(1, 1, ctypes.byref(ok), 3, taps, 7, None, None) == -1           # in place
-    assert L.lib.lsf_convolve_xyz(1, 2, ctypes.byref(L.Grid(3, 4, 8, 6, 0, 4, 0, 0)), 3, taps, 7, None, None) == -2
-    assert L.lib.lsf_convolve_xyz(1, 2, ctypes.byref(L.Grid(3, 4, 8, 8, 1, 4, 0, 0)), 3, taps, 7, None, None) == -2
-    assert L.lib.lsf_convolve_xyz(1, 2, ctypes.byref(L.Grid(2, 1, 8, 8, 0, 1, 0, 0)), 2, taps, 7, None, None) == -2
+    assert L.lib.lsf_convolve_xyz(1, 2, None, 0.0, ctypes.byref(ok), 3, taps, 4, None, None) == -3
+    assert L.lib.lsf_convolve_xyz(1, 1, None, 0.0, ctypes.byref(ok), 3, taps, 7, None, None) == -1    # in place
+    assert L.lib.lsf_convolve_xyz(1, 2, 2, 0.1, ctypes.byref(ok), 3, taps, 7, None, None) == -1       # warp aliases out
+    bad_nx, bad_z, flat = L.Grid(3, 4, 8, 6, 0, 4, 0, 0), L.Grid(3, 4, 8, 8, 1, 4, 0, 0), L.Grid(2, 1, 8, 8, 0, 1, 0, 0)
+    assert L.lib.lsf_convolve_xyz(1, 2, None, 0.0, ctypes.byref(bad_nx), 3, taps, 7, None, None) == -2
+    assert L.lib.lsf_convolve_xyz(1, 2, None, 0.0, ctypes.byref(bad_z), 3, taps, 7, None, None) == -2
+    assert L.lib.lsf_convolve_xyz(1, 2, None, 0.0, ctypes.byref(flat), 2, taps, 7, None, None) == -2
     # the band-only finalize: whole arrays, at most two lists, statistics need canonical + scratch
     lists = (ctypes.c_void_p * 2)(1, 1)
     counts = (ctypes.c_int64 * 2)(5, -1)

@@ -619,6 +619,18 @@ def test_fused_xyz_filter_equals_three_passes(lsf):
             fused = torch.full_like(src, 7.0)
             dev.convolve_xyz(src, fused, grid, taps)
             assert torch.equal(fused, a), (shape, n_taps, float((fused - a).abs().max()))
+            # with the hierarchical update folded in: warp -= rate * filtered, and lsf_hier_update(warp = NULL) then only
+            # leaves the maximum in the record
+            warp0 = torch.randn((3,) + shape, device="cuda", generator=gen)
+            w_ref, w_fused = warp0.clone(), warp0.clone()
+            rec = dev.new_records(2, src.device)
+            dev.hier_update(a, w_ref, grid, 0.3, None, rec, 0)
+            fused.fill_(7.0)
+            dev.convolve_xyz(src, fused, grid, taps, None, w_fused, 0.3)
+            dev.hier_update(fused, None, grid, 0.3, None, rec, 1)
+            assert torch.equal(fused, a) and torch.equal(w_fused, w_ref)
+            dec = dev.decode_records(dev.records_to_host(rec))
+            assert dec["max_value"][0] == dec["max_value"][1] > 0 and dec["argmax"][0] == dec["argmax"][1]
     assert not dev.convolve_xyz_ok(dev.make_grid((16, 16, 18)), np.ones(7))   # nx % 4
     assert not dev.convolve_xyz_ok(dev.make_grid((16, 16, 16)), np.ones(4))   # even tap count
     assert not dev.convolve_xyz_ok(dev.make_grid((4, 16, 16)), np.ones(7))    # shorter than the kernel
