@@ -556,9 +556,10 @@ class SlavchevaOutcome:
             target = torch.empty(self._shape(), dtype=torch.float32, device=self._device())
         else:
             target = live_out
-        if self.state is not None and self._listed is not None:
+        if self.state is not None and self._listed is not None and not (statistics and self._listed[2] is None):
             # outside the band lists nothing ever moves: the input live field and a zero warp are already final there
             live0, bands, unlisted = self._listed
+            unlisted = unlisted or (0, -1)
             if target is not live0:
                 target.copy_(live0)
             warp = torch.zeros(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
@@ -920,8 +921,9 @@ class SlavchevaEngine:
             f.native = None
             if fused_prepare:
                 bands, unlisted = prepared.collect()
-                if not slab:
-                    listed = (live, bands, unlisted)
+                # z-slab runs: the lists cover the whole local array (owned slices + halos), like the dense finalize
+                # pass does; the unlisted counts would too, so statistics (never asked for there) take the dense pass
+                listed = (live, bands, None if slab else unlisted)
             else:
                 bands = dev.band_lists(live, canonical, whole) if self.use_band_list else [dev.BandList.none()]
             f.bands = bands
