@@ -40,6 +40,7 @@ struct Grid {
     long long plane;       // nz*ny*nx: stride between the planes of a planar vector field
     FastDiv div_tiles_x, div_tiles_y, div_chunk, div_nx, div_ny;
     int fast_ok;           // 32-bit buffer addressing is possible: 3 planes of a vector field stay below 4 GiB
+    int wide_ok;           // float4 state kernels: a wave's neighbourhoods may be addressed relative to its first lane
     int e_begin, e_end;    // slices whose energies count (lsf_grid::energy_z_begin / _end; default: all)
 };
 
@@ -69,6 +70,7 @@ __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
     r.div_nx = make_fast_div((unsigned)g->nx);
     r.div_ny = make_fast_div((unsigned)g->ny);
     r.fast_ok = r.plane * 3 * 4 < 0xffffffffll;
+    r.wide_ok = r.fast_ok;
     const bool limited = g->energy_z_end > g->energy_z_begin;
     r.e_begin = limited ? g->energy_z_begin : 0;
     r.e_end = limited ? g->energy_z_end : g->nz;

@@ -79,7 +79,10 @@ struct NbhState : TapsBase<D> {
 // every lane's whole neighbourhood lies inside the array (wave vote or an INTERIOR band list): one per-lane byte offset
 // (the neighbourhood's lowest corner relative to the wave's first lane), the tap chosen by the instruction's scalar
 // offset (dy, dz) and immediate (dx) -- no per-tap VALU address arithmetic, no OOB selects.  32-bit buffer offsets:
-// 16 * nz * ny * nx < 2^32 (Grid::fast_ok as set by the launcher).
+// while 16 * nz * ny * nx < 2^32 (Grid::fast_ok) one resource spans the state and the first lane's corner is part of
+// the scalar offset; `wide` (arrays of 4 GiB and more): the resource STARTS at the first lane's corner (a 64-bit
+// scalar), so that the offsets only have to span one wave's voxels plus a neighbourhood -- the caller checks that per
+// wave (wave_span_ok).  The INTERIOR kernel passes a literal false and keeps the first form only.
 // (Measured and rejected: taking the ten x -/+ 1 taps from the neighbouring lane's own-x taps by wave-wide DPP shifts,
 // with exec-masked loads only for the lanes at the ends of an x-run -- bit-identical, 27 % fewer bytes through the
 // vector L1, yet 4 % SLOWER on both walks: a mostly masked buffer_load_dwordx4 occupies the address path like a full
@@ -87,13 +90,17 @@ struct NbhState : TapsBase<D> {
 template <int D>
 struct NbhStateFast : TapsBase<D> {
     __device__ inline NbhStateFast(const vf4* __restrict__ s, const Grid& g, int x, int y, int z,
-                                   const vf4& centre_value) {
-        const __amdgpu_buffer_rsrc_t rsrc =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<vf4*>(s), 0, -1, 0x00020000);
+                                   const vf4& centre_value, bool wide) {
         const unsigned sy = (unsigned)g.nx * 16u, sz = (unsigned)(g.nx * g.ny) * 16u;
-        const unsigned corner = (unsigned)vidx(g, x, y, z) * 16u - 16u - sy - (D == 3 ? sz : 0u);
-        const unsigned wave_base = (unsigned)__builtin_amdgcn_readfirstlane((int)corner);  // smallest: ascending by lane
-        const unsigned lane_delta = corner - wave_base;
+        // per lane only the low 32 bits matter: the difference to the first lane's corner is < 2^32 (see above)
+        const int i = vidx(g, x, y, z);
+        const unsigned corner = (unsigned)i * 16u - 16u - sy - (D == 3 ? sz : 0u);
+        const int first = __builtin_amdgcn_readfirstlane(i);  // smallest: ascending by lane
+        const long long base = (long long)first * 16 - 16 - (long long)sy - (D == 3 ? (long long)sz : 0ll);
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char*>(reinterpret_cast<const char*>(s)) + (wide ? base : 0ll), 0, -1, 0x00020000);
+        const unsigned wave_base = wide ? 0u : (unsigned)base;
+        const unsigned lane_delta = corner - (unsigned)base;
 #pragma unroll
         for (int dz = (D == 3 ? -1 : 0); dz <= (D == 3 ? 1 : 0); ++dz)
 #pragma unroll
@@ -115,6 +122,15 @@ struct NbhStateFast : TapsBase<D> {
     __device__ static constexpr bool exists(int, int) { return true; }
     __device__ static constexpr bool diag_exists(int, int, int, int) { return true; }
 };
+
+// NbhStateFast's requirement on arrays of 4 GiB and more: every active lane's neighbourhood within 2^32 bytes of the
+// first lane's (voxel indices ascend with the lane in every walk; a list's consecutive entries can still lie far apart)
+__device__ inline bool wave_span_ok(const Grid& g, int i) {
+    if (g.fast_ok) return true;
+    const int first = __builtin_amdgcn_readfirstlane(i);
+    const long long reach = 3ll * 16 + 2ll * 16 * g.nx + 2ll * 16 * g.nx * g.ny;
+    return __all(((long long)i - first) * 16 + reach < 0xffffffffll);
+}
 
 // the re-warp's D-linear gather of the live component (OOB -> 1): lerp z, then y, then x as sample_linear does
 template <int D>
@@ -248,8 +264,8 @@ __global__ __launch_bounds__(kBlock) void slavcheva_state_kernel(const vf4* __re
         if (in_band) {
             double e[3] = {0.0, 0.0, 0.0};
             const bool interior = x > 0 && x < g.nx - 1 && y > 0 && y < g.ny - 1 && (D == 2 || (z > 0 && z < g.nz - 1));
-            if (WALK == kWalkListInterior || (g.fast_ok && __all(interior))) {
-                const NbhStateFast<D> n(state_in, g, x, y, z, sc);
+            if (WALK == kWalkListInterior || (g.wide_ok && __all(interior) && wave_span_ok(g, i))) {
+                const NbhStateFast<D> n(state_in, g, x, y, z, sc, WALK != kWalkListInterior && !g.fast_ok);
                 band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
                 float w_now[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -738,15 +754,19 @@ extern "C" int lsf_slavcheva_state_iteration(const float* state_in, const float*
         return LSF_ERR_BAD_ARGUMENT;
     const int tile_y = 4;
     Grid g = make_grid(grid, tile_y);
-    g.fast_ok = g.plane * 16 < 0xffffffffll;  // 32-bit byte offsets into the float4 state
+    g.fast_ok = g.plane * 16 < 0xffffffffll;  // 32-bit byte offsets into the whole float4 state
+    // the buffer-load neighbourhood needs its scalar tap offsets (two slices + two rows) to fit 32 bits; arrays of
+    // 4 GiB and more then qualify wave by wave (wave_span_ok)
+    g.wide_ok = 16ll * (2ll * grid->nx * grid->ny + 2ll * grid->nx + 3) < 0x7fffffffll;
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
     const bool listed = band_list != nullptr;
     if (listed && (band_count < 0 || band_count > 0x7fffffffll ||
                    !(band_subset == LSF_BAND_ALL || band_subset == LSF_BAND_INTERIOR || band_subset == LSF_BAND_BOUNDARY)))
         return LSF_ERR_BAD_ARGUMENT;
-    const bool all_interior = listed && band_subset == LSF_BAND_INTERIOR;
-    if (all_interior && !g.fast_ok) return LSF_ERR_BAD_ARGUMENT;
+    // the INTERIOR kernel has no other neighbourhood path: on arrays of 4 GiB and more an INTERIOR list runs through the
+    // general list kernel, which takes the same fast path wave by wave
+    const bool all_interior = listed && band_subset == LSF_BAND_INTERIOR && g.fast_ok;
     // list walks: 128 blocks per XCD = the 4 blocks per CU that 108-118 VGPRs allow, all resident from the first to the
     // last unit (measured at 256^3: 0.0356 ms against 0.0372 ms with 256 per XCD and 0.0401 ms with 160)
     const unsigned blocks = listed ? band_list_blocks((unsigned)band_count, 128u) : launch_blocks(t.total, blocks_per_xcd());

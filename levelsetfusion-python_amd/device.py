@@ -324,9 +324,12 @@ class BandList:
 
 
 def buffer_addressing_ok(grid, bytes_per_voxel=16):
-    """INTERIOR lists need 32-bit buffer offsets over the float4 state (16 B per voxel, see
-    lsf_slavcheva_state_iteration)"""
-    return bytes_per_voxel * n_voxels(grid) < 0xffffffff
+    """can the list kernels take their buffer-load neighbourhood path?  Planar fields (4 B per voxel, the Sobolev path):
+    32-bit offsets over all planes.  The float4 state (16 B): offsets are relative to a wave's first voxel
+    (lsf_slavcheva_state_iteration), so only two slices + two rows have to fit 32 bits, and voxel indices int32."""
+    if bytes_per_voxel != 16:
+        return bytes_per_voxel * n_voxels(grid) < 0xffffffff
+    return n_voxels(grid) < 0x7fffffff and 16 * (2 * grid.nx * grid.ny + 2 * grid.nx + 3) < 0x7fffffff
 
 
 def band_lists(live, canonical, grid=None, split=True, bytes_per_voxel=16):

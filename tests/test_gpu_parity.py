@@ -699,6 +699,39 @@ def test_state_finalize_listed_equals_dense_finalize(lsf):
 
 
 # ------------------------------------------------------------ full-size, size-independent properties
+def test_state_of_4gib_and_more_takes_the_same_path(lsf):
+    """a float4 state of 4 GiB and more (656^3 voxels: 4.5 GB): the list kernel's buffer-load neighbourhood addresses
+    relative to each wave's first voxel there.  The same 640^3 sphere pair, padded with truncated voxels to 656^3, must
+    come out bit-identical to the 640^3 run (4.19 GB of state: plain 32-bit offsets) inside the common region."""
+    from levelsetfusion_python_amd import device as dev
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    n, big = 640, 656
+    canon, live0 = sphere_pair(n, 3, "cuda")
+    assert float(live0[-1].min()) == 1.0 and float(canon[:, :, -1].min()) == 1.0  # the band stays clear of the faces
+    kw = dict(compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+              smoothing_term_method=lsf.SmoothingTermMethod.KILLING, maximum_warp_length_lower_threshold=0.0,
+              max_iterations=3, min_iterations=3)
+    small = lsf.SlavchevaOptimizer3d(field_size=n, **kw)
+    live_small = live0.clone()
+    small.optimize(live_small, canon)
+    warp_small = small.warp_field
+    assert dev.n_voxels(dev.make_grid((n, n, n))) * 16 < 2 ** 32 <= dev.n_voxels(dev.make_grid((big, big, big))) * 16
+    canon_big = torch.ones((big, big, big), device="cuda")
+    live_big = torch.ones((big, big, big), device="cuda")
+    canon_big[:n, :n, :n] = canon
+    live_big[:n, :n, :n] = live0
+    del canon, live0
+    wide = lsf.SlavchevaOptimizer3d(field_size=big, **kw)
+    wide.optimize(live_big, canon_big)
+    assert torch.equal(live_big[:n, :n, :n], live_small)
+    assert torch.equal(wide.warp_field[:n, :n, :n], warp_small)
+    assert float(wide.warp_field.abs().max()) == float(warp_small.abs().max()) > 0
+    assert wide.log.max_warps == small.log.max_warps
+    # the arg-max locations are (x, y, z) coordinates: the same in both volumes
+    assert wide.log.max_warp_locations == small.log.max_warp_locations
+    assert np.allclose(wide.log.data_energies, small.log.data_energies, rtol=1e-12)
+
+
 def test_full_size_2d_embedding_256(lsf):
     """BASELINE size 256^3: a z-constant volume must reproduce the 2-D result (computed by the ORACLE at 256^2)
     on interior slices, bit for bit, with w == 0 -- KillingFusion-style and hierarchical."""
