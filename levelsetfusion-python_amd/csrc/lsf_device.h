@@ -129,13 +129,13 @@ constexpr unsigned kBlocksPerXcd = 251;
 
 // tuning knob for measurements (tools/kernel_cases.py): LSF_BLOCKS_PER_XCD overrides the persistent-grid size of the
 // Slavcheva iteration kernel; read once per process
-__host__ inline unsigned blocks_per_xcd() {
+__host__ inline unsigned blocks_per_xcd(unsigned fallback = kBlocksPerXcd) {
     static const unsigned v = [] {
         const char* e = getenv("LSF_BLOCKS_PER_XCD");
         const int n = e ? atoi(e) : 0;
-        return n > 0 ? (unsigned)n : kBlocksPerXcd;
+        return n > 0 ? (unsigned)n : 0u;
     }();
-    return v;
+    return v ? v : fallback;
 }
 
 __host__ inline unsigned launch_blocks(unsigned total_tiles, unsigned per_xcd = kBlocksPerXcd) {

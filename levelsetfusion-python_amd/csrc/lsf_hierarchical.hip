@@ -196,6 +196,13 @@ void launch_hier(bool energy, unsigned blocks, hipStream_t s, const float4* pack
                            gate, record);
 }
 
+// persistent grid of the 3-D iteration kernel: 127 blocks per XCD = 4 per CU, all resident from the first tile to the
+// last (85 VGPRs would allow 5).  Measured at 256^3 (tools/hier_kernel_time.py, LSF_BLOCKS_PER_XCD): the time is not
+// monotonic in the grid size -- 0.255 / 0.275 / 0.301 / 0.269 / 0.306 ms for 127 / 128 / 160 / 251 / 320 blocks per XCD
+// without the in-kernel update: what matters is how the tiles in flight line up with the z +/- 1 slices still in L2,
+// and powers of two alias.  End to end 127 against 251: +2..3 % (Tikhonov), +2 % / +6 % (with the kernel, 256^3 / 512^3).
+constexpr unsigned kHierBlocksPerXcd3d = 127;
+
 template <int D>
 void dispatch_hier(unsigned blocks, hipStream_t s, const float4* packed, const float* canonical, float* warp,
                    const float* g_prev, float* g_out, const Grid& g, const lsf_hier_params* p, const lsf_gate& gate,
@@ -229,7 +236,7 @@ extern "C" int lsf_hier_iteration(const float* packed_live4, const float* canoni
         dispatch_hier<2>(launch_blocks(t.total), as_stream(stream), packed, canonical, warp_planar, g_prev_planar, g_out_planar, g,
                          params, gt, record);
     else
-        dispatch_hier<3>(launch_blocks(t.total), as_stream(stream), packed, canonical, warp_planar, g_prev_planar, g_out_planar, g,
+        dispatch_hier<3>(launch_blocks(t.total, blocks_per_xcd(kHierBlocksPerXcd3d)), as_stream(stream), packed, canonical, warp_planar, g_prev_planar, g_out_planar, g,
                          params, gt, record);
     return launch_status();
 }
