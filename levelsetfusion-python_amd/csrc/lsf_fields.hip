@@ -618,21 +618,17 @@ __global__ __launch_bounds__(kBlock) void convolve_x4_kernel(const float* __rest
 // one zero-preserving pass at LISTED voxels only (SobolevFusion on a band list): the gradient is zero outside the
 // narrow band, a masked pass leaves zeros where its mask source is zero (math_utils/convolution.py:118-127), so only
 // band voxels can hold non-zero output -- everything else stays at the zeros the caller initialised.  One thread per
-// (listed voxel, plane); NT taps read along the axis from the planar field (zero padding outside the array).
+// listed voxel (all planes); NT taps read along the axis from the planar field (zero padding outside the array).
 template <int NT>
 __global__ __launch_bounds__(kBlock) void convolve_list_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                const float* __restrict__ mask_src, Grid g,
-                                                               TapsN<NT> taps, int axis, const int* __restrict__ list,
-                                                               unsigned count, lsf_gate gate) {
+                                                               TapsN<NT> taps, int axis, int planes,
+                                                               const int* __restrict__ list, unsigned count,
+                                                               lsf_gate gate) {
     if (gate_closed(gate)) return;
     const unsigned k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= count) return;
     const unsigned i = (unsigned)list[k];
-    const long long base = (long long)blockIdx.y * g.plane;
-    if (fabsf(mask_src[base + i]) < 1e-6f) {
-        out[base + i] = 0.0f;
-        return;
-    }
     const unsigned zy = fast_div(i, g.div_nx);
     const int x = (int)(i - zy * (unsigned)g.nx);
     const int z = (int)fast_div(zy, g.div_ny);
@@ -641,15 +637,27 @@ __global__ __launch_bounds__(kBlock) void convolve_list_kernel(const float* __re
     const int len = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz);
     const int stride = axis == 0 ? 1 : (axis == 1 ? g.nx : g.nx * g.ny);
     constexpr int c = NT / 2;
-    const float* __restrict__ src = in + base + i;
-    double acc = 0.0;
+    // every plane of the voxel in one thread, mask and taps fetched together (one round trip after the list entry; the
+    // taps of a masked component are then simply not used): these passes are bound by their chains of dependent loads
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {  // out[a] = sum_j k[j] * in[a + c - j], zero outside [0, len)
-        const int d = c - j, q = a + d;
-        const float v = src[(q >= 0 && q < len) ? d * stride : 0];
-        acc = acc + taps.k[j] * ((q >= 0 && q < len) ? (double)v : 0.0);
+    for (int plane = 0; plane < 4; ++plane) {  // planes <= 4 (checked by the entry point)
+        if (plane >= planes) break;
+        const long long base = (long long)plane * g.plane;
+        const float* __restrict__ src = in + base + i;
+        const float m = mask_src[base + i];
+        float v[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {  // out[a] = sum_j k[j] * in[a + c - j], zero outside [0, len)
+            const int d = c - j, q = a + d;
+            const bool inside = q >= 0 && q < len;
+            const float t = src[inside ? d * stride : 0];
+            v[j] = inside ? t : 0.0f;
+        }
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc = acc + taps.k[j] * (double)v[j];
+        out[base + i] = fabsf(m) < 1e-6f ? 0.0f : (float)acc;
     }
-    out[base + i] = (float)acc;
 }
 
 template <int NT>
@@ -658,8 +666,8 @@ static void launch_list_pass(const float* in, float* out, const float* mask, con
                              hipStream_t s) {
     TapsN<NT> taps;
     for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
-    hipLaunchKernelGGL((convolve_list_kernel<NT>), dim3((count + kBlock - 1) / kBlock, (unsigned)planes), dim3(kBlock), 0,
-                       s, in, out, mask, g, taps, axis, list, count, gt);
+    hipLaunchKernelGGL((convolve_list_kernel<NT>), dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, in, out, mask,
+                       g, taps, axis, planes, list, count, gt);
 }
 
 template <int NT>
