@@ -412,21 +412,26 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
 }
 
 
-// ordered fill of one subset's list from the ballots lsf_state_prepare kept (which = 0 INTERIOR, 1 BOUNDARY)
+// ordered fill of one subset's list from the ballots lsf_state_prepare kept (which = 0 INTERIOR, 1 BOUNDARY).  One WAVE
+// per 1024-voxel chunk: its sixteen ballots arrive in one load (lane w holds word w), a chunk without entries -- nine
+// out of ten on a narrow band -- ends there, otherwise the words are handed round and every lane writes its own voxel.
 __global__ __launch_bounds__(kBlock) void band_fill_from_masks_kernel(const unsigned long long* __restrict__ masks,
                                                                       const int* __restrict__ block_sums, int which,
-                                                                      int* __restrict__ list) {
-    const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
-    int at = block_sums[blockIdx.x];
+                                                                      int* __restrict__ list, unsigned chunks) {
+    const int lane = threadIdx.x % kWave;
+    const unsigned chunk = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (chunk >= chunks) return;
+    const unsigned long long mine = lane < 16 ? masks[((size_t)chunk * 16 + lane) * 2 + which] : 0ull;
+    if (__ballot(mine != 0ull) == 0ull) return;
+    int at = block_sums[chunk];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int wv = 0; wv < 4; ++wv) {
-            const unsigned long long m = masks[((size_t)blockIdx.x * 16 + j * 4 + wv) * 2 + which];
-            if (wv == wave && ((m >> lane) & 1ull))
-                list[at + __popcll(m & ((1ull << lane) - 1ull))] = (int)(blockIdx.x * kBandChunk + j * kBlock + t);
-            at += __popcll(m);
-        }
+    for (int w = 0; w < 16; ++w) {
+        const unsigned lo = (unsigned)__shfl((int)(unsigned)mine, w, kWave);
+        const unsigned hi = (unsigned)__shfl((int)(unsigned)(mine >> 32), w, kWave);
+        const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+        if ((m >> lane) & 1ull)
+            list[at + __popcll(m & ((1ull << lane) - 1ull))] = (int)(chunk * kBandChunk + w * kWave + lane);
+        at += __popcll(m);
     }
 }
 
@@ -538,9 +543,9 @@ extern "C" int lsf_band_list_fill_prepared(const lsf_grid* grid, int32_t subset,
     unsigned first, n, chunks;
     if (!band_range(grid, first, n, chunks)) return 0;
     const int which = subset == LSF_BAND_INTERIOR ? 0 : 1;
-    hipLaunchKernelGGL(band_fill_from_masks_kernel, dim3(chunks), dim3(kBlock), 0, as_stream(stream),
-                       prepare_masks(const_cast<int32_t*>(scratch), chunks), scratch + which * (size_t)(chunks + 1), which,
-                       list);
+    hipLaunchKernelGGL(band_fill_from_masks_kernel, dim3((chunks + kBlock / kWave - 1) / (kBlock / kWave)), dim3(kBlock),
+                       0, as_stream(stream), prepare_masks(const_cast<int32_t*>(scratch), chunks),
+                       scratch + which * (size_t)(chunks + 1), which, list, chunks);
     return launch_status();
 }
 

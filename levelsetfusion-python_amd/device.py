@@ -51,6 +51,11 @@ def _ptr(t, numel, name, dtype=torch.float32, allow_none=False):
         raise ValueError("%s: tensor required" % name)
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise ValueError("%s: expected a CUDA/ROCm tensor" % name)
+    if t.device.index != torch.cuda.current_device():
+        # kernels are launched on the CURRENT device's current stream (stream_ptr): a tensor that lives elsewhere
+        # would be reached through a peer mapping at best
+        raise ValueError("%s is on %s but the current device is cuda:%d (torch.cuda.set_device / torch.cuda.device)"
+                         % (name, t.device, torch.cuda.current_device()))
     if t.dtype != dtype:
         raise ValueError("%s: expected dtype %s, got %s" % (name, dtype, t.dtype))
     if not t.is_contiguous():
