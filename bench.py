@@ -115,6 +115,7 @@ def extra_workload(args, device):
         step()
     gc.collect()
     gc.freeze()  # as in main(): keep torch's objects out of the cyclic collector's full passes
+    gc.disable()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     updates = 0
@@ -122,6 +123,7 @@ def extra_workload(args, device):
         updates += step()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     value = updates / elapsed
     achieved = value * b_alg / 1e9
     print(json.dumps(dict(metric="voxel-warp-updates/sec", value=value, unit="voxel-warp-updates/s", n_gpus=1,
@@ -222,15 +224,19 @@ def main():
         executed = step()
     # Python's cyclic collector walks every object torch has created (~40 ms per full collection, measured with
     # tools/step_times.py: one 2.5 ms step in ~25 took 40 ms): park the existing objects in the permanent generation,
-    # as a serving loop would; the per-step garbage is still collected.
+    # as a serving loop would, and keep the cyclic collector out of the timed steps altogether (with few warm-up steps the
+    # objects of the first timed steps would otherwise be walked in a full pass: one 60 ms pause seen in a 5-step
+    # 512^3 run); reference counting still frees every tensor of a step as the step ends.
     gc.collect()
     gc.freeze()
+    gc.disable()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         executed = step()
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         elapsed = max_over_ranks(elapsed)
     assert executed == iters, "expected %d fixed iterations, the gate closed after %d" % (iters, executed)

@@ -25,6 +25,20 @@ def stream_ptr():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_PINNED = {}
+
+
+def pinned_scratch(name, numel, dtype):
+    """a small page-locked host buffer that lives as long as the process (one per device and purpose): the landing
+    place of the few numbers a call reads back, without a host allocation per call.  The optimizers are single-caller
+    objects (as the reference's are): a buffer is consumed before the next call on the same device fills it again."""
+    key = (torch.cuda.current_device(), name, int(numel), dtype)
+    buf = _PINNED.get(key)
+    if buf is None:
+        buf = _PINNED[key] = torch.empty(int(numel), dtype=dtype, pin_memory=True)
+    return buf
+
+
 def make_grid(shape, z_begin=0, z_end=None, z_global_offset=0):
     """shape: spatial extents (ny, nx) or (nz, ny, nx)"""
     shape = tuple(int(s) for s in shape)
@@ -416,7 +430,7 @@ class StatePrepare:
                                     _ptr(self.states[0], 4 * n, "state"), _ptr(self.states[1], 4 * n, "state"),
                                     ctypes.byref(grid), ctypes.c_void_p(self._scratch.data_ptr()),
                                     ctypes.c_void_p(totals.data_ptr()), stream_ptr()), "lsf_state_prepare")
-        self._totals_host = torch.empty(4, dtype=torch.int64, pin_memory=True)
+        self._totals_host = pinned_scratch("prepare totals", 4, torch.int64)
         self._totals_host.copy_(totals, non_blocking=True)
         self._copied = torch.cuda.Event()
         self._copied.record()

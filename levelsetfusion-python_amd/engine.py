@@ -534,7 +534,7 @@ class SlavchevaOutcome:
             if raw is not None:
                 host, done = raw
                 done.synchronize()
-                raw = host.numpy()
+                raw = host.numpy().copy()  # the pinned buffer is reused by the next call
             return target, warp, raw
         return self._finalize_now(live_out, lower_threshold, statistics, to_host=True)
 
@@ -542,7 +542,7 @@ class SlavchevaOutcome:
         """launch the finalize pass now (no host synchronisation); finalize() with the same arguments collects it"""
         target, warp, raw = self._finalize_now(live_out, lower_threshold, statistics, to_host=False)
         if raw is not None:  # on its way to the host behind the pass: the caller's next synchronising read covers it
-            host = torch.empty(raw.shape, dtype=raw.dtype, pin_memory=True)
+            host = dev.pinned_scratch("finalize statistics", raw.numel(), raw.dtype)
             host.copy_(raw, non_blocking=True)
             done = torch.cuda.Event()
             done.record()
