@@ -297,6 +297,13 @@ int64_t lsf_state_finalize_scratch_elements(const lsf_grid *grid);
 int lsf_state_finalize(const float *state, const float *canonical, float *live_out, float *warp_planar_out,
                        float *warp_interleaved_out, const lsf_grid *grid, float lower_threshold,
                        double *statistics16, double *scratch, void *stream);
+/* the same pass for final fields that are planar (the SobolevFusion path: live [z,]y,x and warp [c][z,]y,x): live_out
+ * (may be NULL, must not be live), the interleaved warp and the statistics in one pass instead of a copy, an interleave
+ * and the two statistics kernels.  scratch as lsf_state_finalize. */
+int lsf_planar_finalize(const float *live, const float *warp_planar, const float *canonical, float *live_out,
+                        float *warp_interleaved_out, const lsf_grid *grid, float lower_threshold,
+                        double *statistics16, double *scratch, void *stream);
+
 /* lsf_state_finalize for whole arrays whose band lists are at hand: only the listed voxels are visited -- live_out must
  * already hold the INPUT live field and warp_interleaved_out zeros (nothing else can have changed); the statistics
  * take the unlisted voxels from lsf_state_prepare's counts_out[2..4): opposite_count of them have

@@ -141,6 +141,7 @@ PROTOTYPES = {
     "lsf_state_unpack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp]),
     "lsf_state_finalize_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
     "lsf_state_finalize": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _f32, _vp, _vp, _vp]),
+    "lsf_planar_finalize": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _f32, _vp, _vp, _vp]),
     "lsf_state_finalize_listed": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _P(ctypes.c_void_p), _P(_i64), _i32,
                                                  _i64, _i64, _f32, _vp, _vp, _vp]),
     "lsf_slavcheva_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp,

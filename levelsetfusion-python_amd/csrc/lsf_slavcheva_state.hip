@@ -465,7 +465,10 @@ struct FinalizeAccumulator {
     }
 };
 
+// s == nullptr: the final fields are planar (the SobolevFusion path): src_live and src_warp [c][z][y][x]
 __global__ __launch_bounds__(kBlock) void state_finalize_kernel(const vf4* __restrict__ s,
+                                                                const float* __restrict__ src_live,
+                                                                const float* __restrict__ src_warp,
                                                                 const float* __restrict__ canonical,
                                                                 float* __restrict__ live, float* __restrict__ planar,
                                                                 float* __restrict__ interleaved, long long first,
@@ -475,7 +478,15 @@ __global__ __launch_bounds__(kBlock) void state_finalize_kernel(const vf4* __res
     FinalizeAccumulator acc;
     for (long long k = blockIdx.x * (long long)kBlock + threadIdx.x; k < n; k += (long long)gridDim.x * kBlock) {
         const long long i = first + k;
-        const vf4 v = s[i];
+        vf4 v;
+        if (s) {
+            v = s[i];
+        } else {
+            v.x = src_live[i];
+            v.y = src_warp[i];
+            v.z = src_warp[plane + i];
+            v.w = dims == 3 ? src_warp[2 * plane + i] : 0.0f;
+        }
         if (live) live[i] = v.x;
         if (planar) {
             planar[i] = v.y;
@@ -704,9 +715,29 @@ extern "C" int lsf_state_finalize(const float* state, const float* canonical, fl
     const unsigned blocks = finalize_blocks(n);
     const long long slice = (long long)grid->ny * grid->nx;
     hipLaunchKernelGGL(state_finalize_kernel, dim3(blocks), dim3(kBlock), 0, as_stream(stream),
-                       reinterpret_cast<const vf4*>(state), canonical, live_out, warp_planar_out, warp_interleaved_out,
-                       first, n, (long long)grid->nz * slice, grid->dims, slice * grid->z_global_offset,
-                       lower_threshold, statistics16 ? scratch : (double*)nullptr);
+                       reinterpret_cast<const vf4*>(state), (const float*)nullptr, (const float*)nullptr, canonical,
+                       live_out, warp_planar_out, warp_interleaved_out, first, n, (long long)grid->nz * slice, grid->dims,
+                       slice * grid->z_global_offset, lower_threshold, statistics16 ? scratch : (double*)nullptr);
+    if (statistics16)
+        hipLaunchKernelGGL(state_finalize_combine_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), scratch, blocks,
+                           (double)n, statistics16, 0.0, 0.0, 0ll, 0ll);
+    return launch_status();
+}
+
+extern "C" int lsf_planar_finalize(const float* live, const float* warp_planar, const float* canonical, float* live_out,
+                                   float* warp_interleaved_out, const lsf_grid* grid, float lower_threshold,
+                                   double* statistics16, double* scratch, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!live || !warp_planar || live_out == live || (statistics16 && (!canonical || !scratch)))
+        return LSF_ERR_BAD_ARGUMENT;
+    long long first, n;
+    if (!range_of(grid, first, n)) return statistics16 ? LSF_ERR_BAD_ARGUMENT : 0;
+    const unsigned blocks = finalize_blocks(n);
+    const long long slice = (long long)grid->ny * grid->nx;
+    hipLaunchKernelGGL(state_finalize_kernel, dim3(blocks), dim3(kBlock), 0, as_stream(stream), (const vf4*)nullptr, live,
+                       warp_planar, canonical, live_out, (float*)nullptr, warp_interleaved_out, first, n,
+                       (long long)grid->nz * slice, grid->dims, slice * grid->z_global_offset, lower_threshold,
+                       statistics16 ? scratch : (double*)nullptr);
     if (statistics16)
         hipLaunchKernelGGL(state_finalize_combine_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), scratch, blocks,
                            (double)n, statistics16, 0.0, 0.0, 0ll, 0ll);

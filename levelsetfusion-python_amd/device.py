@@ -503,6 +503,26 @@ def state_finalize(state, canonical, grid, live_out=None, warp_planar_out=None, 
     return stats
 
 
+def planar_finalize(live, warp_planar, canonical, grid, live_out=None, warp_interleaved_out=None, lower_threshold=0.0,
+                    statistics=False):
+    """state_finalize for planar final fields (lsf_planar_finalize); live_out None or a tensor other than `live`"""
+    n = n_voxels(grid)
+    stats = scratch = None
+    if statistics:
+        stats = torch.empty(16, dtype=torch.float64, device=live.device)
+        scratch = torch.empty(int(lib.lsf_state_finalize_scratch_elements(ctypes.byref(grid))), dtype=torch.float64,
+                              device=live.device)
+    check(lib.lsf_planar_finalize(_ptr(live, n, "live"), _ptr(warp_planar, n * grid.dims, "warp"),
+                                  _ptr(canonical, n, "canonical", allow_none=not statistics),
+                                  _ptr(live_out, n, "live_out", allow_none=True),
+                                  _ptr(warp_interleaved_out, n * grid.dims, "warp_interleaved_out", allow_none=True),
+                                  ctypes.byref(grid), float(lower_threshold),
+                                  _ptr(stats, 16, "statistics", dtype=torch.float64, allow_none=True),
+                                  _ptr(scratch, scratch.numel() if scratch is not None else 0, "scratch",
+                                       dtype=torch.float64, allow_none=True), stream_ptr()), "lsf_planar_finalize")
+    return stats
+
+
 def state_finalize_listed(state, canonical, grid, bands, unlisted, live_out=None, warp_interleaved_out=None,
                           lower_threshold=0.0, statistics=False):
     """state_finalize of whole arrays that visits the voxels of `bands` only (lsf_state_finalize_listed): live_out must

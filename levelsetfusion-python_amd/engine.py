@@ -571,12 +571,10 @@ class SlavchevaOutcome:
             raw = dev.state_finalize(self.state, self.canonical, full, target, None, warp, lower_threshold, statistics)
             self._live = target
         else:
-            target.copy_(self._live)
-            warp = dev.interleave(self._warp_planar)
-            raw = None
-            if statistics:
-                raw = torch.cat([dev.warp_statistics(self._warp_planar, self.canonical, self._live, lower_threshold, full),
-                                 dev.tsdf_difference_statistics(self.canonical, self._live, full)])
+            # planar final fields (SobolevFusion path): one pass as well (lsf_planar_finalize)
+            warp = torch.empty(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
+            raw = dev.planar_finalize(self._live, self._warp_planar, self.canonical, full,
+                                      None if target is self._live else target, warp, lower_threshold, statistics)
         if not to_host:
             return target, warp, raw
         if live_out is not None and target is not live_out:

@@ -592,6 +592,10 @@ def test_state_pack_unpack_finalize(lsf):
         assert torch.equal(l3[zs], live[zs]) and torch.equal(i3[zs], dev.interleave(warp)[zs])
         if dims == 3:
             assert float(l3[:1].abs().max()) == 0.0 and float(i3[-2:].abs().max()) == 0.0
+        # the same pass from planar final fields (the SobolevFusion path's layout): identical in every bit
+        l4, i4 = torch.zeros_like(live), torch.zeros(shape + (dims,), device="cuda")
+        raw_planar = dev.planar_finalize(live, warp, canon, g, l4, i4, 0.25, True).cpu().numpy()
+        assert torch.equal(l4, l3) and torch.equal(i4, i3) and np.array_equal(raw_planar, raw)
         want_w = dev.warp_statistics(warp, canon, live, 0.25, g).cpu().numpy()
         want_d = dev.tsdf_difference_statistics(canon, live, g).cpu().numpy()
         for got, want in ((raw[:8], want_w), (raw[8:], want_d)):
