@@ -54,6 +54,9 @@ def parse():
                     help="killing = BASELINE config 4 (default, the metric's configuration); the others are extra "
                          "single-GPU measurements: SobolevFusion-style Slavcheva, hierarchical Tikhonov-only, "
                          "hierarchical Tikhonov + 7-tap kernel")
+    ap.add_argument("--data", default="sphere", choices=["sphere", "depth"],
+                    help="sphere: SURVEY 8(d)'s sphere pair (BASELINE's configuration, default); depth: two synthetic depth "
+                         "frames -> TSDF volumes through the package's own generator (single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-size", type=int, default=128)
     ap.add_argument("--cpu-sample-iterations", type=int, default=24)
@@ -171,7 +174,13 @@ def main():
     n, iters = args.size, args.iterations
     layout = SlabLayout(n * world, rank, world, args.halo if world > 1 else 0)
     sl = layout.local_slice()
-    canonical, live0 = sphere_pair(n, 3, device, (sl.start, sl.stop))
+    if args.data == "depth":
+        if world > 1:
+            raise SystemExit("--data depth is a single-GPU measurement (one surface, not one per slab)")
+        from levelsetfusion_python_amd.synthetic import depth_pair
+        canonical, live0 = depth_pair(n, device)
+    else:
+        canonical, live0 = sphere_pair(n, 3, device, (sl.start, sl.stop))
 
     def make_optimizer():
         comm = SlabComm(layout) if world > 1 else None
@@ -276,7 +285,7 @@ def main():
         try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md), default size only
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 t = json.load(f)
-            if t.get("size") == n and t.get("workload") == "killing":
+            if t.get("size") == n and t.get("workload") == "killing" and args.data == "sphere":
                 return t.get(key)
         except (OSError, ValueError, KeyError):
             pass
@@ -300,7 +309,8 @@ def main():
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
                config=dict(workload="3D %d^3 KillingFusion (Killing + level-set) SlavchevaOptimizer3d, %d fixed "
-                                    "iterations per step, sphere-pair TSDF" % (n, iters),
+                                    "iterations per step, %s" % (n, iters, "sphere-pair TSDF" if args.data == "sphere"
+                                                                 else "TSDF pair from two synthetic depth frames"),
                            voxels_per_gpu=voxels_per_rank, iterations_per_step=iters,
                            parallelism=("z-slab x%d, halo %d, %s" % (
                                world, args.halo, "RCCL send/recv from the library (lsf_slab_state_iteration)"

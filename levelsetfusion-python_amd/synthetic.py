@@ -30,3 +30,30 @@ def sphere_pair(n, dims=3, device="cuda", z_range=None):
         return torch.clamp((torch.sqrt(sq) - r) / h, -1.0, 1.0).to(torch.float32).contiguous()
 
     return tsdf((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), tsdf((1.5, -1.0, 2.0), (1.05, 0.95, 1.0))
+
+
+def depth_image(shift_px=0.0, nearer_m=0.0, width=640, height=480):
+    """SURVEY 8(d) "depth->TSDF" input: a tilted plane at ~1 m with a sinusoidal bump, uint16 millimetres (numpy)"""
+    import numpy as np
+    v, u = np.meshgrid(np.arange(height, dtype=np.float64), np.arange(width, dtype=np.float64), indexing="ij")
+    bump = 0.06 * np.exp(-(((u - 320.0 - shift_px) / 90.0) ** 2 + ((v - 240.0) / 70.0) ** 2)) \
+        * (1.0 + 0.3 * np.sin(u / 17.0) * np.cos(v / 23.0))
+    depth_m = 1.0 + 0.0002 * (u - 320.0) - bump - nearer_m
+    return np.round(depth_m * 1000.0).astype(np.uint16)
+
+
+def depth_pair(n, device="cuda"):
+    """(canonical, live) n^3 TSDF volumes generated ON THE GPU from two synthetic depth frames (the second with the bump
+    shifted 2 px and 8 mm nearer): K = [[700, 0, 320], [0, 700, 240], [0, 0, 1]], depth unit 0.001, the surface at 1 m
+    crosses the middle of the volume; 4 mm voxels up to n = 256, scaled down beyond so that the scene still fills it"""
+    import numpy as np
+    from .tsdf import generation as gen
+    K = np.array([[700.0, 0.0, 320.0], [0.0, 700.0, 240.0], [0.0, 0.0, 1.0]], dtype=np.float32)
+    cam = gen.DepthCamera(intrinsic_matrix=K, depth_unit_ratio=0.001)
+    voxel = 0.004 * min(1.0, 256.0 / n)
+    surface = int(round(1.0 / voxel))
+    offset = np.array([-n // 2, -n // 2, surface - n // 2])
+    frames = (depth_image(), depth_image(shift_px=2.0, nearer_m=0.008))
+    with torch.cuda.device(torch.device(device)):
+        return tuple(gen.generate_3d_tsdf_field_from_depth_image(d, cam, field_size=n, voxel_size=voxel,
+                                                                 array_offset=offset, as_tensor=True) for d in frames)

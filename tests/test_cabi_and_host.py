@@ -189,6 +189,15 @@ def test_sobolev_filter_host_code(pkg, ref_leaf):
     assert np.abs(sobolev_kernel_1d - ref_leaf["sobolev.hardcoded7"]).max() == 0.0
 
 
+def test_synthetic_depth_frames_are_the_oracle_s(pkg):
+    """the package's closed-form depth frames (bench.py --data depth) are the ones the oracle / the TSDF tests use"""
+    from levelsetfusion_python_amd import synthetic
+    from oracle import lsf_oracle as O
+    for kw in (dict(), dict(shift_px=2.0, nearer_m=0.008)):
+        d = synthetic.depth_image(**kw)
+        assert d.dtype == np.uint16 and d.shape == (480, 640) and np.array_equal(d, O.synthetic_depth_image(**kw))
+
+
 def test_record_decoding(pkg):
     """a record is 8 partial slots (lsf_iteration_record): value = max of the packed maxima, sum of the energies"""
     from levelsetfusion_python_amd import device as dev

@@ -105,6 +105,21 @@ def test_depth_to_tsdf_to_optimizer_on_device(gen):
     assert float(warp.abs().max()) > 1e-3
 
 
+def test_synthetic_depth_pair_for_the_bench(gen):
+    """synthetic.depth_pair (bench.py --data depth): two device-resident TSDF volumes, equal to the oracle's generator on
+    the same frames, with a band that the optimizer can work on"""
+    from levelsetfusion_python_amd import synthetic
+    n = 64
+    canonical, live = synthetic.depth_pair(n)
+    assert canonical.is_cuda and canonical.shape == (n, n, n) and canonical.dtype == torch.float32
+    K = np.array([[700., 0., 320.], [0., 700., 240.], [0., 0., 1.]], dtype=np.float32)
+    off = (-n // 2, -n // 2, 250 - n // 2)
+    for field, kw in ((canonical, dict()), (live, dict(shift_px=2.0, nearer_m=0.008))):
+        want = O.tsdf_nearest(O.synthetic_depth_image(**kw), K, 0.001, (n, n, n), array_offset=off)
+        assert maxdiff(field.cpu().numpy(), want) == 0.0
+    assert int(((canonical.abs() < 1) | (live.abs() < 1)).sum()) > 20000 and not torch.equal(canonical, live)
+
+
 def test_tsdf_ewa_matches_oracle_and_reference(gen, ref_ewa):
     """the four EWA generators against the oracle (float64 sums; exp / 2x2 inverse may differ in the last place from
     glibc / LAPACK: tolerance 2e-6) and against the reference's own known answers (its tolerance: atol=2e-5)"""
