@@ -686,6 +686,9 @@ class SlavchevaEngine:
         else:
             mode, (boundary, interior) = _lib.SLAB_LAUNCH, f.widened_parts[0 if j == k - 1 else k - 1 - j]
         if f.native is not None:  # the whole iteration in one host call (lsf_slab.hip): RCCL on the library's stream
+            if exchange and f.pending_face_plan is not None:
+                plan, f.pending_face_plan = f.pending_face_plan, None
+                self._plan_compact_faces(f, *plan)
             status = _lib.lib.lsf_slab_state_iteration(f.native, s_in, f.p_canon, s_out, f.layout_ref, boundary.array,
                                                        boundary.n, interior.array, interior.n, f.params_ref, gate_ref,
                                                        f.record_ptrs[i], mode, f.faces_ref, f.stream)
@@ -860,8 +863,11 @@ class SlavchevaEngine:
         if f.native is not None:
             f.layout = _lib.SlabLayoutC(grid.nz, grid.ny, grid.nx, L.z_begin, L.z_end, h, lo_rank, hi_rank)
             f.layout_ref = ctypes.byref(f.layout)
+            # compact faces are planned when the first exchange is enqueued (_enqueue_state_iteration): the plan costs a
+            # collective and a host read (~0.2 ms) that then wait behind the iterations already queued, not in front of them
+            f.pending_face_plan = None
             if listed and os.environ.get("LSF_SLAB_FACES", "compact") != "full":
-                self._plan_compact_faces(f, live, bands, cut, lo, hi, lo_rank, hi_rank)
+                f.pending_face_plan = (live, bands, cut, lo, hi, lo_rank, hi_rank)
         elif not hasattr(self, "_comm_stream"):
             self._comm_stream = torch.cuda.Stream(device=live.device)
             self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]

@@ -39,7 +39,19 @@ def _timed(self, *a, **k):
     _host[0] += time.perf_counter() - t
     _host[1] += 1
 SlavchevaEngine._enqueue_state_iteration = _timed
-for fixed in (True, False):
+_plan = {}
+def _wrap_plan(name):
+    fn = getattr(SlavchevaEngine, name)
+    def inner(self, *a, **k):
+        t = time.perf_counter()
+        try:
+            return fn(self, *a, **k)
+        finally:
+            _plan[name] = _plan.get(name, 0.0) + time.perf_counter() - t
+    setattr(SlavchevaEngine, name, inner)
+for _name in ("_plan_slab", "_plan_compact_faces"):  # the second runs inside the first
+    _wrap_plan(_name)
+for fixed in ((True,) if os.environ.get("FIXED_ONLY") == "1" else (True, False)):
     kw = dict(maximum_warp_length_lower_threshold=0.0, max_iterations=iters, min_iterations=iters if fixed else 1)
     opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
                                    smoothing_term_method=lsf.SmoothingTermMethod.KILLING, check_interval=50,
@@ -54,8 +66,11 @@ for fixed in (True, False):
         print("%s: %d iterations, %.1f us per iteration (whole optimize %.2f ms)"
               % ("fixed count (no per-iteration all-reduce)" if fixed else "gated (MAX all-reduce per iteration)",
                  len(opt.log.max_warps), dt / max(len(opt.log.max_warps), 1) * 1e6, dt * 1e3), flush=True)
-        print("    host time inside the enqueue call: %.1f us per iteration" % (_host[0] / max(_host[1], 1) * 1e6))
+        print("    host time inside the enqueue call: %.1f us per iteration; launch plan %.0f us per call, of which the "
+              "compact-face plan %.0f us" % (_host[0] / max(_host[1], 1) * 1e6, _plan.get("_plan_slab", 0.0) * 1e6,
+                                            _plan.get("_plan_compact_faces", 0.0) * 1e6))
         _host[0], _host[1] = 0.0, 0
+        _plan.clear()
 if os.environ.get("LB_PROFILE") == "1":
     import cProfile, pstats
     live = live0.clone()
