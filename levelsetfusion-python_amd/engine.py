@@ -50,6 +50,19 @@ def _conv_axis_order(dims):
     return [1, 0] if dims == 2 else [0, 1, 2]
 
 
+class _Lazy:
+    """a value made on first use"""
+
+    def __init__(self, make):
+        self._make, self._value = make, None
+
+    def get(self):
+        if self._value is None:
+            self._value = self._make()
+            self._make = None
+        return self._value
+
+
 def _combine_statistics(rows, has_min):
     """per-rank raw statistics (the 8 doubles of lsf_warp_statistics / lsf_tsdf_difference_statistics over disjoint
     z-ranges, arg-max as GLOBAL voxel index) -> the statistics of the union"""
@@ -680,11 +693,11 @@ class SlavchevaEngine:
         exchange = j == k - 1 and i + 1 < limit
         resume = k > 1 and j == 0 and i > 0   # the iteration before this one left its exchange in flight
         if exchange:
-            mode, (boundary, interior) = (_lib.SLAB_EXCHANGE_DEFERRED if k > 1 else _lib.SLAB_EXCHANGE), f.exchange_parts
+            mode, (boundary, interior) = (_lib.SLAB_EXCHANGE_DEFERRED if k > 1 else _lib.SLAB_EXCHANGE), f.exchange_parts.get()
         elif resume:
-            mode, (boundary, interior) = _lib.SLAB_RESUME, f.resume_parts
+            mode, (boundary, interior) = _lib.SLAB_RESUME, f.resume_parts.get()
         else:
-            mode, (boundary, interior) = _lib.SLAB_LAUNCH, f.widened_parts[0 if j == k - 1 else k - 1 - j]
+            mode, (boundary, interior) = _lib.SLAB_LAUNCH, f.widened_parts[0 if j == k - 1 else k - 1 - j].get()
         if f.native is not None:  # the whole iteration in one host call (lsf_slab.hip): RCCL on the library's stream
             if exchange and f.pending_face_plan is not None:
                 plan, f.pending_face_plan = f.pending_face_plan, None
@@ -742,10 +755,15 @@ class SlavchevaEngine:
         none = (torch.zeros(1, dtype=torch.int32, device=live.device), 0)
         send = [union(L.z_begin, L.z_begin + h) if lo else none, union(L.z_end - h, L.z_end) if hi else none]
         recv = [union(L.z_begin - h, L.z_begin) if lo else none, union(L.z_end, L.z_end + h) if hi else none]
-        mine = torch.tensor([send[0][1], send[1][1], recv[0][1], recv[1][1]], dtype=torch.int64, device=live.device)
-        rows = [torch.zeros_like(mine) for _ in range(torch.distributed.get_world_size(self.comm.group))]
-        torch.distributed.all_gather(rows, mine, group=self.comm.group)
-        rows = [r.tolist() for r in rows]
+        # the cross-check runs on a stream of its own: its host read must not wait for the iterations that are already
+        # queued on the launch stream (this plan is made when the first exchange is enqueued)
+        if getattr(self, "_plan_stream", None) is None or self._plan_stream.device != live.device:
+            self._plan_stream = torch.cuda.Stream(device=live.device)
+        with torch.cuda.stream(self._plan_stream):
+            mine = torch.tensor([send[0][1], send[1][1], recv[0][1], recv[1][1]], dtype=torch.int64, device=live.device)
+            rows = [torch.zeros_like(mine) for _ in range(torch.distributed.get_world_size(self.comm.group))]
+            torch.distributed.all_gather(rows, mine, group=self.comm.group)
+            rows = [r.tolist() for r in rows]
         # every rank sees every row, so all ranks reach the same verdict without a second collective: a rank's lower
         # boundary lands in its lower neighbour's UPPER halo, its upper boundary in the upper neighbour's LOWER halo
         ok = True
@@ -845,18 +863,22 @@ class SlavchevaEngine:
                 return SlavchevaEngine._Parts([(grid_of(ranges[0][0], ranges[-1][1]), lists_of(ranges))])
             return SlavchevaEngine._Parts([(grid_of(z0, z1), [dev.BandList.none()]) for z0, z1 in ranges])
 
+        # Every (boundary part, interior part) pair is built when an iteration first asks for it: only the first
+        # iteration's pair stands between the list sizes and the first launch, the others are made while launches are
+        # already queued (13 descriptors, ~0.1 ms of host work at 256^3)
         empty = SlavchevaEngine._Parts([])
-        f.widened_parts = [(empty, parts([(L.z_begin - (e if lo else 0), L.z_end + (e if hi else 0))]))
+        f.widened_parts = [_Lazy(lambda e=e: (empty, parts([(L.z_begin - (e if lo else 0), L.z_end + (e if hi else 0))])))
                            for e in range(f.exchange_interval)]
         z_lo, z_hi = L.z_begin + (h if lo else 0), L.z_end - (h if hi else 0)
-        f.exchange_parts = (parts(([(L.z_begin, z_lo)] if lo else []) + ([(z_hi, L.z_end)] if hi else [])),
-                            parts([(z_lo, z_hi)]))
+        f.exchange_parts = _Lazy(lambda: (parts(([(L.z_begin, z_lo)] if lo else []) + ([(z_hi, L.z_end)] if hi else [])),
+                                          parts([(z_lo, z_hi)])))
         # first iteration of a group, while the previous group's exchange may still be in flight: the owned slices that
         # do not touch a halo slice first, the rest (the widened range's outer slices) after the halos have arrived
-        e = f.exchange_interval - 1
+        e_last = f.exchange_interval - 1
         in_lo, in_hi = L.z_begin + (1 if lo else 0), L.z_end - (1 if hi else 0)
-        f.resume_parts = (parts([(in_lo, in_hi)]),
-                          parts(([(L.z_begin - e, in_lo)] if lo else []) + ([(in_hi, L.z_end + e)] if hi else [])))
+        f.resume_parts = _Lazy(lambda: (parts([(in_lo, in_hi)]),
+                                        parts(([(L.z_begin - e_last, in_lo)] if lo else []) +
+                                              ([(in_hi, L.z_end + e_last)] if hi else []))))
         self._pending_halos = None
         f.native = self.comm.native()
         f.faces_ref = None
