@@ -970,14 +970,19 @@ class SlavchevaEngine:
                                             canonical, grid, records, gbufs, limit)
                 else:
                     self._enqueue_state_iteration(i, states, limit)
-            if slab:  # global max (idempotent) and, once per record, the energy sums of this batch
+            # z-slab: a gated run's device-side gate reads the records, so they are all-reduced (global max: idempotent;
+            # once per record the energy sums of this batch); a fixed count only needs them on the host: every rank's
+            # partial slots are gathered when they are read
+            ungated = self.min_iterations >= limit
+            if slab and not ungated:
                 self.comm.reduce_records(records, it, it + batch)
             it += batch
             if finalize is not None and not self.sobolev and it == limit and self.min_iterations >= limit:
                 # every launch runs ungated, so the final state is states[limit % 2]: finalize before looking
                 early = SlavchevaOutcome(grid, canonical, state=states[limit % 2], listed=listed)
                 early.enqueue_finalize(*finalize)
-            dec = dev.decode_records(dev.records_to_host(records[:it]))
+            dec = dev.decode_records(self.comm.gather_records(records, 0, it) if slab and ungated
+                                     else dev.records_to_host(records[:it]))
             n_exec = int(dec["executed"].sum())
             if n_exec < it:
                 break

@@ -259,6 +259,20 @@ class SlabComm:
         dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
         view.copy_(mx.to(records.device))
 
+    def gather_records(self, records, first, last):
+        """records [first, last) of EVERY rank on the host: numpy int64 [n, world * slots, 4] -- the ranks' partial slots
+        side by side, which is all device.decode_records needs (max of the packed maxima, sum of the energies).  One
+        collective and one host read where reduce_records + records_to_host take two collectives; for runs whose
+        records no device-side gate reads (fixed iteration counts)."""
+        mine = _slot_view(records)[first:last, :, :4].contiguous()
+        if not self.active:
+            return mine.cpu().numpy()
+        if self.stage_through_host and mine.is_cuda:
+            mine = mine.cpu()
+        rows = [torch.empty_like(mine) for _ in range(dist.get_world_size(self.group))]
+        dist.all_gather(rows, mine, group=self.group)
+        return torch.cat(rows, dim=1).cpu().numpy()
+
     def reduce_records(self, records, first, last, energies=True):
         """all-reduce records [first, last) slot by slot: the packed maxima (non-negative as int64) with MAX
         (idempotent), and -- exactly once per record -- the three energies (float64 bit patterns) with SUM"""
