@@ -419,7 +419,13 @@ class StatePrepare:
     constructor only launches: whatever the host has to set up for the iterations fits between it and collect(), which
     is where the host waits for the list sizes."""
 
-    def __init__(self, live, canonical, grid=None):
+    CHUNK = 1024  # voxels per count of lsf_state_prepare's scratch (kBandChunk)
+
+    def __init__(self, live, canonical, grid=None, cut_chunks=None):
+        """cut_chunks (optional): int64 device tensor of chunk indices <= the number of chunks -- the number of INTERIOR /
+        BOUNDARY list entries in front of voxel 1024 * chunk comes back with the list sizes (collect), e.g. the positions
+        of z cuts in the lists of a slab whose slices are a multiple of 1024 voxels, without a search and a second host
+        read.  (The entry AT the number of chunks is not a count: use cut_totals for a cut at the end of the array.)"""
         self.grid = grid = grid or make_grid(live.shape)
         n = n_voxels(grid)
         self.states = [torch.empty(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device) for _ in range(2)]
@@ -432,6 +438,14 @@ class StatePrepare:
                                     ctypes.c_void_p(totals.data_ptr()), stream_ptr()), "lsf_state_prepare")
         self._totals_host = pinned_scratch("prepare totals", 4, torch.int64)
         self._totals_host.copy_(totals, non_blocking=True)
+        self._cuts_host = self._cut_chunks = None
+        if cut_chunks is not None and cut_chunks.numel():
+            chunks = (n + self.CHUNK - 1) // self.CHUNK
+            # the scratch starts with the two arrays of exclusive prefix counts, chunks + 1 apart (lsf_state_prepare)
+            prefix = self._scratch[:2 * (chunks + 1)].view(2, chunks + 1)
+            cuts = torch.index_select(prefix, 1, cut_chunks)  # indices < chunks + 1: the caller clamps (see collect)
+            self._cuts_host = pinned_scratch("prepare cuts", cuts.numel(), torch.int32)
+            self._cuts_host.copy_(cuts.view(-1), non_blocking=True)
         self._copied = torch.cuda.Event()
         self._copied.record()
 
@@ -451,6 +465,13 @@ class StatePrepare:
                                                       ctypes.c_void_p(indices.data_ptr()), stream_ptr()),
                       "lsf_band_list_fill_prepared")
             lists.append(BandList(indices, count, subset))
+        self.cuts = None
+        if self._cuts_host is not None:  # {subset: positions}, a chunk index past the last chunk = the list's size
+            flat = self._cuts_host.tolist()
+            per = len(flat) // 2
+            self.cuts = {subset: flat[k * per:(k + 1) * per]
+                         for k, subset in enumerate((_lib.BAND_INTERIOR, _lib.BAND_BOUNDARY))}
+            self.cut_totals = {_lib.BAND_INTERIOR: counts[0], _lib.BAND_BOUNDARY: counts[1]}
         return lists, (counts[2], counts[3])
 
 

@@ -755,23 +755,29 @@ class SlavchevaEngine:
         none = (torch.zeros(1, dtype=torch.int32, device=live.device), 0)
         send = [union(L.z_begin, L.z_begin + h) if lo else none, union(L.z_end - h, L.z_end) if hi else none]
         recv = [union(L.z_begin - h, L.z_begin) if lo else none, union(L.z_end, L.z_end + h) if hi else none]
-        # the cross-check runs on a stream of its own: its host read must not wait for the iterations that are already
-        # queued on the launch stream (this plan is made when the first exchange is enqueued)
-        if getattr(self, "_plan_stream", None) is None or self._plan_stream.device != live.device:
-            self._plan_stream = torch.cuda.Stream(device=live.device)
-        with torch.cuda.stream(self._plan_stream):
-            mine = torch.tensor([send[0][1], send[1][1], recv[0][1], recv[1][1]], dtype=torch.int64, device=live.device)
-            rows = [torch.zeros_like(mine) for _ in range(torch.distributed.get_world_size(self.comm.group))]
-            torch.distributed.all_gather(rows, mine, group=self.comm.group)
-            rows = [r.tolist() for r in rows]
-        # every rank sees every row, so all ranks reach the same verdict without a second collective: a rank's lower
-        # boundary lands in its lower neighbour's UPPER halo, its upper boundary in the upper neighbour's LOWER halo
+        # A rank's halo holds the neighbour's boundary slices, so what it expects to receive IS what the neighbour sends --
+        # if the caller cut consistent slabs.  That contract is cross-checked with the neighbours on an optimizer's first
+        # call (a collective and a host read, ~0.2 ms; LSF_SLAB_VERIFY_FACES=always: on every call): a wrong slicing is
+        # systematic and shows there, and mismatched message sizes would otherwise hang the transport.  The check runs
+        # on a stream of its own: its host read must not wait for the iterations already queued on the launch stream.
         ok = True
-        if len(rows) == 1:  # the one-GPU loop-back: this rank is its own neighbour on both sides
-            ok = rows[0][0] == rows[0][3] and rows[0][1] == rows[0][2]
-        else:
-            for r in range(len(rows) - 1):
-                ok &= rows[r][1] == rows[r + 1][2] and rows[r + 1][0] == rows[r][3]
+        if not getattr(self, "_faces_verified", False) or os.environ.get("LSF_SLAB_VERIFY_FACES") == "always":
+            if getattr(self, "_plan_stream", None) is None or self._plan_stream.device != live.device:
+                self._plan_stream = torch.cuda.Stream(device=live.device)
+            with torch.cuda.stream(self._plan_stream):
+                mine = torch.tensor([send[0][1], send[1][1], recv[0][1], recv[1][1]], dtype=torch.int64,
+                                    device=live.device)
+                rows = [torch.zeros_like(mine) for _ in range(torch.distributed.get_world_size(self.comm.group))]
+                torch.distributed.all_gather(rows, mine, group=self.comm.group)
+                rows = [r.tolist() for r in rows]
+            # every rank sees every row, so all ranks reach the same verdict without a second collective: a rank's lower
+            # boundary lands in its lower neighbour's UPPER halo, its upper boundary in the upper neighbour's LOWER halo
+            if len(rows) == 1:  # the one-GPU loop-back: this rank is its own neighbour on both sides
+                ok = rows[0][0] == rows[0][3] and rows[0][1] == rows[0][2]
+            else:
+                for r in range(len(rows) - 1):
+                    ok &= rows[r][1] == rows[r + 1][2] and rows[r + 1][0] == rows[r][3]
+            self._faces_verified = ok
         if not ok:
             import warnings
             warnings.warn("slab halos are not consistent with the neighbours' slabs (band voxel counts differ): whole "
@@ -805,7 +811,16 @@ class SlavchevaEngine:
                     self.array[k].band_count[j] = band.count
                     self.array[k].band_subset[j] = band.subset
 
-    def _plan_slab(self, f, live, grid, bands, limit):
+    def _slab_cut_slices(self, grid):
+        """the slices at which a z-slab run cuts its band lists (ascending): every boundary of a widened, boundary,
+        interior or resume range"""
+        L = self.comm.layout
+        h = L.halo
+        zs = sorted({z for e in range(h + 1) for z in (L.z_begin - e, L.z_end + e)} |
+                    {L.z_begin + h, L.z_end - h, L.z_begin + 1, L.z_end - 1})
+        return [z for z in zs if 0 <= z <= grid.nz]
+
+    def _plan_slab(self, f, live, grid, bands, limit, prepared=None):
         """Launch plan of a z-slab rank (fused path).  ONE band list of the whole local array (owned slices + halos) is
         cut by z -- it is sorted, so every z-range is a contiguous run of it.
         Exchange groups: with a halo of h slices and a fixed iteration count the faces travel only every h-th iteration
@@ -828,10 +843,12 @@ class SlavchevaEngine:
         f.exchange_interval = h if fixed else 1
         slice_voxels = grid.ny * grid.nx
         listed = bands[0].indices is not None
-        if listed:  # positions of the z cuts inside every list: one searchsorted per list, one host read
-            zs = sorted({z for e in range(h + 1) for z in (L.z_begin - e, L.z_end + e)} |
-                        {L.z_begin + h, L.z_end - h, L.z_begin + 1, L.z_end - 1})
-            zs = [z for z in zs if 0 <= z <= grid.nz]
+        if listed and prepared is not None:  # the prepare pass brought the positions of the z cuts along
+            zs = self._slab_cut_slices(grid)
+            cut = [dict(zip(zs, [prepared.cut_totals[b.subset] if z == grid.nz else c
+                                 for z, c in zip(zs, prepared.cuts[b.subset])])) for b in bands]
+        elif listed:  # positions of the z cuts inside every list: one searchsorted per list, one host read
+            zs = self._slab_cut_slices(grid)
             keys = torch.tensor([z * slice_voxels for z in zs], dtype=torch.int32, device=live.device)
             cuts = torch.stack([torch.searchsorted(b.indices[:b.count], keys) if b.count else torch.zeros_like(keys,
                                dtype=torch.int64) for b in bands]).cpu().tolist()
@@ -915,8 +932,19 @@ class SlavchevaEngine:
         fused_prepare = not self.sobolev and self.use_band_list and dev.buffer_addressing_ok(grid)
         if fused_prepare:
             # one pass: both states + the INTERIOR / BOUNDARY band lists of the WHOLE local array.  Launched first: the
-            # host sets up records and launch arguments while it runs, and only then waits for the list sizes
-            prepared = dev.StatePrepare(live, canonical, dev.full_range(grid))
+            # host sets up records and launch arguments while it runs, and only then waits for the list sizes -- and, in
+            # a z-slab run, for the positions of the z cuts in the lists (slices of a multiple of 1024 voxels: the
+            # prepare pass's per-chunk prefix counts hold them)
+            cut_chunks = None
+            if slab and (grid.ny * grid.nx) % dev.StatePrepare.CHUNK == 0:
+                zs = self._slab_cut_slices(grid)
+                key = (tuple(zs), grid.ny * grid.nx, live.device)
+                if getattr(self, "_cut_chunk_cache", (None, None))[0] != key:
+                    per_slice = grid.ny * grid.nx // dev.StatePrepare.CHUNK
+                    self._cut_chunk_cache = (key, torch.tensor([z * per_slice for z in zs], dtype=torch.int64,
+                                                               device=live.device))
+                cut_chunks = self._cut_chunk_cache[1]
+            prepared = dev.StatePrepare(live, canonical, dev.full_range(grid), cut_chunks)
         records = dev.new_records(n_rec, live.device)
         self._last_g = None
         lives = warps = gbufs = states = None
@@ -956,7 +984,8 @@ class SlavchevaEngine:
             self._fast = f
             if slab:
                 self._plan_slab(f, live, grid, bands, 0 if self.min_iterations == 0
-                                else max(self.max_iterations, self.min_iterations))
+                                else max(self.max_iterations, self.min_iterations),
+                                prepared if fused_prepare and prepared.cuts is not None else None)
         # with min_iterations == 0 the reference never enters its loop (max_warp starts at +inf, :354,:360-362)
         limit = 0 if self.min_iterations == 0 else max(self.max_iterations, self.min_iterations)
         it, n_exec = 0, 0

@@ -51,6 +51,23 @@ def _wrap_plan(name):
     setattr(SlavchevaEngine, name, inner)
 for _name in ("_plan_slab", "_plan_compact_faces"):  # the second runs inside the first
     _wrap_plan(_name)
+_marks = []
+if os.environ.get("LB_TIMELINE") == "1":  # start / end of the host-side phases of every optimize() call
+    from levelsetfusion_python_amd import device as _dev, engine as _eng, slab as _slab
+    def _mark(owner, name):
+        fn = getattr(owner, name)
+        def inner(*a, **k):
+            t = time.perf_counter()
+            try:
+                return fn(*a, **k)
+            finally:
+                _marks.append((getattr(owner, "__name__", str(owner)) + "." + name, t, time.perf_counter()))
+        setattr(owner, name, inner)
+    for _o, _n in ((_dev.StatePrepare, "__init__"), (_dev.StatePrepare, "collect"), (_dev, "new_records"),
+                   (_dev.IterationLauncher, "__init__"), (SlavchevaEngine, "_plan_slab"),
+                   (SlavchevaEngine, "_plan_compact_faces"), (_eng.SlavchevaOutcome, "enqueue_finalize"),
+                   (_slab.SlabComm, "gather_records"), (_dev, "decode_records"), (_eng.SlavchevaOutcome, "finalize")):
+        _mark(_o, _n)
 for fixed in ((True,) if os.environ.get("FIXED_ONLY") == "1" else (True, False)):
     kw = dict(maximum_warp_length_lower_threshold=0.0, max_iterations=iters, min_iterations=iters if fixed else 1)
     opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
@@ -59,10 +76,13 @@ for fixed in ((True,) if os.environ.get("FIXED_ONLY") == "1" else (True, False))
     for rep in range(3):
         live = live0.clone()
         torch.cuda.synchronize()
+        del _marks[:]
         t0 = time.perf_counter()
         opt.optimize(live, canonical)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        for _label, _a, _b in _marks:
+            print("      %-44s %8.1f -> %8.1f us" % (_label, (_a - t0) * 1e6, (_b - t0) * 1e6))
         print("%s: %d iterations, %.1f us per iteration (whole optimize %.2f ms)"
               % ("fixed count (no per-iteration all-reduce)" if fixed else "gated (MAX all-reduce per iteration)",
                  len(opt.log.max_warps), dt / max(len(opt.log.max_warps), 1) * 1e6, dt * 1e3), flush=True)
