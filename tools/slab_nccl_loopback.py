@@ -1,7 +1,9 @@
 """Host-side cost per iteration of the N > 1 enqueue path over the REAL transport API (torch.distributed "nccl" = RCCL)
 on ONE GPU: a world of size 1 whose rank plays the middle slab of three and sends both halo faces to ITSELF (RCCL
 allows self send / recv inside a group).  The received data are meaningless; what is exercised and timed is the exact
-call sequence of SlabComm.exchange_state / reduce_* on device tensors.  Tiny volume => wall time per iteration = host."""
+call sequence of the N > 1 path on device tensors.
+Usage: [HALO=8] [ITERS=50] [FIXED_ONLY=1] [LB_TIMELINE=1] [LB_PROFILE=1] slab_nccl_loopback.py [n]
+n = edge of the slab (default 32: a tiny volume, wall time per iteration = host time; 256 = the bench's slab)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
