@@ -45,6 +45,7 @@ def _worker(rank, world, port, n, nz, halo, iterations, sobolev, out_dir):
                             smoothing_term_method=O.TIKHONOV if sobolev else O.KILLING,
                             sobolev_smoothing_enabled=sobolev, sobolev_kernel=kernel)
     records = torch.zeros((iterations, RECORD_SLOTS * SLOT_WORDS), dtype=torch.int64)
+    partial = torch.zeros_like(records)  # this rank's records before any reduction
     own = layout.owned_local()
     opt.max_region = own
     for it in range(iterations):
@@ -61,7 +62,16 @@ def _worker(rank, world, port, n, nz, halo, iterations, sobolev, out_dir):
         warp_planar = warp_l.permute(3, 0, 1, 2).contiguous()
         comm.exchange_halos([live_l, warp_planar])
         warp_l.copy_(warp_planar.permute(1, 2, 3, 0))
+        partial[it] = records[it]
         comm.reduce_records(records, it, it + 1)
+    # the fixed-count path: one gather of every rank's slots instead of the reductions -- decodes to the same values
+    from levelsetfusion_python_amd import device as dev
+    gathered = comm.gather_records(partial, 0, iterations)
+    assert gathered.shape == (iterations, world * RECORD_SLOTS, 4)
+    a, b = dev.decode_records(gathered), dev.decode_records(dev.slot_view(records.numpy())[:, :, :4])
+    for key in ("max_value", "argmax", "executed"):
+        assert np.array_equal(a[key], b[key]), key
+    assert np.allclose(a["data_energy"], b["data_energy"], rtol=1e-15)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), live=live_l.numpy()[own], warp=warp_l.numpy()[own],
              records=records.numpy())
     dist.destroy_process_group()
