@@ -610,6 +610,15 @@ def test_fused_xyz_filter_equals_three_passes(lsf):
     gen = torch.Generator("cuda").manual_seed(3)
     for shape in ((37, 35, 72), (64, 64, 64), (9, 10, 12), (70, 18, 132)):
         grid = dev.make_grid(shape)
+        for planes in (1, 4):  # a scalar field / the four channels of a packed field
+            one = torch.randn((planes,) + shape, device="cuda", generator=gen)
+            k5 = np.linspace(-0.2, 1.0, 5).astype(np.float32)
+            a1, b1, f1 = torch.empty_like(one), torch.empty_like(one), torch.empty_like(one)
+            dev.convolve_axis(one, a1, None, grid, 0, k5)
+            dev.convolve_axis(a1, b1, None, grid, 1, k5)
+            dev.convolve_axis(b1, a1, None, grid, 2, k5)
+            dev.convolve_xyz(one, f1, grid, k5)
+            assert torch.equal(f1, a1), (shape, planes)
         src = torch.randn((3,) + shape, device="cuda", generator=gen)
         src[:, :, :, : shape[2] // 3] = 0.0  # exact zeros as in a gradient that vanishes outside a band
         for n_taps in (3, 5, 7, 9):
@@ -640,6 +649,34 @@ def test_fused_xyz_filter_equals_three_passes(lsf):
     assert not dev.convolve_xyz_ok(dev.make_grid((4, 16, 16)), np.ones(7))    # shorter than the kernel
     with pytest.raises(ValueError):
         dev.convolve_xyz(src, fused, dev.make_grid((16, 16)), np.ones(7))
+
+
+def test_state_prepare_reports_list_positions_of_chunk_boundaries(lsf):
+    """StatePrepare(cut_chunks=...): the number of INTERIOR / BOUNDARY list entries in front of voxel 1024 * chunk comes
+    back with the list sizes -- equal to a search of the filled lists (what a z-slab run otherwise does for its z cuts)"""
+    from levelsetfusion_python_amd import _lib, device as dev
+    gen = torch.Generator("cuda").manual_seed(17)
+    shape = (24, 32, 64)  # 2048 voxels per slice: two chunks
+    live = (torch.rand(shape, device="cuda", generator=gen) * 2 - 1).contiguous()
+    canon = (torch.rand(shape, device="cuda", generator=gen) * 2 - 1).contiguous()
+    far = torch.rand(shape, device="cuda", generator=gen) < 0.7
+    live[far], canon[far] = 1.0, -1.0
+    live[5:9] = 1.0
+    canon[5:9] = 1.0  # a run of slices without any band voxel
+    grid = dev.make_grid(shape)
+    chunks = dev.n_voxels(grid) // 1024
+    picks = torch.tensor([0, 1, 2, 7, 10, 11, 18, chunks - 1, chunks], dtype=torch.int64, device="cuda")
+    prepared = dev.StatePrepare(live, canon, grid, picks)
+    lists, _ = prepared.collect()
+    assert len(lists) == 2 and prepared.cuts is not None
+    for bl in lists:
+        want = torch.searchsorted(bl.indices[:bl.count], (picks * 1024).to(torch.int32)).tolist()
+        got = prepared.cuts[bl.subset]
+        assert got[:-1] == want[:-1]                      # a chunk index of `chunks` is the end: cut_totals
+        assert prepared.cut_totals[bl.subset] == bl.count == want[-1]
+    plain = dev.StatePrepare(live, canon, grid)
+    plain.collect()
+    assert plain.cuts is None
 
 
 def test_state_finalize_listed_equals_dense_finalize(lsf):
