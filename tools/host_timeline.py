@@ -30,7 +30,8 @@ def wrap(owner, name, label=None):
     setattr(owner, name, inner)
 
 
-for owner, name in ((dev, "state_prepare"), (dev, "new_records"), (dev.IterationLauncher, "__init__"),
+for owner, name in ((dev.StatePrepare, "__init__"), (dev.StatePrepare, "collect"), (dev, "new_records"),
+                    (dev.IterationLauncher, "__init__"),
                     (engine.SlavchevaEngine, "_enqueue_state_iteration"), (engine.SlavchevaOutcome, "enqueue_finalize"),
                     (dev, "records_to_host"), (dev, "decode_records"), (engine.SlavchevaOutcome, "finalize"),
                     (engine.SlavchevaEngine, "optimize")):
