@@ -1,0 +1,50 @@
+"""bench.py's one-line JSON contract on a small volume (GPU): the keys the driver reads, the roofline and cpu_baseline
+objects, the --data / --workload variants."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          *flags], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout  # exactly ONE line on stdout
+    return json.loads(lines[0])
+
+
+def test_default_workload_line():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _run("--size", "64", "--iterations", "4", "--cpu-sample-size", "16", "--cpu-sample-iterations", "2")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["metric"] == "voxel-warp-updates/sec" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["value"] > 0 and abs(d["value"] - 64 ** 3 * 4 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel_ms"] > 0
+    assert abs(r["achieved"] - 52 * r["units_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+
+
+def test_depth_data_and_other_workloads():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _run("--size", "64", "--iterations", "4", "--data", "depth", "--no-cpu-baseline")
+    assert "depth" in d["config"]["workload"] and d["roofline"]["traffic"] is None and "cpu_baseline" not in d
+    for workload in ("hier-tik", "hier-full", "sobolev"):
+        d = _run("--size", "64", "--iterations", "3", "--workload", workload, "--no-cpu-baseline")
+        assert d["value"] > 0 and d["n_gpus"] == 1 and d["config"]["workload"]
