@@ -155,7 +155,8 @@ int lsf_convolve_axis(const float *in_planar, float *out_planar, const float *ze
                       int32_t n_taps, const lsf_gate *gate, void *stream);
 
 /* the three passes of a 3-D filter (x, then y, then z: convolution.py:94-105) in one launch, without a zero mask: the
- * result equals three lsf_convolve_axis calls bit for bit.  Whole arrays (z_begin = 0, z_end = nz), nx % 4 == 0,
+ * result equals three lsf_convolve_axis calls bit for bit (x and y passes on every slice the z pass reads, z pass on the
+ * grid's z-range: a z-slab filters its owned slices from raw input whose halo slices are valid).  nx % 4 == 0,
  * 3 / 5 / 7 / 9 taps; LSF_ERR_BAD_DIMS / LSF_ERR_KERNEL_TOO_LONG otherwise (the caller then runs the single passes).
  * warp_planar (may be NULL): the filtered field also moves the warp, warp -= rate * out, component by component -- the
  * hierarchical optimizer's update (hierarchical_optimizer2d.py:220-221) without another pass over out; the caller

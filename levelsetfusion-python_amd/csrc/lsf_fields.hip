@@ -727,8 +727,8 @@ __global__ __launch_bounds__(kBlock, 5) void convolve_xyz_kernel(const float* __
     const int t = threadIdx.x, lx = t & (kTileX - 1), wy = t / kTileX;
     const int x0 = blockIdx.x * kTileX;
     const int y0 = (int)(blockIdx.y / chunks_z) * kXyzRows;
-    const int z0 = (int)(blockIdx.y % chunks_z) * chunk;
-    const int count = min(chunk, g.nz - z0);
+    const int z0 = g.z_begin + (int)(blockIdx.y % chunks_z) * chunk;  // output slices: the grid's z-range; the run-in
+    const int count = min(chunk, g.z_end - z0);                       // reads whatever slices of the array it needs
     const float* __restrict__ src = in + (long long)blockIdx.z * g.plane;
     float* __restrict__ dst = out + (long long)blockIdx.z * g.plane;
     float* __restrict__ moved = warp ? warp + (long long)blockIdx.z * g.plane : nullptr;
@@ -832,7 +832,7 @@ static void launch_xyz(const float* in, float* out, float* warp, float rate, con
     for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
     const unsigned tiles_x = (unsigned)(g.nx + kTileX - 1) / kTileX, tiles_y = (unsigned)(g.ny + kXyzRows - 1) / kXyzRows;
     const int chunk = kXyzChunk;
-    const unsigned chunks_z = (unsigned)(g.nz + chunk - 1) / chunk;
+    const unsigned chunks_z = (unsigned)(g.z_end - g.z_begin + chunk - 1) / chunk;
     hipLaunchKernelGGL((convolve_xyz_kernel<NT>), dim3(tiles_x, tiles_y * chunks_z, (unsigned)planes), dim3(kBlock), 0, s,
                        in, out, warp, rate, g, taps, chunks_z, chunk, gt);
 }
@@ -844,11 +844,12 @@ extern "C" int lsf_convolve_xyz(const float* in_planar, float* out_planar, float
     if (!in_planar || !out_planar || in_planar == out_planar || !taps_host || planes < 1 || planes > 4 ||
         warp_planar == in_planar || (warp_planar && warp_planar == out_planar))
         return LSF_ERR_BAD_ARGUMENT;
-    if (grid->dims != 3 || grid->nx % 4 != 0 || grid->z_begin != 0 || grid->z_end != grid->nz) return LSF_ERR_BAD_DIMS;
+    if (grid->dims != 3 || grid->nx % 4 != 0) return LSF_ERR_BAD_DIMS;
+    if (grid->z_end == grid->z_begin) return 0;
     if (n_taps != 3 && n_taps != 5 && n_taps != 7 && n_taps != 9) return LSF_ERR_KERNEL_TOO_LONG;
     const Grid g = make_grid(grid);
     const unsigned long long blocks_y = (unsigned long long)((g.ny + kXyzRows - 1) / kXyzRows) *
-                                        (unsigned long long)((g.nz + kXyzChunk - 1) / kXyzChunk);
+                                        (unsigned long long)((g.z_end - g.z_begin + kXyzChunk - 1) / kXyzChunk);
     if (blocks_y > 65535ull) return LSF_ERR_BAD_DIMS;
     const lsf_gate gt = gate ? *gate : lsf_gate{nullptr, 0, 0.0f, 0.0f};
     hipStream_t s = as_stream(stream);

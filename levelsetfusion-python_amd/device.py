@@ -296,11 +296,10 @@ XYZ_TAP_COUNTS = (3, 5, 7, 9)
 
 
 def convolve_xyz_ok(grid, taps):
-    """can lsf_convolve_xyz run this 3-D filter (whole array, nx % 4 == 0, 3 / 5 / 7 / 9 taps that fit every axis)?"""
+    """can lsf_convolve_xyz run this 3-D filter (nx % 4 == 0, 3 / 5 / 7 / 9 taps that fit every axis)?"""
     n = len(taps)
-    return (grid.dims == 3 and n in XYZ_TAP_COUNTS and grid.nx % 4 == 0 and grid.z_begin == 0
-            and grid.z_end == grid.nz and min(grid.nx, grid.ny, grid.nz) >= n
-            and ((grid.ny + 15) // 16) * ((grid.nz + 31) // 32) <= 65535)
+    return (grid.dims == 3 and n in XYZ_TAP_COUNTS and grid.nx % 4 == 0 and min(grid.nx, grid.ny, grid.nz) >= n
+            and ((grid.ny + 15) // 16) * ((grid.z_end - grid.z_begin + 31) // 32) <= 65535)
 
 
 def convolve_xyz(src, dst, grid, taps, gate=None, warp=None, rate=0.0):

@@ -290,7 +290,7 @@ class HierarchicalEngine:
             axes = _conv_axis_order(lv.dims)
             src = lv.S[0]
             moved = False
-            if (not slab and self.fused_filter and dev.n_voxels(lv.grid) >= self.fused_filter_min_voxels
+            if (self.fused_filter and dev.n_voxels(lv.grid) >= self.fused_filter_min_voxels
                     and dev.convolve_xyz_ok(lv.grid, self.gradient_kernel)):
                 # x, y, z in one launch, which also moves the warp by its filtered gradient, component by component
                 dev.convolve_xyz(src, out, lv.grid, self.gradient_kernel, gate, lv.warp, self.rate)

@@ -87,10 +87,11 @@ def test_argument_errors_are_reported_not_launched(pkg):
     assert L.lib.lsf_convolve_xyz(1, 2, None, 0.0, ctypes.byref(ok), 3, taps, 4, None, None) == -3
     assert L.lib.lsf_convolve_xyz(1, 1, None, 0.0, ctypes.byref(ok), 3, taps, 7, None, None) == -1    # in place
     assert L.lib.lsf_convolve_xyz(1, 2, 2, 0.1, ctypes.byref(ok), 3, taps, 7, None, None) == -1       # warp aliases out
-    bad_nx, bad_z, flat = L.Grid(3, 4, 8, 6, 0, 4, 0, 0), L.Grid(3, 4, 8, 8, 1, 4, 0, 0), L.Grid(2, 1, 8, 8, 0, 1, 0, 0)
+    bad_nx, flat = L.Grid(3, 4, 8, 6, 0, 4, 0, 0), L.Grid(2, 1, 8, 8, 0, 1, 0, 0)
     assert L.lib.lsf_convolve_xyz(1, 2, None, 0.0, ctypes.byref(bad_nx), 3, taps, 7, None, None) == -2
-    assert L.lib.lsf_convolve_xyz(1, 2, None, 0.0, ctypes.byref(bad_z), 3, taps, 7, None, None) == -2
     assert L.lib.lsf_convolve_xyz(1, 2, None, 0.0, ctypes.byref(flat), 2, taps, 7, None, None) == -2
+    assert L.lib.lsf_convolve_xyz(1, 2, None, 0.0, ctypes.byref(L.Grid(3, 4, 8, 8, 2, 2, 0, 0)), 3, taps, 7, None,
+                                  None) == 0                                                      # empty z-range
     # the band-only finalize: whole arrays, at most two lists, statistics need canonical + scratch
     lists = (ctypes.c_void_p * 2)(1, 1)
     counts = (ctypes.c_int64 * 2)(5, -1)

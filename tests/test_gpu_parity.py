@@ -644,6 +644,20 @@ def test_fused_xyz_filter_equals_three_passes(lsf):
             assert torch.equal(fused, a) and torch.equal(w_fused, w_ref)
             dec = dev.decode_records(dev.records_to_host(rec))
             assert dec["max_value"][0] == dec["max_value"][1] > 0 and dec["argmax"][0] == dec["argmax"][1]
+    # a z-range (what a z-slab filters: its owned slices, from raw input whose halo slices are valid): x and y passes on
+    # every slice, the z pass on the range; slices outside the range are not written
+    shape = (40, 18, 68)
+    src = torch.randn((3,) + shape, device="cuda", generator=gen)
+    taps = lsf.generate_1d_sobolev_kernel(7, 0.1)
+    whole, part = dev.make_grid(shape), dev.make_grid(shape, 5, 33, 11)
+    a, b = torch.empty_like(src), torch.empty_like(src)
+    dev.convolve_axis(src, a, None, whole, 0, taps)
+    dev.convolve_axis(a, b, None, whole, 1, taps)
+    want = torch.full_like(src, 7.0)
+    dev.convolve_axis(b, want, None, part, 2, taps)
+    fused = torch.full_like(src, 7.0)
+    dev.convolve_xyz(src, fused, part, taps)
+    assert torch.equal(fused, want) and float(fused[:, :5].min()) == 7.0 and float(fused[:, 33:].max()) == 7.0
     assert not dev.convolve_xyz_ok(dev.make_grid((16, 16, 18)), np.ones(7))   # nx % 4
     assert not dev.convolve_xyz_ok(dev.make_grid((16, 16, 16)), np.ones(4))   # even tap count
     assert not dev.convolve_xyz_ok(dev.make_grid((4, 16, 16)), np.ones(7))    # shorter than the kernel

@@ -107,10 +107,13 @@ def _hier_worker(rank, world, port, n, nz, halo, kwargs, out_dir):
     layout = SlabLayout(nz, rank, world, halo)
     sl = layout.local_slice()
     canonical, live = sphere_pair(n, 3, "cuda", (sl.start, sl.stop))
+    fused_filter = kwargs.pop("force_fused_filter", False)
     opt = lsf.HierarchicalOptimizer3d(
         comm=SlabComm(layout),
         logging_parameters=lsf.HierarchicalOptimizer3d.LoggingParameters(collect_per_level_convergence_reports=True),
         **kwargs)
+    if fused_filter:  # every level filters with lsf_convolve_xyz on its owned z-range (default: levels of >= 2^23 voxels)
+        opt._engine.fused_filter_min_voxels = 0
     warp = opt.optimize(canonical, live)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), warp=warp.cpu().numpy(),
              counts=np.int64(opt.get_per_level_iteration_counts()),
@@ -119,8 +122,8 @@ def _hier_worker(rank, world, port, n, nz, halo, kwargs, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("config", ["tikhonov_fixed", "tikhonov_kernel_fixed", "data_threshold", "linear_halo4",
-                                    "linear_halo2"])
+@pytest.mark.parametrize("config", ["tikhonov_fixed", "tikhonov_kernel_fixed", "tikhonov_kernel_fused", "data_threshold",
+                                    "linear_halo4", "linear_halo2"])
 def test_two_slab_ranks_hierarchical_equal_whole_volume(tmp_path, config):
     """HierarchicalOptimizer3d on two z-slabs (per-level halos, gradient halo exchange, global gate) == whole volume;
     linear_*: ResamplingStrategy.LINEAR (windows of the restriction and the prolongation reach into the halos)"""
@@ -139,7 +142,7 @@ def test_two_slab_ranks_hierarchical_equal_whole_volume(tmp_path, config):
     elif config == "tikhonov_fixed":
         kwargs.update(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_iteration_count=5,
                       maximum_warp_update_threshold=0.0)
-    elif config == "tikhonov_kernel_fixed":
+    elif config in ("tikhonov_kernel_fixed", "tikhonov_kernel_fused"):
         kwargs.update(tikhonov_term_enabled=True, gradient_kernel_enabled=True,
                       kernel=lsf.generate_1d_sobolev_kernel(7, 0.1), maximum_iteration_count=4,
                       maximum_warp_update_threshold=0.0)
@@ -152,7 +155,8 @@ def test_two_slab_ranks_hierarchical_equal_whole_volume(tmp_path, config):
         trajectory = probe.get_per_level_maximum_updates()[0]
         assert trajectory[12] < trajectory[2]
         kwargs["maximum_warp_update_threshold"] = float(0.5 * (trajectory[11] + trajectory[12]))
-    mp.spawn(_hier_worker, args=(world, _free_port(), n, nz, halo, kwargs, str(tmp_path)), nprocs=world, join=True)
+    worker_kwargs = dict(kwargs, force_fused_filter=True) if config == "tikhonov_kernel_fused" else kwargs
+    mp.spawn(_hier_worker, args=(world, _free_port(), n, nz, halo, worker_kwargs, str(tmp_path)), nprocs=world, join=True)
     canonical, live = sphere_pair(n, 3, "cuda", (0, nz))
     ref = lsf.HierarchicalOptimizer3d(
         logging_parameters=lsf.HierarchicalOptimizer3d.LoggingParameters(collect_per_level_convergence_reports=True),
