@@ -169,12 +169,14 @@ class LsfHipError(RuntimeError):
 
 
 def _load():
-    if not os.path.exists(LIB_PATH):
+    # LSF_HIP_LIBRARY: another build of the SAME HIP library (A/B measurements of kernel variants, tools/ab_state_kernel.py)
+    path = os.environ.get("LSF_HIP_LIBRARY") or LIB_PATH
+    if not os.path.exists(path):
         raise ImportError(
             "liblsf_hip.so is missing (%s).  This package has no CPU fallback: build the HIP library first with\n"
             "    python -c 'import __graft_entry__ as g; g.build()'      (needs hipcc, cross-compiles gfx950)"
-            % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            % path)
+    lib = ctypes.CDLL(path)
     for name, (restype, argtypes) in PROTOTYPES.items():
         if argtypes is None:
             continue

@@ -13,6 +13,8 @@ namespace lsf {
 
 constexpr int kWave = 64;
 constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
+constexpr int kCuBlock = 1024;       // 16 waves: a CU's whole complement at <= 128 VGPRs (see wave_list_walk)
+constexpr int kMaxBlockWaves = kCuBlock / kWave;
 
 // n / d for n < 2^31 by multiply-high and shift (Granlund & Montgomery): the tile walk decomposes a tile number per
 // tile and per wave, and the compiler's expansion of a 32-bit division by a run-time divisor is ~30 instructions each
@@ -226,6 +228,52 @@ __device__ inline ListWalk list_walk(unsigned count) {
     return w;
 }
 
+// The list walk of the fused state kernel: ONE 1024-thread workgroup per CU.  A workgroup of 256 threads at ~126 VGPRs
+// leaves room for four per CU, and a grid of "as many as fit" (928 for the 256^3 sphere pair: every block the same
+// seven 256-entry units) is dealt 4 to some CUs and 3 to others -- measured with in-kernel clocks
+// (tools/state_trace.py): the waves of the full CUs took 32 us, the others 18-21 us, and the launch ends with the
+// slowest.  A CU-sized workgroup cannot be co-scheduled with another, so each of the 256 CUs gets exactly one and an
+// equal share of the list: XCD k owns the k-th eighth (a contiguous z-range, its own L2), the CU's workgroup a
+// contiguous 1/32 of that, and its 16 waves interleave over the share in 64-entry wave-units -- the four waves of a
+// SIMD share its issue slots, so waves that end a unit early leave them to the others.  Sixteen consecutive
+// wave-units are ~1000 consecutive list entries (short x-runs of adjacent rows), whose stencils overlap in the CU's L1.
+struct WaveWalk {
+    unsigned first, step, end;  // wave-units of 64 entries
+};
+
+__device__ inline WaveWalk wave_list_walk(unsigned count) {
+    const unsigned units = (count + kWave - 1) / kWave;
+    const unsigned nb = gridDim.x, bid = blockIdx.x;
+    unsigned begin, end;
+    if (nb % kXcds == 0) {
+        const unsigned per_xcd = (units + kXcds - 1) / kXcds, xcd = bid % kXcds, cus = nb / kXcds;
+        const unsigned x_begin = xcd * per_xcd;
+        const unsigned x_end = x_begin + per_xcd < units ? x_begin + per_xcd : units;
+        const unsigned per_cu = (per_xcd + cus - 1) / cus;
+        begin = x_begin + (bid / kXcds) * per_cu;
+        end = begin + per_cu < x_end ? begin + per_cu : x_end;
+    } else {
+        const unsigned per = (units + nb - 1) / nb;
+        begin = bid * per;
+        end = begin + per < units ? begin + per : units;
+    }
+    WaveWalk w;
+    w.first = begin + threadIdx.x / kWave;
+    w.step = blockDim.x / kWave;
+    w.end = end;
+    return w;
+}
+
+// grid of a wave_list_walk: one kCuBlock workgroup per CU, fewer for short lists (a wave-unit per wave at least)
+__host__ inline unsigned cu_list_blocks(unsigned count, unsigned cus) {
+    const unsigned units = (count + kWave - 1) / kWave;
+    unsigned blocks = (units + kMaxBlockWaves - 1) / kMaxBlockWaves;
+    if (blocks < 1) blocks = 1;
+    if (blocks > cus) blocks = cus;
+    if (blocks > kXcds) blocks -= blocks % kXcds;
+    return blocks;
+}
+
 template <class F>
 __device__ inline void for_each_listed_voxel(const Grid& g, const int* __restrict__ list, unsigned count, F&& f) {
     const bool listed = list != nullptr;
@@ -424,8 +472,8 @@ __device__ inline float unpack_max_value(unsigned long long packed) { return __u
 template <int NS>
 __device__ inline void block_reduce_commit(unsigned long long packed, const double (&sums)[NS > 0 ? NS : 1],
                                            unsigned long long* dst_max, double* const (&dst_sum)[NS > 0 ? NS : 1]) {
-    __shared__ unsigned long long s_max[kBlock / kWave];
-    __shared__ double s_sum[(NS > 0 ? NS : 1)][kBlock / kWave];
+    __shared__ unsigned long long s_max[kMaxBlockWaves];
+    __shared__ double s_sum[(NS > 0 ? NS : 1)][kMaxBlockWaves];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
     const int n_waves = blockDim.x / kWave;
     unsigned long long m = wave_max_u64(packed);
@@ -440,13 +488,11 @@ __device__ inline void block_reduce_commit(unsigned long long packed, const doub
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned long long mm = s_max[0];
-#pragma unroll
         for (int w = 1; w < n_waves; ++w) mm = s_max[w] > mm ? s_max[w] : mm;
         if (dst_max && mm != 0ull) atomicMax(dst_max, mm);
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             double t = 0.0;
-#pragma unroll
             for (int w = 0; w < n_waves; ++w) t += s_sum[i][w];
             if (dst_sum[i] && t != 0.0) atomicAdd(dst_sum[i], t);
         }

@@ -190,24 +190,27 @@ __device__ inline void killing_gradient(const NB& n, const typename NB::Field (&
     }
     if (want_energy) {
         // sum_ic J_ic^2 + lambda * sum_ic J_ic J_ci  =  |J|_F^2 + lambda * (sum_i J_ii^2 + 2 sum_{i<c} J_ic J_ci),
-        // J_ic = d w_i / d c, in float64 with fused multiply-adds: energies are sums the tests compare to 1e-9, not bit
-        // for bit (their accumulation order varies with the launch anyway), and the float64 energy math was 16 % of this
-        // kernel's time in the term-by-term form
-        double j[3][3];
+        // J_ic = d w_i / d c.  The local contribution is formed in float32 like the reference's
+        // (smoothing_term.py:93-98: float32 dot products of the float32 Jacobian) and widened for the sum only: the
+        // float64 form of these products was 16 % of the fused kernel's time.  Order: oracle.killing_gradient.
+        float sq[3][3];
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
-            for (int c = 0; c < D; ++c) j[i][c] = (double)first[c][i];
-        double frob = 0.0, diag = 0.0, off = 0.0;
+            for (int c = 0; c < D; ++c) sq[i][c] = first[c][i] * first[c][i];
+        float frob = sq[0][0], diag = sq[0][0], off = 0.0f;
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
             for (int c = 0; c < D; ++c) {
-                frob = fma(j[i][c], j[i][c], frob);
-                if (c == i) diag = fma(j[i][i], j[i][i], diag);
-                if (c > i) off = fma(j[i][c], j[c][i], off);
+                if (i + c > 0) frob = frob + sq[i][c];
+                if (c == i && i > 0) diag = diag + sq[i][i];
+                if (c > i) {
+                    const float t = first[c][i] * first[i][c];
+                    off = (i == 0 && c == 1) ? t : off + t;
+                }
             }
-        energy = fma(p.lambda64, diag + (off + off), frob);
+        energy = (double)(frob + p.lambda32 * (diag + (off + off)));
     }
 }
 
@@ -251,8 +254,8 @@ __device__ inline void level_set_gradient(const NB& n, const typename NB::Field&
         for (int j = 1; j < D; ++j) hv = hv + hess[i][j] * grad[j];
         gl[i] = coef * hv;
     }
-    const double dn = (double)nrm - 1.0;
-    energy = 0.5 * dn * dn;
+    const float dn = nrm - 1.0f;  // level_set_term.py:63, float32 like the gradient length it is formed from
+    energy = (double)(0.5f * (dn * dn));
 }
 
 // gradient of the energy at one voxel of the narrow-band union (a12-a17); NB = Nbh<D> or NbhFast<D>
@@ -285,7 +288,7 @@ __device__ inline void band_voxel_gradient(const NB& n, const Params& p, float l
     }
 #pragma unroll
     for (int c = 0; c < D; ++c) gv[c] = p.w_data * ((diff * lg[c]) * 10.0f);
-    if (ENERGY != LSF_ENERGY_NONE) en[0] = 0.5 * (double)diff * (double)diff;
+    if (ENERGY != LSF_ENERGY_NONE) en[0] = (double)(0.5f * (diff * diff));  // data_term.py:185, float32
     // ---- level-set term (DIRECT only; skipped where live is truncated, slavcheva_optimizer2d.py:274)
     if (LEVELSET && !live_truncated) {
         float lm1[3], lp1[3];
@@ -322,28 +325,27 @@ __device__ inline void band_voxel_gradient(const NB& n, const Params& p, float l
         tikhonov_gradient<D>(wm, wp, wc, gs);
         if (ENERGY == LSF_ENERGY_DIRECT) {
             // smoothing_term.py:134-139: 0.5 * sum_axis |0.5 (w[+1] - w[-1])|^2, OOB -> centre
-            double e = 0.0;
+            float e = 0.0f;
 #pragma unroll
             for (int a = 0; a < D; ++a)
 #pragma unroll
                 for (int c = 0; c < D; ++c) {
                     const float der = 0.5f * (wp[a][c] - wm[a][c]);
-                    e += (double)der * (double)der;
+                    e = (a + c == 0) ? der * der : e + der * der;
                 }
-            en[1] = 0.5 * e;
+            en[1] = (double)(0.5f * e);
         } else if (ENERGY == LSF_ENERGY_VECTORIZED) {
             // smoothing_term.py:162-177: 0.5 * sum_{c,axis} np.gradient(warp_c)[axis]^2 over the band.
-            // accumulation order (per component: x, y, z) as in oracle.smoothing_energy_vectorized is irrelevant
-            // to the float64 sum at the 1e-9 level the tests ask for
-            double e = 0.0;
+            // float32 per voxel in oracle.smoothing_energy_vectorized's order (per component: x, y, z)
+            float e = 0.0f;
 #pragma unroll
             for (int c = 0; c < D; ++c)
 #pragma unroll
                 for (int a = 0; a < D; ++a) {
                     const float d = np_gradient_from(n, a, wm[a][c], wp[a][c]);
-                    e += (double)d * (double)d;
+                    e = (a + c == 0) ? d * d : e + d * d;
                 }
-            en[1] = 0.5 * e;
+            en[1] = (double)(0.5f * e);
         }
     }
 #pragma unroll

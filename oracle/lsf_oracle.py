@@ -461,20 +461,23 @@ def tikhonov_gradient(warp):
 def tikhonov_energy_direct(warp):
     """smoothing_term.py:134-139 per voxel: 0.5*(|w_x|^2 + |w_y|^2 [+ |w_z|^2]), central diffs, OOB->centre."""
     d = warp.ndim - 1
-    e = np.zeros(warp.shape[:-1], dtype=np.float64)
-    for axis in range(d):
+    e = None  # float32 per voxel (the reference's local contributions are float32 scalars); x, y, z axis order
+    for axis in range(d - 1, -1, -1):
         der = (F32(0.5) * (_shift(warp, axis, 1, 'centre') - _shift(warp, axis, -1, 'centre'))).astype(F32)
-        e += (der.astype(np.float64) ** 2).sum(axis=-1)
-    return 0.5 * e
+        for c in range(d):
+            sq = (der[..., c] * der[..., c]).astype(F32)
+            e = sq if e is None else (e + sq).astype(F32)
+    return (F32(0.5) * e).astype(F32)
 
 
 def smoothing_energy_vectorized(warp, band):
     """smoothing_term.py:162-177: 0.5 * sum over band of sum_{c,axis} np.gradient(warp_c)[axis]^2."""
-    agg = np.zeros(warp.shape[:-1], dtype=np.float64)
+    agg = None  # float32 per voxel, float64 sum over the band (per component: x, y, z)
     for c in range(warp.shape[-1]):
         for g in gradient(np.ascontiguousarray(warp[..., c])):
-            agg += g.astype(np.float64) ** 2
-    return 0.5 * float(agg[band].sum())
+            sq = (g * g).astype(F32)
+            agg = sq if agg is None else (agg + sq).astype(F32)
+    return float((F32(0.5) * agg).astype(F32)[band].astype(np.float64).sum())
 
 
 def killing_gradient(warp, lam):
@@ -520,12 +523,19 @@ def killing_gradient(warp, lam):
         comps.append(g)
     grad = np.stack(comps, axis=-1)
     # energy  vecJ.vecJ + lam * (vecJ^T . vecJ)   (smoothing_term.py:93-98), J[i][c] = d u_i / d c
-    e = np.zeros(warp.shape[:-1], dtype=np.float64)
+    # float32 per voxel, like the reference's float32 dot products; written as
+    # |J|_F^2 + lam * (sum_i J_ii^2 + 2 sum_{i<c} J_ic J_ci) with every sum in (i, c) order
+    frob = diag = off = None
     for i in range(d):
         for c in range(d):
-            jic = first[c][..., i].astype(np.float64)
-            jci = first[i][..., c].astype(np.float64)
-            e += jic * jic + lam * jic * jci
+            sq = (first[c][..., i] * first[c][..., i]).astype(F32)
+            frob = sq if frob is None else (frob + sq).astype(F32)
+            if c == i:
+                diag = sq if diag is None else (diag + sq).astype(F32)
+            if c > i:
+                t = (first[c][..., i] * first[i][..., c]).astype(F32)
+                off = t if off is None else (off + t).astype(F32)
+    e = (frob + (lam32 * (diag + (off + off).astype(F32)).astype(F32)).astype(F32)).astype(F32)
     return grad, e
 
 
@@ -567,7 +577,8 @@ def level_set_gradient(live):
         for j in range(1, d):
             hv = (hv + hess[(i, j)] * grad[j]).astype(F32)
         comps.append((coef * hv).astype(F32))
-    energy = 0.5 * (n.astype(np.float64) - 1.0) ** 2
+    dn = (n - one).astype(F32)
+    energy = (F32(0.5) * (dn * dn).astype(F32)).astype(F32)  # float32 per voxel (level_set_term.py:63)
     return np.stack(comps, axis=-1), energy
 
 
@@ -607,7 +618,9 @@ class SlavchevaOracle:
         band = ~(is_truncated(live) & is_truncated(canonical))
         method = self.data_term_method if direct else BASIC
         gd, diff = data_term_gradient(live, canonical, method)
-        e_data = self.data_term_weight * 0.5 * float((diff.astype(np.float64)[band] ** 2).sum())
+        # local contributions are float32 (data_term.py:185), their sum float64
+        e_data = self.data_term_weight * float((F32(0.5) * (diff * diff).astype(F32)).astype(F32)[band]
+                                               .astype(np.float64).sum())
         g = (F32(self.data_term_weight) * gd).astype(F32)
         e_ls = 0.0
         if direct and self.level_set_term_enabled:
@@ -615,14 +628,14 @@ class SlavchevaOracle:
             active = band & ~is_truncated(live)
             gl[~active] = 0.0
             g = (g + (F32(self.level_set_term_weight) * gl).astype(F32)).astype(F32)
-            e_ls = self.level_set_term_weight * float(el[active].sum())
+            e_ls = self.level_set_term_weight * float(el[active].astype(np.float64).sum())
         if direct and self.smoothing_term_method == KILLING:
             gs, es = killing_gradient(warp, self.isomorphic_enforcement_factor)
-            e_smooth = self.smoothing_term_weight * float(es[band].sum())
+            e_smooth = self.smoothing_term_weight * float(es[band].astype(np.float64).sum())
         else:
             gs = tikhonov_gradient(warp)
             if direct:
-                e_smooth = self.smoothing_term_weight * float(tikhonov_energy_direct(warp)[band].sum())
+                e_smooth = self.smoothing_term_weight * float(tikhonov_energy_direct(warp)[band].astype(np.float64).sum())
             else:
                 e_smooth = self.smoothing_term_weight * smoothing_energy_vectorized(warp, band)
         g = (g + (F32(self.smoothing_term_weight) * gs).astype(F32)).astype(F32)

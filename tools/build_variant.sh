@@ -1,0 +1,27 @@
+#!/bin/bash
+# builds a variant of liblsf_hip.so for A/B measurements: tools/build_variant.sh NAME [git-rev | -] [extra hipcc flags...]
+#   git-rev: take csrc/ and include/ from that revision instead of the working tree ("-" = working tree)
+# output: levelsetfusion-python_amd/lib/variants/NAME.so   (use with LSF_HIP_LIBRARY=...)
+set -eu
+R=$(cd "$(dirname "$0")/.." && pwd)
+NAME=$1; REV=${2:--}; shift; shift || true
+OUT=$R/levelsetfusion-python_amd/lib/variants
+mkdir -p $OUT
+W=$(mktemp -d)
+if [ "$REV" = "-" ]; then
+  mkdir -p $W/levelsetfusion-python_amd $W/include
+  cp -r $R/levelsetfusion-python_amd/csrc $W/levelsetfusion-python_amd/
+  cp $R/include/*.h $W/include/
+else
+  (cd $R && git archive $REV levelsetfusion-python_amd/csrc include) | tar -x -C $W
+fi
+OBJS=""
+for f in $W/levelsetfusion-python_amd/csrc/*.hip; do
+  o=$W/$(basename $f .hip).o
+  hipcc -O3 --offload-arch=gfx950 -fPIC -ffp-contract=off -std=c++17 -Wno-unused-function "$@" -c $f -o $o &
+  OBJS="$OBJS $o"
+done
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/$NAME.so $OBJS -ldl
+rm -rf $W
+echo $OUT/$NAME.so
