@@ -44,6 +44,7 @@ struct Grid {
     int fast_ok;           // 32-bit buffer addressing is possible: 3 planes of a vector field stay below 4 GiB
     int wide_ok;           // float4 state kernels: a wave's neighbourhoods may be addressed relative to its first lane
     int e_begin, e_end;    // slices whose energies count (lsf_grid::energy_z_begin / _end; default: all)
+    unsigned list_group;   // wave-units per group of the fused kernel's list walk (wave_list_walk)
 };
 
 __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
@@ -76,6 +77,7 @@ __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
     const bool limited = g->energy_z_end > g->energy_z_begin;
     r.e_begin = limited ? g->energy_z_begin : 0;
     r.e_end = limited ? g->energy_z_end : g->nz;
+    r.list_group = 4u;
     return r;
 }
 
@@ -232,35 +234,41 @@ __device__ inline ListWalk list_walk(unsigned count) {
 // leaves room for four per CU, and a grid of "as many as fit" (928 for the 256^3 sphere pair: every block the same
 // seven 256-entry units) is dealt 4 to some CUs and 3 to others -- measured with in-kernel clocks
 // (tools/state_trace.py): the waves of the full CUs took 32 us, the others 18-21 us, and the launch ends with the
-// slowest.  A CU-sized workgroup cannot be co-scheduled with another, so each of the 256 CUs gets exactly one and an
-// equal share of the list: XCD k owns the k-th eighth (a contiguous z-range, its own L2), the CU's workgroup a
-// contiguous 1/32 of that, and its 16 waves interleave over the share in 64-entry wave-units -- the four waves of a
-// SIMD share its issue slots, so waves that end a unit early leave them to the others.  Sixteen consecutive
-// wave-units are ~1000 consecutive list entries (short x-runs of adjacent rows), whose stencils overlap in the CU's L1.
+// slowest.  A CU-sized workgroup cannot be co-scheduled with another, so each of the 256 CUs gets exactly one.
+// Work is numbered per workgroup: sequence number n = 0, 1, 2 ... -> wave-unit (64 consecutive list entries)
+//   x_begin + ((n / G) * cus + q) * G + n % G      (G = Grid::list_group, q = the workgroup's rank in its XCD)
+// i.e. XCD k owns the k-th eighth of the list (a contiguous z-range, its own L2), and the `cus` workgroups of an XCD
+// sweep through that eighth TOGETHER in groups of G wave-units dealt round-robin: what one CU reads as the z -/+ 1
+// rows of its voxels, a neighbouring CU reads or writes as centre rows at about the same time, so those rows are
+// served by the XCD's 4 MB L2 instead of the memory side (at 512^3 one slice of band voxels is ~0.5 MB of state; 32 CUs
+// on 32 separate z-ranges cycle through 50 MB).  The G wave-units of a group are consecutive list entries (short
+// x-runs of adjacent rows) whose stencils overlap in the CU's L1.  The waves of a workgroup take sequence numbers
+// as they come free (see the kernel): the SIMD issues oldest-wave-first, so a static deal leaves the last waves behind.
 struct WaveWalk {
-    unsigned first, step, end;  // wave-units of 64 entries
+    unsigned x_begin, x_end, q, cus, group;  // wave-units of 64 entries
+    __device__ inline unsigned unit(unsigned n) const {
+        const unsigned g = n / group;
+        return x_begin + (g * cus + q) * group + (n - g * group);
+    }
 };
 
-__device__ inline WaveWalk wave_list_walk(unsigned count) {
+__device__ inline WaveWalk wave_list_walk(unsigned count, unsigned group) {
     const unsigned units = (count + kWave - 1) / kWave;
     const unsigned nb = gridDim.x, bid = blockIdx.x;
-    unsigned begin, end;
-    if (nb % kXcds == 0) {
-        const unsigned per_xcd = (units + kXcds - 1) / kXcds, xcd = bid % kXcds, cus = nb / kXcds;
-        const unsigned x_begin = xcd * per_xcd;
-        const unsigned x_end = x_begin + per_xcd < units ? x_begin + per_xcd : units;
-        const unsigned per_cu = (per_xcd + cus - 1) / cus;
-        begin = x_begin + (bid / kXcds) * per_cu;
-        end = begin + per_cu < x_end ? begin + per_cu : x_end;
-    } else {
-        const unsigned per = (units + nb - 1) / nb;
-        begin = bid * per;
-        end = begin + per < units ? begin + per : units;
-    }
     WaveWalk w;
-    w.first = begin + threadIdx.x / kWave;
-    w.step = blockDim.x / kWave;
-    w.end = end;
+    w.group = group;
+    if (nb % kXcds == 0) {
+        const unsigned per_xcd = (units + kXcds - 1) / kXcds, xcd = bid % kXcds;
+        w.cus = nb / kXcds;
+        w.q = bid / kXcds;
+        w.x_begin = xcd * per_xcd;
+        w.x_end = w.x_begin + per_xcd < units ? w.x_begin + per_xcd : units;
+    } else {
+        w.cus = nb;
+        w.q = bid;
+        w.x_begin = 0u;
+        w.x_end = units;
+    }
     return w;
 }
 

@@ -129,64 +129,10 @@ struct NbhStateFast : TapsBase<D> {
                         continue;
                     }
                     const unsigned soff = wave_base + (unsigned)(dy + 1) * sy + (D == 3 ? (unsigned)(dz + 1) * sz : 0u);
-#if defined(LSF_STATE_PROBE) && (LSF_STATE_PROBE == 1 || LSF_STATE_PROBE == 2 || LSF_STATE_PROBE == 5)  // measurement only, WRONG results
-                    if (dx != 0) continue;
-#endif
-#if defined(LSF_STATE_PROBE) && LSF_STATE_PROBE == 3  // measurement only, WRONG results: 64-byte aligned quads
-                    this->t[dz + 1][dy + 1][dx + 1] = __builtin_bit_cast(
-                        vf4, __builtin_amdgcn_raw_buffer_load_b128(
-                                 rsrc, (int)(((lane_delta + 16u) & ~63u) + (threadIdx.x & 3u) * 16u), (int)soff, 0));
-                    continue;
-#endif
                     this->t[dz + 1][dy + 1][dx + 1] = __builtin_bit_cast(
                         vf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane_delta + (unsigned)(dx + 1) * 16u),
                                                                    (int)soff, 0));
                 }
-#if defined(LSF_STATE_PROBE) && LSF_STATE_PROBE == 5  // x -/+ 1 taps through LDS from the neighbouring lanes (WRONG at run ends)
-        {
-            __shared__ vf4 probe_rows[kMaxBlockWaves][2][kWave];
-            const unsigned wave = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1);
-            int r = 0;
-#pragma unroll
-            for (int dz = -1; dz <= 1; ++dz)
-#pragma unroll
-                for (int dy = -1; dy <= 1; ++dy) {
-                    if (dz != 0 && dy != 0) continue;
-                    vf4* row = probe_rows[wave][r & 1];
-                    ++r;
-                    row[lane] = this->t[dz + 1][dy + 1][1];
-                    __builtin_amdgcn_wave_barrier();
-                    this->t[dz + 1][dy + 1][0] = row[(lane + 63u) & 63u];
-                    this->t[dz + 1][dy + 1][2] = row[(lane + 1u) & 63u];
-                    __builtin_amdgcn_wave_barrier();
-                }
-        }
-#endif
-#if defined(LSF_STATE_PROBE) && (LSF_STATE_PROBE == 1 || LSF_STATE_PROBE == 2)
-#pragma unroll
-        for (int dz = -1; dz <= 1; ++dz)
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                if (dz != 0 && dy != 0) continue;
-                this->t[dz + 1][dy + 1][0] = this->t[dz + 1][dy + 1][1];
-                this->t[dz + 1][dy + 1][2] = this->t[dz + 1][dy + 1][1];
-            }
-#if LSF_STATE_PROBE == 2  // the cost of exec-masked fix-up loads: three lanes in 64 fetch their x -/+ 1 taps
-        if ((threadIdx.x & 63u) % 21u == 0u) {
-#pragma unroll
-            for (int dz = -1; dz <= 1; ++dz)
-#pragma unroll
-                for (int dy = -1; dy <= 1; ++dy) {
-                    if (dz != 0 && dy != 0) continue;
-                    const unsigned soff = wave_base + (unsigned)(dy + 1) * sy + (unsigned)(dz + 1) * sz;
-                    this->t[dz + 1][dy + 1][0] = __builtin_bit_cast(
-                        vf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_delta, (int)soff, 0));
-                    this->t[dz + 1][dy + 1][2] = __builtin_bit_cast(
-                        vf4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(lane_delta + 32u), (int)soff, 0));
-                }
-        }
-#endif
-#endif
     }
     __device__ static constexpr bool exists(int, int) { return true; }
     __device__ static constexpr bool diag_exists(int, int, int, int) { return true; }
@@ -507,7 +453,12 @@ struct Deferred {
 };
 
 template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, int WALK>
-__global__ __launch_bounds__(WALK == kWalkListInterior ? kCuBlock : kBlock) void slavcheva_state_kernel(const vf4* __restrict__ state_in,
+__global__ __launch_bounds__(WALK == kWalkListInterior ? kCuBlock : kBlock)
+// <= 128 VGPRs for the dense walk (at 132 = 3 waves per SIMD it streamed 20 % slower) and the CU-sized workgroups; the
+// general list walk (voxels on a face, arrays of 4 GiB and more) may take 3 waves' worth instead of spilling -- a list
+// walk runs as fast with 3 waves per SIMD as with 4 (measured with 768-thread workgroups)
+__attribute__((amdgpu_waves_per_eu(WALK == kWalkList ? 3 : 4, 4)))
+void slavcheva_state_kernel(const vf4* __restrict__ state_in,
                                                                  const float* __restrict__ canonical,
                                                                  vf4* __restrict__ state_out, Grid g, Params p,
                                                                  lsf_gate gate, lsf_iteration_record* record,
@@ -555,7 +506,8 @@ __global__ __launch_bounds__(WALK == kWalkListInterior ? kCuBlock : kBlock) void
             if (g.wide_ok && __all(interior) && wave_span_ok(g, i)) {
                 NbhStateFast<D> n;
                 n.load(state_in, g, (unsigned)i, sc, !g.fast_ok);
-                fast_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
+                // the scalar form of the terms: the packed one (INTERIOR lists) costs these walks registers they need
+                band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
                 float w_now[3] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
                 for (int c = 0; c < D; ++c) w_now[c] = (-gv[c]) * p.rate;
@@ -662,33 +614,34 @@ __global__ __launch_bounds__(WALK == kWalkListInterior ? kCuBlock : kBlock) void
         // (INTERIOR lists) a unit's far corner is consumed during the NEXT unit, so that a unit starts with its
         // neighbourhood loads and waits for memory once.  Lanes past the end of the list read its LAST entry (a valid,
         // listed voxel: their loads stay inside the array) and are not processed.
-        WaveWalk w = wave_list_walk(band_count);
-        if (band_count == 0u) w.first = w.end = 0u;  // nothing is read from an empty list
+        const WaveWalk w = wave_list_walk(band_count, g.list_group);
+        const unsigned waves = blockDim.x / kWave, wave = threadIdx.x / kWave;
         auto entry = [&](unsigned unit, bool& listed) {
             const unsigned k = unit * kWave + (threadIdx.x & (kWave - 1));
-            listed = unit < w.end && k < band_count;
+            listed = unit < w.x_end && k < band_count;
             return (unsigned)band_list[k < band_count ? k : band_count - 1u];
         };
-        // Units: the first two of a wave are fixed (w.first, w.first + w.step); INTERIOR lists deal the rest out of an
-        // LDS counter as waves come free -- the SIMD issues oldest-wave-first, so the first waves of a workgroup run
+        // Sequence numbers: the first two of a wave are fixed (wave, wave + waves); INTERIOR lists deal the rest out of
+        // an LDS counter as waves come free -- the SIMD issues oldest-wave-first, so the first waves of a workgroup run
         // ahead of the last ones (traced: 21 us against 27 us for the same six units) and would leave their CU idle early.
         __shared__ unsigned s_next_unit;
         if (WALK == kWalkListInterior) {
-            if (threadIdx.x == 0) s_next_unit = w.first + 2u * w.step;  // thread 0 is in wave 0: w.first = the share's begin
+            if (threadIdx.x == 0) s_next_unit = 2u * waves;
             __syncthreads();
         }
-        auto grab = [&](unsigned after) {
-            if (WALK != kWalkListInterior) return after + w.step;
+        unsigned n_last = wave + waves;
+        auto grab = [&]() {
+            if (WALK != kWalkListInterior) return w.unit(n_last += waves);
             unsigned v = 0u;
             if ((threadIdx.x & (kWave - 1)) == 0) v = atomicAdd(&s_next_unit, 1u);
-            return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+            return w.unit((unsigned)__builtin_amdgcn_readfirstlane((int)v));
         };
-        unsigned u = w.first, u1 = w.first + w.step, u2 = 0u;
+        unsigned u = band_count ? w.unit(wave) : w.x_end, u1 = w.unit(wave + waves), u2 = 0u;  // nothing is read from an empty list
         bool in0 = false, in1 = false, in2 = false;
         unsigned i0 = 0u, i1 = 0u;
         vf4 s0 = {0.0f, 0.0f, 0.0f, 0.0f};
         float c0 = 0.0f;
-        if (u < w.end) {
+        if (u < w.x_end) {
             i0 = entry(u, in0);
             i1 = entry(u1, in1);
             s0 = state_in[i0];
@@ -701,8 +654,8 @@ __global__ __launch_bounds__(WALK == kWalkListInterior ? kCuBlock : kBlock) void
             wave_row[4] = __builtin_readcyclecounter();
         }
 #endif
-        while (u < w.end) {
-            u2 = grab(u1);
+        while (u < w.x_end) {
+            u2 = grab();
             const vf4 s1 = state_in[i1];
             const float c1 = canonical[i1];
             const unsigned i2 = entry(u2, in2);
@@ -1234,6 +1187,12 @@ extern "C" int lsf_slavcheva_state_iteration(const float* state_in, const float*
         const int v = e ? atoi(e) : 0;
         return (v >= 64 && v <= kCuBlock && v % 64 == 0) ? (unsigned)v : (unsigned)kCuBlock;
     }();
+    static const unsigned list_group = [] {  // measurement knob: wave-units per group of the list walk
+        const char* e = getenv("LSF_LIST_GROUP");
+        const int v = e ? atoi(e) : 0;
+        return v > 0 ? (unsigned)v : 0u;
+    }();
+    if (list_group) g.list_group = list_group;
     LaunchArgs a{blocks, all_interior ? list_threads : (unsigned)(kTileX * tile_y), as_stream(stream), reinterpret_cast<const vf4*>(state_in), canonical,
                  reinterpret_cast<vf4*>(state_out), g, make_params(params), gate_or_open(gate), record, band_list,
                  (unsigned)band_count};
