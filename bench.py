@@ -38,7 +38,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", type=int, default=256, help="edge of the per-GPU volume (256 = BASELINE config 4)")
+    ap.add_argument("--size", type=int, default=None,
+                    help="edge of the per-GPU volume (default 256 = BASELINE config 4; multiframe: 512 = config 5)")
     ap.add_argument("--iterations", type=int, default=50)
     ap.add_argument("--halo", type=int, default=8,
                     help="halo slices per interior slab face = iterations per exchange group: the faces travel every "
@@ -50,17 +51,25 @@ def parse():
     ap.add_argument("--share-device", action="store_true",
                     help="all ranks use cuda:0 (test rigs only; requires --backend gloo)")
     ap.add_argument("--workload", default="killing",
-                    choices=["killing", "sobolev", "hier-tik", "hier-full"],
-                    help="killing = BASELINE config 4 (default, the metric's configuration); the others are extra "
-                         "single-GPU measurements: SobolevFusion-style Slavcheva, hierarchical Tikhonov-only, "
-                         "hierarchical Tikhonov + 7-tap kernel")
+                    choices=["killing", "sobolev", "hier-tik", "hier-full", "multiframe"],
+                    help="killing = BASELINE config 4 (default, the metric's configuration); multiframe = BASELINE "
+                         "config 5 (--frames synthetic 512^3 frames, consecutive frames as pairs, hierarchical "
+                         "Tikhonov + 7-tap kernel); the others are extra single-GPU measurements: SobolevFusion-style "
+                         "Slavcheva, hierarchical Tikhonov-only, hierarchical Tikhonov + 7-tap kernel")
+    ap.add_argument("--frames", type=int, default=8, help="multiframe: frames of the synthetic sequence")
+    ap.add_argument("--parallelism", default="replicas", choices=["replicas", "slab"],
+                    help="multiframe on N > 1 GPUs: every rank its own sequence (pairs are independent) or every pair "
+                         "z-slabbed over the ranks")
     ap.add_argument("--data", default="sphere", choices=["sphere", "depth"],
                     help="sphere: SURVEY 8(d)'s sphere pair (BASELINE's configuration, default); depth: two synthetic depth "
                          "frames -> TSDF volumes through the package's own generator (single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-size", type=int, default=128)
     ap.add_argument("--cpu-sample-iterations", type=int, default=24)
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.size is None:
+        args.size = 512 if args.workload == "multiframe" else 256
+    return args
 
 
 def cpu_baseline(size, iterations):
@@ -80,14 +89,74 @@ def cpu_baseline(size, iterations):
                 host_cpus=os.cpu_count(), host_affinity=len(os.sched_getaffinity(0)))
 
 
-def extra_workload(args, device):
-    """single-GPU measurements of the other iteration kernels at the same volume size (not the headline line)"""
+def cpu_baseline_hierarchical(size, iterations, full):
+    """the numpy oracle's HierarchicalOracle on one size^3 pair of the multi-frame sequence, same configuration"""
+    from oracle import lsf_oracle as O
+    canonical, live = O.sphere_frame(size, 0), O.sphere_frame(size, 1)
+    opt = O.HierarchicalOracle(tikhonov_term_enabled=True, gradient_kernel_enabled=full, maximum_chunk_size=8, rate=0.1,
+                               maximum_iteration_count=iterations, maximum_warp_update_threshold=0.0,
+                               tikhonov_strength=0.05, kernel=O.generate_1d_sobolev_kernel(7, 0.1) if full else None)
+    t0 = time.perf_counter()
+    opt.optimize(canonical, live)
+    dt = time.perf_counter() - t0
+    updates = iterations * sum((size >> k) ** 3 for k in range(4))
+    return dict(value=updates / dt, unit="voxel-warp-updates/s", cores=1, kind="port",
+                sample="one %d^3 pair of the sphere sequence, 4 levels x %d fixed iterations, Tikhonov%s, "
+                       "oracle/lsf_oracle.py (numpy, 1 thread), %.1f s" % (size, iterations,
+                                                                          " + 7-tap kernel" if full else "", dt),
+                host_cpus=os.cpu_count(), host_affinity=len(os.sched_getaffinity(0)))
+
+
+def timed_steps(step, args, fence, max_over_ranks=None):
+    """W untimed + K timed steps between fences (barrier + synchronize on both sides), cyclic GC parked as in main();
+    returns (sum of what step() returns over the timed steps, seconds)"""
+    for _ in range(args.warmup):
+        step()
+    gc.collect()
+    gc.freeze()  # keep torch's objects out of the cyclic collector's full passes
+    gc.disable()
+    fence()
+    t0 = time.perf_counter()
+    total = None
+    for _ in range(args.steps):
+        r = step()
+        total = r if total is None else tuple(a + b for a, b in zip(total, r))
+    fence()
+    elapsed = time.perf_counter() - t0
+    gc.enable()
+    if max_over_ranks is not None:
+        elapsed = max_over_ranks(elapsed)
+    return total, elapsed
+
+
+def extra_workload(args, device, world, rank, dist):
+    """the other iteration kernels: SobolevFusion-style Slavcheva, hierarchical Tikhonov (+ 7-tap kernel), and
+    BASELINE config 5 -- the multi-frame sequence (`multiframe`): F synthetic frames, frame k against k + 1 as
+    (canonical, live) (experiment/multiframe_experiment.py:186-233; pair loop run_hierarchical_optimizer3d_multipair.py:
+    403-432) through HierarchicalOptimizer3d with Tikhonov term + 7-tap gradient kernel, fixed iterations per level.
+    N > 1: `replicas` -- every rank optimizes the F - 1 pairs of a sequence of its own (pairs are independent; weak
+    scaling, no data-path collective) -- or `slab` -- ONE sequence, every pair z-slabbed over the ranks (halo exchange
+    per iteration over RCCL)."""
     import levelsetfusion_python_amd as lsf
-    from levelsetfusion_python_amd.synthetic import sphere_pair
+    from levelsetfusion_python_amd.synthetic import sphere_frame, sphere_pair
     n, iters = args.size, args.iterations
-    canonical, live0 = sphere_pair(n, 3, device)
     k7 = lsf.generate_1d_sobolev_kernel(7, 0.1)
+    extra = {}
+    comm = None
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(seconds):
+        t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if args.backend == "gloo" else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
     if args.workload == "sobolev":
+        canonical, live0 = sphere_pair(n, 3, device)
         opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT,
                                        sobolev_smoothing_enabled=True, sobolev_kernel=k7,
                                        maximum_warp_length_lower_threshold=0.0, max_iterations=iters,
@@ -97,46 +166,75 @@ def extra_workload(args, device):
         def step():
             live.copy_(live0)
             opt.optimize(live, canonical)
-            return iters * n ** 3
-        b_alg, name = 76, "3D %d^3 SobolevFusion-style SlavchevaOptimizer3d (Tikhonov + 7-tap Sobolev), %d iterations"
+            band = opt._engine._sobolev_band
+            return iters * n ** 3, iters * (band.count if band is not None else n ** 3)
+        b_alg = 76
+        name = "3D %d^3 SobolevFusion-style SlavchevaOptimizer3d (Tikhonov + 7-tap Sobolev), %d iterations" % (n, iters)
+        note = "rate over the voxels the launches VISIT (the band list; the gradient is zero elsewhere and the " \
+               "zero-preserving filter keeps it there) x B_alg (76 B), all five kernels of the iteration together"
     else:
-        full = args.workload == "hier-full"
+        full = args.workload in ("hier-full", "multiframe")
         # tikhonov_strength 0.05: the reference's recurrence diverges for strength >= 1/12 in 3-D
+        slab = args.workload == "multiframe" and args.parallelism == "slab" and world > 1
+        if slab:
+            from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
+            layout = SlabLayout(n, rank, world, args.halo)
+            comm = SlabComm(layout)
         opt = lsf.HierarchicalOptimizer3d(tikhonov_term_enabled=True, gradient_kernel_enabled=full,
                                           maximum_chunk_size=8, rate=0.1, maximum_iteration_count=iters,
                                           maximum_warp_update_threshold=0.0, tikhonov_strength=0.05,
-                                          kernel=k7 if full else None, check_interval=iters)
-        levels = [(n >> k) ** 3 for k in range(4)]
+                                          kernel=k7 if full else None, check_interval=iters,
+                                          **(dict(comm=comm) if comm is not None else {}))
+        per_pair = iters * sum((n >> k) ** 3 for k in range(4))
+        if args.workload == "multiframe":
+            first = 0 if slab else rank * (args.frames - 1)  # replicas: a sequence of its own per rank
+            if slab:
+                sl = layout.local_slice()
+                frames = [sphere_frame(n, first + k, device)[sl].contiguous() for k in range(args.frames)]
+            else:
+                frames = [sphere_frame(n, first + k, device) for k in range(args.frames)]
 
-        def step():
-            opt.optimize(canonical, live0)
-            return iters * sum(levels)
+            def step():
+                for k in range(args.frames - 1):  # live_frame_index = canonical_frame_index + 1
+                    opt.optimize(frames[k], frames[k + 1])
+                done = (args.frames - 1) * per_pair
+                return (done // world, done // world) if slab else (done, done)
+            name = "3D %d^3 multi-frame sequence, %d frames (%d pairs per step), HierarchicalOptimizer3d: 4 levels, " \
+                   "Tikhonov + 7-tap kernel, %d fixed iterations per level" % (n, args.frames, args.frames - 1, iters)
+            extra["parallelism"] = "single GPU" if world == 1 else (
+                "z-slab x%d of every pair, halo %d" % (world, args.halo) if slab else
+                "replicas x%d: %d independent pairs per rank" % (world, args.frames - 1))
+        else:
+            canonical, live0 = sphere_pair(n, 3, device)
+
+            def step():
+                opt.optimize(canonical, live0)
+                return per_pair, per_pair
+            name = "3D %d^3 HierarchicalOptimizer3d, 4 levels, Tikhonov%s, %d iterations per level" % (
+                n, " + 7-tap kernel" if full else "", iters)
         b_alg = 104 if full else 68
-        name = "3D %d^3 HierarchicalOptimizer3d, 4 levels, Tikhonov" + (" + 7-tap kernel" if full else "") + \
-            ", %d iterations per level"
-    for _ in range(args.warmup):
-        step()
-    gc.collect()
-    gc.freeze()  # as in main(): keep torch's objects out of the cyclic collector's full passes
-    gc.disable()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    updates = 0
-    for _ in range(args.steps):
-        updates += step()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+        note = "whole-step rate x B_alg (%d B/voxel-update), all kernels of the iteration together" % b_alg
+    (updates, visited), elapsed = timed_steps(step, args, fence, max_over_ranks if world > 1 else None)
+    updates, visited = updates * world, visited * world
     value = updates / elapsed
-    achieved = value * b_alg / 1e9
-    print(json.dumps(dict(metric="voxel-warp-updates/sec", value=value, unit="voxel-warp-updates/s", n_gpus=1,
-                          steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
-                          higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-                          config=dict(workload=name % (n, iters)),
-                          roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                                        frac=achieved / HBM_PEAK_GBS, traffic=None,
-                                        note="whole-step rate x B_alg (%d B/voxel-update), all kernels of the "
-                                             "iteration together" % b_alg))), flush=True)
+    achieved = visited / elapsed * b_alg / 1e9 / world  # per GPU
+    out = dict(metric="voxel-warp-updates/sec", value=value, unit="voxel-warp-updates/s", n_gpus=world,
+               steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
+               higher_is_better=True, scaling="weak" if args.parallelism == "replicas" or world == 1 else "strong",
+               vs_baseline=None, dtype="f32", data="synthetic",
+               visited_voxel_updates_per_s=visited / elapsed, config=dict(workload=name, **extra),
+               roofline=dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=achieved / HBM_PEAK_GBS, traffic=None, note=note))
+    if visited != updates:
+        out["roofline"]["dense_equivalent_gbs"] = value * b_alg / 1e9 / world
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline and args.workload != "sobolev":
+            out["cpu_baseline"] = cpu_baseline_hierarchical(64, iters, args.workload != "hier-tik")
+        print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -162,9 +260,9 @@ def main():
             dist.init_process_group("gloo")
 
     if args.workload != "killing":
-        if world > 1:
+        if world > 1 and args.workload != "multiframe":
             raise SystemExit("--workload %s is a single-GPU measurement" % args.workload)
-        return extra_workload(args, device)
+        return extra_workload(args, device, world, rank, dist if world > 1 else None)
 
     import levelsetfusion_python_amd as lsf
     from levelsetfusion_python_amd import _lib, device as dev
@@ -196,21 +294,14 @@ def main():
     comm, opt = make_optimizer()
     live = torch.empty_like(live0)
     if world > 1 and comm.native() is not None:
-        # one call through the library's RCCL transport before anything is timed; if ANY rank's call reports an error
-        # every rank switches to the torch.distributed transport together (same schedule, more host work per iteration)
-        failed = torch.zeros(1, dtype=torch.int32, device="cpu" if args.backend == "gloo" else device)
-        try:
-            live.copy_(live0)
-            opt.optimize(live, canonical)
-            torch.cuda.synchronize()
-        except RuntimeError as exc:
-            sys.stderr.write("rank %d: native slab transport failed (%s)\n" % (rank, exc))
-            failed += 1
-        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
-        if int(failed.item()):
-            comm.close()
-            os.environ["LSF_SLAB_TRANSPORT"] = "torch"
-            comm, opt = make_optimizer()
+        # One call through the library's RCCL transport before anything is timed.  Whether the library transport is
+        # used at all was decided collectively while it was set up (SlabComm.native(): every rank falls back to
+        # torch.distributed together if any rank cannot bind RCCL).  A failure AFTER that is fatal: a rank whose call
+        # raises leaves its neighbours inside a device-side ncclRecv, so there is no collective left to agree on a
+        # fallback with -- the exception ends this process with a non-zero status and the launcher tears the job down.
+        live.copy_(live0)
+        opt.optimize(live, canonical)
+        torch.cuda.synchronize()
 
     def step():
         live.copy_(live0)  # a fresh pair every step (optimize() warps live in place)
@@ -281,14 +372,22 @@ def main():
                     traffic=traffic, kernel=kernel_name, kernel_ms=kernel_ms, units_per_launch=units,
                     algorithmic_bytes_per_launch=alg_bytes, voxels_per_launch=voxels_per_rank)
 
+    build_id = _lib.lib.lsf_build_id().decode()
+    traffic_source = {}
+
     def committed_traffic(key):
-        try:  # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md), default size only
+        """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md) -- only for the default
+        size AND only while the loaded library is the build the counters were collected on (lsf_build_id()): a kernel
+        change without a re-profile reports null, not stale bytes"""
+        try:
             with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
                 t = json.load(f)
-            if t.get("size") == n and t.get("workload") == "killing" and args.data == "sphere":
-                return t.get(key)
-        except (OSError, ValueError, KeyError):
-            pass
+        except (OSError, ValueError):
+            return None
+        traffic_source.update(tag=t.get("tag"), profiled_build_id=t.get("build_id"), loaded_build_id=build_id)
+        if t.get("size") == n and t.get("workload") == "killing" and args.data == "sphere" and \
+                t.get("build_id") == build_id:
+            return t.get(key)
         return None
 
     # Units one launch processes = the voxels it visits: the band list (every other voxel is provably unchanged and
@@ -317,6 +416,10 @@ def main():
                                if comm.native() is not None else "torch.distributed " + args.backend))
                            if world > 1 else "single GPU"),
                roofline=roofline)
+    roofline["traffic_source"] = traffic_source
+    # the rate over the voxels the launches actually visit (band lists): comparable across inputs and rounds, where
+    # `value` (field voxels, as the reference counts its work) grows with the share of the volume outside the band
+    out["visited_voxel_updates_per_s"] = roofline["units_per_launch"] * world * iters * args.steps / elapsed
     if roofline_dense is not None:
         out["roofline_dense_walk"] = roofline_dense
     if rank == 0:

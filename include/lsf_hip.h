@@ -97,6 +97,10 @@ typedef struct lsf_gate {
 int lsf_abi_version(void);
 /* name of the code object's target, e.g. "gfx950" */
 const char *lsf_target_arch(void);
+/* identity of the build: the first 16 hex digits of the SHA-256 over the library's sources (csrc/, include/), set by the
+ * build script; "unknown" when compiled by hand.  bench.py reports the committed rocprofv3 HBM-traffic figures only for
+ * the build they were measured on (profiles/traffic.json carries the id). */
+const char *lsf_build_id(void);
 
 /* ---- layout helpers (API edge only) ---------------------------------------------------------------- */
 /* [z][y][x][c] -> [c][z][y][x] and back; n_voxels = nz*ny*nx, channels = dims */

@@ -27,9 +27,28 @@ def sources():
     return [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
 
+def source_id():
+    """first 16 hex digits of the SHA-256 over the library's sources (names and contents, sorted): lsf_build_id()"""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted(sources() + [os.path.join(CSRC, x) for x in HEADERS]):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+ID_PATH = os.path.join(LIB_DIR, "build_id.txt")
+
+
 def is_stale():
     if not os.path.exists(LIB_PATH):
         return True
+    try:  # a snapshot copy may have fresh mtimes: the recorded id of the sources the library was built from decides
+        with open(ID_PATH) as f:
+            return f.read().strip() != source_id()
+    except OSError:
+        pass
     t = os.path.getmtime(LIB_PATH)
     deps = sources() + [os.path.join(CSRC, h) for h in HEADERS]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
@@ -42,9 +61,10 @@ def build(force=False, verbose=True):
     hipcc = find_hipcc()
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
+    build_id = source_id()
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src).replace(".hip", ".o"))
-        cmd = [hipcc] + HIPCC_FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + HIPCC_FLAGS + ['-DLSF_BUILD_ID="%s"' % build_id, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -53,6 +73,8 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(ID_PATH, "w") as f:
+        f.write(build_id + "\n")
     return LIB_PATH
 
 

@@ -114,6 +114,7 @@ _vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.
 PROTOTYPES = {
     "lsf_abi_version": (ctypes.c_int, []),
     "lsf_target_arch": (ctypes.c_char_p, []),
+    "lsf_build_id": (ctypes.c_char_p, []),
     "lsf_deinterleave": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "lsf_interleave": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "lsf_halo_copy": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void convolve_strided_kernel(const float* _
     const int y_or_z = AXIS == 1 ? g.z_begin + other : other;  // AXIS 1: other = z ; AXIS 2: other = y
     const long long base = (long long)blockIdx.z * g.plane;
     const int fixed = AXIS == 1 ? y_or_z * g.nx * g.ny : y_or_z * g.nx;
-    const int c = taps.n / 2, lo = taps.n - 1 - c;
+    const int c = (taps.n - 1) / 2, lo = taps.n - 1 - c;  // np.convolve(..., 'same') starts at (n - 1) / 2
     const int rows = count + taps.n - 1;
     if (x < g.nx) {
         for (int r = lr; r < rows; r += kBlock / kTileX) {
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kBlock) void convolve_x_kernel(const float* __restr
     const int y0 = (blockIdx.y % tiles_y) * kConvRows;
     const int z = g.z_begin + blockIdx.y / tiles_y;
     const long long base = (long long)blockIdx.z * g.plane;
-    const int c = taps.n / 2, lo = taps.n - 1 - c;
+    const int c = (taps.n - 1) / 2, lo = taps.n - 1 - c;  // np.convolve(..., 'same') starts at (n - 1) / 2
     const int cols = kTileX + taps.n - 1;
     for (int r = ly; r < kConvRows; r += kBlock / kTileX) {
         const int y = y0 + r;
@@ -1048,3 +1048,7 @@ extern "C" int lsf_tsdf_difference_statistics(const float* canonical, const floa
 
 extern "C" int lsf_abi_version(void) { return LSF_ABI_VERSION; }
 extern "C" const char* lsf_target_arch(void) { return "gfx950"; }
+#ifndef LSF_BUILD_ID
+#define LSF_BUILD_ID "unknown"
+#endif
+extern "C" const char* lsf_build_id(void) { return LSF_BUILD_ID; }

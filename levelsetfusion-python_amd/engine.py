@@ -104,6 +104,10 @@ class HierarchicalEngine:
         self.collect_reports = collect_reports
         self.collect_iteration_data = collect_iteration_data  # telemetry: per-iteration warp / gradient snapshots
         self.iteration_data = []
+        # opt-in per-iteration call-back, f(level, iteration, warp, gradient, max_update) with device tensors in the API
+        # layout [..., D]: where the reference calls its visualiser inside the loop (hierarchical_optimizer2d.py:242-245).
+        # None (default): nothing is synchronised or copied per iteration; set: every iteration is read back at once.
+        self.iteration_hook = None
         self.comm = comm  # SlabComm of the FINEST level (z-slab runs), or None
         self.maximum_chunk_size = maximum_chunk_size
         self.rate = rate
@@ -361,7 +365,8 @@ class HierarchicalEngine:
         slab = comm is not None and comm.active
         max_it = self.maximum_iteration_count
         n_vox = canonical.numel()
-        if (self.use_graphs and not slab and not self.collect_iteration_data and max_it >= 4
+        hooked = self.iteration_hook is not None
+        if (self.use_graphs and not slab and not self.collect_iteration_data and not hooked and max_it >= 4
                 and self.check_interval >= 2 and n_vox <= self.graph_max_voxels):
             return self._optimize_level_graph(canonical, packed, warp)
         if slab:
@@ -384,7 +389,7 @@ class HierarchicalEngine:
         n_exec = 0
         dec = None
         while it < max_it:
-            batch = min(self.check_interval, max_it - it)
+            batch = 1 if hooked else min(self.check_interval, max_it - it)
             for i in range(it, it + batch):
                 if self.collect_iteration_data:
                     # telemetry (cpp LoggingParameters.collect_per_level_iteration_data): the two gradient terms
@@ -420,6 +425,11 @@ class HierarchicalEngine:
                 if not (float(wz.item()) < L.halo - 1):
                     raise RuntimeError("cumulative warp of %.3f slices reaches past the %d-slice slab halo; re-run "
                                        "with a wider halo" % (float(wz.item()), L.halo))
+            if hooked and n_exec == it:  # iteration it - 1 ran: its gradient is in the buffer the next one reads
+                g_now = lv.F[it % 2] if lv.F else lv.report_g
+                own = (slice(None), L.owned_local()) if slab else (slice(None),)
+                self.iteration_hook(len(self.level_results), it - 1, dev.interleave(warp[own].contiguous()),
+                                    dev.interleave(g_now[own].contiguous()), float(dec["max_value"][it - 1]))
             if n_exec < it or dec["max_value"][n_exec - 1] < np.float32(thr):
                 break
         if dec is None:  # maximum_iteration_count == 0: the reference's loop body never runs
@@ -629,6 +639,9 @@ class SlavchevaEngine:
         self.iteration_count = 0
         self.log = None
         self._gradient_state = None
+        # opt-in per-iteration call-back f(level = 0, iteration, warp, gradient, max_warp) (device tensors, API layout),
+        # where the reference writes its per-iteration visualisations (slavcheva_optimizer2d.py:387-388).  None: no cost.
+        self.iteration_hook = None
 
     def _grid(self, live):
         if self.comm is not None and self.comm.active:
@@ -991,8 +1004,9 @@ class SlavchevaEngine:
         it, n_exec = 0, 0
         dec = None
         early = None
+        hooked = self.iteration_hook is not None
         while it < limit:
-            batch = min(self.check_interval, limit - it)
+            batch = 1 if hooked else min(self.check_interval, limit - it)
             for i in range(it, it + batch):
                 if self.sobolev:
                     self._enqueue_iteration(i, lives[i % 2], lives[(i + 1) % 2], warps[i % 2], warps[(i + 1) % 2],
@@ -1016,6 +1030,8 @@ class SlavchevaEngine:
             if n_exec < it:
                 break
             m = dec["max_value"][n_exec - 1]
+            if hooked:
+                self._call_hook(it - 1, float(m), lives, warps, states, canonical, grid)
             reach = self.comm.layout.halo if slab else 0
             if slab and not self.sobolev and self._fast.exchange_interval > 1:
                 reach = 1  # inside an exchange group every iteration may consume one slice of validity only
@@ -1055,6 +1071,20 @@ class SlavchevaEngine:
         else:
             self._gradient_state = ("recompute", states[(n_exec - 1) % 2], canonical, grid)
         return outcome
+
+    def _call_hook(self, i, max_warp, lives, warps, states, canonical, grid):
+        """iteration i has run: hand its warp and gradient to the hook in the API layout (owned slices of a slab)"""
+        if self.sobolev:
+            warp_planar, g = warps[(i + 1) % 2], self._last_g
+        else:
+            live_now = torch.empty(tuple(states[0].shape[:-1]), dtype=torch.float32, device=states[0].device)
+            warp_planar = torch.empty((grid.dims,) + tuple(live_now.shape), dtype=torch.float32, device=live_now.device)
+            dev.state_unpack(states[(i + 1) % 2], dev.full_range(grid), live_now, warp_planar, None)
+            self._gradient_state = ("recompute", states[i % 2], canonical, grid)
+            g = self.gradient_field()
+        own = (slice(None), self.comm.layout.owned_local()) if self._slab() else (slice(None),)
+        self.iteration_hook(0, i, dev.interleave(warp_planar[own].contiguous()), dev.interleave(g[own].contiguous()),
+                            max_warp)
 
     def gradient_field(self):
         """planar gradient of the last executed iteration (zeroed where the live field snapped, DIRECT only).

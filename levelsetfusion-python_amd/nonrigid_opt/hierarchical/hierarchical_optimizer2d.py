@@ -66,6 +66,18 @@ class _HierarchicalOptimizerBase:
         self.hierarchy_level = 0
         self._reports = []
 
+    @property
+    def iteration_hook(self):
+        """opt-in call-back f(level, iteration, warp_field, gradient, maximum_update_length) after every iteration --
+        the place where the reference calls its visualiser (hierarchical_optimizer2d.py:242-245).  warp_field is the
+        level's cumulative warp AFTER the update, gradient the (filtered) gradient it was moved by, both device tensors
+        [..., D].  None (default) costs nothing; with a hook every iteration is synchronised and read back."""
+        return self._engine.iteration_hook
+
+    @iteration_hook.setter
+    def iteration_hook(self, hook):
+        self._engine.iteration_hook = hook
+
     def optimize(self, canonical_field, live_field):
         """returns the cumulative warp field, interleaved [.., D] float32: a numpy array for numpy inputs, a
         device tensor when both inputs are ROCm tensors (nothing crosses PCIe then)"""

@@ -103,6 +103,18 @@ class _SlavchevaOptimizerBase:
                              "size (field_size = %d on every side)." % self.field_size)
 
     @property
+    def iteration_hook(self):
+        """opt-in call-back f(level = 0, iteration, warp_field, gradient_field, max_warp) after every iteration, where the
+        reference writes its per-iteration visualisations (slavcheva_optimizer2d.py:387-388); device tensors [..., D].
+        None (default) costs nothing; with a hook every iteration is synchronised (and the fused kernel's gradient, which
+        it does not store, is recomputed by the unfused kernels)."""
+        return self._engine.iteration_hook
+
+    @iteration_hook.setter
+    def iteration_hook(self, hook):
+        self._engine.iteration_hook = hook
+
+    @property
     def gradient_field(self):
         """gradient of the last iteration, interleaved numpy array (reference attribute of the same name)"""
         g = self._engine.gradient_field()

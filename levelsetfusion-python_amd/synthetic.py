@@ -32,6 +32,23 @@ def sphere_pair(n, dims=3, device="cuda", z_range=None):
     return tsdf((0.0, 0.0, 0.0), (1.0, 1.0, 1.0)), tsdf((1.5, -1.0, 2.0), (1.05, 0.95, 1.0))
 
 
+FRAME_STEP = (1.0, -0.5, 1.0)  # voxels per frame along (x, y, z): 1.5 voxels of motion from frame to frame
+
+
+def sphere_frame(n, k, device="cuda"):
+    """frame k of the synthetic multi-frame sequence (BASELINE config 5): the TSDF of the sphere of sphere_pair, its
+    centre moved by k * FRAME_STEP voxels; consecutive frames form the (canonical, live) pairs
+    (experiment/multiframe_experiment.py:186-233: live_frame_index = canonical_frame_index + 1)"""
+    h, r, c = 10.0, 0.3 * n, n / 2.0
+    ax = torch.arange(n, dtype=torch.float64, device=device)
+    zz, yy, xx = torch.meshgrid(ax, ax, ax, indexing="ij")
+    sq = None
+    for q, step in zip((xx, yy, zz), FRAME_STEP):
+        t = (q - (c + k * step)) ** 2
+        sq = t if sq is None else sq + t
+    return torch.clamp((torch.sqrt(sq) - r) / h, -1.0, 1.0).to(torch.float32).contiguous()
+
+
 def depth_image(shift_px=0.0, nearer_m=0.0, width=640, height=480):
     """SURVEY 8(d) "depth->TSDF" input: a tilted plane at ~1 m with a sinusoidal bump, uint16 millimetres (numpy)"""
     import numpy as np

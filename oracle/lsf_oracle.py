@@ -215,11 +215,12 @@ def laplace_replicate(a):
 #  a9/a10  separable convolution of a vector field            (math_utils/convolution.py:70-132)
 # =====================================================================================================
 def _convolve_axis(vf, kernel64, axis):
-    """np.convolve(line, k, 'same') along `axis`, zero padded: out[i] = sum_j k[j]*line[i + c - j], c = len//2.
+    """np.convolve(line, k, 'same') along `axis`, zero padded: out[i] = sum_j k[j]*line[i + c - j], c = (len-1)//2
+    ('same' cuts the full convolution at (N - 1) // 2; for the odd kernels the reference uses that is len // 2).
     Accumulated in float64 in tap order j = 0..n-1 and rounded to float32 on store (convolution.py:78-83:
     float64 kernel => float64 accumulation; with a float32 kernel the reference differs by <= 1 ulp)."""
     n = len(kernel64)
-    c = n // 2
+    c = (n - 1) // 2
     f = np.moveaxis(vf, axis, 0).astype(np.float64)
     length = f.shape[0]
     acc = np.zeros_like(f)
@@ -713,6 +714,21 @@ def tsdf_difference_statistics(canonical, live):
 # =====================================================================================================
 #  synthetic inputs of SURVEY.md section 8(d)  (closed form, deterministic; also used by bench/tests)
 # =====================================================================================================
+FRAME_STEP = (1.0, -0.5, 1.0)  # voxels per frame along (x, y, z), as levelsetfusion-python_amd/synthetic.py
+
+
+def sphere_frame(n, k, dtype=F32):
+    """frame k of the synthetic multi-frame sequence (BASELINE config 5): sphere_pair's sphere, centre moved by
+    k * FRAME_STEP voxels; frames k and k + 1 form a (canonical, live) pair"""
+    h, r, c = 10.0, 0.3 * n, n / 2.0
+    ax = np.arange(n, dtype=np.float64)
+    zz, yy, xx = np.meshgrid(ax, ax, ax, indexing="ij")
+    sq = 0.0
+    for q, step in zip((xx, yy, zz), FRAME_STEP):
+        sq = sq + (q - (c + k * step)) ** 2
+    return np.clip((np.sqrt(sq) - r) / h, -1.0, 1.0).astype(dtype)
+
+
 def sphere_pair(n, d=3, dtype=F32, nz=None, z_offset=0, z_total=None):
     """canonical = TSDF of a sphere (circle for d=2), live = the same sphere translated by (1.5,-1.0,2.0) and
     anisotropically scaled by (1.05,0.95,1.0) (x,y,z); narrow-band half width 10 voxels, values exactly +-1

@@ -38,6 +38,12 @@ def test_default_workload_line():
     assert abs(r["achieved"] - 52 * r["units_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and c["unit"] == d["unit"] and c["sample"]
+    # the rate over the voxels the launches visit, next to the field-voxel rate; committed PMC traffic only for the size
+    # and the build it was measured on (64^3 is neither): null, with the provenance it was checked against
+    assert 0 < d["visited_voxel_updates_per_s"] <= d["value"]
+    assert abs(d["visited_voxel_updates_per_s"] - r["units_per_launch"] * 4 * 2 / (d["ms_per_step"] * 2e-3)) \
+        < 1e-6 * d["value"]
+    assert r["traffic"] is None and r["traffic_source"]["loaded_build_id"]
 
 
 def test_depth_data_and_other_workloads():
@@ -48,3 +54,22 @@ def test_depth_data_and_other_workloads():
     for workload in ("hier-tik", "hier-full", "sobolev"):
         d = _run("--size", "64", "--iterations", "3", "--workload", workload, "--no-cpu-baseline")
         assert d["value"] > 0 and d["n_gpus"] == 1 and d["config"]["workload"]
+        r = d["roofline"]
+        b_alg = {"hier-tik": 68, "hier-full": 104, "sobolev": 76}[workload]
+        # the fraction is over the voxels the launches VISIT; a dense-equivalent figure is labelled as such
+        assert abs(r["achieved"] - d["visited_voxel_updates_per_s"] * b_alg / 1e9) < 1e-6 * r["achieved"]
+        if workload == "sobolev":
+            assert d["visited_voxel_updates_per_s"] < d["value"] and r["dense_equivalent_gbs"] > r["achieved"]
+        else:
+            assert d["visited_voxel_updates_per_s"] == d["value"] and "dense_equivalent_gbs" not in r
+
+
+def test_multiframe_workload_line():
+    """BASELINE config 5 as a bench mode (small: 4 frames of 64^3, 2 iterations per level)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _run("--workload", "multiframe", "--size", "64", "--frames", "4", "--iterations", "2", "--no-cpu-baseline")
+    per_pair = 2 * sum((64 >> k) ** 3 for k in range(4))
+    assert "multi-frame" in d["config"]["workload"] and "4 frames" in d["config"]["workload"]
+    assert abs(d["value"] - 3 * per_pair * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0

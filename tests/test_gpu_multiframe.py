@@ -1,0 +1,99 @@
+"""BASELINE config 5 -- the 3-D multi-frame sequence through the hierarchical optimizer with Tikhonov term and 7-tap
+gradient kernel (frame k against frame k + 1, experiment/multiframe_experiment.py:186-233; pair loop and report table
+run_hierarchical_optimizer3d_multipair.py:403-441) -- exercised in 3-D: the multi-pair table against the oracle at
+64^3 (the coarsest of the four levels must hold the 7 taps, as in the reference), and one full-size 512^3 run checked through the z-constant embedding."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lsf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CONFIG5 = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=True, maximum_chunk_size=8, rate=0.1,
+               maximum_warp_update_threshold=0.0, tikhonov_strength=0.05)
+
+
+def exact(a, b):
+    return float(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64)).max()) == 0.0
+
+
+def test_multipair_table_3d_against_the_oracle(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd.experiment import multipair as mp
+    n, iterations = 64, 6
+    k7 = lsf.generate_1d_sobolev_kernel(7, 0.1)
+    frames = [O.sphere_frame(n, k) for k in range(4)]
+    pairs_dir = str(tmp_path / "pairs")
+    for k in range(3):  # canonical = frame k, live = frame k + 1
+        mp.save_pair(pairs_dir, k, 0, frames[k], frames[k + 1])
+    pairs = mp.load_pairs(pairs_dir)
+    assert [p[0] for p in pairs] == [0, 1, 2] and pairs[1][2].shape == (n, n, n)
+    kw = dict(maximum_iteration_count=iterations, kernel=k7, **CONFIG5)
+    opt = lsf.HierarchicalOptimizer3d(
+        logging_parameters=lsf.HierarchicalOptimizer3d.LoggingParameters(collect_per_level_convergence_reports=True),
+        **kw)
+    df = mp.run_experiment(opt, pairs, str(tmp_path / "out"))
+    levels = 4
+    assert len(df) == 3 and len(df.columns) == 2 + 17 * levels
+    assert list(df["canonical_frame"]) == [0, 1, 2]
+    for name in ("convergence_reports.csv", "analysis.txt", "bad_cases.csv", "all_cases.csv"):
+        assert (tmp_path / "out" / name).exists()
+    for k in range(3):
+        o = O.HierarchicalOracle(**kw)
+        warp_ref = o.optimize(pairs[k][2], pairs[k][3])
+        warp = opt.optimize(pairs[k][2], pairs[k][3])
+        assert exact(warp, warp_ref), "pair %d: warp field" % k
+        assert [int(df["l%d_iter_count" % i][k]) for i in range(levels)] == o.per_level_iteration_counts == \
+            [iterations] * levels
+        assert all(bool(df["l%d_iter_lim_reached" % i][k]) for i in range(levels))
+        last = levels - 1
+        assert np.float32(df["l%d_warp_delta_max" % last][k]) == np.float32(o.per_level_max_updates[last][-1])
+        resampled = O.warp_field(pairs[k][3], warp_ref)
+        diff = np.abs(pairs[k][2].astype(np.float64) - resampled)
+        assert np.isclose(df["l%d_diff_delta_max" % last][k], diff.max(), atol=1e-6)
+        assert np.isclose(df["l%d_diff_delta_mean" % last][k], diff.mean(), atol=1e-7)
+        at = np.unravel_index(int(np.argmax(diff)), diff.shape)  # (z, y, x); the table keeps the reference's x, y columns
+        assert (int(df["l%d_diff_max_x" % last][k]), int(df["l%d_diff_max_y" % last][k])) == (at[2], at[1])
+
+
+def test_full_size_512_run_through_the_z_constant_embedding(monkeypatch):
+    """Config 5's kernels at its own size: a z-constant 512^3 pair, 4 levels x 2 iterations, Tikhonov + 7-tap kernel.
+    Everything but the filter reduces to the 2-D arithmetic on an interior slice (tests/test_gpu_parity.py::
+    test_full_size_2d_embedding_256: lerps along z are exact for w = 0, the z second difference is exactly 0, the 2x2x2
+    mean of equal slices is the 2x2 mean).  The 3-D filter runs x, y, z (math_utils/convolution.py:94-105) where the 2-D
+    one runs y, x, and its z pass is not the identity on a constant: sum_j k[j] * v accumulated in float64 in tap order.
+    So the 2-D ORACLE is run with exactly that filter -- x pass, y pass, constant-z pass -- and must give the middle
+    slice of the 512^3 result bit for bit (the array's z faces are 256 slices away; 4 levels x 2 iterations reach 120)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import levelsetfusion_python_amd as lsf
+    n = 512
+    k7 = lsf.generate_1d_sobolev_kernel(7, 0.1)
+    c2, l2 = O.sphere_pair(n, d=2)
+    kw = dict(maximum_iteration_count=2, kernel=k7, **CONFIG5)
+
+    def filter_of_a_z_constant_volume(vf, kernel):
+        k = np.asarray(kernel, dtype=np.float64)
+        cur = O._convolve_axis(vf, k, 1)   # x
+        cur = O._convolve_axis(cur, k, 0)  # y
+        acc = np.zeros(cur.shape, dtype=np.float64)
+        for j in range(len(k)):            # z on a constant: every tap reads the same value
+            acc = acc + k[j] * cur.astype(np.float64)
+        np.copyto(vf, acc.astype(np.float32))
+        return vf
+    monkeypatch.setattr(O, "convolve_with_kernel", filter_of_a_z_constant_volume)
+    warp2 = O.HierarchicalOracle(**kw).optimize(c2, l2)
+    monkeypatch.undo()
+    c3 = torch.from_numpy(c2).cuda()[None].expand(n, n, n).contiguous()
+    l3 = torch.from_numpy(l2).cuda()[None].expand(n, n, n).contiguous()
+    warp3 = lsf.HierarchicalOptimizer3d(**kw).optimize(c3, l3)
+    assert tuple(warp3.shape) == (n, n, n, 3)
+    mid = warp3[n // 2].cpu().numpy()
+    assert float(np.abs(mid[..., :2]).max()) > 0.0
+    assert exact(mid[..., :2], warp2)
+    assert float(np.abs(mid[..., 2]).max()) == 0.0
+    # translation invariance along z away from the faces: the slices next to the middle one are the same
+    assert torch.equal(warp3[n // 2 - 3], warp3[n // 2]) and torch.equal(warp3[n // 2 + 2], warp3[n // 2])

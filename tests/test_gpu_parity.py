@@ -146,7 +146,9 @@ def test_convolution_kernels(lsf, ref_leaf, ref_literals):
     vf2, vf3 = L["conv.vf2"], L["conv.vf3"]
     k7 = L["sobolev.hardcoded7"]
     for vf, kern in ((vf2, k7), (vf3, k7), (vf2, L["sobolev.k7"]), (vf2, np.array([0.5, 0.2, -0.1, 0.05, 0.3])),
-                     (vf3, np.array([0.5, 0.2, -0.1]))):
+                     (vf3, np.array([0.5, 0.2, -0.1])),
+                     # even-length kernels: np.convolve's 'same' starts at (n - 1) // 2 (tests/test_oracle_golden.py)
+                     (vf2, np.array([0.4, -0.2, 0.7, 0.1])), (vf3, np.array([1.0, 2.0]))):
         assert maxdiff(mc.convolve_with_kernel(vf.copy(), kern), O.convolve_with_kernel(vf.copy(), kern)) == EXACT
     assert maxdiff(mc.convolve_with_kernel_preserve_zeros(vf2.copy(), L["sobolev.k3"]),
                    O.convolve_with_kernel_preserve_zeros(vf2.copy(), L["sobolev.k3"])) == EXACT

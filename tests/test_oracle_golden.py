@@ -79,6 +79,20 @@ def test_convolution_matches_reference(ref_leaf):
                    L["conv.vf2_pz_k7"]) == 0.0
 
 
+def test_even_length_kernels_follow_numpy_same():
+    """np.convolve(line, k, 'same') (math_utils/convolution.py:78-83) cuts the full convolution at (len(k) - 1) // 2:
+    for an even-length, asymmetric kernel that is one sample away from len(k) // 2"""
+    rng = np.random.default_rng(5)
+    for kern in (np.array([0.4, -0.2, 0.7, 0.1]), np.array([1.0, 2.0]), np.array([0.3, 0.1, -0.5, 0.25, 0.6, -0.05])):
+        for shape, order in (((9, 11, 2), (0, 1)), ((6, 7, 8, 3), (2, 1, 0))):
+            vf = rng.standard_normal(shape).astype(np.float32)
+            want = vf.astype(np.float64)
+            for axis in order:  # the reference's pass order, every line through numpy itself
+                want = np.apply_along_axis(lambda line: np.convolve(line, kern, "same"), axis,
+                                           want.astype(np.float32).astype(np.float64))
+            assert maxdiff(O.convolve_with_kernel(vf.copy(), kern), want.astype(np.float32)) <= TIGHT
+
+
 def test_slavcheva_terms_match_reference(ref_leaf):
     L = ref_leaf
     live, canon, warp = L["terms.live"], L["terms.canonical"], L["terms.warp"]

@@ -61,7 +61,10 @@ corr = {k: KNOWN[k] / v for k, v in cal.items() if k in KNOWN}
 # the state kernel moves 16 bytes per lane: corrections of the 16-byte calibration launches
 fetch_corr = corr[("state_unpack_kernel", "FETCH_SIZE")]
 write_corr = corr[("state_pack_kernel", "WRITE_SIZE")]
-result = dict(workload="killing", size=256, fetch_correction=round(fetch_corr, 4), write_correction=round(write_corr, 4),
+sys.path.insert(0, ROOT)
+import levelsetfusion_python_amd as _pkg  # noqa: E402  the build the counters were collected on (same sources)
+
+result = dict(workload="killing", size=256, tag=tag, build_id=_pkg._lib.lib.lsf_build_id().decode(), fetch_correction=round(fetch_corr, 4), write_correction=round(write_corr, 4),
               corrections={"%s %s" % k: round(v, 4) for k, v in corr.items()},
               source="profiles/%s_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
                      "calibrated on launches of known traffic with the same bytes per lane)" % tag)
