@@ -44,7 +44,8 @@ class RecordSlot(ctypes.Structure):
 
 
 class IterationRecord(ctypes.Structure):
-    """8 partial records 256 bytes apart; value = max over the slots' max_packed, sum over their energies"""
+    """8 partial records 4 KiB apart (one per XCD: separate memory channels); value = max over the slots' max_packed,
+    sum over their energies"""
     _fields_ = [("slot", RecordSlot * RECORD_SLOTS)]
 
 

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 from ._lib import Gate, Grid, HierParams, SlavchevaParams, check, lib
 
-RECORD_WORDS = _lib.RECORD_BYTES // 8  # an iteration record is 8 slots x 32 int64 words (see lsf_iteration_record)
+RECORD_WORDS = _lib.RECORD_BYTES // 8  # an iteration record is 8 slots x 512 int64 words (see lsf_iteration_record)
 
 
 def require_gpu():
@@ -32,11 +32,12 @@ def pinned_scratch(name, numel, dtype):
     """a small page-locked host buffer that lives as long as the process (one per device and purpose): the landing
     place of the few numbers a call reads back, without a host allocation per call.  The optimizers are single-caller
     objects (as the reference's are): a buffer is consumed before the next call on the same device fills it again."""
-    key = (torch.cuda.current_device(), name, int(numel), dtype)
+    key = (torch.cuda.current_device(), name, dtype)  # one buffer per purpose, grown to the largest length asked for
     buf = _PINNED.get(key)
-    if buf is None:
-        buf = _PINNED[key] = torch.empty(int(numel), dtype=dtype, pin_memory=True)
-    return buf
+    if buf is None or buf.numel() < int(numel):
+        buf = _PINNED[key] = torch.empty(max(int(numel), 2 * buf.numel() if buf is not None else 0), dtype=dtype,
+                                         pin_memory=True)
+    return buf[:int(numel)]
 
 
 def make_grid(shape, z_begin=0, z_end=None, z_global_offset=0):

@@ -277,6 +277,10 @@ class HierarchicalEngine:
         lv.launcher = f
         return lv
 
+    def invalidate_graphs(self):
+        """a setting changed: captured graphs hold the old rate / threshold / taps / iteration counts"""
+        self._graphs.clear()
+
     def _enqueue(self, lv, rec_idx, prev_idx, parity, comm=None):
         """one iteration: record slot rec_idx, gated on record prev_idx (None: always runs), buffer parity 0/1"""
         f = lv.launcher
@@ -605,6 +609,14 @@ class SlavchevaOutcome:
         return target, warp, (raw.cpu().numpy() if raw is not None else None)
 
 
+class _HaloTooNarrow(Exception):
+    """a z-slab run met a warp update its halo schedule cannot carry (SlavchevaEngine.optimize re-runs it wider)"""
+
+    def __init__(self, max_update, validity):
+        super().__init__("warp update of %.3f voxels against %d slice(s) of validity" % (max_update, validity))
+        self.max_update = float(max_update)
+
+
 class SlavchevaEngine:
     """per-iteration-update optimizer with in-place re-warping of the live field
     (nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:332-408), D = 2 or 3, optionally on a z-slab."""
@@ -667,7 +679,10 @@ class SlavchevaEngine:
         slab = self._slab()
         g0, t1, t2 = gbufs
         band = self._sobolev_band  # None: every voxel
-        dev.slavcheva_gradient(live_in, canonical, warp_in, g0, grid, self.params, gate, records, i, band)
+        # z-slab: the list of the WHOLE local array serves the x / y passes (they also run on the halo slices), its owned
+        # part everything else
+        band_own = self._sobolev_band_owned if slab and band is not None else band
+        dev.slavcheva_gradient(live_in, canonical, warp_in, g0, grid, self.params, gate, records, i, band_own)
         in_plane_grid = grid
         if slab:
             # the z pass of the filter reads len(kernel)//2 slices of the (x,y)-filtered field on either
@@ -677,10 +692,10 @@ class SlavchevaEngine:
         src, dst = g0, t1
         for axis in _conv_axis_order(grid.dims):
             dev.convolve_axis(src, dst, g0, grid if axis == 2 else in_plane_grid, axis, self.sobolev_kernel,
-                              gate, band)
+                              gate, band_own if axis == 2 else band)
             src, dst = dst, (t2 if dst is t1 else t1)
         dev.slavcheva_update_rewarp(live_in, canonical, src, warp_out, live_out, grid, self.params, gate,
-                                    records, i, band)
+                                    records, i, band_own)
         self._last_g = src
         if slab:
             self.comm.exchange_live_and_warp(live_out, warp_out)
@@ -769,12 +784,13 @@ class SlavchevaEngine:
         send = [union(L.z_begin, L.z_begin + h) if lo else none, union(L.z_end - h, L.z_end) if hi else none]
         recv = [union(L.z_begin - h, L.z_begin) if lo else none, union(L.z_end, L.z_end + h) if hi else none]
         # A rank's halo holds the neighbour's boundary slices, so what it expects to receive IS what the neighbour sends --
-        # if the caller cut consistent slabs.  That contract is cross-checked with the neighbours on an optimizer's first
-        # call (a collective and a host read, ~0.2 ms; LSF_SLAB_VERIFY_FACES=always: on every call): a wrong slicing is
-        # systematic and shows there, and mismatched message sizes would otherwise hang the transport.  The check runs
-        # on a stream of its own: its host read must not wait for the iterations already queued on the launch stream.
+        # if the caller cut consistent slabs.  That contract is cross-checked with the neighbours on EVERY call (a
+        # collective and a host read, ~0.2 ms, behind the iterations already queued on the launch stream: the check runs
+        # on a stream of its own): mismatched message sizes would hang or corrupt the transport, and whether to check
+        # cannot depend on anything one rank alone sees (a rank whose data changed would enter the collective alone).
+        # LSF_SLAB_VERIFY_FACES=first: only on an optimizer's first call (measurements).
         ok = True
-        if not getattr(self, "_faces_verified", False) or os.environ.get("LSF_SLAB_VERIFY_FACES") == "always":
+        if not getattr(self, "_faces_verified", False) or os.environ.get("LSF_SLAB_VERIFY_FACES", "always") != "first":
             if getattr(self, "_plan_stream", None) is None or self._plan_stream.device != live.device:
                 self._plan_stream = torch.cuda.Stream(device=live.device)
             with torch.cuda.stream(self._plan_stream):
@@ -853,7 +869,7 @@ class SlavchevaEngine:
         if own < 2 * h:
             raise ValueError("a slab of %d slices is too thin for a %d-slice halo" % (own, h))
         fixed = self.min_iterations >= limit
-        f.exchange_interval = h if fixed else 1
+        f.exchange_interval = h if fixed and not getattr(self, "_exchange_every_iteration", False) else 1
         slice_voxels = grid.ny * grid.nx
         listed = bands[0].indices is not None
         if listed and prepared is not None:  # the prepare pass brought the positions of the z cuts along
@@ -927,8 +943,68 @@ class SlavchevaEngine:
     def optimize(self, live, canonical, finalize=None):
         """live, canonical: float32 device tensors (z-slab runs: the local slab incl. halos).  Returns a
         SlavchevaOutcome holding the final fields on the device; the caller's tensors are not modified.
+
+        z-slab runs never abort on large warps (the reference only stops at 10 000 voxels,
+        slavcheva_optimizer2d.py:360-362): an iteration is exact on a slab while its re-warp gather, floor(|w_z|) + 1
+        slices, stays inside what the halo schedule keeps valid -- one slice inside an exchange group, the halo width
+        with an exchange per iteration.  Every rank sees the same (reduced) maxima, so when a batch breaks that bound
+        all ranks together discard the call's work and run it again from its inputs on a WIDER internal slab: halo
+        ceil(max) + 1 (live and canonical slices fetched from the neighbours), the faces exchanged every iteration
+        ("fall back to a wider exchange if the max exceeds 1").  The result is bit for bit the
+        whole-volume one (tests/test_gpu_slab_many_ranks.py)."""
+        if not self._slab():
+            return self._optimize(live, canonical, finalize)
+        try:
+            return self._optimize(live, canonical, finalize)
+        except _HaloTooNarrow as exc:
+            torch.cuda.synchronize()  # nothing of the abandoned attempt (an exchange left in flight) may linger
+            return self._optimize_widened(live, canonical, exc.max_update)
+
+    def _optimize_widened(self, live, canonical, max_update):
+        import copy
+        import math
+        from .slab import SlabComm, SlabLayout
+        L = self.comm.layout
+        per = L.z1 - L.z0
+        while True:
+            h2 = max(L.halo, int(math.floor(max_update)) + 2)
+            if 2 * h2 > per:  # the boundary / interior split of a slab iteration needs two disjoint boundary ranges
+                raise RuntimeError("warp update of %.3f voxels needs a %d-slice halo, more than half a slab of %d "
+                                   "slices: use fewer, thicker slabs" % (max_update, h2, per))
+            L2 = SlabLayout(L.nz_global, L.rank, L.world, h2)
+            comm2 = SlabComm(L2, self.comm.group)
+            comm2._native = None  # rare path: torch.distributed point-to-point, no second RCCL communicator
+            wide = []
+            for t in (live, canonical):
+                w = torch.empty((L2.nz_local,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+                w[L2.z_begin:L2.z_end] = t[L.z_begin:L.z_end]
+                wide.append(w)
+            comm2.exchange_halos(wide)
+            clone = copy.copy(self)
+            clone.comm = comm2
+            clone._exchange_every_iteration = True
+            for cached in ("_faces_verified", "_cut_chunk_cache", "_fast"):
+                clone.__dict__.pop(cached, None)
+            try:
+                outcome = clone._optimize(wide[0], wide[1], None)
+                break
+            except _HaloTooNarrow as exc:  # a later iteration moved further still
+                torch.cuda.synchronize()
+                max_update = max(max_update + 1.0, exc.max_update)
+        self.iteration_count, self.log = clone.iteration_count, clone.log
+        off = L2.halo_lo - L.halo_lo
+        window = slice(off, off + L.nz_local)
+        self._gradient_state = ("wide", clone, window)
+        grid = self._grid(live)
+        if outcome.state is not None:
+            return SlavchevaOutcome(grid, canonical, state=outcome.state[window].contiguous())
+        return SlavchevaOutcome(grid, canonical, live=outcome.live()[window].contiguous(),
+                                warp_planar=outcome.warp_planar()[:, window].contiguous())
+
+    def _optimize(self, live, canonical, finalize=None):
+        """one attempt of optimize() (see there)
         finalize = (live_out, lower_threshold, statistics): the arguments the caller is going to pass to
-        outcome.finalize() -- with a fixed iteration count (no stop test can fire) the finalize pass is then enqueued
+        outcome.finalize() -- with a fixed iteration count and a whole volume (no stop test can fire) the finalize pass is then enqueued
         right behind the last iteration and the records and statistics are read with ONE host synchronisation."""
         if live.shape != canonical.shape:
             raise ValueError("live and canonical fields must have the same shape")
@@ -968,11 +1044,20 @@ class SlavchevaEngine:
             gbufs = [torch.zeros_like(warps[0]) for _ in range(3)]
             # Band list: the gradient is zero outside the narrow band and the zero-preserving filter keeps it there
             # (math_utils/convolution.py:118-127), so gradient, filter passes and update visit band voxels only; the
-            # zero-initialised g buffers and the two (live, 0) sets hold everything else.  z-slab runs stay dense (the
-            # x / y passes also run on the halo slices there).
-            self._sobolev_band = None
-            if self.use_band_list and not slab and len(self.sobolev_kernel) in dev.LISTED_TAP_COUNTS:
-                self._sobolev_band = dev.band_list(live, canonical, grid, _lib.BAND_ALL)
+            # zero-initialised g buffers and the two (live, 0) sets hold everything else.  z-slab runs list the whole
+            # local array (the x / y passes also run on the halo slices) and cut the owned part out of that list: it
+            # is sorted, so the owned slices are one contiguous run of it.
+            self._sobolev_band = self._sobolev_band_owned = None
+            if self.use_band_list and len(self.sobolev_kernel) in dev.LISTED_TAP_COUNTS:
+                self._sobolev_band = dev.band_list(live, canonical, dev.full_range(grid), _lib.BAND_ALL)
+                if slab:
+                    b = self._sobolev_band
+                    slice_voxels = grid.ny * grid.nx
+                    keys = torch.tensor([grid.z_begin * slice_voxels, grid.z_end * slice_voxels], dtype=torch.int32,
+                                        device=live.device)
+                    lo, hi = torch.searchsorted(b.indices[:b.count], keys).tolist() if b.count else (0, 0)
+                    self._sobolev_band_owned = dev.BandList(b.indices[lo:hi] if hi > lo else b.indices[:1], hi - lo,
+                                                            b.subset)
         else:
             # Both ping-pong states start as (live, 0): the fused kernel only visits the voxels of the band list and
             # the rest must already hold their final values (lsf_slavcheva_state_iteration); slab halos start valid.
@@ -1020,7 +1105,8 @@ class SlavchevaEngine:
             if slab and not ungated:
                 self.comm.reduce_records(records, it, it + batch)
             it += batch
-            if finalize is not None and not self.sobolev and it == limit and self.min_iterations >= limit:
+            if finalize is not None and not self.sobolev and not slab and it == limit and self.min_iterations >= limit:
+                # (a slab run may still have to be discarded -- see optimize() -- and finalize writes the caller's tensor)
                 # every launch runs ungated, so the final state is states[limit % 2]: finalize before looking
                 early = SlavchevaOutcome(grid, canonical, state=states[limit % 2], listed=listed)
                 early.enqueue_finalize(*finalize)
@@ -1030,19 +1116,13 @@ class SlavchevaEngine:
             if n_exec < it:
                 break
             m = dec["max_value"][n_exec - 1]
-            if hooked:
-                self._call_hook(it - 1, float(m), lives, warps, states, canonical, grid)
             reach = self.comm.layout.halo if slab else 0
             if slab and not self.sobolev and self._fast.exchange_interval > 1:
                 reach = 1  # inside an exchange group every iteration may consume one slice of validity only
             if slab and not (dec["max_value"][:n_exec].max() < reach):
-                raise RuntimeError("warp update of %.3f voxels reaches past the slab halo (%d slices, %s); re-run with "
-                                   "a wider halo%s" % (float(dec["max_value"][:n_exec].max()), self.comm.layout.halo,
-                                                       "exchanged every %d iterations" % self._fast.exchange_interval
-                                                       if reach == 1 and self.comm.layout.halo > 1 else
-                                                       "exchanged every iteration",
-                                                       " or min_iterations < max_iterations" if reach == 1 and
-                                                       self.comm.layout.halo > 1 else ""))
+                raise _HaloTooNarrow(float(dec["max_value"][:n_exec].max()), reach)
+            if hooked:
+                self._call_hook(it - 1, float(m), lives, warps, states, canonical, grid)
             if n_exec >= self.min_iterations and not (np.float32(self.lo) < m < np.float32(self.hi)):
                 break
         self.iteration_count = n_exec
@@ -1096,6 +1176,9 @@ class SlavchevaEngine:
             return None
         if st[0] in ("zeros", "ready"):
             return st[1]
+        if st[0] == "wide":  # the call was re-run on a wider internal slab: its gradient, cut to this slab's slices
+            g = st[1].gradient_field()
+            return None if g is None else g[:, st[2]].contiguous()
         _, state_in, canonical, grid = st
         live_in = torch.empty(tuple(state_in.shape[:-1]), dtype=torch.float32, device=state_in.device)
         warp_in = torch.empty((grid.dims,) + tuple(live_in.shape), dtype=torch.float32, device=state_in.device)

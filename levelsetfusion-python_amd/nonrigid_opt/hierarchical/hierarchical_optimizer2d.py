@@ -11,8 +11,30 @@ from ...convergence_report import (ConvergenceReport, build_tsdf_difference_stat
                                    build_warp_delta_statistics)
 
 
+def _engine_setting(name, convert=None):
+    """a constructor setting the reference reads from `self` in every iteration (hierarchical_optimizer2d.py:186-225): kept
+    in ONE place, the engine, so that assigning to it after construction takes effect -- and drops the captured HIP
+    graphs, which bake rate, threshold, taps and iteration counts in"""
+    def get(self):
+        return getattr(self._engine, name)
+
+    def put(self, value):
+        setattr(self._engine, name, convert(value) if convert is not None and value is not None else value)
+        self._engine.invalidate_graphs()
+    return property(get, put)
+
+
 class _HierarchicalOptimizerBase:
     DIMS = 2
+    maximum_chunk_size = _engine_setting("maximum_chunk_size", int)
+    rate = _engine_setting("rate", float)
+    data_term_amplifier = _engine_setting("data_term_amplifier", float)
+    tikhonov_strength = _engine_setting("tikhonov_strength", float)
+    tikhonov_term_enabled = _engine_setting("tikhonov_term_enabled", bool)
+    gradient_kernel = _engine_setting("gradient_kernel", lambda k: np.asarray(k, dtype=np.float64))
+    gradient_kernel_enabled = _engine_setting("gradient_kernel_enabled", bool)
+    maximum_warp_update_threshold = _engine_setting("maximum_warp_update_threshold", float)
+    maximum_iteration_count = _engine_setting("maximum_iteration_count", int)
 
     class VerbosityParameters:
         """stdout verbosity switches (hierarchical_optimizer2d.py:41-60; the 3-D/C++ variant adds the
@@ -53,16 +75,6 @@ class _HierarchicalOptimizerBase:
             collect_reports=self.logging_parameters.collect_per_level_convergence_reports, comm=comm,
             collect_iteration_data=self.logging_parameters.collect_per_level_iteration_data,
             linear_resampling=linear_resampling, use_graphs=use_graphs)
-        e = self._engine
-        self.maximum_chunk_size = e.maximum_chunk_size
-        self.rate = e.rate
-        self.data_term_amplifier = e.data_term_amplifier
-        self.tikhonov_strength = e.tikhonov_strength
-        self.tikhonov_term_enabled = e.tikhonov_term_enabled
-        self.gradient_kernel = e.gradient_kernel
-        self.gradient_kernel_enabled = e.gradient_kernel_enabled
-        self.maximum_warp_update_threshold = e.maximum_warp_update_threshold
-        self.maximum_iteration_count = e.maximum_iteration_count
         self.hierarchy_level = 0
         self._reports = []
 

@@ -18,8 +18,11 @@ import torch
 import torch.distributed as dist
 
 
-# lsf_iteration_record (include/lsf_hip.h): 8 partial slots of 32 int64 words; word 0 = packed max, 1..3 = energies
-RECORD_SLOTS, SLOT_WORDS = 8, 512
+from . import _lib
+
+# lsf_iteration_record (include/lsf_hip.h): LSF_RECORD_SLOTS partial slots, 4 KiB (512 int64 words) apart; word 0 of a
+# slot = packed max, words 1..3 = energies.  The layout is the binding's (derived from the ctypes structures there).
+RECORD_SLOTS, SLOT_WORDS = _lib.RECORD_SLOTS, _lib.SLOT_WORDS
 
 
 def _slot_view(records):
