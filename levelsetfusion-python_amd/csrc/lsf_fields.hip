@@ -522,12 +522,28 @@ struct TapsN {
     double k[NT];
 };
 
+// acc + k * v in float64.  When every tap is a float32 value (the reference's Sobolev kernels are:
+// generate_1d_sobolev_kernel(..., precision=np.float32)) the product of a tap and a float32 sample is EXACT in float64
+// -- 24 + 24 significant bits -- so the fused multiply-add rounds once exactly where the separate add does: the same
+// bits with half the float64 instructions (these filters are bound by float64 issue, not by memory).  The launchers
+// pick FMA only then (taps_are_float32); arbitrary float64 taps keep the two-instruction form.
+template <bool FMA>
+__device__ inline double mac(double acc, double k, double v) {
+    return FMA ? __builtin_fma(k, v, acc) : acc + k * v;
+}
+
+static inline bool taps_are_float32(const double* taps, int n) {
+    for (int j = 0; j < n; ++j)
+        if (!((double)(float)taps[j] == taps[j])) return false;  // also false for NaN
+    return true;
+}
+
 constexpr int kMarch = 32;
 
-template <int AXIS, int NT, bool MASK>
-__global__ __launch_bounds__(kBlock) void convolve_march_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                const float* __restrict__ mask_src, Grid g,
-                                                                TapsN<NT> taps, lsf_gate gate) {
+template <int AXIS, int NT, bool MASK, bool FMA>
+__device__ inline void convolve_march(const float* __restrict__ in, float* __restrict__ out,
+                                      const float* __restrict__ mask_src, const Grid& g, const TapsN<NT>& taps,
+                                      const lsf_gate& gate) {
     if (gate_closed(gate)) return;
     const int lx = threadIdx.x & (kTileX - 1), w = threadIdx.x / kTileX;
     const int x = blockIdx.x * kTileX + lx;
@@ -560,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void convolve_march_kernel(const float* __r
         win[(m + NT - 1) % NT] = (double)v[m + NT - 1];
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc = acc + taps.k[j] * win[(m + NT - 1 - j) % NT];  // = in[a0 + m + c - j]
+        for (int j = 0; j < NT; ++j) acc = mac<FMA>(acc, taps.k[j], win[(m + NT - 1 - j) % NT]);  // = in[a0 + m + c - j]
         if (m < count) {
             float r = (float)acc;
             const int o = (a0 + m) * stride;
@@ -573,7 +589,7 @@ __global__ __launch_bounds__(kBlock) void convolve_march_kernel(const float* __r
 typedef float cvf4 __attribute__((ext_vector_type(4)));
 
 // x pass, nx % 4 == 0, NT <= 9 (reach <= 4): one thread = one aligned quad of outputs
-template <int NT, bool MASK>
+template <int NT, bool MASK, bool FMA>
 __global__ __launch_bounds__(kBlock) void convolve_x4_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                              const float* __restrict__ mask_src, Grid g,
                                                              TapsN<NT> taps, long long first_quad, long long n_quads,
@@ -600,7 +616,7 @@ __global__ __launch_bounds__(kBlock) void convolve_x4_kernel(const float* __rest
     for (int i = 0; i < 4; ++i) {
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc = acc + taps.k[j] * d[4 + i + c - j];
+        for (int j = 0; j < NT; ++j) acc = mac<FMA>(acc, taps.k[j], d[4 + i + c - j]);
         r[i] = (float)acc;
     }
     if (MASK) {
@@ -619,7 +635,7 @@ __global__ __launch_bounds__(kBlock) void convolve_x4_kernel(const float* __rest
 // narrow band, a masked pass leaves zeros where its mask source is zero (math_utils/convolution.py:118-127), so only
 // band voxels can hold non-zero output -- everything else stays at the zeros the caller initialised.  One thread per
 // listed voxel (all planes); NT taps read along the axis from the planar field (zero padding outside the array).
-template <int NT>
+template <int NT, bool FMA>
 __global__ __launch_bounds__(kBlock) void convolve_list_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                                const float* __restrict__ mask_src, Grid g,
                                                                TapsN<NT> taps, int axis, int planes,
@@ -655,7 +671,7 @@ __global__ __launch_bounds__(kBlock) void convolve_list_kernel(const float* __re
         }
         double acc = 0.0;
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc = acc + taps.k[j] * (double)v[j];
+        for (int j = 0; j < NT; ++j) acc = mac<FMA>(acc, taps.k[j], (double)v[j]);
         out[base + i] = fabsf(m) < 1e-6f ? 0.0f : (float)acc;
     }
 }
@@ -666,8 +682,26 @@ static void launch_list_pass(const float* in, float* out, const float* mask, con
                              hipStream_t s) {
     TapsN<NT> taps;
     for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
-    hipLaunchKernelGGL((convolve_list_kernel<NT>), dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, in, out, mask,
-                       g, taps, axis, planes, list, count, gt);
+    if (taps_are_float32(taps_host, NT))
+        hipLaunchKernelGGL((convolve_list_kernel<NT, true>), dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, in,
+                           out, mask, g, taps, axis, planes, list, count, gt);
+    else
+        hipLaunchKernelGGL((convolve_list_kernel<NT, false>), dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, in,
+                           out, mask, g, taps, axis, planes, list, count, gt);
+}
+
+template <int NT, bool MASK, bool FMA>
+__global__ __launch_bounds__(kBlock) void march_y_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         const float* __restrict__ mask_src, Grid g, TapsN<NT> taps,
+                                                         lsf_gate gate) {
+    convolve_march<1, NT, MASK, FMA>(in, out, mask_src, g, taps, gate);
+}
+
+template <int NT, bool MASK, bool FMA>
+__global__ __launch_bounds__(kBlock) void march_z_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                         const float* __restrict__ mask_src, Grid g, TapsN<NT> taps,
+                                                         lsf_gate gate) {
+    convolve_march<2, NT, MASK, FMA>(in, out, mask_src, g, taps, gate);
 }
 
 template <int NT>
@@ -677,26 +711,32 @@ static bool launch_window_pass(const float* in, float* out, const float* mask, c
     for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
     const int slices = g.z_end - g.z_begin;
     const unsigned tiles_x = (unsigned)(g.nx + kTileX - 1) / kTileX, waves = kBlock / kTileX;
+    const bool fma = taps_are_float32(taps_host, NT);
+#define LSF_LAUNCH_PASS(KERNEL, ...)                                                                                 \
+    do {                                                                                                             \
+        if (mask && fma) hipLaunchKernelGGL((KERNEL<NT, true, true>), grid, dim3(kBlock), 0, s, __VA_ARGS__);          \
+        else if (mask) hipLaunchKernelGGL((KERNEL<NT, true, false>), grid, dim3(kBlock), 0, s, __VA_ARGS__);           \
+        else if (fma) hipLaunchKernelGGL((KERNEL<NT, false, true>), grid, dim3(kBlock), 0, s, __VA_ARGS__);            \
+        else hipLaunchKernelGGL((KERNEL<NT, false, false>), grid, dim3(kBlock), 0, s, __VA_ARGS__);                    \
+    } while (0)
     if (axis == 0) {
         if (g.nx % 4 != 0) return false;
         const long long quads_per_slice = (long long)g.ny * (g.nx / 4);
         const long long first = quads_per_slice * g.z_begin, n = quads_per_slice * slices;
         const dim3 grid((unsigned)((n + kBlock - 1) / kBlock), (unsigned)planes);
-        if (mask) hipLaunchKernelGGL((convolve_x4_kernel<NT, true>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, first, n, gt);
-        else hipLaunchKernelGGL((convolve_x4_kernel<NT, false>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, first, n, gt);
+        LSF_LAUNCH_PASS(convolve_x4_kernel, in, out, mask, g, taps, first, n, gt);
     } else if (axis == 1) {
         const unsigned runs = (unsigned)(g.ny + kMarch - 1) / kMarch;
         const dim3 grid(tiles_x, runs * (((unsigned)slices + waves - 1) / waves), (unsigned)planes);
         if (grid.y > 65535u) return false;
-        if (mask) hipLaunchKernelGGL((convolve_march_kernel<1, NT, true>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, gt);
-        else hipLaunchKernelGGL((convolve_march_kernel<1, NT, false>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, gt);
+        LSF_LAUNCH_PASS(march_y_kernel, in, out, mask, g, taps, gt);
     } else {
         const unsigned runs = (unsigned)(slices + kMarch - 1) / kMarch;
         const dim3 grid(tiles_x, runs * (((unsigned)g.ny + waves - 1) / waves), (unsigned)planes);
         if (grid.y > 65535u) return false;
-        if (mask) hipLaunchKernelGGL((convolve_march_kernel<2, NT, true>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, gt);
-        else hipLaunchKernelGGL((convolve_march_kernel<2, NT, false>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, gt);
+        LSF_LAUNCH_PASS(march_z_kernel, in, out, mask, g, taps, gt);
     }
+#undef LSF_LAUNCH_PASS
     return true;
 }
 
@@ -712,7 +752,7 @@ constexpr int kXyzRows = 16;
 constexpr int kXyzChunk = 32;
 constexpr int kXyzCols = kTileX + 8;  // the tile's columns plus one aligned quad on either side (reach <= 4)
 
-template <int NT>
+template <int NT, bool FMA>
 __global__ __launch_bounds__(kBlock, 5) void convolve_xyz_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                               float* __restrict__ warp, float rate, Grid g,
                                                               TapsN<NT> taps, unsigned chunks_z, int chunk,
@@ -782,7 +822,7 @@ __global__ __launch_bounds__(kBlock, 5) void convolve_xyz_kernel(const float* __
                 if (r < kStaged) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc = acc + taps.k[j] * (double)raw[r][lx + 4 + R - j];
+                    for (int j = 0; j < NT; ++j) acc = mac<FMA>(acc, taps.k[j], (double)raw[r][lx + 4 + R - j]);
                     xs[r][lx] = (float)acc;
                 }
             }
@@ -796,7 +836,7 @@ __global__ __launch_bounds__(kBlock, 5) void convolve_xyz_kernel(const float* __
             for (int k = 0; k < 4; ++k) {
                 double acc = 0.0;
 #pragma unroll
-                for (int j = 0; j < NT; ++j) acc = acc + taps.k[j] * d[k + 2 * R - j];
+                for (int j = 0; j < NT; ++j) acc = mac<FMA>(acc, taps.k[j], d[k + 2 * R - j]);
                 value[k] = (float)acc;
             }
         }
@@ -814,7 +854,7 @@ __global__ __launch_bounds__(kBlock, 5) void convolve_xyz_kernel(const float* __
                 if (y < g.ny) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc = acc + taps.k[j] * (double)win[k][2 * R - j];
+                    for (int j = 0; j < NT; ++j) acc = mac<FMA>(acc, taps.k[j], (double)win[k][2 * R - j]);
                     const long long o = ((long long)po * g.ny + y) * g.nx + x0 + lx;
                     const float r = (float)acc;
                     dst[o] = r;
@@ -833,8 +873,12 @@ static void launch_xyz(const float* in, float* out, float* warp, float rate, con
     const unsigned tiles_x = (unsigned)(g.nx + kTileX - 1) / kTileX, tiles_y = (unsigned)(g.ny + kXyzRows - 1) / kXyzRows;
     const int chunk = kXyzChunk;
     const unsigned chunks_z = (unsigned)(g.z_end - g.z_begin + chunk - 1) / chunk;
-    hipLaunchKernelGGL((convolve_xyz_kernel<NT>), dim3(tiles_x, tiles_y * chunks_z, (unsigned)planes), dim3(kBlock), 0, s,
-                       in, out, warp, rate, g, taps, chunks_z, chunk, gt);
+    if (taps_are_float32(taps_host, NT))
+        hipLaunchKernelGGL((convolve_xyz_kernel<NT, true>), dim3(tiles_x, tiles_y * chunks_z, (unsigned)planes),
+                           dim3(kBlock), 0, s, in, out, warp, rate, g, taps, chunks_z, chunk, gt);
+    else
+        hipLaunchKernelGGL((convolve_xyz_kernel<NT, false>), dim3(tiles_x, tiles_y * chunks_z, (unsigned)planes),
+                           dim3(kBlock), 0, s, in, out, warp, rate, g, taps, chunks_z, chunk, gt);
 }
 
 extern "C" int lsf_convolve_xyz(const float* in_planar, float* out_planar, float* warp_planar, float rate,

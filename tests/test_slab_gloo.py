@@ -1,9 +1,10 @@
-"""Multi-rank path on CPU: world_size 2, gloo backend.  The product's z-slab communicator (SlabComm: halo exchange
+"""Multi-rank path on CPU: world_size 2, 3 and 4 (middle ranks with two neighbours), gloo backend.  The product's z-slab communicator (SlabComm: halo exchange
 + iteration-record reduction, the same code that runs over RCCL/xGMI on the GPUs) drives the ORACLE's per-iteration
 step on each rank's slab (+ halo); the stitched result must equal the oracle run on the whole volume.
 
-Tolerance 2e-6 rather than 0: the oracle forms gather positions z + w from the slab-LOCAL z, and the float32
-rounding of that sum depends on z's magnitude (the HIP kernels use the global z for exactly this reason and are
+Tolerance 1e-5 (the north-star bound) rather than 0: the oracle forms gather positions z + w from the slab-LOCAL z, and
+the float32 rounding of that sum depends on z's magnitude -- 2e-6 with two slabs, 4e-6 with the larger offsets of three
+and four (the HIP kernels use the global z for exactly this reason and are
 bit-identical -- tests/test_gpu_parity.py::test_full_size_fixed_point_and_slab_invariance_256)."""
 import os
 import socket
@@ -77,10 +78,10 @@ def _worker(rank, world, port, n, nz, halo, iterations, sobolev, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("sobolev", [False])
-def test_two_rank_slab_run_matches_whole_volume(tmp_path, sobolev):
+@pytest.mark.parametrize("world,nz", [(2, 16), (3, 24), (4, 32)])
+def test_slab_run_matches_whole_volume(tmp_path, world, nz):
     from oracle import lsf_oracle as O
-    n, nz, halo, iterations, world = 24, 16, 3, 3, 2
+    n, halo, iterations, sobolev = 24, 3, 3, False
     port = _free_port()
     mp.spawn(_worker, args=(world, port, n, nz, halo, iterations, sobolev, str(tmp_path)), nprocs=world, join=True)
     canonical, live = O.sphere_pair(n, d=3, nz=nz)
@@ -92,14 +93,15 @@ def test_two_rank_slab_run_matches_whole_volume(tmp_path, sobolev):
     live_cat = np.concatenate([p["live"] for p in parts], axis=0)
     warp_cat = np.concatenate([p["warp"] for p in parts], axis=0)
     assert live_cat.shape == live.shape
-    assert np.abs(live_cat - live).max() <= 2e-6
-    assert np.abs(warp_cat - opt.warp_field).max() <= 2e-6
-    # reduced records are identical on both ranks and carry the global max / arg-max and the summed partials
-    assert np.array_equal(parts[0]["records"], parts[1]["records"])
+    assert np.abs(live_cat - live).max() <= 1e-5
+    assert np.abs(warp_cat - opt.warp_field).max() <= 1e-5
+    # reduced records are identical on every rank and carry the global max / arg-max and the summed partials
+    for p in parts[1:]:
+        assert np.array_equal(parts[0]["records"], p["records"])
     rec = parts[0]["records"]
     packed = rec[:, 0].view(np.uint64)
     got_max = (packed >> np.uint64(32)).astype(np.uint32).view(np.float32)
-    assert np.allclose(got_max, np.float32(opt.log["max_warps"]), atol=2e-6)
+    assert np.allclose(got_max, np.float32(opt.log["max_warps"]), atol=1e-5)
     got_idx = (~packed.astype(np.uint32)).astype(np.int64)
     want_idx = [np.ravel_multi_index(at, live.shape) for at in opt.log["max_warp_locations"]]
     assert list(got_idx) == [int(i) for i in want_idx]
