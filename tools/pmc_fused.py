@@ -1,6 +1,6 @@
-"""launches the fused Slavcheva state kernel a few times on the 256^3 sphere pair (band lists) and on an all-in-band
-pair (band lists, then dense walk) -- target for rocprofv3 --pmc passes; dispatch order: 6 x sphere/lists,
-6 x all/lists (interior + boundary launch each), 6 x all/dense"""
+"""launches the fused Slavcheva state kernel a few times on the 256^3 sphere pair: 6 x band lists (the bench's launches,
+grid 256 x 1024), then 6 x the dense walk of the same pair (grid 2008 x 256) -- target for rocprofv3 --pmc passes
+(tools/pmc_passes.sh; the summary separates the two by grid size).  CASES=all adds an all-in-band pair (lists + dense)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,7 +19,10 @@ c_s, l_s = sphere_pair(n, 3, "cuda")
 z, y, x = torch.meshgrid(*[torch.arange(n, device="cuda", dtype=torch.float32)] * 3, indexing="ij")
 ramp_c = (0.8 * torch.sin(x * 0.05) * torch.cos(y * 0.04) * torch.cos(z * 0.03)).contiguous()
 ramp_l = (0.8 * torch.sin(x * 0.05 + 0.1) * torch.cos(y * 0.04 - 0.05) * torch.cos(z * 0.03 + 0.08)).contiguous()
-for c, l, listed in ((c_s, l_s, True), (ramp_c, ramp_l, True), (ramp_c, ramp_l, False)):
+cases = [(c_s, l_s, True), (c_s, l_s, False)]
+if os.environ.get("CASES") == "all":
+    cases += [(ramp_c, ramp_l, True), (ramp_c, ramp_l, False)]
+for c, l, listed in cases:
     bands = dev.band_lists(l, c, grid, bytes_per_voxel=16) if listed else [None]
     st = dev.state_pack(l, None, grid)
     for i in range(6):
