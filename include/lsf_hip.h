@@ -86,6 +86,7 @@ typedef struct lsf_iteration_record {
  *   mode LSF_GATE_SLAVCHEVA:    run iff  a < max  AND  max < b   (a, b = lower / upper warp thresholds) */
 #define LSF_GATE_HIERARCHICAL 0
 #define LSF_GATE_SLAVCHEVA 1
+#define LSF_GATE_OPEN 2 /* never closes; only names the previous record (lsf_hier_params::previous_max) */
 typedef struct lsf_gate {
     const lsf_iteration_record *prev_record; /* DEVICE pointer or NULL */
     int32_t mode;
@@ -189,7 +190,12 @@ typedef struct lsf_hier_params {
     int32_t tikhonov_enabled;
     int32_t apply_update;
     int32_t compute_energy;    /* accumulate sum(diff^2) into the record's data_energy */
-    int32_t reserved[2];
+    int32_t previous_max;      /* 3-D, Tikhonov on, apply_update off, gate->prev_record set: ALSO write the maximum length
+                                  (and arg-max) of g_prev -- the previous iteration's final gradient, which this kernel
+                                  reads anyway -- into gate->prev_record.  For runs whose stop test cannot fire
+                                  (threshold <= 0): the maximum is then only a log value and needs no pass of its own
+                                  (lsf_hier_update with a NULL warp) except after the last iteration. */
+    int32_t reserved;
 } lsf_hier_params;
 
 int lsf_hier_iteration(const float *packed_live4, const float *canonical, float *warp_planar,

@@ -24,7 +24,7 @@ ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNE
 SMOOTHING_TIKHONOV, SMOOTHING_KILLING = 0, 1
 DATA_BASIC, DATA_THRESHOLDED_FDM = 0, 2
 ENERGY_NONE, ENERGY_DIRECT, ENERGY_VECTORIZED = 0, 1, 2
-GATE_HIERARCHICAL, GATE_SLAVCHEVA = 0, 1
+GATE_HIERARCHICAL, GATE_SLAVCHEVA, GATE_OPEN = 0, 1, 2
 
 
 class Grid(ctypes.Structure):
@@ -81,7 +81,7 @@ class SlabFaces(ctypes.Structure):
 class HierParams(ctypes.Structure):
     _fields_ = [("data_term_amplifier", ctypes.c_float), ("tikhonov_strength", ctypes.c_float),
                 ("rate", ctypes.c_float), ("tikhonov_enabled", ctypes.c_int32), ("apply_update", ctypes.c_int32),
-                ("compute_energy", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2)]
+                ("compute_energy", ctypes.c_int32), ("previous_max", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class SlavchevaParams(ctypes.Structure):

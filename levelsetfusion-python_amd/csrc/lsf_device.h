@@ -45,6 +45,7 @@ struct Grid {
     int wide_ok;           // float4 state kernels: a wave's neighbourhoods may be addressed relative to its first lane
     int e_begin, e_end;    // slices whose energies count (lsf_grid::energy_z_begin / _end; default: all)
     unsigned list_group;   // wave-units per group of the fused kernel's list walk (wave_list_walk)
+    int list_store_nt;     // list walk: non-temporal stores of the new state (lists too long for the Infinity Cache)
 };
 
 __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
@@ -78,6 +79,7 @@ __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
     r.e_begin = limited ? g->energy_z_begin : 0;
     r.e_end = limited ? g->energy_z_end : g->nz;
     r.list_group = 4u;
+    r.list_store_nt = 0;
     return r;
 }
 
@@ -523,7 +525,7 @@ __device__ inline float second_difference_f64(float am, float a0, float ap) {
 
 // device-side convergence gate (see lsf_gate in include/lsf_hip.h) ------------------------------------------
 __device__ inline bool gate_closed(const lsf_gate& gate) {
-    if (!gate.prev_record) return false;
+    if (!gate.prev_record || gate.mode == LSF_GATE_OPEN) return false;
     unsigned long long p = 0ull;
 #pragma unroll
     for (int k = 0; k < LSF_RECORD_SLOTS; ++k) {

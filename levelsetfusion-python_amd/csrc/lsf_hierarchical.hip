@@ -107,7 +107,8 @@ __device__ inline float laplace_replicate(const float* __restrict__ a, const Gri
     return out + d2x;
 }
 
-template <int D, bool TIK, bool UPDATE, bool ENERGY>
+// PREVMAX: also the maximum of |g_prev| into gate.prev_record (lsf_hier_params::previous_max)
+template <int D, bool TIK, bool UPDATE, bool ENERGY, bool PREVMAX = false>
 __global__ __launch_bounds__(kBlock) void hier_iteration_kernel(const float4* __restrict__ packed,
                                                                 const float* __restrict__ canonical,
                                                                 float* __restrict__ warp,
@@ -150,12 +151,21 @@ __global__ __launch_bounds__(kBlock) void hier_iteration_kernel(const float4* __
             unsigned long long p = pack_max(vec_length<D>(gv), linear_index(g, x, y, z));
             best = p > best ? p : best;
         }
+        if (PREVMAX) {  // the centre values the Laplacian has loaded already
+            float gp[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int c = 0; c < D; ++c) gp[c] = g_prev[c * g.plane + i];
+            unsigned long long p = pack_max(vec_length<D>(gp), linear_index(g, x, y, z));
+            best = p > best ? p : best;
+        }
         if (ENERGY) sums[0] += (double)diff * (double)diff;
     });
-    if (UPDATE || ENERGY) {
+    if (UPDATE || ENERGY || PREVMAX) {
         double* dst[2] = {ENERGY ? &record_slot(record)->data_energy : nullptr,
                           ENERGY && TIK ? &record_slot(record)->smoothing_energy : nullptr};
-        block_reduce_commit<2>(best, sums, UPDATE ? record_max(record) : nullptr, dst);
+        unsigned long long* max_dst = UPDATE ? record_max(record) : nullptr;
+        if (PREVMAX) max_dst = record_max(const_cast<lsf_iteration_record*>(gate.prev_record));
+        block_reduce_commit<2>(best, sums, max_dst, dst);
     }
 }
 
@@ -208,6 +218,17 @@ void dispatch_hier(unsigned blocks, hipStream_t s, const float4* packed, const f
                    const float* g_prev, float* g_out, const Grid& g, const lsf_hier_params* p, const lsf_gate& gate,
                    lsf_iteration_record* record) {
     const bool e = p->compute_energy != 0;
+    if (D == 3 && p->previous_max && p->tikhonov_enabled && !p->apply_update && gate.prev_record) {
+        if (e)
+            hipLaunchKernelGGL((hier_iteration_kernel<3, true, false, true, true>), dim3(blocks), dim3(kBlock), 0, s,
+                               packed, canonical, warp, g_prev, g_out, g, p->data_term_amplifier, p->tikhonov_strength,
+                               p->rate, gate, record);
+        else
+            hipLaunchKernelGGL((hier_iteration_kernel<3, true, false, false, true>), dim3(blocks), dim3(kBlock), 0, s,
+                               packed, canonical, warp, g_prev, g_out, g, p->data_term_amplifier, p->tikhonov_strength,
+                               p->rate, gate, record);
+        return;
+    }
     if (p->tikhonov_enabled) {
         if (p->apply_update) launch_hier<D, true, true>(e, blocks, s, packed, canonical, warp, g_prev, g_out, g, p, gate, record);
         else launch_hier<D, true, false>(e, blocks, s, packed, canonical, warp, g_prev, g_out, g, p, gate, record);

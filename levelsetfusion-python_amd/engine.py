@@ -98,7 +98,7 @@ class HierarchicalEngine:
                  kernel, compute_energy=False, check_interval=32, collect_reports=False, comm=None,
                  collect_iteration_data=False, linear_resampling=False, use_graphs=True, graph_max_voxels=1 << 20):
         self.use_graphs = use_graphs                # HIP-graph replay for launch-bound levels
-        self.graph_max_voxels = graph_max_voxels    # ... i.e. levels of at most this many voxels
+        self.graph_max_voxels = int(os.environ.get("LSF_GRAPH_MAX_VOXELS", graph_max_voxels))  # ... i.e. levels of at most this many voxels (the variable: a measurement knob)
         self._graphs = {}
         self.linear_resampling = linear_resampling  # ResamplingStrategy.LINEAR (3-D): math_utils/resampling.py
         self.collect_reports = collect_reports
@@ -275,14 +275,31 @@ class HierarchicalEngine:
         lv.p_report = f.pointer(lv.report_g, n * dims, "gradient", allow_none=True)
         lv.params_ref = ctypes.byref(lv.params)
         lv.launcher = f
+        # Deferred maximum (3-D levels whose filter runs in lsf_convolve_xyz, Tikhonov on): when the stop test cannot
+        # fire (threshold <= 0) the maximum update length is only a log value, and the NEXT iteration's kernel reads the
+        # gradient it belongs to anyway (as g_prev, for the Laplacian): that kernel writes it into the previous record
+        # (lsf_hier_params::previous_max, an LSF_GATE_OPEN gate naming the record), and only the last iteration of a
+        # batch keeps the separate maximum pass (44 us of 520 per 256^3 iteration).
+        lv.defer_max = (dims == 3 and tik and ker and float(self.maximum_warp_update_threshold) <= 0.0
+                        and self.fused_filter and n >= self.fused_filter_min_voxels
+                        and dev.convolve_xyz_ok(grid, self.gradient_kernel)
+                        and os.environ.get("LSF_HIER_DEFER_MAX", "1") != "0")
+        if lv.defer_max:
+            lv.params_prevmax = _lib.HierParams.from_buffer_copy(lv.params)
+            lv.params_prevmax.previous_max = 1
+            lv.params_prevmax_ref = ctypes.byref(lv.params_prevmax)
+            base = lv.records.data_ptr()
+            lv.open_gates = [_lib.Gate(base + i * _lib.RECORD_BYTES, _lib.GATE_OPEN, 0.0, 0.0) for i in range(n_records)]
+            lv.open_gate_refs = [ctypes.byref(g) for g in lv.open_gates]
         return lv
 
     def invalidate_graphs(self):
         """a setting changed: captured graphs hold the old rate / threshold / taps / iteration counts"""
         self._graphs.clear()
 
-    def _enqueue(self, lv, rec_idx, prev_idx, parity, comm=None):
-        """one iteration: record slot rec_idx, gated on record prev_idx (None: always runs), buffer parity 0/1"""
+    def _enqueue(self, lv, rec_idx, prev_idx, parity, comm=None, defer_max=False, prev_deferred=False):
+        """one iteration: record slot rec_idx, gated on record prev_idx (None: always runs), buffer parity 0/1.
+        defer_max: leave this iteration's maximum to the next one (see _make_level); prev_deferred: the previous did"""
         f = lv.launcher
         tik, ker = self.tikhonov_term_enabled, self.gradient_kernel_enabled
         gate_ref = f.gate_ref(prev_idx)
@@ -290,8 +307,13 @@ class HierarchicalEngine:
         lib_hier = _lib.lib.lsf_hier_iteration
         if ker:
             prev, out = (lv.p_F[parity] if tik else None), lv.F[1 - parity]
-            _lib.check(lib_hier(lv.p_packed, lv.p_canon, lv.p_warp, prev, lv.p_S[0], f.grid_ref, lv.params_ref, gate_ref,
-                                f.record_ptrs[rec_idx], dev.stream_ptr()), "lsf_hier_iteration")
+            if prev_deferred and prev_idx is not None and prev_idx >= 0:
+                _lib.check(lib_hier(lv.p_packed, lv.p_canon, lv.p_warp, prev, lv.p_S[0], f.grid_ref,
+                                    lv.params_prevmax_ref, lv.open_gate_refs[prev_idx], f.record_ptrs[rec_idx],
+                                    dev.stream_ptr()), "lsf_hier_iteration")
+            else:
+                _lib.check(lib_hier(lv.p_packed, lv.p_canon, lv.p_warp, prev, lv.p_S[0], f.grid_ref, lv.params_ref,
+                                    gate_ref, f.record_ptrs[rec_idx], dev.stream_ptr()), "lsf_hier_iteration")
             slab = comm is not None and comm.active
             if slab:  # the z pass reads taps/2 slices of the (x,y)-filtered field on either side
                 comm.exchange_halos([lv.S[0]], width=len(self.gradient_kernel) // 2)
@@ -308,7 +330,8 @@ class HierarchicalEngine:
                 dev.convolve_axis(src, dst, None, lv.grid if axis == 2 else lv.full_grid, axis, self.gradient_kernel,
                                   gate)
                 src = dst
-            dev.hier_update(out, None if moved else lv.warp, lv.grid, self.rate, gate, lv.records, rec_idx)
+            if not (moved and defer_max):
+                dev.hier_update(out, None if moved else lv.warp, lv.grid, self.rate, gate, lv.records, rec_idx)
         elif tik:
             _lib.check(lib_hier(lv.p_packed, lv.p_canon, lv.p_warp, lv.p_F[parity], lv.p_F[1 - parity], f.grid_ref,
                                 lv.params_ref, gate_ref, f.record_ptrs[rec_idx], dev.stream_ptr()),
@@ -409,7 +432,9 @@ class HierarchicalEngine:
                         dev.hier_iteration(packed, canonical, warp, lv.F[i % 2], t_snap, grid,
                                            _lib.HierParams(0.0, -1.0, 0.0, 1, 0, 0), gate, records, i)
                     snapshots.append([None, d_snap, t_snap])
-                self._enqueue(lv, i, i - 1 if i > 0 else None, i % 2, comm)
+                defer = lv.defer_max and not slab and not hooked and not self.collect_iteration_data
+                self._enqueue(lv, i, i - 1 if i > 0 else None, i % 2, comm, defer_max=defer and i + 1 < it + batch,
+                              prev_deferred=defer and i > it)
                 if self.collect_iteration_data:
                     snapshots[-1][0] = warp.clone()
                 if slab:

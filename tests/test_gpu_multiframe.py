@@ -97,3 +97,27 @@ def test_full_size_512_run_through_the_z_constant_embedding(monkeypatch):
     assert float(np.abs(mid[..., 2]).max()) == 0.0
     # translation invariance along z away from the faces: the slices next to the middle one are the same
     assert torch.equal(warp3[n // 2 - 3], warp3[n // 2]) and torch.equal(warp3[n // 2 + 2], warp3[n // 2])
+
+
+def test_deferred_maximum_changes_nothing(monkeypatch):
+    """With a threshold <= 0 the stop test cannot fire, so on the large 3-D levels (filter in lsf_convolve_xyz) an
+    iteration's maximum update length is written by the NEXT iteration's kernel, which reads that gradient anyway
+    (lsf_hier_params::previous_max), and only the last iteration of a batch keeps a maximum pass of its own.  Same warp,
+    same per-iteration maxima and arg-max locations as with a pass per iteration -- batches of 3 and a remainder."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd.synthetic import sphere_frame
+    n = 256
+    canonical, live = sphere_frame(n, 0), sphere_frame(n, 1)
+    kw = dict(maximum_iteration_count=5, kernel=lsf.generate_1d_sobolev_kernel(7, 0.1), check_interval=3, **CONFIG5)
+    runs = []
+    for defer in ("1", "0"):
+        monkeypatch.setenv("LSF_HIER_DEFER_MAX", defer)
+        opt = lsf.HierarchicalOptimizer3d(**kw)
+        warp = opt.optimize(canonical, live)
+        res = opt._engine.level_results
+        runs.append((warp, opt.get_per_level_maximum_updates(), [list(r.argmax) for r in res]))
+    assert torch.equal(runs[0][0], runs[1][0])
+    assert runs[0][1] == runs[1][1] and all(len(m) == 5 and min(m) > 0.0 for m in runs[0][1])
+    assert runs[0][2] == runs[1][2]
