@@ -1,4 +1,4 @@
 set -e
 cd $GRAFT_REPO_ROOT
-PAIRS=1 python tools/ab_state_kernel.py --sizes 256,512 pairs2= pairs3=levelsetfusion-python_amd/lib/variants/pair3.so > gpurun_out/r02_ab_pairs.log 2>&1
-cut -c1-120 gpurun_out/r02_ab_pairs.log
+python tools/_depth_probe.py
+LSF_HIP_LIBRARY=$GRAFT_REPO_ROOT/levelsetfusion-python_amd/lib/variants/r01.so python tools/_depth_probe.py
