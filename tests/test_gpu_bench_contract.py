@@ -73,3 +73,38 @@ def test_multiframe_workload_line():
     assert "multi-frame" in d["config"]["workload"] and "4 frames" in d["config"]["workload"]
     assert abs(d["value"] - 3 * per_pair * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["frac"] > 0
+
+
+def _run_ranks(world, *flags):
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank) -- here with gloo and
+    all ranks on the one GPU of the test box (the only difference to the 8-GPU node is the transport)"""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", str(world), "--steps", "2", "--warmup", "1", "--backend", "gloo", "--share-device",
+                          "--no-cpu-baseline", *flags], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout  # rank 0 alone prints the JSON line
+    return json.loads(lines[0])
+
+
+def test_two_rank_lines():
+    """N = 2: the z-slabbed default workload, and config 5 both ways (replicas: pairs dealt to ranks; slab: every pair cut)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _run_ranks(2, "--size", "64", "--iterations", "6", "--halo", "2")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "z-slab x2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 64 ** 3 * 6 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    per_pair = 3 * sum((64 >> k) ** 3 for k in range(4))
+    d = _run_ranks(2, "--workload", "multiframe", "--size", "64", "--frames", "3", "--iterations", "3")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "replicas x2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 2 * per_pair * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    d = _run_ranks(2, "--workload", "multiframe", "--parallelism", "slab", "--halo", "4", "--size", "64", "--frames", "3",
+                   "--iterations", "3")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "z-slab x2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * per_pair * 2 / (d["ms_per_step"] * 2e-3)) < 2e-6 * d["value"]
