@@ -75,3 +75,20 @@ def test_slavcheva_iteration_hook(lsf, sobolev):
     live2 = live0.copy()
     opt.optimize(live2, canonical)
     assert exact(live2, live_ref)
+
+
+def test_hierarchical_settings_write_through(lsf):
+    """the reference reads rate, thresholds, ... from `self` in every iteration (hierarchical_optimizer2d.py:186-225):
+    assigning to them after construction must take effect -- also on levels that replay a captured HIP graph"""
+    canonical, live = O.sphere_pair(64, d=2)
+    kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=8, maximum_iteration_count=8,
+              maximum_warp_update_threshold=0.0, tikhonov_strength=0.05)
+    opt = lsf.HierarchicalOptimizer2d(rate=0.1, **kw)
+    first = opt.optimize(canonical, live)  # captures the graphs of the small levels with rate 0.1
+    opt.rate = 0.25
+    opt.maximum_iteration_count = 6
+    assert opt.rate == 0.25 and opt._engine.rate == 0.25
+    changed = opt.optimize(canonical, live)
+    fresh = lsf.HierarchicalOptimizer2d(rate=0.25, **dict(kw, maximum_iteration_count=6)).optimize(canonical, live)
+    assert exact(changed, fresh) and not exact(changed, first)
+    assert opt.get_per_level_iteration_counts() == [6] * len(opt.get_per_level_iteration_counts())
