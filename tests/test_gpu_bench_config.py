@@ -85,18 +85,19 @@ def test_depth_pair_20_iterations_equal_the_oracle(lsf):
     assert float(np.abs(live - live0).max()) > 0.0
 
 
-def test_full_size_list_walk_equals_dense_walk_256(lsf):
-    """BASELINE config 4 at full size, 50 iterations: the band-list walk (what the bench times: INTERIOR lists, CU-sized
-    workgroups, the taps-in-registers re-warp) against the SAME kernel walking every voxel -- fields and the records of
-    all 50 iterations bit for bit.  Size-independent property; the oracle would need 3.5 minutes here."""
+@pytest.mark.parametrize("n,iterations", [(256, 50), (512, 20)])
+def test_full_size_list_walk_equals_dense_walk(lsf, n, iterations):
+    """BASELINE config 4 at full size (and the 512^3 of config 5), 50 (20) iterations: the band-list walk (what the bench
+    times: INTERIOR lists, CU-sized workgroups, the taps-in-registers re-warp; streaming stores at 512^3) against the SAME
+    kernel walking every voxel -- fields and the records of every iteration bit for bit.  Size-independent property; the
+    oracle would need 3.5 minutes at 256^3."""
     from levelsetfusion_python_amd.synthetic import sphere_pair
-    n = 256
     canonical, live0 = sphere_pair(n, 3, "cuda")
     runs = []
     for use_list in (True, False):
         opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT,
-                                       smoothing_term_method=lsf.SmoothingTermMethod.KILLING, max_iterations=50,
-                                       min_iterations=50, check_interval=50, **BENCH)
+                                       smoothing_term_method=lsf.SmoothingTermMethod.KILLING, max_iterations=iterations,
+                                       min_iterations=iterations, check_interval=iterations, **BENCH)
         opt._engine.use_band_list = use_list
         live = live0.clone()
         opt.optimize(live, canonical)
