@@ -46,6 +46,8 @@ struct Grid {
     int e_begin, e_end;    // slices whose energies count (lsf_grid::energy_z_begin / _end; default: all)
     unsigned list_group;   // wave-units per group of the fused kernel's list walk (wave_list_walk)
     int list_store_nt;     // list walk: non-temporal stores of the new state (lists too long for the Infinity Cache)
+    int shift_x, shift_y;  // log2(nx), log2(ny) when both are powers of two (voxel index -> x, y, z by shifts), else -1
+    unsigned index_offset; // linear_index(g, x, y, z) - vidx(g, x, y, z) = z_global_offset * ny * nx
 };
 
 __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
@@ -80,6 +82,15 @@ __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
     r.e_end = limited ? g->energy_z_end : g->nz;
     r.list_group = 4u;
     r.list_store_nt = 0;
+    auto log2_of = [](int v) {
+        int k = 0;
+        while ((1 << k) < v) ++k;
+        return (1 << k) == v ? k : -1;
+    };
+    r.shift_x = log2_of(g->nx);
+    r.shift_y = log2_of(g->ny);
+    if (r.shift_x < 0 || r.shift_y < 0) r.shift_x = r.shift_y = -1;
+    r.index_offset = (unsigned)((long long)g->z_global_offset * g->ny * g->nx);
     return r;
 }
 
@@ -344,6 +355,22 @@ __host__ inline unsigned band_list_blocks(unsigned count, unsigned default_per_x
 
 // (A dynamic variant -- per-XCD work queues with atomic heads and stealing -- was measured and rejected: device-scope
 // returning atomics on a contended address serialise at ~140 ns here, 16 K grabs per 256^3 launch cost 0.29 ms.)
+
+// voxel index -> (x, y, z): shifts and masks when nx and ny are powers of two (BASELINE's 256^3 / 512^3: four full-rate
+// instructions), else two multiply-high divisions (quarter rate on CDNA: ~22 issue slots); wave-uniform choice
+__device__ inline void decode_voxel(const Grid& g, unsigned i, int& x, int& y, int& z) {
+    if (g.shift_x >= 0) {
+        x = (int)(i & ((1u << g.shift_x) - 1u));
+        const unsigned zy = i >> g.shift_x;
+        y = (int)(zy & ((1u << g.shift_y) - 1u));
+        z = (int)(zy >> g.shift_y);
+    } else {
+        const unsigned zy = fast_div(i, g.div_nx);
+        x = (int)(i - zy * (unsigned)g.nx);
+        z = (int)fast_div(zy, g.div_ny);
+        y = (int)zy - z * g.ny;
+    }
+}
 
 __device__ inline unsigned linear_index(const Grid& g, int x, int y, int z) {
     return (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);

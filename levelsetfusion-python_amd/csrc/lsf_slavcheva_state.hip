@@ -567,10 +567,8 @@ void slavcheva_state_kernel(const vf4* __restrict__ state_in,
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         LSF_TRACE(3);
 #endif
-        const unsigned zy = fast_div(i, g.div_nx);
-        const int x = (int)(i - zy * (unsigned)g.nx);
-        const int z = (int)fast_div(zy, g.div_ny);
-        const int y = (int)zy - z * g.ny;
+        int x, y, z;
+        decode_voxel(g, i, x, y, z);
         Deferred d;
         d.i = listed ? (int)i : -1;
         const float l = sc.x;
@@ -595,7 +593,7 @@ void slavcheva_state_kernel(const vf4* __restrict__ state_in,
             d.rw.lerp = false;
             d.rw.R = l;
         }
-        const unsigned long long q = listed ? pack_max(len, linear_index(g, x, y, z)) : 0ull;
+        const unsigned long long q = listed ? pack_max(len, i + g.index_offset) : 0ull;  // = linear_index(g, x, y, z)
         best = q > best ? q : best;
         LSF_TRACE(4);
         return d;
