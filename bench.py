@@ -237,14 +237,33 @@ def extra_workload(args, device, world, rank, dist):
         dist.destroy_process_group()
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` as a child (rendezvous on 127.0.0.1, a free port), pass its output through -- rank 0 prints the one
+    JSON line -- and return its exit status.  The pair loop this scales: run_hierarchical_optimizer3d_multipair.py:403-432."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this image
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # plain `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU), as a CHILD process --
+            # nothing in this process has touched the GPU yet, and it never will
+            raise SystemExit(self_launch(args.gpus))
         args.gpus = world
     if args.share_device:
         if args.backend != "gloo":

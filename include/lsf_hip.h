@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define LSF_ABI_VERSION 1
+#define LSF_ABI_VERSION 2
 #define LSF_MAX_KERNEL_TAPS 31
 
 #define LSF_ERR_BAD_ARGUMENT (-1)

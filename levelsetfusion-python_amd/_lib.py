@@ -16,7 +16,7 @@ from ._build import LIB_PATH
 c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
 MAX_KERNEL_TAPS = 31
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED"}

@@ -1138,14 +1138,17 @@ class SlavchevaEngine:
             dec = dev.decode_records(self.comm.gather_records(records, 0, it) if slab and ungated
                                      else dev.records_to_host(records[:it]))
             n_exec = int(dec["executed"].sum())
-            if n_exec < it:
-                break
-            m = dec["max_value"][n_exec - 1]
+            # z-slab: every EXECUTED iteration must have stayed inside what the halo schedule keeps valid -- also those
+            # of a batch in which the gate then closed (a large update followed by convergence inside one
+            # check_interval).  Every rank sees the same reduced / gathered records, so the raise is collective.
             reach = self.comm.layout.halo if slab else 0
             if slab and not self.sobolev and self._fast.exchange_interval > 1:
                 reach = 1  # inside an exchange group every iteration may consume one slice of validity only
-            if slab and not (dec["max_value"][:n_exec].max() < reach):
+            if slab and n_exec > 0 and not (dec["max_value"][:n_exec].max() < reach):
                 raise _HaloTooNarrow(float(dec["max_value"][:n_exec].max()), reach)
+            if n_exec < it:
+                break
+            m = dec["max_value"][n_exec - 1]
             if hooked:
                 self._call_hook(it - 1, float(m), lives, warps, states, canonical, grid)
             if n_exec >= self.min_iterations and not (np.float32(self.lo) < m < np.float32(self.hi)):

@@ -19,7 +19,15 @@ def _engine_setting(name, convert=None):
         return getattr(self._engine, name)
 
     def put(self, value):
-        setattr(self._engine, name, convert(value) if convert is not None and value is not None else value)
+        value = convert(value) if convert is not None and value is not None else value
+        # the reference keeps plain attributes and would fail inside its loop on a filter that is switched on without
+        # taps (convolve_with_kernel(None)); say so at the assignment instead
+        kernel = value if name == "gradient_kernel" else self._engine.gradient_kernel
+        enabled = value if name == "gradient_kernel_enabled" else self._engine.gradient_kernel_enabled
+        if name in ("gradient_kernel", "gradient_kernel_enabled") and enabled and kernel is None:
+            raise ValueError("gradient_kernel_enabled needs a gradient_kernel (assign the kernel first, or disable the "
+                             "filter before removing it)")
+        setattr(self._engine, name, value)
         self._engine.invalidate_graphs()
     return property(get, put)
 

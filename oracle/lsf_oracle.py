@@ -37,9 +37,12 @@ LEVEL_SET_EPS = F32(1e-5)   # level_set_term.py:28
 # =====================================================================================================
 #  a1/a2  D-linear resampling under a warp         (utils/sampling.py:139-175,222-263; field_warping.py:67-109)
 # =====================================================================================================
-def _grid_positions(warp):
+def _grid_positions(warp, axis0_offset=0):
     """float32 sample positions p + warp[p], one array per spatial axis (axis order), as
-    field_warping.py:82  Point2d(x, y) + Point2d(coordinates=warp[y, x])  evaluates them under numpy>=2."""
+    field_warping.py:82  Point2d(x, y) + Point2d(coordinates=warp[y, x])  evaluates them under numpy>=2.
+    axis0_offset: the array is a z-slab whose slice 0 is slice `axis0_offset` of the whole volume -- positions along
+    axis 0 are formed from the GLOBAL coordinate (float32 rounding of coordinate + displacement depends on the
+    coordinate's magnitude), sample_linear takes the same offset back out of the tap indices."""
     shape = warp.shape[:-1]
     d = len(shape)
     pos = []
@@ -48,11 +51,13 @@ def _grid_positions(warp):
         idx_shape = [1] * d
         idx_shape[axis] = shape[axis]
         coord = np.arange(shape[axis], dtype=F32).reshape(idx_shape)
+        if axis == 0 and axis0_offset:
+            coord = (coord + F32(axis0_offset)).astype(F32)
         pos.append((coord + warp[..., c]).astype(F32))
     return pos
 
 
-def sample_linear(field, pos, oob):
+def sample_linear(field, pos, oob, axis0_offset=0):
     """D-linear interpolation of `field` at float32 positions `pos` (list, axis order).  Every tap that
     falls outside the array reads `oob` (scalar or per-output array).  Lerp order: slowest axis first
     (2-D: along y then x, sampling.py:170-172; 3-D adds z in front -- DESIGN.md section 3)."""
@@ -61,7 +66,8 @@ def sample_linear(field, pos, oob):
     base = [np.floor(p) for p in pos]
     ratio = [(p - b).astype(F32) for p, b in zip(pos, base)]
     inv = [(F32(1.0) - r).astype(F32) for r in ratio]
-    base_i = [np.clip(b, -2, shape[a] + 1).astype(np.int64) for a, b in enumerate(base)]
+    base_i = [np.clip(b - (axis0_offset if a == 0 else 0), -2, shape[a] + 1).astype(np.int64)
+              for a, b in enumerate(base)]
     oob_arr = np.broadcast_to(np.asarray(oob, dtype=F32), pos[0].shape)
 
     def tap(offsets):
@@ -105,12 +111,12 @@ def is_truncated(field):
 
 
 def warp_field_advanced(canonical, live, warp, gradient=None, band_union_only=False, known_values_only=False,
-                        substitute_original=False):
+                        substitute_original=False, axis0_offset=0):
     """field_warping.py:112-151.  Returns the new live field; zeroes warp[p] (and gradient[p]) in place where
-    the resampled value snaps to +-1."""
-    pos = _grid_positions(warp)
+    the resampled value snaps to +-1.  axis0_offset: see _grid_positions (z-slab tests only)."""
+    pos = _grid_positions(warp, axis0_offset)
     oob = live if substitute_original else F32(1.0)
-    new = sample_linear(live, pos, oob)
+    new = sample_linear(live, pos, oob, axis0_offset)
     snap = (F32(1.0) - np.abs(new)) < SNAP_EPS
     new = np.where(snap, np.sign(new), new).astype(F32)
     skip = np.zeros(live.shape, dtype=bool)
@@ -611,6 +617,7 @@ class SlavchevaOracle:
         self.log = None
         self.iteration_hook = None  # f(it, live, warp, gradient, energies(dict), max_warp, location)
         self.max_region = None      # optional slice along axis 0: restrict the max-warp search (slab tests)
+        self.axis0_offset = 0       # slab tests: global index of the array's slice 0 (see _grid_positions)
 
     def iteration(self, live, canonical, warp):
         """slavcheva_optimizer2d.py:163-236 (VECTORIZED) / :238-330 (DIRECT).  live, warp updated in place.
@@ -653,7 +660,7 @@ class SlavchevaOracle:
         max_warp = float(lengths[at])
         # DIRECT passes gradient_field to warp_field_advanced (zeroed where snapped, :324-327);
         # VECTORIZED hands only u,v to the C++ twin (:224-234), so its gradient_field is left alone.
-        new_live = warp_field_advanced(canonical, live, warp, g if direct else None)
+        new_live = warp_field_advanced(canonical, live, warp, g if direct else None, axis0_offset=self.axis0_offset)
         np.copyto(live, new_live)
         self.gradient_field = g
         return max_warp, at, dict(data=e_data, smoothing=e_smooth, level_set=e_ls)

@@ -62,7 +62,7 @@ def test_ctypes_structs_match_header_layout(pkg):
     assert ctypes.sizeof(L.HierParams) == 32
     assert ctypes.sizeof(L.SlavchevaParams) == 56 and L.SlavchevaParams.rate.offset == 8
     text = open(HEADER).read()
-    for macro, value in (("LSF_ABI_VERSION", 1), ("LSF_MAX_KERNEL_TAPS", L.MAX_KERNEL_TAPS),
+    for macro, value in (("LSF_ABI_VERSION", 2), ("LSF_MAX_KERNEL_TAPS", L.MAX_KERNEL_TAPS),
                          ("LSF_SMOOTHING_KILLING", L.SMOOTHING_KILLING),
                          ("LSF_DATA_THRESHOLDED_FDM", L.DATA_THRESHOLDED_FDM),
                          ("LSF_ENERGY_VECTORIZED", L.ENERGY_VECTORIZED), ("LSF_GATE_SLAVCHEVA", L.GATE_SLAVCHEVA)):
@@ -265,3 +265,32 @@ def test_multipair_report_tables(pkg, tmp_path):
     mp.save_pair(str(tmp_path / "pairs"), 3, 300, c, c + 2)
     pairs = mp.load_pairs(str(tmp_path / "pairs"))
     assert [(p[0], p[1]) for p in pairs] == [(3, 300), (12, 300)] and float(pairs[1][3][0, 0]) == 1.0
+
+
+def test_bench_plain_form_starts_its_own_launcher(monkeypatch):
+    """`python bench.py --gpus N` without torch.distributed.run in front: bench.main() hands the same arguments to a child
+    `python -m torch.distributed.run --nproc-per-node N ... bench.py`, before anything touches the GPU, and exits with the
+    child's status (the GPU suite runs the real thing: test_gpu_bench_contract.py)"""
+    import importlib.util
+    import subprocess
+    spec = importlib.util.spec_from_file_location("_bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    for name in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(name, raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3", "--warmup", "1"])
+    monkeypatch.setattr(bench.torch.cuda, "set_device", lambda *_: (_ for _ in ()).throw(AssertionError("GPU touched")))
+    with pytest.raises(SystemExit) as exit_info:
+        bench.main()
+    assert exit_info.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-7:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

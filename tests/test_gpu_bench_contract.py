@@ -108,3 +108,21 @@ def test_two_rank_lines():
                    "--iterations", "3")
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "z-slab x2" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * per_pair * 2 / (d["ms_per_step"] * 2e-3)) < 2e-6 * d["value"]
+
+
+def test_plain_form_launches_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher in front (the shape of the driver's N = 1 command): bench.py starts
+    torch.distributed.run itself as a child process and relays rank 0's one JSON line and the exit status"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR",
+                                                           "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--backend", "gloo", "--share-device", "--no-cpu-baseline", "--size", "64", "--iterations", "6",
+                          "--halo", "2"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "z-slab x2" in d["config"]["parallelism"]
+    assert abs(d["value"] - 2 * 64 ** 3 * 6 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]

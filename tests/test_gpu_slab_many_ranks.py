@@ -74,6 +74,9 @@ CASES = {
     "three_slabs_sobolev_lists": (3, "sphere", 3, 4, True),
     "two_slabs_large_updates": (2, "ortho", 2, 5, False),
     "four_slabs_large_updates": (4, "ortho", 2, 4, False),
+    # gated run: an update longer than the halo is followed by the stop test firing INSIDE the same check_interval batch
+    # (the reach check has to look at a batch's executed iterations before the loop leaves)
+    "two_slabs_large_update_then_stop": (2, "ortho", 2, "upper", False),
 }
 
 
@@ -92,7 +95,19 @@ def test_slab_ranks_equal_whole_volume(tmp_path, case):
     else:
         kwargs = dict(compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
                       smoothing_term_method=lsf.SmoothingTermMethod.KILLING, check_interval=4)
-    if fixed is not None:
+    if fixed == "upper":
+        # the whole volume, ungated, tells where the first update longer than the 2-slice halo happens; the upper
+        # threshold is put between the halo and that update, so the gated run executes it and then stops
+        probe = lsf.SlavchevaOptimizer3d(field_size=n, maximum_warp_length_lower_threshold=0.0, max_iterations=5,
+                                         min_iterations=5, **kwargs)
+        probe._run_checks = lambda *a: None
+        pc, pl = (torch.from_numpy(v).cuda() for v in _volume(kind, n, nz))
+        probe.optimize(pl, pc)
+        k = next(i for i, m in enumerate(probe.log.max_warps) if m > 2.0)
+        kwargs.update(maximum_warp_length_lower_threshold=0.0,
+                      maximum_warp_length_upper_threshold=0.5 * (2.0 + probe.log.max_warps[k]), max_iterations=8,
+                      min_iterations=1, check_interval=8)
+    elif fixed is not None:
         kwargs.update(maximum_warp_length_lower_threshold=0.0, max_iterations=fixed, min_iterations=fixed)
     else:
         kwargs.update(maximum_warp_length_lower_threshold=0.0319, max_iterations=30, min_iterations=2)
@@ -105,6 +120,8 @@ def test_slab_ranks_equal_whole_volume(tmp_path, case):
         assert max(ref.log.max_warps) > 2.0, "this pair is meant to move by several voxels per iteration"
     if fixed is None:
         assert 2 < len(ref.log.max_warps) < 30
+    if fixed == "upper":
+        assert len(ref.log.max_warps) == k + 1 < 8 and ref.log.max_warps[-1] > 2.0
     parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     assert np.array_equal(np.concatenate([p["live"] for p in parts], 0), live.cpu().numpy())
     assert np.array_equal(np.concatenate([p["warp"] for p in parts], 0), ref.warp_field.cpu().numpy())

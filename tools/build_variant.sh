@@ -15,13 +15,17 @@ if [ "$REV" = "-" ]; then
 else
   (cd $R && git archive $REV levelsetfusion-python_amd/csrc include) | tar -x -C $W
 fi
-OBJS=""
+# lsf_build_id() of a variant: the hash of ITS sources and extra flags (bench.py reports the committed PMC traffic only for
+# the build it was measured on; a variant must not inherit the shipped library's id)
+ID=$( (cat $(ls $W/levelsetfusion-python_amd/csrc/* $W/include/*.h | sort); echo "$@") | sha256sum | cut -c1-16)
+OBJS=""; PIDS=""
 for f in $W/levelsetfusion-python_amd/csrc/*.hip; do
   o=$W/$(basename $f .hip).o
-  hipcc -O3 --offload-arch=gfx950 -fPIC -ffp-contract=off -std=c++17 -Wno-unused-function "$@" -c $f -o $o &
+  hipcc -O3 --offload-arch=gfx950 -fPIC -ffp-contract=off -std=c++17 -Wno-unused-function "-DLSF_BUILD_ID=\"v$ID\"" "$@" -c $f -o $o &
+  PIDS="$PIDS $!"
   OBJS="$OBJS $o"
 done
-wait
+for p in $PIDS; do wait $p || { echo "compile failed" >&2; exit 1; }; done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/$NAME.so $OBJS -ldl
 rm -rf $W
 echo $OUT/$NAME.so
