@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, name), "liblsf_hip.so does not export %s" % name
         assert name in pkg._lib.PROTOTYPES, "no ctypes prototype for %s" % name
     assert sorted(pkg._lib.PROTOTYPES) == names
-    assert pkg._lib.lib.lsf_abi_version() == 1
+    assert pkg._lib.lib.lsf_abi_version() == pkg._lib.ABI_VERSION == 2
     assert pkg._lib.lib.lsf_target_arch() == b"gfx950"
 
 
