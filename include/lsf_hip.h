@@ -41,6 +41,7 @@ extern "C" {
 #define LSF_ERR_KERNEL_TOO_LONG (-3)
 #define LSF_ERR_RCCL_UNAVAILABLE (-4) /* librccl.so could not be bound at run time */
 #define LSF_ERR_RCCL_FAILED (-5)      /* an RCCL call returned an error (its text goes to stderr) */
+#define LSF_ERR_NOT_RESIDENT (-6)     /* lsf_slavcheva_state_chain: its workgroups cannot all be resident on this device */
 
 /* extents of one field as stored on this device */
 typedef struct lsf_grid {
@@ -318,15 +319,45 @@ int lsf_planar_finalize(const float *live, const float *warp_planar, const float
 /* lsf_state_finalize for whole arrays whose band lists are at hand: only the listed voxels are visited -- live_out must
  * already hold the INPUT live field and warp_interleaved_out zeros (nothing else can have changed); the statistics
  * take the unlisted voxels from lsf_state_prepare's counts_out[2..4): opposite_count of them have
- * |canonical - live| = 2, the first one at voxel first_opposite (-1: none), the others 0.  scratch as lsf_state_finalize. */
+ * |canonical - live| = 2, the first one at voxel first_opposite (-1: none), the others 0.  scratch as lsf_state_finalize.
+ * skip_flag (may be NULL): a DEVICE word; when it is non-zero as the pass runs, live_out and warp_interleaved_out are
+ * left untouched (and the statistics are meaningless) -- see lsf_slavcheva_state_chain. */
 int lsf_state_finalize_listed(const float *state, const float *canonical, float *live_out, float *warp_interleaved_out,
                               const lsf_grid *grid, const int32_t *const *band_lists, const int64_t *band_counts,
                               int32_t n_lists, int64_t opposite_count, int64_t first_opposite, float lower_threshold,
-                              double *statistics16, double *scratch, void *stream);
+                              double *statistics16, double *scratch, const int32_t *skip_flag, void *stream);
 int lsf_slavcheva_state_iteration(const float *state_in, const float *canonical, float *state_out,
                                   const lsf_grid *grid, const lsf_slavcheva_params *params, const lsf_gate *gate,
                                   lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,
                                   int32_t band_subset, void *stream);
+
+/* ---- K fused iterations in ONE launch: the chain kernel ------------------------------------------
+ * replaces K consecutive passes of the loop body nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:238-330 (DIRECT; the
+ * VECTORIZED form :163-236 with its parameter block) for runs whose stop test (:360-362) cannot fire in between: iteration
+ * j = 0 .. iterations - 1 reads state_a (j even) or state_b (j odd), writes the other and reduces into records[j], exactly
+ * as lsf_slavcheva_state_iteration would in K launches -- bit for bit while every warp update stays below 2 voxels.
+ * One CU-sized workgroup per CU stays resident; a workgroup waits only for the few neighbouring list chunks its stencils
+ * and re-warp gather reach (progress words in `scratch`), never for the whole chip.  Requirements: an INTERIOR band list
+ * of the WHOLE array (z_begin = 0, z_end = nz; no BOUNDARY voxels besides it), 16 * nz * ny * nx < 2^32.
+ *   scratch   lsf_state_chain_scratch_elements(band_count, stages) int32 of device memory (16-byte aligned);
+ *             lsf_state_chain_plan fills its dependency windows ONCE per list, every lsf_slavcheva_state_chain call on
+ *             that list (same band_count and stages) reuses them and zeroes the words it polls.
+ *   stages    1: every CU owns one chunk and runs all iterations on it.  S > 1 (long lists only, else treated as 1): the
+ *             CUs form S groups, group s runs iterations s, s + S, ... over all chunks, so that an iteration's output is
+ *             consumed from the Infinity Cache by the next iteration instead of travelling through HBM.
+ *   scratch[0] != 0 after the launch: a wait timed out (records[iterations - 1] then decodes to a NaN maximum);
+ *   scratch[1] != 0: an update of 2 voxels or more -- the result is NOT the reference's; lsf_state_finalize_listed(...,
+ *             skip_flag = scratch + 1) then leaves the caller's fields untouched and the caller repeats the call with
+ *             lsf_slavcheva_state_iteration.  The same verdict follows from the records' maxima.
+ * Returns LSF_ERR_NOT_RESIDENT (nothing launched) when a CU cannot hold one 1024-thread workgroup of the kernel. */
+int64_t lsf_state_chain_scratch_elements(int64_t band_count, int32_t stages);
+int lsf_state_chain_shape(int64_t band_count, int32_t stages, int32_t *out4 /* workgroups, stages, chunks, wave-units */);
+int lsf_state_chain_plan(const lsf_grid *grid, const int32_t *band_list, int64_t band_count, int32_t stages,
+                         int32_t *scratch, void *stream);
+int lsf_slavcheva_state_chain(float *state_a, float *state_b, const float *canonical, const lsf_grid *grid,
+                              const lsf_slavcheva_params *params, lsf_iteration_record *records,
+                              const int32_t *band_list, int64_t band_count, int32_t iterations, int32_t stages,
+                              int32_t *scratch, void *stream);
 
 /* ---- z-slab runtime of the fused path for multi-GPU runs (new design) -----------------------------
  * One process per GPU; rank r owns z-slices [z_begin, z_end) of its local array and keeps `halo` slices of its

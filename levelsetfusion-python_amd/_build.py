@@ -8,8 +8,10 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "liblsf_hip.so")
-SOURCES = ["lsf_fields.hip", "lsf_hierarchical.hip", "lsf_slavcheva.hip", "lsf_slavcheva_state.hip", "lsf_slab.hip", "lsf_tsdf.hip"]
-HEADERS = ["lsf_device.h", "lsf_slavcheva_terms.h", os.path.join("..", "..", "include", "lsf_hip.h")]
+SOURCES = ["lsf_fields.hip", "lsf_hierarchical.hip", "lsf_slavcheva.hip", "lsf_slavcheva_state.hip",
+           "lsf_slavcheva_chain.hip", "lsf_slab.hip", "lsf_tsdf.hip"]
+HEADERS = ["lsf_device.h", "lsf_slavcheva_terms.h", "lsf_slavcheva_state_taps.h",
+           os.path.join("..", "..", "include", "lsf_hip.h")]
 # -ffp-contract=off: multiply and add stay separately rounded so that results are bit-identical to the numpy
 # oracle (numpy never fuses); the path is HBM/L1-bound, the lost FMAs do not show.
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-std=c++17",
@@ -62,13 +64,17 @@ def build(force=False, verbose=True):
     os.makedirs(LIB_DIR, exist_ok=True)
     objs = []
     build_id = source_id()
-    for src in sources():
+    jobs = []
+    for src in sources():  # one hipcc per source, all at once (7 files on 8 cores: ~25 s instead of ~60 s)
         obj = os.path.join(LIB_DIR, os.path.basename(src).replace(".hip", ".o"))
         cmd = [hipcc] + HIPCC_FLAGS + ['-DLSF_BUILD_ID="%s"' % build_id, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        jobs.append((cmd, subprocess.Popen(cmd)))
         objs.append(obj)
+    failed = [cmd for cmd, job in jobs if job.wait() != 0]
+    if failed:
+        raise subprocess.CalledProcessError(1, failed[0])
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)

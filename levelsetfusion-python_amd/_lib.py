@@ -19,7 +19,8 @@ MAX_KERNEL_TAPS = 31
 ABI_VERSION = 2
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
-          -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED"}
+          -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
+ERR_NOT_RESIDENT = -6
 
 SMOOTHING_TIKHONOV, SMOOTHING_KILLING = 0, 1
 DATA_BASIC, DATA_THRESHOLDED_FDM = 0, 2
@@ -145,7 +146,12 @@ PROTOTYPES = {
     "lsf_state_finalize": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _f32, _vp, _vp, _vp]),
     "lsf_planar_finalize": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _f32, _vp, _vp, _vp]),
     "lsf_state_finalize_listed": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _P(ctypes.c_void_p), _P(_i64), _i32,
-                                                 _i64, _i64, _f32, _vp, _vp, _vp]),
+                                                 _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
+    "lsf_state_chain_scratch_elements": (ctypes.c_int64, [_i64, _i32]),
+    "lsf_state_chain_shape": (ctypes.c_int, [_i64, _i32, _P(_i32)]),
+    "lsf_state_chain_plan": (ctypes.c_int, [_P(Grid), _vp, _i64, _i32, _vp, _vp]),
+    "lsf_slavcheva_state_chain": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _vp, _vp, _i64, _i32,
+                                                 _i32, _vp, _vp]),
     "lsf_slavcheva_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp,
                                                      _vp, _i64, _i32, _vp]),
     "lsf_band_scratch_elements": (ctypes.c_int64, [_P(Grid)]),

@@ -552,9 +552,10 @@ def planar_finalize(live, warp_planar, canonical, grid, live_out=None, warp_inte
 
 
 def state_finalize_listed(state, canonical, grid, bands, unlisted, live_out=None, warp_interleaved_out=None,
-                          lower_threshold=0.0, statistics=False):
+                          lower_threshold=0.0, statistics=False, skip_flag=None):
     """state_finalize of whole arrays that visits the voxels of `bands` only (lsf_state_finalize_listed): live_out must
-    hold the input live field and warp_interleaved_out zeros already; `unlisted` as state_prepare returned it"""
+    hold the input live field and warp_interleaved_out zeros already; `unlisted` as state_prepare returned it;
+    skip_flag: device address of a word that turns the pass into a no-op when non-zero (StateChain.violation_ptr)"""
     n = n_voxels(grid)
     bands = [b for b in bands if b.count]
     stats = scratch = None
@@ -573,9 +574,53 @@ def state_finalize_listed(state, canonical, grid, bands, unlisted, live_out=None
                                         int(unlisted[1]), float(lower_threshold),
                                         _ptr(stats, 16, "statistics", dtype=torch.float64, allow_none=True),
                                         _ptr(scratch, scratch.numel() if scratch is not None else 0, "scratch",
-                                             dtype=torch.float64, allow_none=True), stream_ptr()),
+                                             dtype=torch.float64, allow_none=True),
+                                        ctypes.c_void_p(skip_flag or 0), stream_ptr()),
           "lsf_state_finalize_listed")
     return stats
+
+
+class StateChain:
+    """K fused iterations of an INTERIOR band list per launch (lsf_slavcheva_state_chain): the dependency windows of the
+    list are planned once (lsf_state_chain_plan), every launch(first, count) then runs iterations first .. first + count - 1
+    of the call -- iteration j reads states[j % 2], writes the other, reduces into records[j].
+    REACH_LIMIT: update length from which the windows no longer cover the re-warp gather (the launch then raises its
+    violation word, which a finalize pass given violation_ptr honours, and the records' maxima tell the host)."""
+
+    REACH_LIMIT = 2.0
+
+    def __init__(self, states, canonical, grid, params, records, band, stages=1):
+        if band.subset != _lib.BAND_INTERIOR or not band.count:
+            raise ValueError("the chain kernel walks a non-empty INTERIOR band list")
+        self.grid = full_range(grid)
+        n = n_voxels(grid)
+        self.stages = int(stages)
+        self._keep = (states, canonical, records, band, params)
+        self._states = [_ptr(t, 4 * n, "state") for t in states]
+        self._canonical = _ptr(canonical, n, "canonical")
+        self._params = ctypes.byref(params)
+        self._records = records
+        self._band = band
+        words = int(lib.lsf_state_chain_scratch_elements(band.count, self.stages))
+        self.scratch = torch.empty(words, dtype=torch.int32, device=states[0].device)
+        self._scratch = ctypes.c_void_p(self.scratch.data_ptr())
+        self.violation_ptr = self.scratch.data_ptr() + 4
+        shape = (ctypes.c_int32 * 4)()
+        check(lib.lsf_state_chain_shape(band.count, self.stages, shape), "lsf_state_chain_shape")
+        self.workgroups, self.stages_used, self.chunks, self.units = (int(v) for v in shape)
+        check(lib.lsf_state_chain_plan(ctypes.byref(self.grid), band.pointer, band.count, self.stages, self._scratch,
+                                       stream_ptr()), "lsf_state_chain_plan")
+
+    def launch(self, first, count):
+        """False: the kernel's workgroups cannot all be resident on this device (nothing was launched)"""
+        a, b = self._states[first % 2], self._states[(first + 1) % 2]
+        status = lib.lsf_slavcheva_state_chain(a, b, self._canonical, ctypes.byref(self.grid), self._params,
+                                               _record_ptr(self._records, first), self._band.pointer, self._band.count,
+                                               int(count), self.stages, self._scratch, stream_ptr())
+        if status == _lib.ERR_NOT_RESIDENT:
+            return False
+        check(status, "lsf_slavcheva_state_chain")
+        return True
 
 
 def full_range(grid):

@@ -615,8 +615,10 @@ class SlavchevaOutcome:
             if target is not live0:
                 target.copy_(live0)
             warp = torch.zeros(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
+            chain = getattr(self, "_chain", None)  # the pass leaves `target` alone if the chain launch flagged its result
             raw = dev.state_finalize_listed(self.state, self.canonical, full, bands, unlisted, target, warp,
-                                            lower_threshold, statistics)
+                                            lower_threshold, statistics,
+                                            skip_flag=chain.violation_ptr if chain is not None else None)
             self._live = target
         elif self.state is not None:
             warp = torch.empty(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
@@ -640,6 +642,11 @@ class _HaloTooNarrow(Exception):
     def __init__(self, max_update, validity):
         super().__init__("warp update of %.3f voxels against %d slice(s) of validity" % (max_update, validity))
         self.max_update = float(max_update)
+
+
+class _ChainReachExceeded(Exception):
+    """a chain launch (dev.StateChain) met a warp update its dependency windows do not cover; nothing of the caller's has
+    been modified (SlavchevaEngine.optimize repeats the call with per-iteration launches)"""
 
 
 class SlavchevaEngine:
@@ -978,7 +985,13 @@ class SlavchevaEngine:
         ("fall back to a wider exchange if the max exceeds 1").  The result is bit for bit the
         whole-volume one (tests/test_gpu_slab_many_ranks.py)."""
         if not self._slab():
-            return self._optimize(live, canonical, finalize)
+            try:
+                return self._optimize(live, canonical, finalize)
+            except _ChainReachExceeded:
+                # an update of two voxels or more: beyond the chain kernel's dependency windows.  The finalize pass has
+                # left the caller's tensors alone (its skip flag), so the call simply runs again, one launch per iteration
+                self._chain_disabled = True
+                return self._optimize(live, canonical, finalize)
         try:
             return self._optimize(live, canonical, finalize)
         except _HaloTooNarrow as exc:
@@ -1061,7 +1074,7 @@ class SlavchevaEngine:
             prepared = dev.StatePrepare(live, canonical, dev.full_range(grid), cut_chunks)
         records = dev.new_records(n_rec, live.device)
         self._last_g = None
-        lives = warps = gbufs = states = None
+        lives = warps = gbufs = states = chain = None
         if self.sobolev:
             lives = [live.clone(), live.clone()]
             warps = [torch.zeros((dims,) + tuple(live.shape), dtype=torch.float32, device=live.device)
@@ -1105,6 +1118,14 @@ class SlavchevaEngine:
                 bands = dev.band_lists(live, canonical, whole) if self.use_band_list else [dev.BandList.none()]
             f.bands = bands
             self._fast = f
+            # Fixed-count runs on ONE interior list: K iterations per launch (lsf_slavcheva_state_chain) instead of K
+            # launches -- the stop test cannot fire in between, and a launch's fixed ~9 us are paid once
+            if (not slab and listed is not None and self.min_iterations >= max(self.max_iterations, self.min_iterations)
+                    and self.min_iterations > 0 and self.iteration_hook is None and len(bands) == 1
+                    and bands[0].subset == _lib.BAND_INTERIOR and bands[0].count > 0 and 16 * n < 0xffffffff
+                    and not getattr(self, "_chain_disabled", False) and os.environ.get("LSF_CHAIN", "1") != "0"):
+                stages = int(os.environ.get("LSF_CHAIN_STAGES", "0")) or (4 if bands[0].count * 32 > 200e6 else 1)
+                chain = dev.StateChain(states, canonical, grid, self.params, records, bands[0], stages)
             if slab:
                 self._plan_slab(f, live, grid, bands, 0 if self.min_iterations == 0
                                 else max(self.max_iterations, self.min_iterations),
@@ -1117,7 +1138,10 @@ class SlavchevaEngine:
         hooked = self.iteration_hook is not None
         while it < limit:
             batch = 1 if hooked else min(self.check_interval, limit - it)
-            for i in range(it, it + batch):
+            if chain is not None and not chain.launch(it, batch):
+                chain = None  # a CU cannot hold the kernel's workgroup on this device: one launch per iteration
+            self._chain_used = chain is not None
+            for i in range(it, it + batch) if chain is None else ():
                 if self.sobolev:
                     self._enqueue_iteration(i, lives[i % 2], lives[(i + 1) % 2], warps[i % 2], warps[(i + 1) % 2],
                                             canonical, grid, records, gbufs, limit)
@@ -1134,10 +1158,19 @@ class SlavchevaEngine:
                 # (a slab run may still have to be discarded -- see optimize() -- and finalize writes the caller's tensor)
                 # every launch runs ungated, so the final state is states[limit % 2]: finalize before looking
                 early = SlavchevaOutcome(grid, canonical, state=states[limit % 2], listed=listed)
+                early._chain = chain
                 early.enqueue_finalize(*finalize)
             dec = dev.decode_records(self.comm.gather_records(records, 0, it) if slab and ungated
                                      else dev.records_to_host(records[:it]))
             n_exec = int(dec["executed"].sum())
+            if chain is not None and n_exec > 0:
+                longest = dec["max_value"][:n_exec].max()
+                if np.isnan(longest):
+                    raise RuntimeError("lsf_slavcheva_state_chain: a workgroup waited for its neighbours longer than the "
+                                       "launch allows and the launch gave up (is another process holding CUs of this "
+                                       "GPU?); LSF_CHAIN=0 selects one launch per iteration")
+                if not longest < dev.StateChain.REACH_LIMIT:
+                    raise _ChainReachExceeded()
             # z-slab: every EXECUTED iteration must have stayed inside what the halo schedule keeps valid -- also those
             # of a batch in which the gate then closed (a large update followed by convergence inside one
             # check_interval).  Every rank sees the same reduced / gathered records, so the raise is collective.

@@ -96,13 +96,26 @@ def test_argument_errors_are_reported_not_launched(pkg):
     lists = (ctypes.c_void_p * 2)(1, 1)
     counts = (ctypes.c_int64 * 2)(5, -1)
     assert L.lib.lsf_state_finalize_listed(1, 1, 1, 1, ctypes.byref(ok), lists, counts, 3, 0, -1, 0.0, None, None,
-                                           None) == -1                                            # three lists
+                                           None, None) == -1                                      # three lists
     assert L.lib.lsf_state_finalize_listed(1, 1, 1, 1, ctypes.byref(ok), lists, counts, 2, 0, -1, 0.0, None, None,
-                                           None) == -1                                            # negative count
+                                           None, None) == -1                                      # negative count
     assert L.lib.lsf_state_finalize_listed(1, None, 1, 1, ctypes.byref(ok), lists, counts, 1, 0, -1, 0.0, 1, 1,
-                                           None) == -1                                            # statistics, no canonical
+                                           None, None) == -1                                      # statistics, no canonical
     assert L.lib.lsf_state_finalize_listed(1, 1, 1, 1, ctypes.byref(L.Grid(3, 4, 8, 8, 1, 4, 0, 0)), lists, counts, 1,
-                                           0, -1, 0.0, None, None, None) == -1                    # not a whole array
+                                           0, -1, 0.0, None, None, None, None) == -1              # not a whole array
+    # the chain kernel: an INTERIOR list of a WHOLE array, distinct states, a scratch block
+    sp = L.SlavchevaParams()
+    assert L.lib.lsf_slavcheva_state_chain(1, 1, 1, ctypes.byref(ok), ctypes.byref(sp), 1, 1, 5, 3, 1, 1, None) == -1
+    assert L.lib.lsf_slavcheva_state_chain(1, 2, 1, ctypes.byref(ok), ctypes.byref(sp), 1, None, 5, 3, 1, 1, None) == -1
+    assert L.lib.lsf_slavcheva_state_chain(1, 2, 1, ctypes.byref(L.Grid(3, 4, 8, 8, 1, 4, 0, 0)), ctypes.byref(sp), 1, 1,
+                                           5, 3, 1, 1, None) == -1                                # not a whole array
+    assert L.lib.lsf_slavcheva_state_chain(1, 2, 1, ctypes.byref(ok), ctypes.byref(sp), 1, 1, 5, 3, 1, None, None) == -1
+    assert L.lib.lsf_state_chain_plan(ctypes.byref(ok), None, 5, 1, 1, None) == -1
+    assert L.lib.lsf_state_chain_scratch_elements(0, 1) == 0
+    # 20 000 entries = 313 wave-units: fewer than 16 per CU of any device, so 19 -> 16 workgroups = chunks, one stage
+    shape = (ctypes.c_int32 * 4)()
+    assert L.lib.lsf_state_chain_shape(20000, 4, shape) == 0 and list(shape) == [16, 1, 16, 313]
+    assert L.lib.lsf_state_chain_scratch_elements(20000, 4) == 16 + 16 + 2 * 16
     with pytest.raises(pkg._lib.LsfHipError):
         pkg._lib.check(-2, "x")
 
