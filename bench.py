@@ -388,7 +388,7 @@ def main():
         (lsf_slavcheva_state_chain); per-iteration time = its duration / iters, HIP events on its stream"""
         states = dev.state_pack(live0, None, grid, copies=2)
         records = dev.new_records(iters, device)
-        stages = int(os.environ.get("LSF_CHAIN_STAGES", "0")) or (4 if band.count * 32 > 200e6 else 1)
+        stages = int(os.environ.get("LSF_CHAIN_STAGES", "1"))
         chain = dev.StateChain(states, canonical, grid, eng.params, records, band, stages)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()

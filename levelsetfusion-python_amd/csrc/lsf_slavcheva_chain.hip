@@ -42,27 +42,41 @@ typedef unsigned __attribute__((address_space(1))) gu32;  // agent-scope accesse
 
 constexpr unsigned kControlWords = 16;      // [0] abort (a wait timed out), [1] reach violated; then the progress words
 constexpr unsigned kMaxChunks = 4096;       // chain_plan_kernel keeps two words per chunk in LDS
-constexpr unsigned kMinChunkUnits = 16;     // a wave-unit per wave of a CU-sized workgroup at least
 constexpr unsigned kStageChunkUnits = 96;   // target chunk size when chunks are dealt round-robin (S > 1)
 constexpr float kReachLimit = 2.0f;         // windows cover stencil + gather for update lengths below this
 constexpr int kReachSlices = 2;
 
 struct ChainShape {
-    unsigned workgroups, stages, members, chunks, units, progress_words;
+    unsigned workgroups, stages, members, chunks, units, progress_words, threads;
 };
+
+// Threads per workgroup (LSF_CHAIN_THREADS: 1024 / 512 / 256; measurement knob).  Smaller workgroups -- two or four
+// independent ones per CU, so that one walks while another drains, reduces, publishes and waits -- measured SLOWER
+// (256^3: 31.2 / 32.4 / 38.7 us per iteration with 1 / 2 / 4 workgroups per CU): the SIMDs issue oldest-wave-first, the
+// younger workgroup of a CU takes 32 us for what the older does in 20, and everybody's window ends up waiting for it.
+inline unsigned chain_threads() {
+    static const unsigned v = [] {
+        const char* e = getenv("LSF_CHAIN_THREADS");
+        const int n = e ? atoi(e) : 0;
+        return (n == 1024 || n == 512 || n == 256) ? (unsigned)n : (unsigned)kCuBlock;
+    }();
+    return v;
+}
 
 // One policy for the three entry points (scratch size, plan, launch): how a list of `count` entries is cut and dealt.
 inline ChainShape chain_shape(long long count, int stages_wanted, unsigned cus) {
     ChainShape s;
+    s.threads = chain_threads();
     s.units = (unsigned)((count + kWave - 1) / kWave);
-    unsigned wg = s.units / kMinChunkUnits;
+    const unsigned slots = cus * (kCuBlock / s.threads);  // resident workgroups of the whole device
+    unsigned wg = s.units / (s.threads / kWave);          // a wave-unit per wave at least
     if (wg < 1) wg = 1;
-    if (wg > cus) wg = cus;
+    if (wg > slots) wg = slots;
     if (wg > kXcds) wg -= wg % kXcds;
     s.workgroups = wg;
     s.stages = 1;
-    if (stages_wanted > 1 && wg == cus && cus % (unsigned)stages_wanted == 0 &&
-        s.units / kStageChunkUnits >= 2u * cus)  // a sweep through the list is longer than the pipeline of stages
+    if (stages_wanted > 1 && wg == slots && slots % (unsigned)stages_wanted == 0 &&
+        s.units / kStageChunkUnits >= 2u * slots)  // a sweep through the list is longer than the pipeline of stages
         s.stages = (unsigned)stages_wanted;
     s.members = wg / s.stages;
     if (s.stages == 1) {
@@ -76,6 +90,17 @@ inline ChainShape chain_shape(long long count, int stages_wanted, unsigned cus) 
     s.progress_words = (s.chunks + 15u) & ~15u;
     return s;
 }
+
+#ifdef LSF_CHAIN_TRACE  // measurement builds only (tools/chain_trace.py): 100 MHz stamps per work item
+__device__ unsigned long long* g_chain_trace = nullptr;  // [workgroup][item < kTraceItems][kTraceWords]
+constexpr unsigned kTraceItems = 64, kTraceWords = 32;
+#define LSF_CT(slot)                                                                                \
+    do {                                                                                            \
+        if (trace_row && threadIdx.x == 0) trace_row[slot] = __builtin_amdgcn_s_memrealtime();       \
+    } while (0)
+#else
+#define LSF_CT(slot) do {} while (0)
+#endif
 
 struct ChainPlan {
     unsigned iterations, chunks, units, stages, members, progress_words, timeout_ticks;
@@ -138,6 +163,19 @@ void slavcheva_state_chain_kernel(vf4* state_a, vf4* state_b, const float* __res
         lsf_iteration_record* record = records + it;
         for (unsigned c = member; c < plan.chunks; c += plan.members) {
             const unsigned u_begin = chunk_begin(c, base, extra), u_end = chunk_begin(c + 1, base, extra);
+#ifdef LSF_CHAIN_TRACE
+            unsigned long long* trace_row = nullptr;
+            {
+                const unsigned item = (it / plan.stages) * ((plan.chunks + plan.members - 1) / plan.members) + c / plan.members;
+                if (g_chain_trace && item < kTraceItems)
+                    trace_row = g_chain_trace + ((unsigned long long)blockIdx.x * kTraceItems + item) * kTraceWords;
+                if (trace_row && threadIdx.x == 0) {
+                    trace_row[7] = ((unsigned long long)it << 32) | c;
+                    trace_row[8] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));  // XCC_ID
+                }
+            }
+#endif
+            LSF_CT(0);
             // ---- wait until the window's chunks have finished iteration it - 1 (ONE wave polls, relaxed, then ONE acquire)
             if (threadIdx.x == 0) s_next_unit = u_begin + 2u * waves;
             if (wave == 0 && it > 0) {
@@ -148,6 +186,9 @@ void slavcheva_state_chain_kernel(vf4* state_a, vf4* state_b, const float* __res
                     for (unsigned d = lo + lane; d <= hi; d += kWave)
                         ok &= __hip_atomic_load(progress + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= it;
                     if (__all(ok)) break;
+#ifdef LSF_CHAIN_TRACE
+                    if (trace_row && threadIdx.x == 0) trace_row[9] += 1;  // polls that did not match
+#endif
                     const unsigned gone = __hip_atomic_load(control, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (gone != 0u || __builtin_amdgcn_s_memrealtime() - t0 > plan.timeout_ticks) {
                         if (lane == 0) {
@@ -161,11 +202,14 @@ void slavcheva_state_chain_kernel(vf4* state_a, vf4* state_b, const float* __res
                     }
                     __builtin_amdgcn_s_sleep(4);
                 }
+                LSF_CT(1);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                LSF_CT(2);
             }
             __syncthreads();
             if (s_abort) return;
+            LSF_CT(3);
 
             // ---- the chunk's wave-units: the software-pipelined INTERIOR walk of lsf_slavcheva_state.hip
             unsigned long long best = 0ull;
@@ -256,6 +300,9 @@ void slavcheva_state_chain_kernel(vf4* state_a, vf4* state_b, const float* __res
             finish(pending);
             // every storing wave drains BEFORE the barrier behind which one lane signals for all of them
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LSF_CHAIN_TRACE
+            if (trace_row && lane == 0) trace_row[16 + wave] = __builtin_amdgcn_s_memrealtime();
+#endif
             if (c == 0 && threadIdx.x == 0) {  // the arg-max of an all-zero update: the first voxel of the launch's range
                 const unsigned long long q = pack_max(0.0f, linear_index(g, 0, 0, g.z_begin));
                 best = q > best ? q : best;
@@ -272,24 +319,30 @@ void slavcheva_state_chain_kernel(vf4* state_a, vf4* state_b, const float* __res
                 for (int k = 0; k < 3; ++k) s_sum[k][wave] = s[k];
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned long long mm = s_max[0];
-                for (unsigned w = 1; w < waves; ++w) mm = s_max[w] > mm ? s_max[w] : mm;
-                lsf_record_slot* slot = record_slot(record);
-                if (mm != 0ull) atomicMax(reinterpret_cast<unsigned long long*>(&slot->max_packed), mm);
+            LSF_CT(4);
+            if (wave == 0) {
+                // the waves' partial results, one per lane (a serial loop over LDS words on one lane took 3 us per item)
+                unsigned long long mm = wave_max_u64(lane < waves ? s_max[lane] : 0ull);
+                double t[3] = {0.0, 0.0, 0.0};
                 if (ENERGY != LSF_ENERGY_NONE) {
-                    double* dst[3] = {&slot->data_energy, &slot->smoothing_energy, &slot->level_set_energy};
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        double t = 0.0;
-                        for (unsigned w = 0; w < waves; ++w) t += s_sum[k][w];
-                        if (t != 0.0) atomicAdd(dst[k], t);
-                    }
+                    for (int k = 0; k < 3; ++k) t[k] = wave_sum_f64(lane < waves ? s_sum[k][lane] : 0.0);
                 }
-                const unsigned bits = (unsigned)(mm >> 32);
-                if (bits > s_worst_bits) s_worst_bits = bits;
-                __hip_atomic_store(progress + c, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (lane == 0) {
+                    lsf_record_slot* slot = record_slot(record);
+                    if (mm != 0ull) atomicMax(reinterpret_cast<unsigned long long*>(&slot->max_packed), mm);
+                    if (ENERGY != LSF_ENERGY_NONE) {
+                        double* dst[3] = {&slot->data_energy, &slot->smoothing_energy, &slot->level_set_energy};
+#pragma unroll
+                        for (int k = 0; k < 3; ++k)
+                            if (t[k] != 0.0) atomicAdd(dst[k], t[k]);
+                    }
+                    const unsigned bits = (unsigned)(mm >> 32);
+                    if (bits > s_worst_bits) s_worst_bits = bits;
+                    __hip_atomic_store(progress + c, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
+            LSF_CT(5);
         }
     }
     if (threadIdx.x == 0 && !(__uint_as_float(s_worst_bits) < plan.reach_limit))
@@ -297,7 +350,7 @@ void slavcheva_state_chain_kernel(vf4* state_a, vf4* state_b, const float* __res
 }
 
 struct ChainArgs {
-    unsigned blocks;
+    unsigned blocks, threads;
     hipStream_t s;
     vf4 *state_a, *state_b;
     const float* canonical;
@@ -314,15 +367,15 @@ struct ChainArgs {
 template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
 void chain_one(const ChainArgs& a) {
     auto kernel = slavcheva_state_chain_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY>;
-    static int fits = -1;  // per instantiation; the same on every device of one kind
+    static int fits = -1;  // per instantiation (the workgroup size is fixed per process); the same on every device of one kind
     if (fits < 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), kCuBlock, 0) != hipSuccess) n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), (int)a.threads, 0) != hipSuccess) n = 0;
         fits = n;
     }
     *a.resident = fits;
-    if (fits < 1) return;
-    hipLaunchKernelGGL(kernel, dim3(a.blocks), dim3(kCuBlock), 0, a.s, a.state_a, a.state_b, a.canonical, a.g, a.p,
+    if (fits < (int)(kCuBlock / a.threads)) return;
+    hipLaunchKernelGGL(kernel, dim3(a.blocks), dim3(a.threads), 0, a.s, a.state_a, a.state_b, a.canonical, a.g, a.p,
                        a.records, a.band_list, a.band_count, a.plan, a.scratch);
 }
 
@@ -376,6 +429,12 @@ inline bool chain_list_ok(const lsf_grid* grid, const int32_t* band_list, int64_
 }
 
 }  // namespace
+
+#ifdef LSF_CHAIN_TRACE
+extern "C" int lsf_debug_set_chain_trace(void* rows) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_trace), &rows, sizeof(rows));
+}
+#endif
 
 extern "C" int64_t lsf_state_chain_scratch_elements(int64_t band_count, int32_t stages) {
     if (band_count <= 0) return 0;
@@ -431,12 +490,12 @@ extern "C" int lsf_slavcheva_state_chain(float* state_a, float* state_b, const f
     if (hipMemsetAsync(scratch, 0, (size_t)(kControlWords + s.progress_words) * 4u, as_stream(stream)) != hipSuccess)
         return (int)hipGetLastError();
     int resident = 0;
-    ChainArgs a{s.workgroups, as_stream(stream), reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b),
+    ChainArgs a{s.workgroups, s.threads, as_stream(stream), reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b),
                 canonical, g, p, records, band_list, (unsigned)band_count, plan, reinterpret_cast<unsigned*>(scratch),
                 &resident};
     if (grid->dims == 2) chain_terms<2>(params, a);
     else chain_terms<3>(params, a);
-    if (resident < 1) return LSF_ERR_NOT_RESIDENT;
+    if (resident < (int)(kCuBlock / s.threads)) return LSF_ERR_NOT_RESIDENT;
     return launch_status();
 }
 

@@ -1118,13 +1118,16 @@ class SlavchevaEngine:
                 bands = dev.band_lists(live, canonical, whole) if self.use_band_list else [dev.BandList.none()]
             f.bands = bands
             self._fast = f
-            # Fixed-count runs on ONE interior list: K iterations per launch (lsf_slavcheva_state_chain) instead of K
-            # launches -- the stop test cannot fire in between, and a launch's fixed ~9 us are paid once
+            # Fixed-count runs on ONE interior list MAY run K iterations per launch (lsf_slavcheva_state_chain) instead of K
+            # launches -- the stop test cannot fire in between.  Opt-in (LSF_CHAIN=1): bit-identical, but measured 4 %
+            # SLOWER than one launch per iteration at 256^3 and 512^3: what a launch
+            # boundary costs (~3.5 us) the chain pays again as wait + acquire + publish, and the rest of a launch's
+            # "fixed" time is the drain of each wave's last unit, which a resident workgroup has as well
             if (not slab and listed is not None and self.min_iterations >= max(self.max_iterations, self.min_iterations)
                     and self.min_iterations > 0 and self.iteration_hook is None and len(bands) == 1
                     and bands[0].subset == _lib.BAND_INTERIOR and bands[0].count > 0 and 16 * n < 0xffffffff
-                    and not getattr(self, "_chain_disabled", False) and os.environ.get("LSF_CHAIN", "1") != "0"):
-                stages = int(os.environ.get("LSF_CHAIN_STAGES", "0")) or (4 if bands[0].count * 32 > 200e6 else 1)
+                    and not getattr(self, "_chain_disabled", False) and os.environ.get("LSF_CHAIN", "0") == "1"):
+                stages = int(os.environ.get("LSF_CHAIN_STAGES", "1"))
                 chain = dev.StateChain(states, canonical, grid, self.params, records, bands[0], stages)
             if slab:
                 self._plan_slab(f, live, grid, bands, 0 if self.min_iterations == 0

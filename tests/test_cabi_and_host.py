@@ -112,7 +112,8 @@ def test_argument_errors_are_reported_not_launched(pkg):
     assert L.lib.lsf_slavcheva_state_chain(1, 2, 1, ctypes.byref(ok), ctypes.byref(sp), 1, 1, 5, 3, 1, None, None) == -1
     assert L.lib.lsf_state_chain_plan(ctypes.byref(ok), None, 5, 1, 1, None) == -1
     assert L.lib.lsf_state_chain_scratch_elements(0, 1) == 0
-    # 20 000 entries = 313 wave-units: fewer than 16 per CU of any device, so 19 -> 16 workgroups = chunks, one stage
+    # 20 000 entries = 313 wave-units: a unit per wave of a 1024-thread workgroup at least, so 19 -> 16 workgroups =
+    # chunks (a multiple of the 8 XCDs), one stage however many are asked for
     shape = (ctypes.c_int32 * 4)()
     assert L.lib.lsf_state_chain_shape(20000, 4, shape) == 0 and list(shape) == [16, 1, 16, 313]
     assert L.lib.lsf_state_chain_scratch_elements(20000, 4) == 16 + 16 + 2 * 16

@@ -73,13 +73,14 @@ def _same(a, b):
         assert np.allclose(x, y, rtol=1e-12, atol=0.0)
 
 
-@pytest.mark.parametrize("n,iterations", [(48, 40), (64, 50), (128, 60), (256, 50)])
+@pytest.mark.parametrize("n,iterations", [(80, 40), (96, 50), (128, 60), (256, 50)])
 def test_chain_equals_per_iteration_launches(lsf, n, iterations):
-    """48^3 / 64^3: fewer workgroups than CUs; 128^3: one per CU with short chunks; 256^3: the bench's launch"""
+    """80^3 / 96^3: fewer workgroups than CUs (below 72^3 the sphere pair's band touches the array's faces and the call
+    takes per-iteration launches); 128^3: one per CU with short chunks; 256^3: the bench's launch"""
     from levelsetfusion_python_amd.synthetic import sphere_pair
     canonical, live0 = sphere_pair(n, 3, "cuda")
     a = _run(lsf, canonical, live0, iterations, chain=True)
-    assert a[0]._engine._fast is not None
+    assert a[0]._engine._chain_used
     b = _run(lsf, canonical, live0, iterations, chain=False)
     _same(a, b)
     assert 0.0 < max(a[0].log.max_warps) < 1.0
@@ -90,7 +91,7 @@ def test_chain_is_what_runs_and_splits_into_batches(lsf):
     ping-pong parity right"""
     from levelsetfusion_python_amd import device as dev
     from levelsetfusion_python_amd.synthetic import sphere_pair
-    canonical, live0 = sphere_pair(64, 3, "cuda")
+    canonical, live0 = sphere_pair(80, 3, "cuda")
     launches = []
     original = dev.StateChain.launch
 
@@ -108,8 +109,8 @@ def test_chain_is_what_runs_and_splits_into_batches(lsf):
 
 
 def test_chain_with_other_terms_and_the_oracle(lsf):
-    """Tikhonov smoothing + thresholded-FDM data term, 30 iterations at 48^3, against the numpy oracle"""
-    canonical, live0 = O.sphere_pair(48, d=3)
+    """Tikhonov smoothing + thresholded-FDM data term, 30 iterations at 80^3, against the numpy oracle"""
+    canonical, live0 = O.sphere_pair(80, d=3)
     kw = dict(data_term_method=lsf.DataTermMethod.THRESHOLDED_FDM)
     c, l0 = torch.from_numpy(canonical).cuda(), torch.from_numpy(live0).cuda()
     opt, live = _run(lsf, c, l0, 30, chain=True, smoothing_term_method=lsf.SmoothingTermMethod.TIKHONOV, **kw)
@@ -117,6 +118,7 @@ def test_chain_with_other_terms_and_the_oracle(lsf):
                           max_iterations=30, min_iterations=30, **BENCH)
     live_ref = live0.copy()
     o.optimize(live_ref, canonical)
+    assert opt._engine._chain_used
     assert np.array_equal(live.cpu().numpy(), live_ref)
     assert np.array_equal(opt.warp_field.cpu().numpy(), o.warp_field)
     assert np.array_equal(np.float32(opt.log.max_warps), np.float32(o.log["max_warps"]))
@@ -146,9 +148,9 @@ def test_updates_beyond_the_windows_fall_back(lsf):
     launches -- the result is the per-iteration one, and the optimizer stays on that path"""
     from levelsetfusion_python_amd import device as dev
     from levelsetfusion_python_amd.synthetic import sphere_pair
-    canonical, live0 = sphere_pair(64, 3, "cuda")  # its band touches no face of the array: one INTERIOR list
+    canonical, live0 = sphere_pair(80, 3, "cuda")  # its band touches no face of the array: one INTERIOR list
     kw = dict(level_set_term_enabled=True, maximum_warp_length_lower_threshold=0.0, gradient_descent_rate=4.0)
-    args = dict(field_size=64, compute_method=lsf.ComputeMethod.DIRECT,
+    args = dict(field_size=80, compute_method=lsf.ComputeMethod.DIRECT,
                 smoothing_term_method=lsf.SmoothingTermMethod.KILLING, max_iterations=5, min_iterations=5,
                 check_interval=5, **kw)
     with _Env(LSF_CHAIN="0"):
