@@ -40,6 +40,11 @@ def ref_slavcheva():
 
 
 @pytest.fixture(scope="session")
+def ref_config1():
+    return load_golden("ref_config1.npz")
+
+
+@pytest.fixture(scope="session")
 def ref_tsdf():
     return load_golden("ref_tsdf.npz")
 

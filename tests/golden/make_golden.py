@@ -9,6 +9,7 @@ Outputs
   ref_leaf.npz            leaf functions of SURVEY section 8a run by the reference on seeded inputs
   ref_hierarchical.npz    HierarchicalOptimizer2d runs (per-iteration warp fields)
   ref_slavcheva.npz       SlavchevaOptimizer2d runs (per-iteration live / warp / gradient / energies)
+  ref_config1.npz         BASELINE config 1 at full length: the 64 x 64 orthographic pair, 100 fixed iterations
 """
 import ast
 import contextlib
@@ -272,6 +273,52 @@ def hierarchical():
     print("ref_hierarchical.npz:", len(out), "arrays")
 
 
+def config1():
+    """BASELINE config 1 at its full length: the reference's 64 x 64 orthographic pair, 100 fixed iterations --
+    SobolevFusion (VECTORIZED, Tikhonov + 7-tap Sobolev kernel) and KillingFusion (DIRECT, Killing + level set) -- with
+    snapshots on the way (a 3-iteration excerpt is in ref_slavcheva.npz)"""
+    out = {}
+    sampling.set_focus_coordinates(0, 0)
+    live_full, canon_full = tsdf_gen.generate_initial_orthographic_2d_tsdf_fields(field_size=128)
+    live64 = live_full[30:94, 30:94].copy()
+    canon64 = canon_full[30:94, 30:94].copy()
+    k7 = generate_1d_sobolev_kernel(size=7, strength=0.1)
+    configs = {
+        "sobolev_vec": dict(compute_method=so.ComputeMethod.VECTORIZED, sobolev_smoothing_enabled=True,
+                            sobolev_kernel=k7),
+        "killing": dict(compute_method=so.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                        smoothing_term_method=st.SmoothingTermMethod.KILLING),
+    }
+    captured = {}
+
+    def hook(self, iteration_number, warp_field, gradient_field, live_field, canonical_field):
+        if iteration_number in (9, 24, 49, 99):
+            captured[iteration_number] = (warp_field.copy(), live_field.copy())
+
+    sviz.SlavchevaVisualizer.write_all_iteration_visualizations = hook
+    tmp = tempfile.mkdtemp()
+    for name, kw in configs.items():
+        opt = so.SlavchevaOptimizer2d(out_path=tmp, field_size=64, maximum_warp_length_lower_threshold=0.0,
+                                      max_iterations=100, min_iterations=100, enable_convergence_status_logging=True, **kw)
+        live = live64.copy()
+        captured.clear()
+        with contextlib.redirect_stdout(io.StringIO()):
+            opt.optimize(live, canon64)
+        tag = "ortho64.%s.100" % name
+        out[tag + ".final_live"] = live
+        out[tag + ".final_gradient"] = opt.gradient_field.copy()
+        out[tag + ".max_warps"] = np.array(opt.log.max_warps, dtype=np.float64)
+        out[tag + ".data_energies"] = np.array(opt.log.data_energies, dtype=np.float64)
+        out[tag + ".smoothing_energies"] = np.array(opt.log.smoothing_energies, dtype=np.float64)
+        out[tag + ".level_set_energies"] = np.array(opt.log.level_set_energies, dtype=np.float64)
+        for it, (w, l) in sorted(captured.items()):
+            out["%s.it%d.warp" % (tag, it)] = w
+            out["%s.it%d.live" % (tag, it)] = l
+        print(tag, "max warp first / last: %.4f / %.4f" % (opt.log.max_warps[0], opt.log.max_warps[-1]))
+    np.savez_compressed(os.path.join(HERE, "ref_config1.npz"), **out)
+    print("ref_config1.npz:", len(out), "arrays")
+
+
 def slavcheva():
     out = {}
     sampling.set_focus_coordinates(0, 0)
@@ -468,10 +515,14 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "ewa":
         ewa()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "config1":
+        config1()
+        sys.exit(0)
     literals()
     leaf()
     hierarchical()
     slavcheva()
+    config1()
     tsdf()
     ewa()
     for f in sorted(os.listdir(HERE)):

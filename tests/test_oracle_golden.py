@@ -277,6 +277,37 @@ def test_slavcheva_runs_match_reference(ref_slavcheva, size_tag, n_it, name):
             assert maxdiff(l, S["%s.it%d.live" % (tag, it)]) <= TIGHT
 
 
+@pytest.mark.parametrize("name", ["sobolev_vec", "killing"])
+def test_config1_one_hundred_iterations_match_reference(ref_slavcheva, ref_config1, name):
+    """BASELINE config 1 at its full length (64 x 64 orthographic pair, 100 fixed iterations) against the reference's own
+    run (tests/golden/make_golden.py config1): KillingFusion (DIRECT) bit for bit in every snapshot -- through the snap
+    discontinuity of warp_field_advanced and updates of 4 to 6 voxels per iteration --, SobolevFusion (VECTORIZED, 7-tap
+    filter: numpy accumulates its float32 convolution in an unspecified order) within 5e-6"""
+    S, C = ref_slavcheva, ref_config1
+    kw = dict(SLAVCHEVA_CONFIGS[name])
+    kernel = kw.pop("kernel", None)
+    o = O.SlavchevaOracle(maximum_warp_length_lower_threshold=0.0, max_iterations=100, min_iterations=100,
+                          sobolev_kernel=S[kernel] if kernel else None, **kw)
+    per = {}
+    o.iteration_hook = lambda it, live, warp, g, en, mw, at: per.__setitem__(it, (warp.copy(), live.copy())) \
+        if it in (9, 24, 49, 99) else None
+    live = S["ortho64.live"].copy()
+    o.optimize(live, S["ortho64.canonical"])
+    tag = "ortho64.%s.100" % name
+    tol = 0.0 if name == "killing" else 5e-6
+    assert maxdiff(live, C[tag + ".final_live"]) <= tol
+    assert maxdiff(o.gradient_field, C[tag + ".final_gradient"]) <= 10.0 * tol  # warp = -gradient * rate, rate 0.1
+    assert maxdiff(o.log["max_warps"], C[tag + ".max_warps"]) <= tol
+    assert sorted(per) == [9, 24, 49, 99]
+    for it, (w, l) in per.items():
+        assert maxdiff(w, C["%s.it%d.warp" % (tag, it)]) <= tol
+        assert maxdiff(l, C["%s.it%d.live" % (tag, it)]) <= tol
+    for mine, theirs in ((o.log["data_energies"], C[tag + ".data_energies"]),
+                         (o.log["smoothing_energies"], C[tag + ".smoothing_energies"]),
+                         (o.log["level_set_energies"], C[tag + ".level_set_energies"])):
+        assert np.allclose(mine, theirs, rtol=1e-5, atol=1e-7)
+
+
 # ------------------------------------------------------------- 3-D rules: 2-D embedding (pins A.12)
 def test_3d_embedding_of_2d_is_exact():
     rng = np.random.default_rng(5)
