@@ -197,6 +197,12 @@ typedef struct lsf_hier_params {
                                   (threshold <= 0): the maximum is then only a log value and needs no pass of its own
                                   (lsf_hier_update with a NULL warp) except after the last iteration. */
     int32_t reserved;
+    /* z-slab runs (3-D): the packed live field -- the only operand read through the data-dependent gather -- may hold MORE
+     * slices than the grid: packed_nz > 0 says how many, packed_z_global_offset the global z of its slice 0 (0 for a copy
+     * of the whole level replicated on every rank, SURVEY 8e: the gather then never leaves the device however far the
+     * cumulative warp reaches).  packed_nz == 0: the packed field has the grid's own extent and offset. */
+    int32_t packed_nz;
+    int32_t packed_z_global_offset;
 } lsf_hier_params;
 
 int lsf_hier_iteration(const float *packed_live4, const float *canonical, float *warp_planar,

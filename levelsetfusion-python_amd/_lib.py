@@ -82,7 +82,8 @@ class SlabFaces(ctypes.Structure):
 class HierParams(ctypes.Structure):
     _fields_ = [("data_term_amplifier", ctypes.c_float), ("tikhonov_strength", ctypes.c_float),
                 ("rate", ctypes.c_float), ("tikhonov_enabled", ctypes.c_int32), ("apply_update", ctypes.c_int32),
-                ("compute_energy", ctypes.c_int32), ("previous_max", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("compute_energy", ctypes.c_int32), ("previous_max", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("packed_nz", ctypes.c_int32), ("packed_z_global_offset", ctypes.c_int32)]
 
 
 class SlavchevaParams(ctypes.Structure):

@@ -48,6 +48,8 @@ struct Grid {
     int list_store_nt;     // list walk: non-temporal stores of the new state (lists too long for the Infinity Cache)
     int shift_x, shift_y;  // log2(nx), log2(ny) when both are powers of two (voxel index -> x, y, z by shifts), else -1
     unsigned index_offset; // linear_index(g, x, y, z) - vidx(g, x, y, z) = z_global_offset * ny * nx
+    int gather_nz, gather_z_offset;  // slices / global z of slice 0 of the hierarchical kernel's GATHER operand (the packed
+                                     // live field): the grid's own, or a wider / replicated copy (lsf_hier_params::packed_nz)
 };
 
 __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
@@ -91,6 +93,8 @@ __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
     r.shift_y = log2_of(g->ny);
     if (r.shift_x < 0 || r.shift_y < 0) r.shift_x = r.shift_y = -1;
     r.index_offset = (unsigned)((long long)g->z_global_offset * g->ny * g->nx);
+    r.gather_nz = g->nz;
+    r.gather_z_offset = g->z_global_offset;
     return r;
 }
 

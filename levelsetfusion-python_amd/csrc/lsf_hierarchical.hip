@@ -51,7 +51,9 @@ __device__ inline Packed gather_packed(const float4* __restrict__ s, const Grid&
                 c[ox][oy] = select_packed(s[xy], (ox ? ax.v1 : ax.v0) && (oy ? ay.v1 : ay.v0));
             }
     } else {
-        const AxisTaps az = axis_taps(pz, g.nz, g.z_global_offset);
+        // the gather operand may hold more slices than the launch's grid (a z-slab run whose warps outgrow the halo
+        // reads a replicated copy of the whole level: lsf_hier_params::packed_nz)
+        const AxisTaps az = axis_taps(pz, g.gather_nz, g.gather_z_offset);
         const int slice = g.nx * g.ny;
         const int s0 = az.c0 * slice, s1 = az.c1 * slice;
 #pragma unroll
@@ -248,7 +250,14 @@ extern "C" int lsf_hier_iteration(const float* packed_live4, const float* canoni
     if (!packed_live4 || !canonical || !warp_planar || !params || !record) return LSF_ERR_BAD_ARGUMENT;
     if (params->tikhonov_enabled && (!g_prev_planar || g_prev_planar == g_out_planar)) return LSF_ERR_BAD_ARGUMENT;
     if (!params->apply_update && !g_out_planar) return LSF_ERR_BAD_ARGUMENT;
+    if (params->packed_nz < 0 || (params->packed_nz > 0 && grid->dims != 3) ||
+        (long long)params->packed_nz * grid->ny * grid->nx > 0x7fffffffll)
+        return LSF_ERR_BAD_ARGUMENT;
     Grid g = make_grid(grid);
+    if (params->packed_nz > 0) {
+        g.gather_nz = params->packed_nz;
+        g.gather_z_offset = params->packed_z_global_offset;
+    }
     Tiling t = make_tiling(g);
     if (t.total == 0) return 0;
     const float4* packed = reinterpret_cast<const float4*>(packed_live4);

@@ -320,7 +320,9 @@ def convolve_xyz(src, dst, grid, taps, gate=None, warp=None, rate=0.0):
 # ------------------------------------------------------------------------------------- optimizer kernels
 def hier_iteration(packed, canonical, warp, g_prev, g_out, grid, params, gate, records, index):
     n = n_voxels(grid)
-    check(lib.lsf_hier_iteration(_ptr(packed, 4 * n, "packed live"), _ptr(canonical, n, "canonical"),
+    # params.packed_nz > 0: the gather operand holds that many slices (a wider or replicated copy of the level)
+    n_packed = params.packed_nz * grid.ny * grid.nx if params.packed_nz > 0 else n
+    check(lib.lsf_hier_iteration(_ptr(packed, 4 * n_packed, "packed live"), _ptr(canonical, n, "canonical"),
                                  _ptr(warp, n * grid.dims, "warp"),
                                  _ptr(g_prev, n * grid.dims, "g_prev", allow_none=True),
                                  _ptr(g_out, n * grid.dims, "g_out", allow_none=True), ctypes.byref(grid),

@@ -225,6 +225,10 @@ class HierarchicalEngine:
         canon_levels, packed_levels, comms = self.build_pyramids(canonical, live)
         self.level_results = []
         self.iteration_data = []
+        # z-slab runs: levels whose gather operand had to be replicated on every rank because the cumulative warp
+        # outgrew the halo (optimize_level); once a level needed it the finer ones start that way -- warps are not
+        # rescaled between levels (hierarchical_optimizer2d.py:155-156), so they only grow
+        self.replicated_levels = 0
         warp = None
         for level, (canon_l, packed_l, comm_l) in enumerate(zip(canon_levels, packed_levels, comms)):
             if level == 0:
@@ -254,20 +258,26 @@ class HierarchicalEngine:
     class _Level:
         pass
 
-    def _make_level(self, canonical, packed, warp, grid, full_grid, n_records):
+    def _make_level(self, canonical, packed, warp, grid, full_grid, n_records, packed_global=None):
+        """packed_global: the packed live field of the WHOLE level (every rank's owned slices, SlabComm.all_gather_owned)
+        for the gather instead of the local slab + halo"""
         lv = HierarchicalEngine._Level()
         dims = canonical.dim()
         tik, ker = self.tikhonov_term_enabled, self.gradient_kernel_enabled
         lv.canonical, lv.packed, lv.warp, lv.grid, lv.full_grid, lv.dims = canonical, packed, warp, grid, full_grid, dims
         lv.params = _lib.HierParams(float(self.data_term_amplifier), float(self.tikhonov_strength), float(self.rate),
                                     int(tik), int(not ker), int(self.compute_energy))
+        lv.packed_global = packed_global
+        if packed_global is not None:
+            lv.params.packed_nz, lv.params.packed_z_global_offset = int(packed_global.shape[0]), 0
         lv.F = [torch.zeros_like(warp) for _ in range(2)] if (tik or ker) else []
         lv.S = [torch.zeros_like(warp) for _ in range(2)] if ker else []
         lv.report_g = torch.zeros_like(warp) if (self.collect_reports and not lv.F) else None
         lv.records = dev.new_records(n_records, canonical.device)
         f = dev.IterationLauncher(grid, lv.records, _lib.GATE_HIERARCHICAL, float(self.maximum_warp_update_threshold))
         n = dev.n_voxels(grid)
-        lv.p_packed = f.pointer(packed, 4 * n, "packed live")
+        lv.p_packed = f.pointer(packed, 4 * n, "packed live") if packed_global is None else \
+            f.pointer(packed_global, packed_global.numel(), "packed live (whole level)")
         lv.p_canon = f.pointer(canonical, n, "canonical")
         lv.p_warp = f.pointer(warp, n * dims, "warp")
         lv.p_F = [f.pointer(t, n * dims, "gradient buffer") for t in lv.F]
@@ -374,7 +384,16 @@ class HierarchicalEngine:
                                              warp_delta_statistics_from_raw)
             L = slab_layout
             whole = dev.make_grid(lv.canonical.shape, 0, L.nz_local, L.z_global_offset)
-            resampled = dev.warp_field(lv.packed[..., 0].contiguous(), lv.warp, 1.0, whole)
+            if lv.packed_global is None:
+                resampled = dev.warp_field(lv.packed[..., 0].contiguous(), lv.warp, 1.0, whole)
+            else:
+                # the warp reaches past the halo: resample the replicated live field under the whole level's warp (every
+                # rank the same work; reports are an opt-in) and keep the owned slices
+                c_l = self._slab_comm_of(L)
+                warp_g = torch.stack([c_l.all_gather_owned(lv.warp[c]) for c in range(lv.warp.shape[0])])
+                whole_level = dev.warp_field(lv.packed_global[..., 0].contiguous(), warp_g, 1.0)
+                resampled = torch.zeros_like(lv.canonical)
+                resampled[L.owned_local()] = whole_level[L.z0:L.z1]
             g_final = self.last_gradient if self.last_gradient is not None else torch.zeros_like(lv.warp)
             raw = torch.stack([dev.warp_statistics(g_final, lv.canonical, resampled, thr, lv.grid),
                                dev.tsdf_difference_statistics(lv.canonical, resampled, lv.grid)])
@@ -409,7 +428,13 @@ class HierarchicalEngine:
             grid = full_grid = dev.make_grid(canonical.shape)
         thr = float(self.maximum_warp_update_threshold)
         tik = self.tikhonov_term_enabled
-        lv = self._make_level(canonical, packed, warp, grid, full_grid, max(max_it, 1))
+        packed_global = warp_at_start = None
+        if slab and getattr(self, "replicated_levels", 0) > 0:
+            packed_global = comm.all_gather_owned(packed)
+            self.replicated_levels += 1
+        elif slab:
+            warp_at_start = warp.clone()  # what a restart of this level on the replicated field begins from
+        lv = self._make_level(canonical, packed, warp, grid, full_grid, max(max_it, 1), packed_global)
         records = lv.records
         snapshots = []
         it = 0
@@ -424,13 +449,15 @@ class HierarchicalEngine:
                     # produced by two extra launches of the same kernel on the pre-update warp
                     gate = lv.launcher.gates[i - 1] if i > 0 else None
                     d_snap = torch.zeros_like(warp)
-                    dev.hier_iteration(packed, canonical, warp, None, d_snap, grid,
-                                       _lib.HierParams(1.0, 0.0, 0.0, 0, 0, 0), gate, records, i)
+                    gathered = packed if packed_global is None else packed_global
+                    wide = (0, 0, 0, 0) if packed_global is None else (0, 0, int(packed_global.shape[0]), 0)
+                    dev.hier_iteration(gathered, canonical, warp, None, d_snap, grid,
+                                       _lib.HierParams(1.0, 0.0, 0.0, 0, 0, 0, *wide), gate, records, i)
                     t_snap = None
                     if tik:
                         t_snap = torch.zeros_like(warp)  # = laplace(previous gradient): 0*gd - (-1)*lap
-                        dev.hier_iteration(packed, canonical, warp, lv.F[i % 2], t_snap, grid,
-                                           _lib.HierParams(0.0, -1.0, 0.0, 1, 0, 0), gate, records, i)
+                        dev.hier_iteration(gathered, canonical, warp, lv.F[i % 2], t_snap, grid,
+                                           _lib.HierParams(0.0, -1.0, 0.0, 1, 0, 0, *wide), gate, records, i)
                     snapshots.append([None, d_snap, t_snap])
                 defer = lv.defer_max and not slab and not hooked and not self.collect_iteration_data
                 self._enqueue(lv, i, i - 1 if i > 0 else None, i % 2, comm, defer_max=defer and i + 1 < it + batch,
@@ -447,13 +474,18 @@ class HierarchicalEngine:
             it += batch
             dec = dev.decode_records(dev.records_to_host(records[:it]))  # the only host sync of the batch
             n_exec = int(dec["executed"].sum())
-            if slab:
-                # the gather follows the cumulative warp: it must stay inside the halo of the static packed field
+            if slab and packed_global is None:
+                # the gather follows the cumulative warp: it must stay inside the halo of the static packed field.  When it
+                # does not, the reference does not stop either (hierarchical_optimizer2d.py:169-171 tests the update
+                # threshold only): every rank sees the same reduced maximum, so all of them together discard this level's
+                # iterations, replicate the level's packed field (5 x 512 MiB at 512^3 against 288 GB) and run
+                # the level again from the warp it started with -- the gather then never leaves the device
                 wz = warp[2][L.owned_local()].abs().max().reshape(1)
                 comm.reduce_scalar_max(wz)
                 if not (float(wz.item()) < L.halo - 1):
-                    raise RuntimeError("cumulative warp of %.3f slices reaches past the %d-slice slab halo; re-run "
-                                       "with a wider halo" % (float(wz.item()), L.halo))
+                    warp.copy_(warp_at_start)
+                    self.replicated_levels = 1
+                    return self.optimize_level(canonical, packed, warp, comm)
             if hooked and n_exec == it:  # iteration it - 1 ran: its gradient is in the buffer the next one reads
                 g_now = lv.F[it % 2] if lv.F else lv.report_g
                 own = (slice(None), L.owned_local()) if slab else (slice(None),)

@@ -229,6 +229,18 @@ class SlabComm:
         for req in dist.batch_isend_irecv(ops):
             req.wait()
 
+    def all_gather_owned(self, local):
+        """the OWNED slices of every rank's local array, concatenated along z: the whole level on every rank (static
+        operands of the hierarchical optimizer whose gather outgrows the halo).  One collective."""
+        own = local[self.layout.owned_local()].contiguous()
+        if not self.active:
+            return own
+        world = dist.get_world_size(self.group)
+        mine = own.cpu() if (self.stage_through_host and own.is_cuda) else own
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=self.group)
+        return torch.cat(parts, 0).to(local.device)
+
     def gather_rows(self, value):
         """every rank's copy of a small float64 device tensor, as a list of host arrays in rank order"""
         if not self.active:

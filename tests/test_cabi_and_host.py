@@ -59,7 +59,7 @@ def test_ctypes_structs_match_header_layout(pkg):
     from levelsetfusion_python_amd import slab
     assert (slab.RECORD_SLOTS, slab.SLOT_WORDS) == (L.RECORD_SLOTS, L.SLOT_WORDS)
     assert ctypes.sizeof(L.Gate) == 24 and L.Gate.mode.offset == 8 and L.Gate.a.offset == 12
-    assert ctypes.sizeof(L.HierParams) == 32
+    assert ctypes.sizeof(L.HierParams) == 40 and L.HierParams.packed_nz.offset == 32
     assert ctypes.sizeof(L.SlavchevaParams) == 56 and L.SlavchevaParams.rate.offset == 8
     text = open(HEADER).read()
     for macro, value in (("LSF_ABI_VERSION", 2), ("LSF_MAX_KERNEL_TAPS", L.MAX_KERNEL_TAPS),

@@ -128,3 +128,80 @@ def test_slab_ranks_equal_whole_volume(tmp_path, case):
     for p in parts:
         assert np.array_equal(p["max_warps"], np.float32(ref.log.max_warps))
         assert np.allclose(p["data"], ref.log.data_energies, rtol=1e-10)
+
+
+# ---- the hierarchical optimizer on z-slabs when the cumulative warp outgrows the halo ------------------------------------
+def _shifted_spheres(n, nz):
+    """(canonical, live) float32 numpy [nz, n, n]: a sphere and the same sphere moved by (1, -1, 5) voxels along
+    (x, y, z) -- the optimizer has to build up a warp of several slices along z, across the slab faces"""
+    z, y, x = np.meshgrid(np.arange(nz, dtype=np.float64), np.arange(n, dtype=np.float64),
+                          np.arange(n, dtype=np.float64), indexing="ij")
+
+    def tsdf(cx, cy, cz):
+        d = np.sqrt((x - cx) ** 2 + (y - cy) ** 2 + (z - cz) ** 2)
+        return np.clip((d - 0.28 * n) / 10.0, -1.0, 1.0).astype(np.float32)
+    return tsdf(n / 2.0, n / 2.0, nz / 2.0), tsdf(n / 2.0 + 1.0, n / 2.0 - 1.0, nz / 2.0 + 5.0)
+
+
+def _hier_worker(rank, world, port, n, nz, halo, kwargs, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
+    layout = SlabLayout(nz, rank, world, halo)
+    sl = layout.local_slice()
+    canonical, live = (torch.from_numpy(np.ascontiguousarray(v[sl])).cuda() for v in _shifted_spheres(n, nz))
+    opt = lsf.HierarchicalOptimizer3d(
+        comm=SlabComm(layout),
+        logging_parameters=lsf.HierarchicalOptimizer3d.LoggingParameters(collect_per_level_convergence_reports=True),
+        **kwargs)
+    warp = opt.optimize(canonical, live)
+    reports = opt.get_per_level_convergence_reports()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), warp=warp.cpu().numpy(),
+             counts=np.int64(opt.get_per_level_iteration_counts()),
+             last_max=np.float32([m[-1] for m in opt.get_per_level_maximum_updates()]),
+             replicated=np.int64(opt._engine.replicated_levels),
+             diff_max=np.float64([r.tsdf_difference_statistics.difference_max for r in reports]),
+             diff_mean=np.float64([r.tsdf_difference_statistics.difference_mean for r in reports]))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,config", [(2, "data"), (4, "data"), (2, "tikhonov_kernel")])
+def test_hierarchical_slabs_follow_warps_past_the_halo(tmp_path, world, config):
+    """the reference never aborts on a long warp (hierarchical_optimizer2d.py:169-171 tests the update threshold only), and
+    neither does a z-slab run: when the cumulative |w_z| reaches the halo of the static packed field, all ranks together
+    restart the level on a copy of the whole level's packed field -- bit-equal to the whole-volume run"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    import levelsetfusion_python_amd as lsf
+    n, nz = 64, 128
+    if config == "data":
+        halo = 2
+        kwargs = dict(maximum_chunk_size=8, rate=1.0, tikhonov_term_enabled=False, gradient_kernel_enabled=False,
+                      maximum_iteration_count=60, maximum_warp_update_threshold=0.0, check_interval=8)
+    else:
+        halo = 4
+        kwargs = dict(maximum_chunk_size=8, rate=2.0, tikhonov_term_enabled=True, tikhonov_strength=0.05,
+                      gradient_kernel_enabled=True, kernel=lsf.generate_1d_sobolev_kernel(7, 0.1),
+                      maximum_iteration_count=60, maximum_warp_update_threshold=0.0, check_interval=8)
+    mp.spawn(_hier_worker, args=(world, _free_port(), n, nz, halo, kwargs, str(tmp_path)), nprocs=world, join=True)
+    canonical, live = (torch.from_numpy(v).cuda() for v in _shifted_spheres(n, nz))
+    ref = lsf.HierarchicalOptimizer3d(
+        logging_parameters=lsf.HierarchicalOptimizer3d.LoggingParameters(collect_per_level_convergence_reports=True),
+        **kwargs)
+    warp = ref.optimize(canonical, live).cpu().numpy()
+    assert float(np.abs(warp[..., 2]).max()) > halo, "this pair is meant to need a warp longer than the halo"
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert all(int(p["replicated"]) >= 1 for p in parts), "the run was meant to outgrow its halo"
+    got = np.concatenate([p["warp"] for p in parts], 0)
+    assert np.array_equal(got, warp)
+    reports = ref.get_per_level_convergence_reports()
+    for p in parts:
+        assert list(p["counts"]) == ref.get_per_level_iteration_counts()
+        assert np.array_equal(p["last_max"], np.float32([m[-1] for m in ref.get_per_level_maximum_updates()]))
+        assert np.allclose(p["diff_max"], [r.tsdf_difference_statistics.difference_max for r in reports], rtol=1e-9)
+        assert np.allclose(p["diff_mean"], [r.tsdf_difference_statistics.difference_mean for r in reports], rtol=1e-9)
