@@ -487,19 +487,54 @@ __device__ inline double shfl_down_f64(double v, int delta) {
     return __longlong_as_double((long long)shfl_down_u64((unsigned long long)__double_as_longlong(v), delta));
 }
 
-__device__ inline unsigned long long wave_max_u64(unsigned long long v) {
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) {
-        unsigned long long o = shfl_down_u64(v, d);
-        v = o > v ? o : v;
-    }
-    return v;
+// Wave-wide reductions by DPP (data-parallel primitives: a VALU move that reads another lane's register, no LDS round
+// trip): xor-1, xor-2 inside quads, rotate by 4 and 8 inside rows of 16, then the last lane of a row into the next row and
+// lane 31 into rows 2 and 3 -- six steps, the result in lane 63, handed to every lane by a readlane.  Lanes without a
+// source (row 0 of row_bcast:15, rows 0-1 of row_bcast:31) receive the identity.  ~85 VALU instructions for one packed
+// maximum + three float64 sums where six ds_bpermute steps each took ~1 us at the end of every wave of the fused kernel.
+// ALL 64 lanes must be active.
+template <int CTRL>
+__device__ inline unsigned long long dpp_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xf, 0xf, false);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
+__device__ inline unsigned long long broadcast_lane63_u64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// maximum over the wave, in EVERY lane
+__device__ inline unsigned long long wave_max_u64(unsigned long long v) {
+#define LSF_STEP(CTRL)                                   \
+    {                                                    \
+        const unsigned long long o = dpp_u64<CTRL>(v);   \
+        v = o > v ? o : v;                               \
+    }
+    LSF_STEP(0xb1)   // quad_perm:[1,0,3,2]
+    LSF_STEP(0x4e)   // quad_perm:[2,3,0,1]
+    LSF_STEP(0x124)  // row_ror:4
+    LSF_STEP(0x128)  // row_ror:8
+    LSF_STEP(0x142)  // row_bcast:15
+    LSF_STEP(0x143)  // row_bcast:31
+#undef LSF_STEP
+    return broadcast_lane63_u64(v);
+}
+
+// sum over the wave, in EVERY lane (a fixed association, the same in every launch)
 __device__ inline double wave_sum_f64(double v) {
-#pragma unroll
-    for (int d = kWave / 2; d > 0; d >>= 1) v += shfl_down_f64(v, d);
-    return v;
+#define LSF_STEP(CTRL)                                                                                               \
+    v += __longlong_as_double((long long)dpp_u64<CTRL>((unsigned long long)__double_as_longlong(v)));
+    LSF_STEP(0xb1)
+    LSF_STEP(0x4e)
+    LSF_STEP(0x124)
+    LSF_STEP(0x128)
+    LSF_STEP(0x142)
+    LSF_STEP(0x143)
+#undef LSF_STEP
+    return __longlong_as_double((long long)broadcast_lane63_u64((unsigned long long)__double_as_longlong(v)));
 }
 
 __device__ inline unsigned long long pack_max(float length, unsigned linear_index) {
@@ -527,15 +562,18 @@ __device__ inline void block_reduce_commit(unsigned long long packed, const doub
         for (int i = 0; i < NS; ++i) s_sum[i][wave] = s[i];
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long mm = s_max[0];
-        for (int w = 1; w < n_waves; ++w) mm = s_max[w] > mm ? s_max[w] : mm;
-        if (dst_max && mm != 0ull) atomicMax(dst_max, mm);
+    if (wave == 0) {
+        // one wave's partial results per lane, reduced the same way (a serial loop over the LDS words on one lane took
+        // ~2 us at the end of every CU-sized workgroup)
+        const unsigned long long mm = wave_max_u64(lane < n_waves ? s_max[lane] : 0ull);
+        double t[NS > 0 ? NS : 1];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            double t = 0.0;
-            for (int w = 0; w < n_waves; ++w) t += s_sum[i][w];
-            if (dst_sum[i] && t != 0.0) atomicAdd(dst_sum[i], t);
+        for (int i = 0; i < NS; ++i) t[i] = wave_sum_f64(lane < n_waves ? s_sum[i][lane] : 0.0);
+        if (lane == 0) {
+            if (dst_max && mm != 0ull) atomicMax(dst_max, mm);
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+                if (dst_sum[i] && t[i] != 0.0) atomicAdd(dst_sum[i], t[i]);
         }
     }
 }
