@@ -96,7 +96,7 @@ class HierarchicalEngine:
     def __init__(self, tikhonov_term_enabled, gradient_kernel_enabled, maximum_chunk_size, rate,
                  maximum_iteration_count, maximum_warp_update_threshold, data_term_amplifier, tikhonov_strength,
                  kernel, compute_energy=False, check_interval=32, collect_reports=False, comm=None,
-                 collect_iteration_data=False, linear_resampling=False, use_graphs=True, graph_max_voxels=1 << 20):
+                 collect_iteration_data=False, linear_resampling=False, use_graphs=True, graph_max_voxels=1 << 21):
         self.use_graphs = use_graphs                # HIP-graph replay for launch-bound levels
         self.graph_max_voxels = int(os.environ.get("LSF_GRAPH_MAX_VOXELS", graph_max_voxels))  # ... i.e. levels of at most this many voxels (the variable: a measurement knob)
         self._graphs = {}
@@ -1172,7 +1172,10 @@ class SlavchevaEngine:
         early = None
         hooked = self.iteration_hook is not None
         while it < limit:
-            batch = 1 if hooked else min(self.check_interval, limit - it)
+            # a run whose stop test cannot fire (min_iterations == max_iterations) has nothing to look at in between: all of
+            # it is enqueued at once, whatever check_interval says (the chain kernel keeps its batches: a launch per batch)
+            batch = 1 if hooked else (limit - it if self.min_iterations >= limit and chain is None
+                                      else min(self.check_interval, limit - it))
             if chain is not None and not chain.launch(it, batch):
                 chain = None  # a CU cannot hold the kernel's workgroup on this device: one launch per iteration
             self._chain_used = chain is not None
