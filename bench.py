@@ -427,8 +427,8 @@ def main():
         """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md) -- only for the default
         size AND only while the loaded library is the build the counters were collected on (lsf_build_id()): a kernel
         change without a re-profile reports null, not stale bytes"""
-        try:
-            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+        try:  # one file per profiled size: traffic.json (256^3, the default workload), traffic_512.json
+            with open(os.path.join(ROOT, "profiles", "traffic.json" if n == 256 else "traffic_%d.json" % n)) as f:
                 t = json.load(f)
         except (OSError, ValueError):
             return None

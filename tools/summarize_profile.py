@@ -3,7 +3,9 @@
   <tag>_bench_kernel_stats.csv   the --kernel-trace --stats table, our kernels first
   <tag>_pmc_hbm_traffic.csv      per-kernel means of FETCH_SIZE / WRITE_SIZE (bench + calibration launches)
   traffic.json                   calibrated HBM bytes per launch of the fused kernel (read by bench.py)
-usage: summarize_profile.py gpurun_out/<dir> <tag>"""
+usage: summarize_profile.py gpurun_out/<dir> <tag> [size [traffic file name]]
+  size (default 256): the bench's --size of the profiled run; a size other than 256 writes traffic_<size>.json
+  a directory without PMC passes (PASSES=stats) only yields the kernel-stats table"""
 import csv
 import glob
 import json
@@ -14,7 +16,22 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, tag = sys.argv[1], sys.argv[2]
+size = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+traffic_name = sys.argv[4] if len(sys.argv) > 4 else ("traffic.json" if size == 256 else "traffic_%d.json" % size)
 out_dir = os.path.join(ROOT, "profiles")
+
+
+def write_stats():
+    stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
+    table = list(csv.DictReader(open(stats)))
+    with open(os.path.join(out_dir, tag + "_bench_kernel_stats.csv"), "w") as f:
+        cols = ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"]
+        f.write(",".join(cols) + "\n")
+        for row in table:
+            row = dict(row)
+            row["Name"] = '"%s"' % short(row["Name"])
+            f.write(",".join(str(row.get(c, "")) for c in cols) + "\n")
+    print(open(os.path.join(out_dir, tag + "_bench_kernel_stats.csv")).read()[:1500])
 csv.field_size_limit(1 << 30)
 
 
@@ -31,6 +48,10 @@ def counter_means(sub):
             acc[(short(row["Kernel_Name"]), row["Counter_Name"])].append(float(row["Counter_Value"]))
     return acc
 
+
+if not os.path.isdir(os.path.join(src, "pmc_fetch")):
+    write_stats()
+    sys.exit(0)
 
 rows = []
 fused = {"list": {}, "dense": {}}
@@ -64,7 +85,7 @@ write_corr = corr[("state_pack_kernel", "WRITE_SIZE")]
 sys.path.insert(0, ROOT)
 import levelsetfusion_python_amd as _pkg  # noqa: E402  the build the counters were collected on (same sources)
 
-result = dict(workload="killing", size=256, tag=tag, build_id=_pkg._lib.lib.lsf_build_id().decode(), fetch_correction=round(fetch_corr, 4), write_correction=round(write_corr, 4),
+result = dict(workload="killing", size=size, tag=tag, build_id=_pkg._lib.lib.lsf_build_id().decode(), fetch_correction=round(fetch_corr, 4), write_correction=round(write_corr, 4),
               corrections={"%s %s" % k: round(v, 4) for k, v in corr.items()},
               source="profiles/%s_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
                      "calibrated on launches of known traffic with the same bytes per lane)" % tag)
@@ -75,16 +96,6 @@ for walk, key in (("list", "hbm_bytes_per_launch"), ("dense", "dense_hbm_bytes_p
         result[walk + "_fetch_size_KiB"] = c["FETCH_SIZE"][0]
         result[walk + "_write_size_KiB"] = c["WRITE_SIZE"][0]
         result[walk + "_dispatches"] = c["FETCH_SIZE"][1]
-json.dump(result, open(os.path.join(out_dir, "traffic.json"), "w"), indent=1)
-
-stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
-table = list(csv.DictReader(open(stats)))
-with open(os.path.join(out_dir, tag + "_bench_kernel_stats.csv"), "w") as f:
-    cols = ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"]
-    f.write(",".join(cols) + "\n")
-    for row in table:
-        row = dict(row)
-        row["Name"] = '"%s"' % short(row["Name"])
-        f.write(",".join(str(row.get(c, "")) for c in cols) + "\n")
-print(open(os.path.join(out_dir, "traffic.json")).read())
-print(open(os.path.join(out_dir, tag + "_bench_kernel_stats.csv")).read()[:1500])
+json.dump(result, open(os.path.join(out_dir, traffic_name), "w"), indent=1)
+print(open(os.path.join(out_dir, traffic_name)).read())
+write_stats()
