@@ -102,7 +102,7 @@ def cpu_baseline_hierarchical(size, iterations, full):
     dt = time.perf_counter() - t0
     updates = iterations * sum((size >> k) ** 3 for k in range(4))
     return dict(value=updates / dt, unit="voxel-warp-updates/s", cores=1, kind="port",
-                sample="one %d^3 pair of the sphere sequence, 4 levels x %d fixed iterations, Tikhonov%s, "
+                sample="one %d^3 pair of the sphere sequence, 4 levels x %d fixed iterations, Tikhonov (strength 0.05)%s, "
                        "oracle/lsf_oracle.py (numpy, 1 thread), %.1f s" % (size, iterations,
                                                                           " + 7-tap kernel" if full else "", dt),
                 host_cpus=os.cpu_count(), host_affinity=len(os.sched_getaffinity(0)))
@@ -201,7 +201,8 @@ def extra_workload(args, device, world, rank, dist):
                 done = (args.frames - 1) * per_pair
                 return (done // world, done // world) if slab else (done, done)
             name = "3D %d^3 multi-frame sequence, %d frames (%d pairs per step), HierarchicalOptimizer3d: 4 levels, " \
-                   "Tikhonov + 7-tap kernel, %d fixed iterations per level" % (n, args.frames, args.frames - 1, iters)
+                   "Tikhonov (tikhonov_strength 0.05: the reference's recurrence diverges from 1/12 up in 3-D) + 7-tap " \
+                   "kernel, %d fixed iterations per level" % (n, args.frames, args.frames - 1, iters)
             extra["parallelism"] = "single GPU" if world == 1 else (
                 "z-slab x%d of every pair, halo %d" % (world, args.halo) if slab else
                 "replicas x%d: %d independent pairs per rank" % (world, args.frames - 1))
@@ -211,8 +212,8 @@ def extra_workload(args, device, world, rank, dist):
             def step():
                 opt.optimize(canonical, live0)
                 return per_pair, per_pair
-            name = "3D %d^3 HierarchicalOptimizer3d, 4 levels, Tikhonov%s, %d iterations per level" % (
-                n, " + 7-tap kernel" if full else "", iters)
+            name = "3D %d^3 HierarchicalOptimizer3d, 4 levels, Tikhonov (tikhonov_strength 0.05)%s, %d iterations per " \
+                   "level" % (n, " + 7-tap kernel" if full else "", iters)
         b_alg = 104 if full else 68
         note = "whole-step rate x B_alg (%d B/voxel-update), all kernels of the iteration together" % b_alg
     (updates, visited), elapsed = timed_steps(step, args, fence, max_over_ranks if world > 1 else None)
