@@ -1042,8 +1042,11 @@ class SlavchevaEngine:
                 raise RuntimeError("warp update of %.3f voxels needs a %d-slice halo, more than half a slab of %d "
                                    "slices: use fewer, thicker slabs" % (max_update, h2, per))
             L2 = SlabLayout(L.nz_global, L.rank, L.world, h2)
-            comm2 = SlabComm(L2, self.comm.group)
-            comm2._native = None  # rare path: torch.distributed point-to-point, no second RCCL communicator
+            # the same kind of communicator on the wider layout; it BORROWS the library-side RCCL communicator (which knows
+            # ranks, not layouts: every call names its layout), so the re-run keeps the one-host-call-per-iteration
+            # transport instead of ~150 us of torch.distributed point-to-point per iteration
+            comm2 = type(self.comm)(L2, self.comm.group)
+            comm2._native = self.comm.native()
             wide = []
             for t in (live, canonical):
                 w = torch.empty((L2.nz_local,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
