@@ -422,7 +422,7 @@ def main():
         return out
 
     build_id = _lib.lib.lsf_build_id().decode()
-    traffic_source = {}
+    traffic_source = dict(loaded_build_id=build_id)
 
     def committed_traffic(key):
         """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md) -- only for the default
