@@ -108,3 +108,31 @@ def test_slab_run_matches_whole_volume(tmp_path, world, nz):
     want_idx = [np.ravel_multi_index(at, live.shape) for at in opt.log["max_warp_locations"]]
     assert list(got_idx) == [int(i) for i in want_idx]
     assert np.all(rec[:, 1].view(np.float64) > 0)
+
+
+def _gather_worker(rank, world, port, nz, halo, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
+    layout = SlabLayout(nz, rank, world, halo)
+    comm = SlabComm(layout)
+    sl = layout.local_slice()
+    whole = torch.arange(nz * 3 * 5 * 4, dtype=torch.float32).reshape(nz, 3, 5, 4)  # a "packed" field [z, y, x, 4]
+    local = whole[sl].clone()
+    local[:layout.z_begin] = -1.0  # halo contents must not travel
+    local[layout.z_end:] = -1.0
+    got = comm.all_gather_owned(local)
+    assert torch.equal(got, whole), "rank %d" % rank
+    open(os.path.join(out_dir, "ok%d" % rank), "w").close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_all_gather_owned_rebuilds_the_whole_level(tmp_path, world):
+    """SlabComm.all_gather_owned: every rank's OWNED slices, in rank order = the whole level on every rank (the static
+    gather operand of a hierarchical slab run whose warp outgrows the halo)"""
+    mp.spawn(_gather_worker, args=(world, _free_port(), 6 * world, 2, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
