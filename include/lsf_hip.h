@@ -420,6 +420,17 @@ int lsf_slab_state_iteration(lsf_slab_comm *comm, const float *state_in, const f
                              int32_t exchange /* LSF_SLAB_* */,
                              const lsf_slab_faces *faces /* NULL: whole slices travel */, void *stream);
 
+/* the LAST pass of the zero-preserving filter at the voxels of a band list (axis = 2 in 3-D, 0 in 2-D:
+ * math_utils/convolution.py:94-111,114-132; 3 / 5 / 7 / 9 taps) fused with lsf_slavcheva_update_rewarp
+ * (slavcheva_optimizer2d.py:208-236): in_planar = the output of the passes before, zero_mask_source = the RAW gradient,
+ * g_out_planar receives the final gradient; results are those of lsf_convolve_axis_listed + lsf_slavcheva_update_rewarp. */
+int lsf_slavcheva_filter_update_rewarp(const float *in_planar, const float *zero_mask_source, const float *live,
+                                       float *g_out_planar, float *warp_out_planar, float *live_out,
+                                       const lsf_grid *grid, const lsf_slavcheva_params *params, int32_t axis,
+                                       const double *taps_host, int32_t n_taps, const lsf_gate *gate,
+                                       lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,
+                                       void *stream);
+
 int lsf_slavcheva_update_rewarp(const float *live, const float *canonical, float *g_planar /* inout */,
                                 float *warp_out_planar, float *live_out, const lsf_grid *grid,
                                 const lsf_slavcheva_params *params, const lsf_gate *gate,

@@ -163,6 +163,9 @@ PROTOTYPES = {
     "lsf_slab_comm_destroy": (ctypes.c_int, [_vp]),
     "lsf_slab_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(SlabLayoutC), _P(SlabPart), _i32, _P(SlabPart),
                                                 _i32, _P(SlavchevaParams), _P(Gate), _vp, _i32, _P(SlabFaces), _vp]),
+    "lsf_slavcheva_filter_update_rewarp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),
+                                                          _i32, _P(ctypes.c_double), _i32, _P(Gate), _vp, _vp, _i64,
+                                                          _vp]),
     "lsf_slavcheva_update_rewarp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),
                                                    _P(Gate), _vp, _vp, _i64, _vp]),
     "lsf_warp_statistics": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp, _vp]),

@@ -578,6 +578,28 @@ __device__ inline void block_reduce_commit(unsigned long long packed, const doub
     }
 }
 
+// taps of one separable-filter pass, by value in the kernel arguments
+template <int NT>
+struct TapsN {
+    double k[NT];
+};
+
+// acc + k * v in float64.  When every tap is a float32 value (the reference's Sobolev kernels are:
+// generate_1d_sobolev_kernel(..., precision=np.float32)) the product of a tap and a float32 sample is EXACT in float64
+// -- 24 + 24 significant bits -- so the fused multiply-add rounds once exactly where the separate add does: the same
+// bits with half the float64 instructions (these filters are bound by float64 issue, not by memory).  The launchers
+// pick FMA only then (taps_are_float32); arbitrary float64 taps keep the two-instruction form.
+template <bool FMA>
+__device__ inline double mac(double acc, double k, double v) {
+    return FMA ? __builtin_fma(k, v, acc) : acc + k * v;
+}
+
+static inline bool taps_are_float32(const double* taps, int n) {
+    for (int j = 0; j < n; ++j)
+        if (!((double)(float)taps[j] == taps[j])) return false;  // also false for NaN
+    return true;
+}
+
 // vector length as np.linalg.norm(axis=-1) evaluates it in float32: sqrt((a^2 + b^2) [+ c^2])
 template <int D>
 __device__ inline float vec_length(const float (&v)[3]) {

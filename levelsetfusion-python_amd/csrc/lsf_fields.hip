@@ -517,27 +517,6 @@ __global__ __launch_bounds__(kBlock) void convolve_x_kernel(const float* __restr
 //     re-read by the neighbouring run (x 1.19 at kMarch = 32, from L2);
 //   x pass: a thread computes 4 consecutive outputs from three aligned float4 loads (previous, own, next quad).
 // Same arithmetic as the tiled kernels: float64 products and sums in tap order, one rounding per pass.
-template <int NT>
-struct TapsN {
-    double k[NT];
-};
-
-// acc + k * v in float64.  When every tap is a float32 value (the reference's Sobolev kernels are:
-// generate_1d_sobolev_kernel(..., precision=np.float32)) the product of a tap and a float32 sample is EXACT in float64
-// -- 24 + 24 significant bits -- so the fused multiply-add rounds once exactly where the separate add does: the same
-// bits with half the float64 instructions (these filters are bound by float64 issue, not by memory).  The launchers
-// pick FMA only then (taps_are_float32); arbitrary float64 taps keep the two-instruction form.
-template <bool FMA>
-__device__ inline double mac(double acc, double k, double v) {
-    return FMA ? __builtin_fma(k, v, acc) : acc + k * v;
-}
-
-static inline bool taps_are_float32(const double* taps, int n) {
-    for (int j = 0; j < n; ++j)
-        if (!((double)(float)taps[j] == taps[j])) return false;  // also false for NaN
-    return true;
-}
-
 constexpr int kMarch = 32;
 
 template <int AXIS, int NT, bool MASK, bool FMA>

@@ -157,6 +157,57 @@ __global__ __launch_bounds__(kBlock) void slavcheva_update_rewarp_kernel(const f
     block_reduce_commit<0>(best, sums, record_max(record), dst);
 }
 
+// The LAST pass of the zero-preserving filter (3-D: z, 2-D: x -- math_utils/convolution.py:94-111) at the voxels of a
+// band list, fused with the update and the truncation-aware re-warp (slavcheva_optimizer2d.py:208-236): the filtered
+// gradient of a voxel is all the update needs, so it never travels through memory in between and one of the five launches
+// of a SobolevFusion iteration goes away.  Same arithmetic as convolve_list_kernel + slavcheva_update_rewarp_kernel:
+// float64 products and sums in tap order, one float32 rounding, the mask of the RAW gradient, then update_and_rewarp.
+// g_out receives the final gradient (zeroed where the live value snapped when the mode says so).
+template <int D, int NT, bool FMA>
+__global__ __launch_bounds__(kBlock) void slavcheva_filter_update_rewarp_kernel(
+    const float* __restrict__ in, const float* __restrict__ mask_src, const float* __restrict__ live,
+    float* __restrict__ g_out, float* __restrict__ warp_out, float* __restrict__ live_out, Grid g, Params p,
+    TapsN<NT> taps, int axis, lsf_gate gate, lsf_iteration_record* record, const int* __restrict__ band_list,
+    unsigned band_count) {
+    if (gate_closed(gate)) return;
+    unsigned long long best = 0ull;
+    constexpr int c = NT / 2;
+    const int len = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz);
+    const int stride = axis == 0 ? 1 : (axis == 1 ? g.nx : g.nx * g.ny);
+    for_each_listed_voxel(g, band_list, band_count, [&](int x, int y, int z) {
+        const int i = vidx(g, x, y, z);
+        const int a = axis == 0 ? x : (axis == 1 ? y : z);
+        float gv[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int plane = 0; plane < D; ++plane) {
+            const long long base = (long long)plane * g.plane;
+            const float* __restrict__ src = in + base + i;
+            const float m = mask_src[base + i];
+            float v[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {  // out[a] = sum_j k[j] * in[a + c - j], zero outside [0, len)
+                const int d = c - j, q = a + d;
+                const bool inside = q >= 0 && q < len;
+                const float t = src[inside ? d * stride : 0];
+                v[j] = inside ? t : 0.0f;
+            }
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc = mac<FMA>(acc, taps.k[j], (double)v[j]);
+            gv[plane] = fabsf(m) < 1e-6f ? 0.0f : (float)acc;
+        }
+        const unsigned long long q = update_and_rewarp<D>(live, g, p, x, y, z, i, gv, warp_out, live_out, g_out);
+        best = q > best ? q : best;
+    });
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // the unlisted voxels: zero update, smallest index
+        const unsigned long long q = pack_max(0.0f, linear_index(g, 0, 0, g.z_begin));
+        best = q > best ? q : best;
+    }
+    const double sums[1] = {0.0};
+    double* dst[1] = {nullptr};
+    block_reduce_commit<0>(best, sums, record_max(record), dst);
+}
+
 Params make_params(const lsf_slavcheva_params* q) {
     Params p;
     p.lambda64 = q->isomorphic_enforcement_factor_f64;
@@ -482,6 +533,55 @@ extern "C" int lsf_slavcheva_update_rewarp(const float* live, const float* canon
     else
         hipLaunchKernelGGL(slavcheva_update_rewarp_kernel<3>, dim3(blocks), dim3(kBlock), 0, as_stream(stream), live,
                            g_planar, warp_out_planar, live_out, g, p, gt, record, band_list, (unsigned)band_count);
+    return launch_status();
+}
+
+template <int D, int NT>
+static void launch_filter_update(bool fma, unsigned blocks, hipStream_t s, const float* in, const float* mask,
+                                 const float* live, float* g_out, float* warp_out, float* live_out, const Grid& g,
+                                 const Params& p, const double* taps_host, int axis, const lsf_gate& gt,
+                                 lsf_iteration_record* record, const int* list, unsigned count) {
+    TapsN<NT> taps;
+    for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
+    if (fma)
+        hipLaunchKernelGGL((slavcheva_filter_update_rewarp_kernel<D, NT, true>), dim3(blocks), dim3(kBlock), 0, s, in, mask,
+                           live, g_out, warp_out, live_out, g, p, taps, axis, gt, record, list, count);
+    else
+        hipLaunchKernelGGL((slavcheva_filter_update_rewarp_kernel<D, NT, false>), dim3(blocks), dim3(kBlock), 0, s, in, mask,
+                           live, g_out, warp_out, live_out, g, p, taps, axis, gt, record, list, count);
+}
+
+extern "C" int lsf_slavcheva_filter_update_rewarp(const float* in_planar, const float* zero_mask_source,
+                                                  const float* live, float* g_out_planar, float* warp_out_planar,
+                                                  float* live_out, const lsf_grid* grid,
+                                                  const lsf_slavcheva_params* params, int32_t axis,
+                                                  const double* taps_host, int32_t n_taps, const lsf_gate* gate,
+                                                  lsf_iteration_record* record, const int32_t* band_list,
+                                                  int64_t band_count, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!in_planar || !zero_mask_source || !live || !g_out_planar || !warp_out_planar || !live_out ||
+        live_out == live || g_out_planar == in_planar || !params || !record || !taps_host || !band_list ||
+        band_count < 0 || band_count > 0x7fffffffll || axis < 0 || axis >= grid->dims)
+        return LSF_ERR_BAD_ARGUMENT;
+    if (n_taps != 3 && n_taps != 5 && n_taps != 7 && n_taps != 9) return LSF_ERR_KERNEL_TOO_LONG;
+    Grid g = make_grid(grid);
+    if (g.z_end == g.z_begin) return 0;
+    const Params p = make_params(params);
+    const lsf_gate gt = gate_or_open(gate);
+    const unsigned blocks = band_list_blocks((unsigned)band_count);
+    hipStream_t s = as_stream(stream);
+    bool fma = true;
+    for (int j = 0; j < n_taps; ++j) fma = fma && (double)(float)taps_host[j] == taps_host[j];
+    const int* list = band_list;
+    const unsigned count = (unsigned)band_count;
+#define LSF_FUR(D, NT) launch_filter_update<D, NT>(fma, blocks, s, in_planar, zero_mask_source, live, g_out_planar, \
+                                                 warp_out_planar, live_out, g, p, taps_host, axis, gt, record, list, count)
+    if (grid->dims == 2) {
+        switch (n_taps) { case 3: LSF_FUR(2, 3); break; case 5: LSF_FUR(2, 5); break; case 7: LSF_FUR(2, 7); break; default: LSF_FUR(2, 9); break; }
+    } else {
+        switch (n_taps) { case 3: LSF_FUR(3, 3); break; case 5: LSF_FUR(3, 5); break; case 7: LSF_FUR(3, 7); break; default: LSF_FUR(3, 9); break; }
+    }
+#undef LSF_FUR
     return launch_status();
 }
 

@@ -655,6 +655,22 @@ def slavcheva_update_rewarp(live, canonical, g, warp_out, live_out, grid, params
           "lsf_slavcheva_update_rewarp")
 
 
+def slavcheva_filter_update_rewarp(src, mask_source, live, g_out, warp_out, live_out, grid, params, axis, taps, gate,
+                                   records, index, band):
+    """last zero-preserving filter pass at the band voxels + update + re-warp in one launch
+    (lsf_slavcheva_filter_update_rewarp); taps: 3 / 5 / 7 / 9 (LISTED_TAP_COUNTS)"""
+    taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float64))
+    n = n_voxels(grid)
+    nd = n * grid.dims
+    check(lib.lsf_slavcheva_filter_update_rewarp(_ptr(src, nd, "filter src"), _ptr(mask_source, nd, "zero mask"),
+                                                 _ptr(live, n, "live"), _ptr(g_out, nd, "g_out"),
+                                                 _ptr(warp_out, nd, "warp_out"), _ptr(live_out, n, "live_out"),
+                                                 ctypes.byref(grid), ctypes.byref(params), int(axis),
+                                                 taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), taps.size,
+                                                 _gate_ref(gate), _record_ptr(records, index), band.pointer, band.count,
+                                                 stream_ptr()), "lsf_slavcheva_filter_update_rewarp")
+
+
 class IterationLauncher:
     """Pre-validated launch arguments for the per-iteration kernels of one level: tensors are checked ONCE, their
     device pointers, the grid, the parameter block and one gate / record pointer per iteration slot are materialised as
