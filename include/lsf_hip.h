@@ -365,6 +365,30 @@ int lsf_slavcheva_state_chain(float *state_a, float *state_b, const float *canon
                               const int32_t *band_list, int64_t band_count, int32_t iterations, int32_t stages,
                               int32_t *scratch, void *stream);
 
+/* ---- the SobolevFusion iteration on the float4 layouts (band lists) ------------------------------
+ * replaces one pass of slavcheva_optimizer2d.py:163-236 / :238-330 WITH a Sobolev filter (math_utils/convolution.py:
+ * 114-132) exactly as lsf_slavcheva_gradient + lsf_convolve_axis_listed x D + lsf_slavcheva_update_rewarp do on planar
+ * fields -- same results -- with one vector-memory instruction per neighbour / tap instead of one per component:
+ *   state  float4 [z][y][x] = (live, u, v, w)        as lsf_slavcheva_state_iteration (two ping-pong copies, both
+ *                                                    (live, 0) at unlisted voxels: lsf_state_prepare / lsf_state_pack)
+ *   g4     float4 [z][y][x] = (g_x, g_y, g_z, 0)     raw gradient, filter intermediates, final gradient; the caller
+ *                                                    zero-initialises them once (unlisted voxels are never written)
+ * One iteration = lsf_sobolev_state_gradient, lsf_convolve_axis_listed4 for every axis but the last (3-D: x, y; 2-D: y),
+ * lsf_sobolev_state_update for the last (3-D: z, 2-D: x) -- each once per band list (ascending voxel indices of any
+ * LSF_BAND_* subset; first_list != 0 on the call that stands for the unlisted voxels' zero update in the arg-max).
+ * 3 / 5 / 7 / 9 taps (LSF_ERR_KERNEL_TOO_LONG otherwise); 16 * nz * ny * nx need not fit 32 bits. */
+int lsf_sobolev_state_gradient(const float *state, const float *canonical, float *g_raw4, const lsf_grid *grid,
+                               const lsf_slavcheva_params *params, const lsf_gate *gate, lsf_iteration_record *record,
+                               const int32_t *band_list, int64_t band_count, void *stream);
+int lsf_convolve_axis_listed4(const float *in4, float *out4, const float *zero_mask_source4, const lsf_grid *grid,
+                              int32_t axis, const double *taps_host, int32_t n_taps, const lsf_gate *gate,
+                              const int32_t *band_list, int64_t band_count, void *stream);
+int lsf_sobolev_state_update(const float *in4, const float *zero_mask_source4, const float *state_in, float *state_out,
+                             float *g_out4, const lsf_grid *grid, const lsf_slavcheva_params *params, int32_t axis,
+                             const double *taps_host, int32_t n_taps, const lsf_gate *gate,
+                             lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,
+                             int32_t first_list, void *stream);
+
 /* ---- z-slab runtime of the fused path for multi-GPU runs (new design) -----------------------------
  * One process per GPU; rank r owns z-slices [z_begin, z_end) of its local array and keeps `halo` slices of its
  * neighbours on either interior side.  lsf_slab_state_iteration enqueues ONE whole iteration with one host call:

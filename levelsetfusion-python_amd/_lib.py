@@ -166,6 +166,12 @@ PROTOTYPES = {
     "lsf_slavcheva_filter_update_rewarp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),
                                                           _i32, _P(ctypes.c_double), _i32, _P(Gate), _vp, _vp, _i64,
                                                           _vp]),
+    "lsf_sobolev_state_gradient": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp, _vp, _i64,
+                                                  _vp]),
+    "lsf_convolve_axis_listed4": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _i32, _P(ctypes.c_double), _i32, _P(Gate), _vp,
+                                                 _i64, _vp]),
+    "lsf_sobolev_state_update": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _i32,
+                                                _P(ctypes.c_double), _i32, _P(Gate), _vp, _vp, _i64, _i32, _vp]),
     "lsf_slavcheva_update_rewarp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),
                                                    _P(Gate), _vp, _vp, _i64, _vp]),
     "lsf_warp_statistics": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp, _vp]),

@@ -1,0 +1,351 @@
+// The SobolevFusion iteration (zero-preserving separable filter between gradient and update) on the float4 layouts, at
+// the voxels of band lists.  Reference: nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:163-236 (VECTORIZED) / :238-330
+// (DIRECT) with math_utils/convolution.py:114-132.
+//
+// Why another set of kernels: the list passes of this path cost per vector-memory INSTRUCTION, not per byte (DESIGN.md
+// section 7, round 3: one plane of the planar filter pass takes 13 us at 256^3, three planes 17 / 22 / 35 us) -- and on
+// planar fields every tap of every component is an instruction of its own.  Here
+//   state   float4 [z][y][x] = (live, u, v, w)   the fused path's layout: live and warp of a neighbour in ONE load
+//   g4      float4 [z][y][x] = (g_x, g_y, g_z, 0)  gradient, filter intermediates: the three components of a tap in ONE load
+// so that per listed voxel the gradient reads 7 (Tikhonov) to 19 (Killing / level set) neighbours instead of 28 to 76
+// dwords, a filter pass 8 float4s instead of 24 dwords, and the last pass + update + re-warp writes two float4s instead
+// of seven dwords.  Same per-voxel arithmetic as the planar kernels (lsf_slavcheva.hip) and as the fused kernel
+// (lsf_slavcheva_state_taps.h): results are bit-identical to both.
+#include "lsf_slavcheva_state_taps.h"
+
+using namespace lsf;
+using namespace lsf::slav;
+
+namespace {
+
+// gradient (+ energies) of the listed voxels -> g_raw4; everything else in g_raw4 keeps the caller's zeros
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
+__global__ __launch_bounds__(kBlock) void sobolev_state_gradient_kernel(const vf4* __restrict__ state,
+                                                                        const float* __restrict__ canonical,
+                                                                        vf4* __restrict__ g_raw, Grid g, Params p,
+                                                                        lsf_gate gate, lsf_iteration_record* record,
+                                                                        const int* __restrict__ band_list,
+                                                                        unsigned band_count) {
+    if (gate_closed(gate)) return;
+    double en[3] = {0.0, 0.0, 0.0};
+    for_each_listed_voxel(g, band_list, band_count, [&](int x, int y, int z) {
+        const int i = vidx(g, x, y, z);
+        const vf4 sc = state[i];
+        const float l = sc.x, cn = canonical[i];
+        float gv[3] = {0.0f, 0.0f, 0.0f};
+        // outside the narrow-band union (tsdf_set_routines.py:19-52): a listed voxel may have left it by snapping to +-1
+        if (!(fabsf(l) == 1.0f && fabsf(cn) == 1.0f)) {
+            double e[3] = {0.0, 0.0, 0.0};
+            const bool interior = x > 0 && x < g.nx - 1 && y > 0 && y < g.ny - 1 && (D == 2 || (z > 0 && z < g.nz - 1));
+            if (g.wide_ok && __all(interior) && wave_span_ok(g, i)) {
+                NbhStateFast<D> n;
+                n.load(state, g, (unsigned)i, sc, !g.fast_ok);
+                band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
+            } else {
+                const NbhState<D> n(state, g, x, y, z, sc);
+                band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
+            }
+            if (z >= g.e_begin && z < g.e_end) {
+                en[0] += e[0];
+                en[1] += e[1];
+                en[2] += e[2];
+            }
+        }
+        vf4 o;
+        o.x = gv[0]; o.y = gv[1]; o.z = D == 3 ? gv[2] : 0.0f; o.w = 0.0f;
+        g_raw[i] = o;
+    });
+    if (ENERGY != LSF_ENERGY_NONE) {
+        double* dst[3] = {&record_slot(record)->data_energy, &record_slot(record)->smoothing_energy,
+                          &record_slot(record)->level_set_energy};
+        block_reduce_commit<3>(0ull, en, nullptr, dst);
+    }
+}
+
+// out[a] = sum_j k[j] * in[a + c - j] per component, zero outside [0, len), float64 in tap order, one float32 rounding,
+// forced to 0 where the RAW gradient's component is below 1e-6 (math_utils/convolution.py:118,123,127)
+template <int NT, bool FMA>
+__device__ inline vf4 filtered_at(const vf4* __restrict__ in, const vf4* __restrict__ mask_src, const TapsN<NT>& taps,
+                                  unsigned i, int a, int len, int stride) {
+    constexpr int c = NT / 2;
+    const vf4 m = mask_src[i];
+    vf4 v[NT];
+    const vf4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int d = c - j, q = a + d;
+        const bool inside = q >= 0 && q < len;
+        const vf4 t = in[(long long)i + (inside ? d * stride : 0)];
+        v[j] = inside ? t : zero;
+    }
+    double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        acc[0] = mac<FMA>(acc[0], taps.k[j], (double)v[j].x);
+        acc[1] = mac<FMA>(acc[1], taps.k[j], (double)v[j].y);
+        acc[2] = mac<FMA>(acc[2], taps.k[j], (double)v[j].z);
+    }
+    vf4 o;
+    o.x = fabsf(m.x) < 1e-6f ? 0.0f : (float)acc[0];
+    o.y = fabsf(m.y) < 1e-6f ? 0.0f : (float)acc[1];
+    o.z = fabsf(m.z) < 1e-6f ? 0.0f : (float)acc[2];
+    o.w = 0.0f;
+    return o;
+}
+
+__device__ inline void decode_listed(const Grid& g, unsigned i, int& x, int& y, int& z) {
+    const unsigned zy = fast_div(i, g.div_nx);
+    x = (int)(i - zy * (unsigned)g.nx);
+    z = (int)fast_div(zy, g.div_ny);
+    y = (int)zy - z * g.ny;
+}
+
+// one zero-preserving pass at listed voxels (one thread per voxel; convolve_list_kernel on the float4 layout)
+template <int NT, bool FMA>
+__global__ __launch_bounds__(kBlock) void convolve_list4_kernel(const vf4* __restrict__ in, vf4* __restrict__ out,
+                                                                const vf4* __restrict__ mask_src, Grid g,
+                                                                TapsN<NT> taps, int axis, const int* __restrict__ list,
+                                                                unsigned count, lsf_gate gate) {
+    if (gate_closed(gate)) return;
+    const unsigned k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    const unsigned i = (unsigned)list[k];
+    int x, y, z;
+    decode_listed(g, i, x, y, z);
+    const int a = axis == 0 ? x : (axis == 1 ? y : z);
+    const int len = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz);
+    const int stride = axis == 0 ? 1 : (axis == 1 ? g.nx : g.nx * g.ny);
+    out[i] = filtered_at<NT, FMA>(in, mask_src, taps, i, a, len, stride);
+}
+
+// the LAST pass + warp = -g * rate + the truncation-aware re-warp (slavcheva_optimizer2d.py:208-236,
+// field_warping.py:112-151): state' = (re-warped live, warp), g_out4 = the final gradient (zeroed where the live value
+// snapped, DIRECT only), record max = the longest update
+template <int D, int NT, bool FMA>
+__global__ __launch_bounds__(kBlock) void sobolev_state_update_kernel(const vf4* __restrict__ in,
+                                                                      const vf4* __restrict__ mask_src,
+                                                                      const vf4* __restrict__ state_in,
+                                                                      vf4* __restrict__ state_out, vf4* __restrict__ g_out,
+                                                                      Grid g, Params p, TapsN<NT> taps, int axis,
+                                                                      lsf_gate gate, lsf_iteration_record* record,
+                                                                      const int* __restrict__ band_list,
+                                                                      unsigned band_count, int first_list) {
+    if (gate_closed(gate)) return;
+    unsigned long long best = 0ull;
+    const int len = axis == 0 ? g.nx : (axis == 1 ? g.ny : g.nz);
+    const int stride = axis == 0 ? 1 : (axis == 1 ? g.nx : g.nx * g.ny);
+    for_each_listed_voxel(g, band_list, band_count, [&](int x, int y, int z) {
+        const int i = vidx(g, x, y, z);
+        const int a = axis == 0 ? x : (axis == 1 ? y : z);
+        const vf4 gf = filtered_at<NT, FMA>(in, mask_src, taps, (unsigned)i, a, len, stride);
+        float gv[3] = {gf.x, gf.y, D == 3 ? gf.z : 0.0f};
+        float wv[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < D; ++c) wv[c] = (-gv[c]) * p.rate;
+        const float len_w = vec_length<D>(wv);
+        const float l = state_in[i].x;
+        float v;
+        if (wv[0] == 0.0f && wv[1] == 0.0f && wv[2] == 0.0f) {
+            v = l;  // zero displacement: every lerp is a * 1 + b * 0 = a exactly, the gather returns live[p] bit for bit
+        } else {
+            v = state_gather<D>(state_in, g, (float)x + wv[0], (float)y + wv[1],
+                                D == 3 ? (float)(z + g.z_global_offset) + wv[2] : 0.0f);
+        }
+        if (1.0f - fabsf(v) < 1e-6f) {  // field_warping.py:138-141
+            v = v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : v);
+            wv[0] = wv[1] = wv[2] = 0.0f;
+            if (p.zero_gradient_on_snap) gv[0] = gv[1] = gv[2] = 0.0f;
+        }
+        vf4 o, go;
+        o.x = v; o.y = wv[0]; o.z = wv[1]; o.w = wv[2];
+        go.x = gv[0]; go.y = gv[1]; go.z = gv[2]; go.w = 0.0f;
+        state_out[i] = o;
+        g_out[i] = go;
+        const unsigned long long q = pack_max(len_w, linear_index(g, x, y, z));
+        best = q > best ? q : best;
+    });
+    if (first_list && blockIdx.x == 0 && threadIdx.x == 0) {  // the unlisted voxels: zero update, smallest index
+        const unsigned long long q = pack_max(0.0f, linear_index(g, 0, 0, g.z_begin));
+        best = q > best ? q : best;
+    }
+    const double sums[1] = {0.0};
+    double* dst[1] = {nullptr};
+    block_reduce_commit<0>(best, sums, record_max(record), dst);
+}
+
+Params params_of(const lsf_slavcheva_params* q) {
+    Params p;
+    p.lambda64 = q->isomorphic_enforcement_factor_f64;
+    p.rate = q->rate;
+    p.w_data = q->data_term_weight;
+    p.w_smooth = q->smoothing_term_weight;
+    p.w_level_set = q->level_set_term_weight;
+    p.lambda32 = q->isomorphic_enforcement_factor;
+    p.killing_c1 = q->killing_c1;
+    p.zero_gradient_on_snap = q->zero_gradient_on_snap;
+    return p;
+}
+
+// the state kernels' addressing limits (lsf_slavcheva_state_iteration)
+Grid state_grid(const lsf_grid* grid) {
+    Grid g = make_grid(grid, 4);
+    g.fast_ok = g.plane * 16 < 0xffffffffll;
+    g.wide_ok = 16ll * (2ll * grid->nx * grid->ny + 2ll * grid->nx + 3) < 0x7fffffffll;
+    return g;
+}
+
+struct GradArgs {
+    unsigned blocks;
+    hipStream_t s;
+    const vf4* state;
+    const float* canonical;
+    vf4* g_raw;
+    Grid g;
+    Params p;
+    lsf_gate gate;
+    lsf_iteration_record* record;
+    const int* list;
+    unsigned count;
+};
+
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
+void grad_one(const GradArgs& a) {
+    hipLaunchKernelGGL((sobolev_state_gradient_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY>), dim3(a.blocks), dim3(kBlock),
+                       0, a.s, a.state, a.canonical, a.g_raw, a.g, a.p, a.gate, a.record, a.list, a.count);
+}
+
+template <int D, int SMOOTH, bool LEVELSET, int DATA>
+void grad_energy(int energy, const GradArgs& a) {
+    switch (energy) {
+        case LSF_ENERGY_DIRECT: grad_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_DIRECT>(a); break;
+        case LSF_ENERGY_VECTORIZED: grad_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_VECTORIZED>(a); break;
+        default: grad_one<D, SMOOTH, LEVELSET, DATA, LSF_ENERGY_NONE>(a); break;
+    }
+}
+
+template <int D>
+void grad_terms(const lsf_slavcheva_params* q, const GradArgs& a) {
+    const bool killing = q->smoothing_method == LSF_SMOOTHING_KILLING;
+    const bool ls = q->level_set_enabled != 0;
+    const bool fdm = q->data_method == LSF_DATA_THRESHOLDED_FDM;
+    const int e = q->energy_mode;
+#define LSF_PICK(S, L, DM) grad_energy<D, S, L, DM>(e, a)
+    if (killing) {
+        if (ls) { if (fdm) LSF_PICK(LSF_SMOOTHING_KILLING, true, LSF_DATA_THRESHOLDED_FDM); else LSF_PICK(LSF_SMOOTHING_KILLING, true, LSF_DATA_BASIC); }
+        else    { if (fdm) LSF_PICK(LSF_SMOOTHING_KILLING, false, LSF_DATA_THRESHOLDED_FDM); else LSF_PICK(LSF_SMOOTHING_KILLING, false, LSF_DATA_BASIC); }
+    } else {
+        if (ls) { if (fdm) LSF_PICK(LSF_SMOOTHING_TIKHONOV, true, LSF_DATA_THRESHOLDED_FDM); else LSF_PICK(LSF_SMOOTHING_TIKHONOV, true, LSF_DATA_BASIC); }
+        else    { if (fdm) LSF_PICK(LSF_SMOOTHING_TIKHONOV, false, LSF_DATA_THRESHOLDED_FDM); else LSF_PICK(LSF_SMOOTHING_TIKHONOV, false, LSF_DATA_BASIC); }
+    }
+#undef LSF_PICK
+}
+
+inline bool taps_ok(int32_t n) { return n == 3 || n == 5 || n == 7 || n == 9; }
+
+template <int NT>
+void launch_pass4(const vf4* in, vf4* out, const vf4* mask, const Grid& g, int axis, const double* taps_host,
+                  const int* list, unsigned count, const lsf_gate& gt, hipStream_t s) {
+    TapsN<NT> taps;
+    for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
+    const dim3 grid((count + kBlock - 1) / kBlock);
+    if (taps_are_float32(taps_host, NT))
+        hipLaunchKernelGGL((convolve_list4_kernel<NT, true>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, axis, list,
+                           count, gt);
+    else
+        hipLaunchKernelGGL((convolve_list4_kernel<NT, false>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, axis, list,
+                           count, gt);
+}
+
+template <int D, int NT>
+void launch_update4(const vf4* in, const vf4* mask, const vf4* state_in, vf4* state_out, vf4* g_out, const Grid& g,
+                    const Params& p, int axis, const double* taps_host, const lsf_gate& gt, lsf_iteration_record* record,
+                    const int* list, unsigned count, int first_list, hipStream_t s) {
+    TapsN<NT> taps;
+    for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
+    const dim3 grid(band_list_blocks(count));
+    if (taps_are_float32(taps_host, NT))
+        hipLaunchKernelGGL((sobolev_state_update_kernel<D, NT, true>), grid, dim3(kBlock), 0, s, in, mask, state_in,
+                           state_out, g_out, g, p, taps, axis, gt, record, list, count, first_list);
+    else
+        hipLaunchKernelGGL((sobolev_state_update_kernel<D, NT, false>), grid, dim3(kBlock), 0, s, in, mask, state_in,
+                           state_out, g_out, g, p, taps, axis, gt, record, list, count, first_list);
+}
+
+}  // namespace
+
+extern "C" int lsf_sobolev_state_gradient(const float* state, const float* canonical, float* g_raw4,
+                                          const lsf_grid* grid, const lsf_slavcheva_params* params, const lsf_gate* gate,
+                                          lsf_iteration_record* record, const int32_t* band_list, int64_t band_count,
+                                          void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!state || !canonical || !g_raw4 || !params || !record || !band_list || band_count < 0 ||
+        band_count > 0x7fffffffll)
+        return LSF_ERR_BAD_ARGUMENT;
+    const Grid g = state_grid(grid);
+    if (g.z_end == g.z_begin || band_count == 0) return 0;
+    GradArgs a{band_list_blocks((unsigned)band_count), as_stream(stream), reinterpret_cast<const vf4*>(state), canonical,
+               reinterpret_cast<vf4*>(g_raw4), g, params_of(params), gate_or_open(gate), record, band_list,
+               (unsigned)band_count};
+    if (grid->dims == 2) grad_terms<2>(params, a);
+    else grad_terms<3>(params, a);
+    return launch_status();
+}
+
+extern "C" int lsf_convolve_axis_listed4(const float* in4, float* out4, const float* zero_mask_source4,
+                                         const lsf_grid* grid, int32_t axis, const double* taps_host, int32_t n_taps,
+                                         const lsf_gate* gate, const int32_t* band_list, int64_t band_count,
+                                         void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!in4 || !out4 || in4 == out4 || !zero_mask_source4 || !taps_host || !band_list || band_count < 0 ||
+        band_count > 0x7fffffffll || axis < 0 || axis >= grid->dims)
+        return LSF_ERR_BAD_ARGUMENT;
+    if (!taps_ok(n_taps)) return LSF_ERR_KERNEL_TOO_LONG;
+    const Grid g = state_grid(grid);
+    if (band_count == 0) return 0;
+    const vf4* in = reinterpret_cast<const vf4*>(in4);
+    vf4* out = reinterpret_cast<vf4*>(out4);
+    const vf4* mask = reinterpret_cast<const vf4*>(zero_mask_source4);
+    const lsf_gate gt = gate_or_open(gate);
+    hipStream_t s = as_stream(stream);
+    const unsigned count = (unsigned)band_count;
+    switch (n_taps) {
+        case 3: launch_pass4<3>(in, out, mask, g, axis, taps_host, band_list, count, gt, s); break;
+        case 5: launch_pass4<5>(in, out, mask, g, axis, taps_host, band_list, count, gt, s); break;
+        case 7: launch_pass4<7>(in, out, mask, g, axis, taps_host, band_list, count, gt, s); break;
+        default: launch_pass4<9>(in, out, mask, g, axis, taps_host, band_list, count, gt, s); break;
+    }
+    return launch_status();
+}
+
+extern "C" int lsf_sobolev_state_update(const float* in4, const float* zero_mask_source4, const float* state_in,
+                                        float* state_out, float* g_out4, const lsf_grid* grid,
+                                        const lsf_slavcheva_params* params, int32_t axis, const double* taps_host,
+                                        int32_t n_taps, const lsf_gate* gate, lsf_iteration_record* record,
+                                        const int32_t* band_list, int64_t band_count, int32_t first_list, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!in4 || !zero_mask_source4 || !state_in || !state_out || state_out == state_in || !g_out4 || g_out4 == in4 ||
+        !params || !record || !taps_host || !band_list || band_count < 0 || band_count > 0x7fffffffll || axis < 0 ||
+        axis >= grid->dims)
+        return LSF_ERR_BAD_ARGUMENT;
+    if (!taps_ok(n_taps)) return LSF_ERR_KERNEL_TOO_LONG;
+    const Grid g = state_grid(grid);
+    if (g.z_end == g.z_begin) return 0;
+    const vf4* in = reinterpret_cast<const vf4*>(in4);
+    const vf4* mask = reinterpret_cast<const vf4*>(zero_mask_source4);
+    const vf4* s_in = reinterpret_cast<const vf4*>(state_in);
+    vf4* s_out = reinterpret_cast<vf4*>(state_out);
+    vf4* g_out = reinterpret_cast<vf4*>(g_out4);
+    const Params p = params_of(params);
+    const lsf_gate gt = gate_or_open(gate);
+    hipStream_t s = as_stream(stream);
+    const unsigned count = (unsigned)band_count;
+#define LSF_UPD(D, NT) launch_update4<D, NT>(in, mask, s_in, s_out, g_out, g, p, axis, taps_host, gt, record, band_list, \
+                                             count, first_list, s)
+    if (grid->dims == 2) {
+        switch (n_taps) { case 3: LSF_UPD(2, 3); break; case 5: LSF_UPD(2, 5); break; case 7: LSF_UPD(2, 7); break; default: LSF_UPD(2, 9); break; }
+    } else {
+        switch (n_taps) { case 3: LSF_UPD(3, 3); break; case 5: LSF_UPD(3, 5); break; case 7: LSF_UPD(3, 7); break; default: LSF_UPD(3, 9); break; }
+    }
+#undef LSF_UPD
+    return launch_status();
+}

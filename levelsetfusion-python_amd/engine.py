@@ -50,6 +50,13 @@ def _conv_axis_order(dims):
     return [1, 0] if dims == 2 else [0, 1, 2]
 
 
+class _Counted:
+    """stands for a band list where only the number of listed voxels matters"""
+
+    def __init__(self, count):
+        self.count = int(count)
+
+
 class _Lazy:
     """a value made on first use"""
 
@@ -676,6 +683,55 @@ class _HaloTooNarrow(Exception):
         self.max_update = float(max_update)
 
 
+class _SobolevStatePlan:
+    """launch arguments of the SobolevFusion iteration on the float4 layouts (lsf_sobolev_state.hip), materialised once per
+    optimize() call: iteration i reads states[i % 2] and writes the other; g4 = [raw gradient, filter buffer A, filter
+    buffer B] (float4, zero-initialised: unlisted voxels are never written).  3-D: gradient -> raw, x pass raw -> A,
+    y pass A -> B, z pass + update + re-warp B -> final gradient in A; 2-D: y pass raw -> A, x pass + update A -> B."""
+
+    def __init__(self, launcher, states, canonical, grid, params, bands, g4, taps, min_iterations):
+        f = self.f = launcher
+        n = dev.n_voxels(grid)
+        self.p_state = [f.pointer(t, 4 * n, "state") for t in states]
+        self.p_canon = f.pointer(canonical, n, "canonical")
+        self.p_g = [f.pointer(t, 4 * n, "gradient buffer") for t in g4]
+        self.g4 = g4
+        self.bands = [b for b in bands if b.count] or bands[:1]
+        self.params_ref = ctypes.byref(params)
+        self.taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float64))
+        self.p_taps = self.taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        self.n_taps = int(self.taps.size)
+        self.min_iterations = min_iterations
+        self.stream = dev.stream_ptr()
+        self.axes = _conv_axis_order(grid.dims)
+        self.final = 1 if grid.dims == 3 else 2  # index of the buffer that holds the final gradient
+
+    def enqueue(self, i):
+        f, lib, check = self.f, _lib.lib, _lib.check
+        s_in, s_out = self.p_state[i % 2], self.p_state[(i + 1) % 2]
+        gate = None if i < self.min_iterations else f.gate_ref(i - 1)
+        rec = f.record_ptrs[i]
+        raw, a, b = self.p_g
+        for band in self.bands:
+            check(lib.lsf_sobolev_state_gradient(s_in, self.p_canon, raw, f.grid_ref, self.params_ref, gate, rec,
+                                                 band.pointer, band.count, self.stream), "lsf_sobolev_state_gradient")
+        src, dst = raw, a
+        for axis in self.axes[:-1]:
+            for band in self.bands:
+                check(lib.lsf_convolve_axis_listed4(src, dst, raw, f.grid_ref, axis, self.p_taps, self.n_taps, gate,
+                                                    band.pointer, band.count, self.stream), "lsf_convolve_axis_listed4")
+            src, dst = dst, (b if dst is a else a)
+        for k, band in enumerate(self.bands):
+            check(lib.lsf_sobolev_state_update(src, raw, s_in, s_out, dst, f.grid_ref, self.params_ref, self.axes[-1],
+                                               self.p_taps, self.n_taps, gate, rec, band.pointer, band.count,
+                                               int(k == 0), self.stream), "lsf_sobolev_state_update")
+
+    def final_gradient_planar(self, dims):
+        """[c][z,]y,x float32 from the float4 buffer of the last executed iteration (API edge only)"""
+        g4 = self.g4[self.final]
+        return g4[..., :dims].movedim(-1, 0).contiguous()
+
+
 class _ChainReachExceeded(Exception):
     """a chain launch (dev.StateChain) met a warp update its dependency windows do not cover; nothing of the caller's has
     been modified (SlavchevaEngine.optimize repeats the call with per-iteration launches)"""
@@ -1102,7 +1158,14 @@ class SlavchevaEngine:
                 raise ValueError("slab halo of %d slices is too narrow: this configuration needs >= %d"
                                  % (self.comm.layout.halo, need))
         prepared = None
-        fused_prepare = not self.sobolev and self.use_band_list and dev.buffer_addressing_ok(grid)
+        # SobolevFusion on band lists of a whole volume runs on the float4 layouts too (one vector-memory instruction per
+        # neighbour / tap instead of one per component: lsf_sobolev_state.hip); z-slabs, filters of other lengths and
+        # list-less runs keep the planar kernels
+        sob_state = (self.sobolev and self.use_band_list and not slab and dev.buffer_addressing_ok(grid)
+                     and len(self.sobolev_kernel) in dev.LISTED_TAP_COUNTS
+                     and os.environ.get("LSF_SOBOLEV_STATE", "1") != "0")
+        planar_sobolev = self.sobolev and not sob_state
+        fused_prepare = not planar_sobolev and self.use_band_list and dev.buffer_addressing_ok(grid)
         if fused_prepare:
             # one pass: both states + the INTERIOR / BOUNDARY band lists of the WHOLE local array.  Launched first: the
             # host sets up records and launch arguments while it runs, and only then waits for the list sizes -- and, in
@@ -1120,8 +1183,8 @@ class SlavchevaEngine:
             prepared = dev.StatePrepare(live, canonical, dev.full_range(grid), cut_chunks)
         records = dev.new_records(n_rec, live.device)
         self._last_g = None
-        lives = warps = gbufs = states = chain = None
-        if self.sobolev:
+        lives = warps = gbufs = states = chain = sob = None
+        if planar_sobolev:
             lives = [live.clone(), live.clone()]
             warps = [torch.zeros((dims,) + tuple(live.shape), dtype=torch.float32, device=live.device)
                      for _ in range(2)]
@@ -1164,12 +1227,18 @@ class SlavchevaEngine:
                 bands = dev.band_lists(live, canonical, whole) if self.use_band_list else [dev.BandList.none()]
             f.bands = bands
             self._fast = f
+            if sob_state:
+                g4 = [torch.zeros(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device) for _ in range(3)]
+                sob = _SobolevStatePlan(f, states, canonical, grid, self.params, bands, g4, self.sobolev_kernel,
+                                        self.min_iterations)
+                self._sobolev_band = _Counted(sum(b.count for b in bands))  # what bench.py prices this path over
             # Fixed-count runs on ONE interior list MAY run K iterations per launch (lsf_slavcheva_state_chain) instead of K
             # launches -- the stop test cannot fire in between.  Opt-in (LSF_CHAIN=1): bit-identical, but measured 4 %
             # SLOWER than one launch per iteration at 256^3 and 512^3: what a launch
             # boundary costs (~3.5 us) the chain pays again as wait + acquire + publish, and the rest of a launch's
             # "fixed" time is the drain of each wave's last unit, which a resident workgroup has as well
-            if (not slab and listed is not None and self.min_iterations >= max(self.max_iterations, self.min_iterations)
+            if (not slab and not self.sobolev and listed is not None
+                    and self.min_iterations >= max(self.max_iterations, self.min_iterations)
                     and self.min_iterations > 0 and self.iteration_hook is None and len(bands) == 1
                     and bands[0].subset == _lib.BAND_INTERIOR and bands[0].count > 0 and 16 * n < 0xffffffff
                     and not getattr(self, "_chain_disabled", False) and os.environ.get("LSF_CHAIN", "0") == "1"):
@@ -1194,9 +1263,11 @@ class SlavchevaEngine:
                 chain = None  # a CU cannot hold the kernel's workgroup on this device: one launch per iteration
             self._chain_used = chain is not None
             for i in range(it, it + batch) if chain is None else ():
-                if self.sobolev:
+                if planar_sobolev:
                     self._enqueue_iteration(i, lives[i % 2], lives[(i + 1) % 2], warps[i % 2], warps[(i + 1) % 2],
                                             canonical, grid, records, gbufs, limit)
+                elif sob is not None:
+                    sob.enqueue(i)
                 else:
                     self._enqueue_state_iteration(i, states, limit)
             # z-slab: a gated run's device-side gate reads the records, so they are all-reduced (global max: idempotent;
@@ -1206,7 +1277,7 @@ class SlavchevaEngine:
             if slab and not ungated:
                 self.comm.reduce_records(records, it, it + batch)
             it += batch
-            if finalize is not None and not self.sobolev and not slab and it == limit and self.min_iterations >= limit:
+            if finalize is not None and not planar_sobolev and not slab and it == limit and self.min_iterations >= limit:
                 # (a slab run may still have to be discarded -- see optimize() -- and finalize writes the caller's tensor)
                 # every launch runs ungated, so the final state is states[limit % 2]: finalize before looking
                 early = SlavchevaOutcome(grid, canonical, state=states[limit % 2], listed=listed)
@@ -1235,7 +1306,7 @@ class SlavchevaEngine:
                 break
             m = dec["max_value"][n_exec - 1]
             if hooked:
-                self._call_hook(it - 1, float(m), lives, warps, states, canonical, grid)
+                self._call_hook(it - 1, float(m), lives, warps, states, canonical, grid, sob)
             if n_exec >= self.min_iterations and not (np.float32(self.lo) < m < np.float32(self.hi)):
                 break
         self.iteration_count = n_exec
@@ -1247,7 +1318,7 @@ class SlavchevaEngine:
                         data_energies=(wd * dec["data_energy"][:n_exec]).tolist(),
                         smoothing_energies=(ws * dec["smoothing_energy"][:n_exec]).tolist(),
                         level_set_energies=(wl * dec["level_set_energy"][:n_exec]).tolist())
-        if self.sobolev:
+        if planar_sobolev:
             outcome = SlavchevaOutcome(grid, canonical, live=lives[n_exec % 2], warp_planar=warps[n_exec % 2])
         elif early is not None and n_exec == limit:
             outcome = early
@@ -1257,18 +1328,25 @@ class SlavchevaEngine:
         if n_exec == 0:
             self._gradient_state = ("zeros", torch.zeros((dims,) + tuple(live.shape), dtype=torch.float32,
                                                          device=live.device))
+        elif sob is not None:
+            # the gradient buffers rotate identically every iteration, so the last executed iteration's filtered gradient is
+            # in the buffer the (gated, skipped) later launches would have used too
+            self._gradient_state = ("float4", sob, dims)
         elif self.sobolev:
-            # g buffers rotate identically every iteration, so the last executed iteration's filtered gradient
-            # is in the buffer the (gated, skipped) later launches would have used too
             self._gradient_state = ("ready", self._last_g)
         else:
             self._gradient_state = ("recompute", states[(n_exec - 1) % 2], canonical, grid)
         return outcome
 
-    def _call_hook(self, i, max_warp, lives, warps, states, canonical, grid):
+    def _call_hook(self, i, max_warp, lives, warps, states, canonical, grid, sob=None):
         """iteration i has run: hand its warp and gradient to the hook in the API layout (owned slices of a slab)"""
-        if self.sobolev:
+        if self.sobolev and sob is None:
             warp_planar, g = warps[(i + 1) % 2], self._last_g
+        elif sob is not None:
+            live_now = torch.empty(tuple(states[0].shape[:-1]), dtype=torch.float32, device=states[0].device)
+            warp_planar = torch.empty((grid.dims,) + tuple(live_now.shape), dtype=torch.float32, device=live_now.device)
+            dev.state_unpack(states[(i + 1) % 2], dev.full_range(grid), live_now, warp_planar, None)
+            g = sob.final_gradient_planar(grid.dims)
         else:
             live_now = torch.empty(tuple(states[0].shape[:-1]), dtype=torch.float32, device=states[0].device)
             warp_planar = torch.empty((grid.dims,) + tuple(live_now.shape), dtype=torch.float32, device=live_now.device)
@@ -1289,6 +1367,10 @@ class SlavchevaEngine:
             return None
         if st[0] in ("zeros", "ready"):
             return st[1]
+        if st[0] == "float4":  # SobolevFusion on the float4 layouts: the final gradient, made planar on demand
+            g = st[1].final_gradient_planar(st[2])
+            self._gradient_state = ("ready", g)
+            return g
         if st[0] == "wide":  # the call was re-run on a wider internal slab: its gradient, cut to this slab's slices
             g = st[1].gradient_field()
             return None if g is None else g[:, st[2]].contiguous()
