@@ -292,7 +292,9 @@ int lsf_band_list_fill(const float *live, const float *canonical, const lsf_grid
  * lsf_state_pack: (live, warp planar or NULL = 0) -> state_a and, if not NULL, state_b, slices [z_begin, z_end).
  * lsf_state_unpack: state -> live and / or planar warp [c][z][y][x] and / or interleaved warp [z][y][x][c]. */
 /* lsf_state_prepare: the start of an optimize() call in one pass over WHOLE arrays (z_begin = 0, z_end = nz): both
- * ping-pong states = (live, 0) and the counting step of lsf_band_count for the INTERIOR and the BOUNDARY subset at once.
+ * ping-pong states = (live, 0) (state_b may be NULL: the caller then writes it with lsf_state_pack behind its copy of
+ * counts_out, where it overlaps the host's wait) and the counting step of lsf_band_count for the INTERIOR and the
+ * BOUNDARY subset at once.
  * scratch: lsf_state_prepare_scratch_elements(grid) int32 (8-byte aligned); counts_out[0..4) (device) = INTERIOR and
  * BOUNDARY totals, then the number of voxels OUTSIDE the band with live = -canonical and the first of them (-1: none)
  * -- what lsf_state_finalize_listed needs to know about the voxels no list holds.  lsf_band_list_fill_prepared then writes one subset's list from the ballots the prepare pass kept

@@ -402,8 +402,9 @@ __global__ __launch_bounds__(1024) void band_scan_kernel(int* __restrict__ sums_
 
 typedef float vf4 __attribute__((ext_vector_type(4)));
 
-// start of an optimize() call on the fused path in ONE pass over live and canonical: both ping-pong states = (live, 0)
-// (lsf_state_pack) and the per-chunk counts of the INTERIOR and the BOUNDARY band voxels (lsf_band_count twice)
+// start of an optimize() call on the fused path in ONE pass over live and canonical: the ping-pong states = (live, 0)
+// (lsf_state_pack; `b` may be null -- the caller then fills the second state while the host waits for the list sizes)
+// and the per-chunk counts of the INTERIOR and the BOUNDARY band voxels (lsf_band_count twice)
 __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __restrict__ live,
                                                                const float* __restrict__ canonical,
                                                                vf4* __restrict__ a, vf4* __restrict__ b, unsigned n,
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
             vf4 o;
             o.x = l; o.y = 0.0f; o.z = 0.0f; o.w = 0.0f;
             a[v] = o;
-            b[v] = o;
+            if (b) b[v] = o;
             const unsigned zy = fast_div(v, g.div_nx);
             const int x = (int)(v - zy * (unsigned)g.nx);
             const int z = (int)fast_div(zy, g.div_ny);
@@ -652,7 +653,7 @@ extern "C" int lsf_band_list_fill_prepared(const lsf_grid* grid, int32_t subset,
 extern "C" int lsf_state_prepare(const float* live, const float* canonical, float* state_a, float* state_b,
                                  const lsf_grid* grid, int32_t* scratch, int64_t* counts_out, void* stream) {
     if (int e = check_grid(grid)) return e;
-    if (!live || !canonical || !state_a || !state_b || !scratch || !counts_out) return LSF_ERR_BAD_ARGUMENT;
+    if (!live || !canonical || !state_a || !scratch || !counts_out) return LSF_ERR_BAD_ARGUMENT;  // state_b: optional
     if (grid->z_begin != 0 || grid->z_end != grid->nz) return LSF_ERR_BAD_ARGUMENT;  // whole arrays only
     unsigned first, n, chunks;
     band_range(grid, first, n, chunks);

@@ -695,6 +695,39 @@ def test_state_prepare_reports_list_positions_of_chunk_boundaries(lsf):
     assert plain.cuts is None
 
 
+@pytest.mark.gpu
+def test_state_prepare_second_state_behind_the_sizes_or_in_the_pass(lsf, monkeypatch):
+    """the second ping-pong state is written either by the counting pass itself (above StatePrepare.SPLIT_MAX_VOXELS, or
+    LSF_PREPARE_SPLIT=0) or by lsf_state_pack behind the copy of the list sizes: same states, same lists either way"""
+    from levelsetfusion_python_amd import device as dev
+    gen = torch.Generator("cuda").manual_seed(23)
+    shape = (20, 24, 40)
+    live = (torch.rand(shape, device="cuda", generator=gen) * 2 - 1).contiguous()
+    canon = (torch.rand(shape, device="cuda", generator=gen) * 2 - 1).contiguous()
+    far = torch.rand(shape, device="cuda", generator=gen) < 0.6
+    live[far], canon[far] = -1.0, 1.0
+    results = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LSF_PREPARE_SPLIT", mode)
+        prepared = dev.StatePrepare(live, canon)
+        lists, unlisted = prepared.collect()
+        torch.cuda.synchronize()
+        results.append((prepared.states, lists, unlisted))
+    want = torch.zeros(shape + (4,), device="cuda")
+    want[..., 0] = live
+    for states, lists, unlisted in results:
+        assert torch.equal(states[0], want) and torch.equal(states[1], want)
+        assert unlisted == results[0][2]
+        for a, b in zip(lists, results[0][1]):
+            assert a.count == b.count and torch.equal(a.indices[:a.count], b.indices[:b.count])
+    monkeypatch.setattr(dev.StatePrepare, "SPLIT_MAX_VOXELS", 1)
+    monkeypatch.setenv("LSF_PREPARE_SPLIT", "1")
+    big = dev.StatePrepare(live, canon)
+    big.collect()
+    torch.cuda.synchronize()
+    assert torch.equal(big.states[1], want)
+
+
 def test_state_finalize_listed_equals_dense_finalize(lsf):
     """lsf_state_finalize_listed (band voxels only + lsf_state_prepare's counts of the rest) against lsf_state_finalize
     over every voxel: fields bit-identical, counts / extrema / arg-max exact, float64 sums to rounding.  Cases: a band
