@@ -1,5 +1,6 @@
-"""time of lsf_convolve_axis_listed4 per axis at 256^3 on the sphere pair's band list (LSF_SOBOLEV_PIPE = blocks per XCD of
-the pipelined variant, 0 = one-shot blocks)"""
+"""HIP-event time of lsf_convolve_axis_listed4 (one zero-preserving filter pass on the float4 gradient layout) per axis at
+256^3 on the sphere pair's band list.  (The persistent, software-pipelined variant DESIGN.md section 7 compares it with
+was selected by LSF_SOBOLEV_PIPE = workgroups per XCD in a measurement build; it is not in the tree.)"""
 import os, sys, ctypes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,7 +13,7 @@ c, l = sphere_pair(n, 3, "cuda")
 grid = dev.make_grid((n, n, n))
 band = dev.band_list(l, c, grid, _lib.BAND_ALL)
 k7 = np.ascontiguousarray(np.asarray(lsf.generate_1d_sobolev_kernel(7, 0.1), dtype=np.float64))
-src = torch.randn((n, n, n, 4), device="cuda")
+src = torch.randn((n, n, n, 4), device="cuda", generator=torch.Generator("cuda").manual_seed(1))
 outs = {}
 for axis in (0, 1, 2):
     dst = torch.zeros_like(src)
@@ -26,4 +27,4 @@ for axis in (0, 1, 2):
         e1.record(); torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 100.0
         best = t if best is None else min(best, t)
-    print("pipe=%s axis %d: %.1f us, checksum %.6f" % (os.environ.get("LSF_SOBOLEV_PIPE", "0"), axis, best, float(dst.double().sum().item())))
+    print("axis %d: %.1f us per pass" % (axis, best))
