@@ -1091,10 +1091,16 @@ class SlavchevaEngine:
                 # left the caller's tensors alone (its skip flag), so the call simply runs again, one launch per iteration
                 self._chain_disabled = True
                 return self._optimize(live, canonical, finalize)
+        self._slab_restore = None
         try:
-            return self._optimize(live, canonical, finalize)
+            outcome = self._optimize(live, canonical, finalize)
+            self._slab_restore = None
+            return outcome
         except _HaloTooNarrow as exc:
             torch.cuda.synchronize()  # nothing of the abandoned attempt (an exchange left in flight) may linger
+            if self._slab_restore is not None:  # the abandoned attempt's finalize pass has written the caller's tensor
+                self._slab_restore[0].copy_(self._slab_restore[1])
+                self._slab_restore = None
             return self._optimize_widened(live, canonical, exc.max_update)
 
     def _optimize_widened(self, live, canonical, max_update):
@@ -1187,6 +1193,13 @@ class SlavchevaEngine:
                                                                device=live.device))
                 cut_chunks = self._cut_chunk_cache[1]
             prepared = dev.StatePrepare(live, canonical, dev.full_range(grid), cut_chunks)
+        live_at_entry = None
+        if slab and finalize is not None and finalize[0] is not None and not planar_sobolev \
+                and self.min_iterations >= max(self.max_iterations, self.min_iterations):
+            # the finalize pass of a fixed-count slab call is enqueued behind the last iteration, before the records of
+            # every rank have said whether the call stands: what it overwrites is kept (a copy while the card waits for
+            # the host anyway) -- instead of a launch, a synchronisation and a read-back behind the records
+            live_at_entry = finalize[0].clone()
         records = dev.new_records(n_rec, live.device)
         self._last_g = None
         lives = warps = gbufs = states = chain = sob = None
@@ -1283,11 +1296,14 @@ class SlavchevaEngine:
             if slab and not ungated:
                 self.comm.reduce_records(records, it, it + batch)
             it += batch
-            if finalize is not None and not planar_sobolev and not slab and it == limit and self.min_iterations >= limit:
-                # (a slab run may still have to be discarded -- see optimize() -- and finalize writes the caller's tensor)
-                # every launch runs ungated, so the final state is states[limit % 2]: finalize before looking
+            if finalize is not None and not planar_sobolev and it == limit and self.min_iterations >= limit:
+                # every launch runs ungated, so the final state is states[limit % 2]: finalize before looking.  A slab run
+                # may still have to be discarded (see optimize()), and the pass writes the caller's tensor: optimize() puts
+                # the copy taken below back before it runs the call again
                 early = SlavchevaOutcome(grid, canonical, state=states[limit % 2], listed=listed)
                 early._chain = chain
+                if slab and finalize[0] is not None:
+                    self._slab_restore = (finalize[0], live_at_entry)
                 early.enqueue_finalize(*finalize)
             dec = dev.decode_records(self.comm.gather_records(records, 0, it) if slab and ungated
                                      else dev.records_to_host(records[:it]))
