@@ -30,10 +30,13 @@ _PINNED = {}
 
 
 def pinned_scratch(name, numel, dtype):
-    """a small page-locked host buffer that lives as long as the process (one per device and purpose): the landing
-    place of the few numbers a call reads back, without a host allocation per call.  The optimizers are single-caller
-    objects (as the reference's are): a buffer is consumed before the next call on the same device fills it again."""
-    key = (torch.cuda.current_device(), name, dtype)  # one buffer per purpose, grown to the largest length asked for
+    """a small page-locked host buffer that lives as long as the process (one per device, STREAM and purpose): the
+    landing place of the few numbers a call reads back, without a host allocation per call.  The optimizers are
+    single-caller objects (as the reference's are): a buffer is consumed before the next call on the same stream fills it
+    again -- and optimizers that run side by side (experiment/multipair.py: pairs in flight, one thread and one stream
+    each) never share one."""
+    # one buffer per purpose, grown to the largest length asked for
+    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, name, dtype)
     buf = _PINNED.get(key)
     if buf is None or buf.numel() < int(numel):
         buf = _PINNED[key] = torch.empty(max(int(numel), 2 * buf.numel() if buf is not None else 0), dtype=dtype,

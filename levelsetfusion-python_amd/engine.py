@@ -7,6 +7,7 @@ iterations, reads back the tiny iteration records to learn whether the device-si
 """
 import ctypes
 import os
+import threading
 
 import numpy as np
 import torch
@@ -49,6 +50,20 @@ def _conv_axis_order(dims):
     # 3-D: x, y, z (math_utils/convolution.py:94-105)
     return [1, 0] if dims == 2 else [0, 1, 2]
 
+
+
+# HIP graphs and host threads (experiment/multipair.py runs optimizers side by side, a thread and a stream each): captures
+# are thread-local and one at a time (the lock); and a captured graph is never DESTROYED while another thread captures --
+# torch's graph destructor synchronises the device, which a capture in progress turns into a fatal error, and Python may
+# finalise an abandoned optimizer in any thread at any time.  Engines therefore retire their graphs into a list that is
+# emptied under the lock, right before the next capture (or never: a few KB each).
+_CAPTURE_LOCK = threading.Lock()
+_RETIRED_GRAPHS = []
+
+
+def _retire_graphs(graphs):
+    _RETIRED_GRAPHS.extend(graphs.values())  # list.extend is atomic under the GIL
+    graphs.clear()
 
 class _Counted:
     """stands for a band list where only the number of listed voxels matters"""
@@ -105,6 +120,9 @@ class HierarchicalEngine:
                  kernel, compute_energy=False, check_interval=32, collect_reports=False, comm=None,
                  collect_iteration_data=False, linear_resampling=False, use_graphs=True, graph_max_voxels=1 << 21):
         self.use_graphs = use_graphs                # HIP-graph replay for launch-bound levels
+        # False: levels without a captured graph run eagerly (same results) -- set while optimizers work side by side in
+        # several host threads: HIP refuses ordinary calls of OTHER threads while a capture is in progress
+        self.allow_graph_capture = True
         self.graph_max_voxels = int(os.environ.get("LSF_GRAPH_MAX_VOXELS", graph_max_voxels))  # ... i.e. levels of at most this many voxels (the variable: a measurement knob)
         self._graphs = {}
         self.linear_resampling = linear_resampling  # ResamplingStrategy.LINEAR (3-D): math_utils/resampling.py
@@ -310,9 +328,19 @@ class HierarchicalEngine:
             lv.open_gate_refs = [ctypes.byref(g) for g in lv.open_gates]
         return lv
 
+    def _graph_key(self, canonical):
+        K = min(self.check_interval, self.maximum_iteration_count)
+        return (tuple(canonical.shape), canonical.device, K - K % 2)
+
     def invalidate_graphs(self):
         """a setting changed: captured graphs hold the old rate / threshold / taps / iteration counts"""
-        self._graphs.clear()
+        _retire_graphs(self._graphs)
+
+    def __del__(self):
+        try:
+            _retire_graphs(self._graphs)
+        except Exception:  # noqa: BLE001 -- interpreter shutdown: nothing left to protect
+            pass
 
     def _enqueue(self, lv, rec_idx, prev_idx, parity, comm=None, defer_max=False, prev_deferred=False):
         """one iteration: record slot rec_idx, gated on record prev_idx (None: always runs), buffer parity 0/1.
@@ -420,7 +448,8 @@ class HierarchicalEngine:
         n_vox = canonical.numel()
         hooked = self.iteration_hook is not None
         if (self.use_graphs and not slab and not self.collect_iteration_data and not hooked and max_it >= 4
-                and self.check_interval >= 2 and n_vox <= self.graph_max_voxels):
+                and self.check_interval >= 2 and n_vox <= self.graph_max_voxels
+                and (self.allow_graph_capture or self._graph_key(canonical) in self._graphs)):
             return self._optimize_level_graph(canonical, packed, warp)
         if slab:
             L = comm.layout
@@ -515,9 +544,8 @@ class HierarchicalEngine:
         iteration counts and results are exactly those of the eager path (tests demand equality)."""
         max_it = self.maximum_iteration_count
         thr = np.float32(self.maximum_warp_update_threshold)
-        K = min(self.check_interval, max_it)
-        K -= K % 2
-        key = (tuple(canonical.shape), canonical.device, K)
+        key = self._graph_key(canonical)
+        K = key[2]
         entry = self._graphs.get(key)
         if entry is None:
             grid = dev.make_grid(canonical.shape)
@@ -532,11 +560,15 @@ class HierarchicalEngine:
                 self._enqueue(lv, 0, None, 0)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                lv.records[K].copy_(lv.records[K - 1])
-                lv.records[:K].zero_()
-                for j in range(K):
-                    self._enqueue(lv, j, K if j == 0 else j - 1, j % 2)
+            # thread_local: another optimizer working in another host thread on another stream (experiment/multipair.py:
+            # pairs in flight) must not invalidate this capture; two captures at once are kept apart by the lock
+            with _CAPTURE_LOCK:
+                del _RETIRED_GRAPHS[:]  # graphs of engines that are gone die here, with no capture in progress
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    lv.records[K].copy_(lv.records[K - 1])
+                    lv.records[:K].zero_()
+                    for j in range(K):
+                        self._enqueue(lv, j, K if j == 0 else j - 1, j % 2)
             entry = self._graphs[key] = (lv, graph)
         lv, graph = entry
         lv.canonical.copy_(canonical)

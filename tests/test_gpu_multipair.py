@@ -48,3 +48,39 @@ def test_multipair_run(tmp_path):
     # an optimizer without report collection is rejected loudly
     with pytest.raises(ValueError):
         mp.run_pairs(lsf.HierarchicalOptimizer2d(**kw), pairs[:1])
+
+
+def test_pairs_in_flight_give_the_same_table(tmp_path):
+    """run_pairs with a sequence of optimizers: two / three pairs in flight at once (a thread and a stream per optimizer)
+    -- the same report table as one optimizer pair after pair, 2-D and 3-D (the reference's loop is embarrassingly
+    parallel: run_hierarchical_optimizer3d_multipair.py:403-432)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd.experiment import multipair as mp
+    for d, n, cls, extra in ((2, 64, lsf.HierarchicalOptimizer2d, {}),
+                             (3, 32, lsf.HierarchicalOptimizer3d, {})):
+        base_c, base_l = O.sphere_pair(n, d=d)
+        pairs = [(100 + k, 7, base_c, np.roll(base_l, k % 4, axis=d - 1)) for k in range(7)]
+        kw = dict(tikhonov_term_enabled=True, tikhonov_strength=0.2, gradient_kernel_enabled=False, maximum_chunk_size=4,
+                  rate=0.2, maximum_iteration_count=25, maximum_warp_update_threshold=0.02, **extra)
+
+        def make():
+            return cls(logging_parameters=cls.LoggingParameters(collect_per_level_convergence_reports=True), **kw)
+        one = mp.post_process_convergence_report_sets(*mp.run_pairs(make(), pairs))
+        seen = []
+        for lanes in (2, 3):
+            many = mp.post_process_convergence_report_sets(
+                *mp.run_pairs([make() for _ in range(lanes)], pairs, progress=lambda k, total: seen.append(k)))
+            # the two standard deviations come out of float64 sums whose order varies from launch to launch (1e-14,
+            # also between two runs of ONE optimizer); every other column is exact
+            loose = [c for c in one.columns if c.endswith("_std")]
+            exact = [c for c in one.columns if c not in loose]
+            assert many[exact].equals(one[exact]), "pairs in flight changed the table (%d-D, %d lanes)" % (d, lanes)
+            assert np.allclose(many[loose].to_numpy(dtype=np.float64), one[loose].to_numpy(dtype=np.float64),
+                               rtol=1e-11, atol=1e-13)
+        assert sorted(seen) == sorted(list(range(7)) * 2)
+    # a failure inside a lane reaches the caller
+    with pytest.raises(ValueError):
+        mp.run_pairs([lsf.HierarchicalOptimizer2d(**{k: v for k, v in kw.items()}) for _ in range(2)],
+                     [(1, 1) + O.sphere_pair(64, d=2)] * 3)
