@@ -11,14 +11,19 @@
 
 typedef float vf4 __attribute__((ext_vector_type(4)));
 
-template <int NT, bool DWORD>
+template <int NT, bool DWORD, bool CONTIG = false>
 __global__ __launch_bounds__(1024) void walk(const vf4* __restrict__ state, const float* __restrict__ canonical,
                                              vf4* __restrict__ out, const int* __restrict__ list, unsigned count, int nx,
                                              int ny) {
     const unsigned units = (count + 63) / 64, waves = gridDim.x * 16;
     const unsigned wave = blockIdx.x * 16 + threadIdx.x / 64, lane = threadIdx.x & 63;
     const int sy = nx, sz = nx * ny;
-    for (unsigned u = wave; u < units; u += waves) {
+    // CONTIG: a workgroup owns a contiguous range of the list and its 16 waves go through it side by side
+    const unsigned per_block = (units + gridDim.x - 1) / gridDim.x;
+    const unsigned first = CONTIG ? blockIdx.x * per_block + threadIdx.x / 64 : wave;
+    const unsigned last = CONTIG ? min(units, (blockIdx.x + 1) * per_block) : units;
+    const unsigned step = CONTIG ? 16u : waves;
+    for (unsigned u = first; u < last; u += step) {
         const unsigned k = u * 64 + lane;
         const int i = list[k < count ? k : count - 1];
         vf4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -43,14 +48,20 @@ __global__ __launch_bounds__(1024) void walk(const vf4* __restrict__ state, cons
 
 int main(int argc, char** argv) {
     const int n = argc > 1 ? atoi(argv[1]) : 256;
+    // list order: patches of PZ slices x PY rows (x whole), the patches in z-major order, inside a patch z, y, x ascending
+    // (PZ = PY = 1: the plain ascending list of the package)
+    const int PZ = argc > 2 ? atoi(argv[2]) : 1, PY = argc > 3 ? atoi(argv[3]) : 1;
     std::vector<int> host;
     const float r = 0.3f * n, c = n / 2.0f;
-    for (int z = 1; z < n - 1; ++z)
-        for (int y = 1; y < n - 1; ++y)
-            for (int x = 1; x < n - 1; ++x) {
-                const float d = sqrtf((x - c) * (x - c) + (y - c) * (y - c) + (z - c) * (z - c));
-                if (fabsf(d - r) < 11.0f) host.push_back((z * n + y) * n + x);
-            }
+    for (int z0 = 0; z0 < n; z0 += PZ)
+        for (int y0 = 0; y0 < n; y0 += PY)
+            for (int z = z0; z < z0 + PZ && z < n - 1; ++z)
+                for (int y = y0; y < y0 + PY && y < n - 1; ++y)
+                    for (int x = 1; x < n - 1; ++x) {
+                        if (z < 1 || y < 1) continue;
+                        const float d = sqrtf((x - c) * (x - c) + (y - c) * (y - c) + (z - c) * (z - c));
+                        if (fabsf(d - r) < 11.0f) host.push_back((z * n + y) * n + x);
+                    }
     const unsigned count = (unsigned)host.size();
     const long long N = (long long)n * n * n;
     vf4 *state, *out;
@@ -64,7 +75,7 @@ int main(int argc, char** argv) {
     hipMemset(out, 0, N * 16);
     hipMemset(canonical, 0, N * 4);
     hipMemcpy(list, host.data(), count * 4ll, hipMemcpyHostToDevice);
-    printf("%d^3, band list %u entries (%u wave-units)\n", n, count, (count + 63) / 64);
+    printf("%d^3, band list %u entries (%u wave-units), patches of %d slices x %d rows\n", n, count, (count + 63) / 64, PZ, PY);
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -86,6 +97,7 @@ int main(int argc, char** argv) {
                bytes_per_voxel * count / best / 1e6, bytes_per_voxel);
     };
     run("19 float4 taps + canonical + store", walk<19, false>, 19 * 16 + 4 + 16 + 4);
+    run("19 float4 taps, contiguous range per CU", walk<19, false, true>, 19 * 16 + 4 + 16 + 4);
     run(" 7 float4 taps + canonical + store", walk<7, false>, 7 * 16 + 4 + 16 + 4);
     run(" 1 float4 tap  + canonical + store", walk<1, false>, 1 * 16 + 4 + 16 + 4);
     run("19 dword  taps + canonical + store", walk<19, true>, 19 * 4 + 4 + 16 + 4);
