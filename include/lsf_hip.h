@@ -11,9 +11,10 @@
  * Rules of the ABI
  *   - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns 0 on success or a
  *     hipError_t value; nothing throws.  LSF_ERR_* (negative) flag argument errors detected on the host.
- *   - The library owns no memory and keeps no global state.  All pointers are DEVICE pointers supplied by
- *     the caller (e.g. torch.Tensor.data_ptr()), all launches are asynchronous on `stream` (a hipStream_t
- *     passed as void*; NULL = the default stream).  Re-entrant across streams and devices.
+ *   - The library owns no memory.  Its only process-wide state is read-only after first use: the table of RCCL entry
+ *     points the z-slab runtime binds once (under a mutex) and per-device cached device attributes.  All pointers are
+ *     DEVICE pointers supplied by the caller (e.g. torch.Tensor.data_ptr()), all launches are asynchronous on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream).  Re-entrant across streams and devices.
  *   - Layouts (MI355X-first):
  *       scalar fields      float32 [z][y][x]            (nz = 1 for 2-D)
  *       vector fields      float32 PLANAR [c][z][y][x]  c = 0:x(u) 1:y(v) 2:z(w); `dims` planes
@@ -33,7 +34,7 @@
 extern "C" {
 #endif
 
-#define LSF_ABI_VERSION 2
+#define LSF_ABI_VERSION 3
 #define LSF_MAX_KERNEL_TAPS 31
 
 #define LSF_ERR_BAD_ARGUMENT (-1)
@@ -41,7 +42,7 @@ extern "C" {
 #define LSF_ERR_KERNEL_TOO_LONG (-3)
 #define LSF_ERR_RCCL_UNAVAILABLE (-4) /* librccl.so could not be bound at run time */
 #define LSF_ERR_RCCL_FAILED (-5)      /* an RCCL call returned an error (its text goes to stderr) */
-#define LSF_ERR_NOT_RESIDENT (-6)     /* lsf_slavcheva_state_chain: its workgroups cannot all be resident on this device */
+#define LSF_ERR_NOT_RESIDENT (-6)     /* lsf_hip_chain.h: the chain kernel's workgroups cannot all be resident on this device */
 
 /* extents of one field as stored on this device */
 typedef struct lsf_grid {
@@ -97,6 +98,12 @@ typedef struct lsf_gate {
 
 /* ---------------------------------------------------------------------------------------------------- */
 int lsf_abi_version(void);
+/* first 16 hex digits of the SHA-256 over the NORMALISED text of this header (comments stripped, white space collapsed:
+ * _build.py::abi_hash) as it stood when the library was compiled -- every struct and prototype goes into it, so a
+ * binding written against another revision of the header is refused at load time (levelsetfusion-python_amd/_lib.py
+ * compares it with the hash of the header it was written against) whether or not someone remembered to bump
+ * LSF_ABI_VERSION.  "unknown" when compiled by hand. */
+const char *lsf_abi_hash(void);
 /* name of the code object's target, e.g. "gfx950" */
 const char *lsf_target_arch(void);
 /* identity of the build: the first 16 hex digits of the SHA-256 over the library's sources (csrc/, include/), set by the
@@ -329,7 +336,7 @@ int lsf_planar_finalize(const float *live, const float *warp_planar, const float
  * take the unlisted voxels from lsf_state_prepare's counts_out[2..4): opposite_count of them have
  * |canonical - live| = 2, the first one at voxel first_opposite (-1: none), the others 0.  scratch as lsf_state_finalize.
  * skip_flag (may be NULL): a DEVICE word; when it is non-zero as the pass runs, live_out and warp_interleaved_out are
- * left untouched (and the statistics are meaningless) -- see lsf_slavcheva_state_chain. */
+ * left untouched (and the statistics are meaningless) -- the chain add-on (include/lsf_hip_chain.h) raises such a word. */
 int lsf_state_finalize_listed(const float *state, const float *canonical, float *live_out, float *warp_interleaved_out,
                               const lsf_grid *grid, const int32_t *const *band_lists, const int64_t *band_counts,
                               int32_t n_lists, int64_t opposite_count, int64_t first_opposite, float lower_threshold,
@@ -338,34 +345,6 @@ int lsf_slavcheva_state_iteration(const float *state_in, const float *canonical,
                                   const lsf_grid *grid, const lsf_slavcheva_params *params, const lsf_gate *gate,
                                   lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,
                                   int32_t band_subset, void *stream);
-
-/* ---- K fused iterations in ONE launch: the chain kernel ------------------------------------------
- * replaces K consecutive passes of the loop body nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:238-330 (DIRECT; the
- * VECTORIZED form :163-236 with its parameter block) for runs whose stop test (:360-362) cannot fire in between: iteration
- * j = 0 .. iterations - 1 reads state_a (j even) or state_b (j odd), writes the other and reduces into records[j], exactly
- * as lsf_slavcheva_state_iteration would in K launches -- bit for bit while every warp update stays below 2 voxels.
- * One CU-sized workgroup per CU stays resident; a workgroup waits only for the few neighbouring list chunks its stencils
- * and re-warp gather reach (progress words in `scratch`), never for the whole chip.  Requirements: an INTERIOR band list
- * of the WHOLE array (z_begin = 0, z_end = nz; no BOUNDARY voxels besides it), 16 * nz * ny * nx < 2^32.
- *   scratch   lsf_state_chain_scratch_elements(band_count, stages) int32 of device memory (16-byte aligned);
- *             lsf_state_chain_plan fills its dependency windows ONCE per list, every lsf_slavcheva_state_chain call on
- *             that list (same band_count and stages) reuses them and zeroes the words it polls.
- *   stages    1: every CU owns one chunk and runs all iterations on it.  S > 1 (long lists only, else treated as 1): the
- *             CUs form S groups, group s runs iterations s, s + S, ... over all chunks, so that an iteration's output is
- *             consumed from the Infinity Cache by the next iteration instead of travelling through HBM.
- *   scratch[0] != 0 after the launch: a wait timed out (records[iterations - 1] then decodes to a NaN maximum);
- *   scratch[1] != 0: an update of 2 voxels or more -- the result is NOT the reference's; lsf_state_finalize_listed(...,
- *             skip_flag = scratch + 1) then leaves the caller's fields untouched and the caller repeats the call with
- *             lsf_slavcheva_state_iteration.  The same verdict follows from the records' maxima.
- * Returns LSF_ERR_NOT_RESIDENT (nothing launched) when a CU cannot hold one 1024-thread workgroup of the kernel. */
-int64_t lsf_state_chain_scratch_elements(int64_t band_count, int32_t stages);
-int lsf_state_chain_shape(int64_t band_count, int32_t stages, int32_t *out4 /* workgroups, stages, chunks, wave-units */);
-int lsf_state_chain_plan(const lsf_grid *grid, const int32_t *band_list, int64_t band_count, int32_t stages,
-                         int32_t *scratch, void *stream);
-int lsf_slavcheva_state_chain(float *state_a, float *state_b, const float *canonical, const lsf_grid *grid,
-                              const lsf_slavcheva_params *params, lsf_iteration_record *records,
-                              const int32_t *band_list, int64_t band_count, int32_t iterations, int32_t stages,
-                              int32_t *scratch, void *stream);
 
 /* ---- the SobolevFusion iteration on the float4 layouts (band lists) ------------------------------
  * replaces one pass of slavcheva_optimizer2d.py:163-236 / :238-330 WITH a Sobolev filter (math_utils/convolution.py:

@@ -11,12 +11,18 @@ import os
 # with hipErrorNoDevice.
 import torch  # noqa: F401
 
-from ._build import LIB_PATH
+from ._build import CHAIN_LIB_PATH, LIB_PATH
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
 MAX_KERNEL_TAPS = 31
-ABI_VERSION = 2
+ABI_VERSION = 3
+# _build.abi_hash() of the include/lsf_hip.h THIS binding was written against (structures and prototypes below mirror
+# it).  The library carries the hash of the header it was compiled from (lsf_abi_hash()); a mismatch is refused at load
+# time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
+# a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
+# called through structures of another shape.
+HEADER_ABI_HASH = "1f584e9034976f19"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -118,6 +124,7 @@ PROTOTYPES = {
     "lsf_abi_version": (ctypes.c_int, []),
     "lsf_target_arch": (ctypes.c_char_p, []),
     "lsf_build_id": (ctypes.c_char_p, []),
+    "lsf_abi_hash": (ctypes.c_char_p, []),
     "lsf_deinterleave": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "lsf_interleave": (ctypes.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "lsf_halo_copy": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -148,11 +155,6 @@ PROTOTYPES = {
     "lsf_planar_finalize": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _f32, _vp, _vp, _vp]),
     "lsf_state_finalize_listed": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _P(ctypes.c_void_p), _P(_i64), _i32,
                                                  _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
-    "lsf_state_chain_scratch_elements": (ctypes.c_int64, [_i64, _i32]),
-    "lsf_state_chain_shape": (ctypes.c_int, [_i64, _i32, _P(_i32)]),
-    "lsf_state_chain_plan": (ctypes.c_int, [_P(Grid), _vp, _i64, _i32, _vp, _vp]),
-    "lsf_slavcheva_state_chain": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _vp, _vp, _i64, _i32,
-                                                 _i32, _vp, _vp]),
     "lsf_slavcheva_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp,
                                                      _vp, _i64, _i32, _vp]),
     "lsf_band_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
@@ -182,6 +184,16 @@ PROTOTYPES = {
 }
 
 
+# the optional chain add-on liblsf_chain.so: every symbol include/lsf_hip_chain.h declares
+CHAIN_PROTOTYPES = {
+    "lsf_state_chain_scratch_elements": (ctypes.c_int64, [_i64, _i32]),
+    "lsf_state_chain_shape": (ctypes.c_int, [_i64, _i32, _P(_i32)]),
+    "lsf_state_chain_plan": (ctypes.c_int, [_P(Grid), _vp, _i64, _i32, _vp, _vp]),
+    "lsf_slavcheva_state_chain": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _vp, _vp, _i64, _i32,
+                                                 _i32, _vp, _vp]),
+}
+
+
 class LsfHipError(RuntimeError):
     pass
 
@@ -204,10 +216,35 @@ def _load():
     if lib.lsf_abi_version() != ABI_VERSION:
         raise ImportError("liblsf_hip.so ABI version %d != binding version %d: rebuild" %
                           (lib.lsf_abi_version(), ABI_VERSION))
+    built_against = lib.lsf_abi_hash().decode()
+    if built_against != HEADER_ABI_HASH:
+        raise ImportError("%s was compiled from an include/lsf_hip.h whose structures / prototypes hash to %s; this binding "
+                          "was written against %s: rebuild the library (or update the binding to the header)"
+                          % (path, built_against, HEADER_ABI_HASH))
     return lib
 
 
 lib = _load()
+
+_chain = None
+
+
+def chain_lib():
+    """the optional chain add-on (include/lsf_hip_chain.h; LSF_CHAIN=1, tests/test_gpu_chain.py), loaded on first use.
+    Not part of the product library: the chain kernel measured 4 % slower than one launch per iteration."""
+    global _chain
+    if _chain is None:
+        path = os.environ.get("LSF_CHAIN_LIBRARY") or CHAIN_LIB_PATH
+        if not os.path.exists(path):
+            raise ImportError("liblsf_chain.so is missing (%s): build the add-on with\n"
+                              "    python -c 'import __graft_entry__ as g; g.build()'" % path)
+        handle = ctypes.CDLL(path)
+        for name, (restype, argtypes) in CHAIN_PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _chain = handle
+    return _chain
 
 
 def check(status, what):

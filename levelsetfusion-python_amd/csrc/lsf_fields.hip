@@ -1075,3 +1075,7 @@ extern "C" const char* lsf_target_arch(void) { return "gfx950"; }
 #define LSF_BUILD_ID "unknown"
 #endif
 extern "C" const char* lsf_build_id(void) { return LSF_BUILD_ID; }
+#ifndef LSF_ABI_HASH
+#define LSF_ABI_HASH "unknown"
+#endif
+extern "C" const char* lsf_abi_hash(void) { return LSF_ABI_HASH; }

@@ -12,7 +12,9 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <type_traits>
 
 #include "../../include/lsf_hip.h"
 
@@ -32,14 +34,14 @@ struct RcclApi {
 
 RcclApi g_rccl;
 
-template <class F>
-bool bind(F& fn, const char* name) {
-    fn = reinterpret_cast<F>(dlsym(g_rccl.handle, name));
-    return fn != nullptr;
-}
-
+// The one piece of process-wide state in the library: the table of RCCL entry points, bound ONCE per process (a mutex
+// serialises the attempts; a failed attempt leaves the table empty so that a later call may name another path).  Once
+// bound the table is read-only, so concurrent iteration calls on different communicators never race on it.
 int load_rccl(const char* path) {
+    static std::mutex guard;
+    std::lock_guard<std::mutex> lock(guard);
     if (g_rccl.handle) return 0;
+    RcclApi api;
     const char* candidates[] = {path, "librccl.so", "librccl.so.1"};
     for (const char* c : candidates) {
         if (!c || !c[0]) continue;
@@ -47,19 +49,21 @@ int load_rccl(const char* path) {
         void* h = dlopen(c, RTLD_NOW | RTLD_NOLOAD);
         if (!h) h = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
         if (h) {
-            g_rccl.handle = h;
+            api.handle = h;
             break;
         }
     }
-    if (!g_rccl.handle) return LSF_ERR_RCCL_UNAVAILABLE;
-    const bool ok = bind(g_rccl.GetUniqueId, "ncclGetUniqueId") && bind(g_rccl.CommInitRank, "ncclCommInitRank") &&
-                    bind(g_rccl.CommDestroy, "ncclCommDestroy") && bind(g_rccl.GroupStart, "ncclGroupStart") &&
-                    bind(g_rccl.GroupEnd, "ncclGroupEnd") && bind(g_rccl.Send, "ncclSend") &&
-                    bind(g_rccl.Recv, "ncclRecv") && bind(g_rccl.GetErrorString, "ncclGetErrorString");
-    if (!ok) {
-        g_rccl = RcclApi();
-        return LSF_ERR_RCCL_UNAVAILABLE;
-    }
+    if (!api.handle) return LSF_ERR_RCCL_UNAVAILABLE;
+    auto bind = [&](auto& fn, const char* name) {
+        fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(api.handle, name));
+        return fn != nullptr;
+    };
+    const bool ok = bind(api.GetUniqueId, "ncclGetUniqueId") && bind(api.CommInitRank, "ncclCommInitRank") &&
+                    bind(api.CommDestroy, "ncclCommDestroy") && bind(api.GroupStart, "ncclGroupStart") &&
+                    bind(api.GroupEnd, "ncclGroupEnd") && bind(api.Send, "ncclSend") &&
+                    bind(api.Recv, "ncclRecv") && bind(api.GetErrorString, "ncclGetErrorString");
+    if (!ok) return LSF_ERR_RCCL_UNAVAILABLE;
+    g_rccl = api;  // the handle is stored last of all members' owner: readers test it first
     return 0;
 }
 

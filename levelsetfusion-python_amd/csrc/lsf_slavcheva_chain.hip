@@ -32,6 +32,7 @@
 // (control word 1) which the finalize pass honours (it leaves the caller's fields alone) and the host sees in the records'
 // maxima: the caller then repeats the call with per-iteration launches.
 #include "lsf_slavcheva_state_taps.h"
+#include "../../include/lsf_hip_chain.h"
 
 using namespace lsf;
 using namespace lsf::slav;
@@ -194,6 +195,9 @@ void slavcheva_state_chain_kernel(vf4* state_a, vf4* state_b, const float* __res
                         if (lane == 0) {
                             s_abort = 1;
                             __hip_atomic_store(control, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            // an aborted launch's state is half written: the finalize pass behind it (skip_flag = control
+                            // word 1) must leave the caller's fields alone exactly as after a reach violation
+                            __hip_atomic_store(control + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             // the host reads records, not this scratch: an all-ones maximum decodes as NaN
                             atomicMax(reinterpret_cast<unsigned long long*>(&records[plan.iterations - 1].slot[0].max_packed),
                                       ~0ull);
@@ -367,12 +371,15 @@ struct ChainArgs {
 template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
 void chain_one(const ChainArgs& a) {
     auto kernel = slavcheva_state_chain_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY>;
-    static int fits = -1;  // per instantiation (the workgroup size is fixed per process); the same on every device of one kind
-    if (fits < 0) {
+    static int cached[64];  // per instantiation (the workgroup size is fixed per process) and device: 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cached[dev] == 0) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kernel), (int)a.threads, 0) != hipSuccess) n = 0;
-        fits = n;
+        cached[dev] = n + 1;
     }
+    const int fits = cached[dev] - 1;
     *a.resident = fits;
     if (fits < (int)(kCuBlock / a.threads)) return;
     hipLaunchKernelGGL(kernel, dim3(a.blocks), dim3(a.threads), 0, a.s, a.state_a, a.state_b, a.canonical, a.g, a.p,
@@ -474,7 +481,13 @@ extern "C" int lsf_slavcheva_state_chain(float* state_a, float* state_b, const f
     plan.stages = s.stages;
     plan.members = s.members;
     plan.progress_words = s.progress_words;
-    plan.timeout_ticks = 200u * 1000u * 1000u;  // 2 s of the 100 MHz clock: healthy waits take microseconds
+    // 2 s of the 100 MHz clock: healthy waits take microseconds (LSF_CHAIN_TIMEOUT_MS: debugging knob)
+    static const unsigned timeout_ticks = [] {
+        const char* e = getenv("LSF_CHAIN_TIMEOUT_MS");
+        const long v = e ? atol(e) : 0;
+        return (v > 0 && v <= 20000) ? (unsigned)v * 100000u : 200u * 1000u * 1000u;
+    }();
+    plan.timeout_ticks = timeout_ticks;
     plan.reach_limit = kReachLimit;
     Params p;
     p.lambda64 = params->isomorphic_enforcement_factor_f64;
@@ -488,7 +501,7 @@ extern "C" int lsf_slavcheva_state_chain(float* state_a, float* state_b, const f
     // every polled word starts at zero in EVERY launch (control + progress: a block of its own at the allocation's
     // start, a multiple of 16 bytes)
     if (hipMemsetAsync(scratch, 0, (size_t)(kControlWords + s.progress_words) * 4u, as_stream(stream)) != hipSuccess)
-        return (int)hipGetLastError();
+        return launch_status();  // a hipError_t value, as the ABI's rules say (and the sticky error is cleared)
     int resident = 0;
     ChainArgs a{s.workgroups, s.threads, as_stream(stream), reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b),
                 canonical, g, p, records, band_list, (unsigned)band_count, plan, reinterpret_cast<unsigned*>(scratch),

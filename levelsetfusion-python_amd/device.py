@@ -616,26 +616,31 @@ class StateChain:
         self._params = ctypes.byref(params)
         self._records = records
         self._band = band
-        words = int(lib.lsf_state_chain_scratch_elements(band.count, self.stages))
+        self._lib = clib = _lib.chain_lib()  # the optional add-on library (include/lsf_hip_chain.h)
+        words = int(clib.lsf_state_chain_scratch_elements(band.count, self.stages))
         self.scratch = torch.empty(words, dtype=torch.int32, device=states[0].device)
         self._scratch = ctypes.c_void_p(self.scratch.data_ptr())
         self.violation_ptr = self.scratch.data_ptr() + 4
         shape = (ctypes.c_int32 * 4)()
-        check(lib.lsf_state_chain_shape(band.count, self.stages, shape), "lsf_state_chain_shape")
+        check(clib.lsf_state_chain_shape(band.count, self.stages, shape), "lsf_state_chain_shape")
         self.workgroups, self.stages_used, self.chunks, self.units = (int(v) for v in shape)
-        check(lib.lsf_state_chain_plan(ctypes.byref(self.grid), band.pointer, band.count, self.stages, self._scratch,
+        check(clib.lsf_state_chain_plan(ctypes.byref(self.grid), band.pointer, band.count, self.stages, self._scratch,
                                        stream_ptr()), "lsf_state_chain_plan")
 
     def launch(self, first, count):
         """False: the kernel's workgroups cannot all be resident on this device (nothing was launched)"""
         a, b = self._states[first % 2], self._states[(first + 1) % 2]
-        status = lib.lsf_slavcheva_state_chain(a, b, self._canonical, ctypes.byref(self.grid), self._params,
+        status = self._lib.lsf_slavcheva_state_chain(a, b, self._canonical, ctypes.byref(self.grid), self._params,
                                                _record_ptr(self._records, first), self._band.pointer, self._band.count,
                                                int(count), self.stages, self._scratch, stream_ptr())
         if status == _lib.ERR_NOT_RESIDENT:
             return False
         check(status, "lsf_slavcheva_state_chain")
         return True
+
+    def aborted(self):
+        """True when a wait of the last launch timed out (control word 0; a host read: call it behind the records)"""
+        return bool(int(self.scratch[0].item()))
 
 
 def full_range(grid):

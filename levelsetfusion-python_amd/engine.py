@@ -765,8 +765,9 @@ class _SobolevStatePlan:
 
 
 class _ChainReachExceeded(Exception):
-    """a chain launch (dev.StateChain) met a warp update its dependency windows do not cover; nothing of the caller's has
-    been modified (SlavchevaEngine.optimize repeats the call with per-iteration launches)"""
+    """a chain launch (dev.StateChain) met a warp update its dependency windows do not cover, or gave up waiting (CUs held
+    by something else); nothing of the caller's has been modified (SlavchevaEngine.optimize repeats the call with
+    per-iteration launches)"""
 
 
 class SlavchevaEngine:
@@ -1340,13 +1341,20 @@ class SlavchevaEngine:
             dec = dev.decode_records(self.comm.gather_records(records, 0, it) if slab and ungated
                                      else dev.records_to_host(records[:it]))
             n_exec = int(dec["executed"].sum())
-            if chain is not None and n_exec > 0:
-                longest = dec["max_value"][:n_exec].max()
-                if np.isnan(longest):
-                    raise RuntimeError("lsf_slavcheva_state_chain: a workgroup waited for its neighbours longer than the "
-                                       "launch allows and the launch gave up (is another process holding CUs of this "
-                                       "GPU?); LSF_CHAIN=0 selects one launch per iteration")
-                if not longest < dev.StateChain.REACH_LIMIT:
+            if chain is not None:
+                # A wait that timed out poisons the LAST record of the launch (an all-ones maximum decodes as NaN) and every
+                # workgroup leaves: records in between may never have been written, so `executed` is not a prefix then --
+                # look at every record of the launch, and at the launch's own abort word.  The finalize pass behind an
+                # aborted launch has left the caller's fields alone (the kernel raises its skip word on abort too), so the
+                # call can simply run again with one launch per iteration.
+                aborted = bool(np.isnan(dec["max_value"][:it]).any()) or chain.aborted()
+                if aborted or n_exec < it:
+                    import warnings
+                    warnings.warn("lsf_slavcheva_state_chain: a workgroup waited for its neighbours longer than the launch "
+                                  "allows and the launch gave up (is something else holding CUs of this GPU?); the call "
+                                  "is repeated with one launch per iteration")
+                    raise _ChainReachExceeded()
+                if n_exec > 0 and not dec["max_value"][:n_exec].max() < dev.StateChain.REACH_LIMIT:
                     raise _ChainReachExceeded()
             # z-slab: every EXECUTED iteration must have stayed inside what the halo schedule keeps valid -- also those
             # of a batch in which the gate then closed (a large update followed by convergence inside one

@@ -40,8 +40,42 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, name), "liblsf_hip.so does not export %s" % name
         assert name in pkg._lib.PROTOTYPES, "no ctypes prototype for %s" % name
     assert sorted(pkg._lib.PROTOTYPES) == names
-    assert pkg._lib.lib.lsf_abi_version() == pkg._lib.ABI_VERSION == 2
+    assert pkg._lib.lib.lsf_abi_version() == pkg._lib.ABI_VERSION == 3
     assert pkg._lib.lib.lsf_target_arch() == b"gfx950"
+
+
+def test_chain_addon_exports_every_declared_symbol(pkg):
+    """the optional chain add-on (include/lsf_hip_chain.h -> liblsf_chain.so) is NOT part of the product library"""
+    from levelsetfusion_python_amd import _build
+    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lsf_hip_chain.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(lsf_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(pkg._lib.CHAIN_PROTOTYPES) and len(names) == 4
+    addon = ctypes.CDLL(_build.build_chain(verbose=False))
+    product = ctypes.CDLL(pkg._lib.LIB_PATH)
+    for name in names:
+        assert hasattr(addon, name), "liblsf_chain.so does not export %s" % name
+        assert not hasattr(product, name), "the product library still carries %s" % name
+    assert b"chain" not in open(pkg._lib.LIB_PATH, "rb").read()
+
+
+def test_abi_hash_binds_library_binding_and_header(pkg, tmp_path):
+    """ABI drift is refused, not remembered: the library carries the hash of the header it was compiled from, the
+    binding the hash of the header it was written against, and both must be the header in the tree"""
+    from levelsetfusion_python_amd import _build
+    L = pkg._lib
+    assert _build.abi_hash() == L.HEADER_ABI_HASH == L.lib.lsf_abi_hash().decode()
+    # comments and layout do not count, a struct member or a prototype does
+    text = open(HEADER).read()
+    cosmetic = tmp_path / "cosmetic.h"
+    cosmetic.write_text(text.replace("int lsf_abi_version(void);", "int   lsf_abi_version( void ) ;  /* same */\n")
+                        .replace("( void ) ;", "(void);"))
+    assert _build.abi_hash(str(cosmetic)) == _build.abi_hash()
+    grown = tmp_path / "grown.h"
+    grown.write_text(text.replace("int32_t packed_nz", "int32_t one_more_member;\n    int32_t packed_nz", 1))
+    assert "one_more_member" in grown.read_text() and _build.abi_hash(str(grown)) != _build.abi_hash()
+    changed = tmp_path / "changed.h"
+    changed.write_text(text.replace("const int32_t *skip_flag, void *stream);", "void *stream);", 1))
+    assert _build.abi_hash(str(changed)) != _build.abi_hash()
 
 
 def test_code_object_targets_gfx950_only(pkg):
@@ -62,7 +96,7 @@ def test_ctypes_structs_match_header_layout(pkg):
     assert ctypes.sizeof(L.HierParams) == 40 and L.HierParams.packed_nz.offset == 32
     assert ctypes.sizeof(L.SlavchevaParams) == 56 and L.SlavchevaParams.rate.offset == 8
     text = open(HEADER).read()
-    for macro, value in (("LSF_ABI_VERSION", 2), ("LSF_MAX_KERNEL_TAPS", L.MAX_KERNEL_TAPS),
+    for macro, value in (("LSF_ABI_VERSION", 3), ("LSF_MAX_KERNEL_TAPS", L.MAX_KERNEL_TAPS),
                          ("LSF_SMOOTHING_KILLING", L.SMOOTHING_KILLING),
                          ("LSF_DATA_THRESHOLDED_FDM", L.DATA_THRESHOLDED_FDM),
                          ("LSF_ENERGY_VECTORIZED", L.ENERGY_VECTORIZED), ("LSF_GATE_SLAVCHEVA", L.GATE_SLAVCHEVA)):
@@ -105,18 +139,19 @@ def test_argument_errors_are_reported_not_launched(pkg):
                                            0, -1, 0.0, None, None, None, None) == -1              # not a whole array
     # the chain kernel: an INTERIOR list of a WHOLE array, distinct states, a scratch block
     sp = L.SlavchevaParams()
-    assert L.lib.lsf_slavcheva_state_chain(1, 1, 1, ctypes.byref(ok), ctypes.byref(sp), 1, 1, 5, 3, 1, 1, None) == -1
-    assert L.lib.lsf_slavcheva_state_chain(1, 2, 1, ctypes.byref(ok), ctypes.byref(sp), 1, None, 5, 3, 1, 1, None) == -1
-    assert L.lib.lsf_slavcheva_state_chain(1, 2, 1, ctypes.byref(L.Grid(3, 4, 8, 8, 1, 4, 0, 0)), ctypes.byref(sp), 1, 1,
+    C = L.chain_lib()  # the optional add-on library
+    assert C.lsf_slavcheva_state_chain(1, 1, 1, ctypes.byref(ok), ctypes.byref(sp), 1, 1, 5, 3, 1, 1, None) == -1
+    assert C.lsf_slavcheva_state_chain(1, 2, 1, ctypes.byref(ok), ctypes.byref(sp), 1, None, 5, 3, 1, 1, None) == -1
+    assert C.lsf_slavcheva_state_chain(1, 2, 1, ctypes.byref(L.Grid(3, 4, 8, 8, 1, 4, 0, 0)), ctypes.byref(sp), 1, 1,
                                            5, 3, 1, 1, None) == -1                                # not a whole array
-    assert L.lib.lsf_slavcheva_state_chain(1, 2, 1, ctypes.byref(ok), ctypes.byref(sp), 1, 1, 5, 3, 1, None, None) == -1
-    assert L.lib.lsf_state_chain_plan(ctypes.byref(ok), None, 5, 1, 1, None) == -1
-    assert L.lib.lsf_state_chain_scratch_elements(0, 1) == 0
+    assert C.lsf_slavcheva_state_chain(1, 2, 1, ctypes.byref(ok), ctypes.byref(sp), 1, 1, 5, 3, 1, None, None) == -1
+    assert C.lsf_state_chain_plan(ctypes.byref(ok), None, 5, 1, 1, None) == -1
+    assert C.lsf_state_chain_scratch_elements(0, 1) == 0
     # 20 000 entries = 313 wave-units: a unit per wave of a 1024-thread workgroup at least, so 19 -> 16 workgroups =
     # chunks (a multiple of the 8 XCDs), one stage however many are asked for
     shape = (ctypes.c_int32 * 4)()
-    assert L.lib.lsf_state_chain_shape(20000, 4, shape) == 0 and list(shape) == [16, 1, 16, 313]
-    assert L.lib.lsf_state_chain_scratch_elements(20000, 4) == 16 + 16 + 2 * 16
+    assert C.lsf_state_chain_shape(20000, 4, shape) == 0 and list(shape) == [16, 1, 16, 313]
+    assert C.lsf_state_chain_scratch_elements(20000, 4) == 16 + 16 + 2 * 16
     with pytest.raises(pkg._lib.LsfHipError):
         pkg._lib.check(-2, "x")
 

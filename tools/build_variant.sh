@@ -18,10 +18,12 @@ fi
 # lsf_build_id() of a variant: the hash of ITS sources and extra flags (bench.py reports the committed PMC traffic only for
 # the build it was measured on; a variant must not inherit the shipped library's id)
 ID=$( (cat $(ls $W/levelsetfusion-python_amd/csrc/* $W/include/*.h | sort); echo "$@") | sha256sum | cut -c1-16)
+# lsf_abi_hash() of a variant: the hash of ITS header (the binding refuses a variant whose structs / prototypes differ)
+ABI=$(python3 -c "import importlib.util as u,sys; s=u.spec_from_file_location('b','$R/levelsetfusion-python_amd/_build.py'); m=u.module_from_spec(s); s.loader.exec_module(m); print(m.abi_hash('$W/include/lsf_hip.h'))")
 OBJS=""; PIDS=""
 for f in $W/levelsetfusion-python_amd/csrc/*.hip; do
   o=$W/$(basename $f .hip).o
-  hipcc -O3 --offload-arch=gfx950 -fPIC -ffp-contract=off -std=c++17 -Wno-unused-function "-DLSF_BUILD_ID=\"v$ID\"" "$@" -c $f -o $o &
+  hipcc -O3 --offload-arch=gfx950 -fPIC -ffp-contract=off -std=c++17 -Wno-unused-function "-DLSF_BUILD_ID=\"v$ID\"" "-DLSF_ABI_HASH=\"$ABI\"" "$@" -c $f -o $o &
   PIDS="$PIDS $!"
   OBJS="$OBJS $o"
 done
