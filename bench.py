@@ -5,15 +5,23 @@ Workload (BASELINE.json config 4, the configuration the metric is quoted on): 3-
 optimizer -- SlavchevaOptimizer3d, DIRECT, Killing regulariser (lambda 0.1, weight 0.2) + level-set term
 (weight 0.2), no Sobolev filter, rate 0.1, FIXED 50 iterations -- on the synthetic "sphere pair" of SURVEY.md
 section 8(d), fp32.  One *step* = one optimize(live, canonical) call = 50 iterations of the fused warp-update kernel
-over one 256^3 pair -- on one GPU ONE launch of the chain kernel (lsf_slavcheva_state_chain), on z-slabs one launch per
-iteration and part -- (+ the convergence-statistics reductions the reference also runs per call).
+over one 256^3 pair: one launch of lsf_slavcheva_state_iteration per iteration and band list (the chain add-on, K
+iterations per launch, only with LSF_CHAIN=1 -- the roofline block then reports the chain launch) -- plus the
+prepare / finalize passes and the convergence-statistics reductions the reference also runs per call.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns a 256^3 z-slab of a
-256 x 256 x (256 N) volume with an 8-slice halo; every 8th iteration the band voxels of the 8 boundary slices of the
-state (live field + warp) travel to the z-neighbours (RCCL send / recv over xGMI, issued by the library:
-lsf_slab_state_iteration) while the interior -- and the halo-independent part of the next iteration -- is computed; the
-iterations in between recompute the neighbours' slices they still have valid inputs for; the iteration records are
-all-reduced once per step.
+N > 1 (launched by torch.distributed.run, one rank per GPU; `python bench.py --gpus N` starts it itself):
+  --scaling weak (default): every rank owns a 256^3 z-slab of a 256 x 256 x (256 N) volume whose spheres are centred ON
+    the slab faces (--pattern faces), so that every interior face cuts a narrow band through its equator (~15 % of the
+    face) and the halo exchange carries data; the band voxels per rank equal the single-GPU sphere pair's.
+  --scaling strong: BASELINE config 4 as written -- ONE 256^3 sphere pair z-slabbed over the N ranks (256 / N slices each).
+With an h-slice halo the band voxels of the h boundary slices of the state (live field + warp) travel to the z-neighbours
+every h-th iteration (RCCL send / recv over xGMI, issued by the library: lsf_slab_state_iteration) while the interior --
+and the halo-independent part of the next iteration -- is computed; the iterations in between recompute the neighbours'
+slices they still have valid inputs for; the iteration records are gathered once per step.  The N > 1 line carries
+`halo_band_voxels_per_face` and `halo_bytes_per_exchange` (what actually travels).
+
+`secondary` (single GPU, default run only): short measurements of the other configurations of BASELINE.json on the
+same box, so that every figure the documentation quotes is on the driver's line.
 
 Prints ONE JSON line on rank 0.
 """
@@ -42,21 +50,35 @@ def parse():
     ap.add_argument("--size", type=int, default=None,
                     help="edge of the per-GPU volume (default 256 = BASELINE config 4; multiframe: 512 = config 5)")
     ap.add_argument("--iterations", type=int, default=50)
-    ap.add_argument("--halo", type=int, default=8,
+    ap.add_argument("--halo", type=int, default=None,
                     help="halo slices per interior slab face = iterations per exchange group: the faces travel every "
                          "--halo iterations, the iterations in between recompute the neighbours' slices (exact while "
-                         "every warp update stays below one voxel; the engine raises otherwise)")
+                         "every warp update stays below one voxel; the engine re-runs wider otherwise).  Default: 8 for "
+                         "weak scaling; strong scaling picks it from the slab height (slices per rank / 8, 1..8), so that "
+                         "the recomputed slices stay below ~10 %% of a slab")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every rank a --size^3 slab of a --size x --size x (--size N) volume (default); "
+                         "strong = ONE --size^3 pair z-slabbed over the N ranks (BASELINE config 4 as written)")
+    ap.add_argument("--pattern", default=None, choices=["faces", "centered"],
+                    help="weak scaling input: faces = spheres centred on the slab faces, every interior face cuts a band "
+                         "(default for N > 1); centered = one sphere inside every slab (no band voxel near a face: the "
+                         "compact halo exchange then carries nothing)")
+    ap.add_argument("--secondary-divisor", type=int, default=1,
+                    help="test rigs only: run the secondary measurements at 1/divisor of their edge lengths")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the short secondary measurements (512^3, hierarchical, multi-frame, SobolevFusion, 2-D)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the real thing); gloo stages halos through the host -- only for "
                          "exercising the N > 1 flow on a box with fewer GPUs than ranks (see --share-device)")
     ap.add_argument("--share-device", action="store_true",
                     help="all ranks use cuda:0 (test rigs only; requires --backend gloo)")
     ap.add_argument("--workload", default="killing",
-                    choices=["killing", "sobolev", "hier-tik", "hier-full", "multiframe"],
+                    choices=["killing", "sobolev", "hier-tik", "hier-full", "multiframe", "hier2d"],
                     help="killing = BASELINE config 4 (default, the metric's configuration); multiframe = BASELINE "
                          "config 5 (--frames synthetic 512^3 frames, consecutive frames as pairs, hierarchical "
                          "Tikhonov + 7-tap kernel); the others are extra single-GPU measurements: SobolevFusion-style "
-                         "Slavcheva, hierarchical Tikhonov-only, hierarchical Tikhonov + 7-tap kernel")
+                         "Slavcheva, hierarchical Tikhonov-only, hierarchical Tikhonov + 7-tap kernel; hier2d = BASELINE "
+                         "config 2 (2-D 512^2 HierarchicalOptimizer2d, 3 levels, Tikhonov, 100 iterations per level)")
     ap.add_argument("--frames", type=int, default=8, help="multiframe: frames of the synthetic sequence")
     ap.add_argument("--parallelism", default="replicas", choices=["replicas", "slab"],
                     help="multiframe on N > 1 GPUs: every rank its own sequence (pairs are independent) or every pair "
@@ -69,7 +91,7 @@ def parse():
     ap.add_argument("--cpu-sample-iterations", type=int, default=24)
     args = ap.parse_args()
     if args.size is None:
-        args.size = 512 if args.workload == "multiframe" else 256
+        args.size = 512 if args.workload in ("multiframe", "hier2d") else 256
     return args
 
 
@@ -141,6 +163,8 @@ def extra_workload(args, device, world, rank, dist):
     import levelsetfusion_python_amd as lsf
     from levelsetfusion_python_amd.synthetic import sphere_frame, sphere_pair
     n, iters = args.size, args.iterations
+    if args.halo is None:
+        args.halo = 8
     k7 = lsf.generate_1d_sobolev_kernel(7, 0.1)
     extra = {}
     comm = None
@@ -156,7 +180,27 @@ def extra_workload(args, device, world, rank, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    if args.workload == "sobolev":
+    if args.workload == "hier2d":
+        # BASELINE config 2: 2-D n^2 (512^2) circle pair, maximum_chunk_size 4 => 3 levels n/4, n/2, n (pyramid.py:45),
+        # Tikhonov only, rate 0.1, `iters` FIXED iterations per level (threshold 0).  tikhonov_strength 0.05: with the
+        # class default 0.2 the reference's recurrence diverges (4 D s >= 1) -- same kernels, same cost
+        canonical, live0 = sphere_pair(n, 2, device)
+        opt = lsf.HierarchicalOptimizer2d(tikhonov_term_enabled=True, gradient_kernel_enabled=False,
+                                          maximum_chunk_size=4, rate=0.1, maximum_iteration_count=iters,
+                                          maximum_warp_update_threshold=0.0, tikhonov_strength=0.05, check_interval=iters)
+        per_pair = iters * sum((n >> k) ** 2 for k in range(3))
+
+        def step():
+            opt.optimize(canonical, live0)
+            return per_pair, per_pair
+        b_alg = 48
+        name = "2D %d^2 HierarchicalOptimizer2d, 3 levels (maximum_chunk_size 4), Tikhonov (tikhonov_strength 0.05), %d " \
+               "fixed iterations per level" % (n, iters)
+        note = "LAUNCH-BOUND, not a roofline point: a %d^2 level is %d KiB per field and an iteration is one ~4-8 us " \
+               "kernel replayed from a HIP graph; read us_per_iteration.  frac = whole-step rate x B_alg (48 B) for " \
+               "completeness" % (n, n * n * 4 // 1024)
+        extra["us_per_iteration_of"] = "3 levels x %d iterations" % iters
+    elif args.workload == "sobolev":
         canonical, live0 = sphere_pair(n, 3, device)
         opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT,
                                        sobolev_smoothing_enabled=True, sobolev_kernel=k7,
@@ -229,14 +273,13 @@ def extra_workload(args, device, world, rank, dist):
                              frac=achieved / HBM_PEAK_GBS, traffic=None, note=note))
     if visited != updates:
         out["roofline"]["dense_equivalent_gbs"] = value * b_alg / 1e9 / world
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and args.workload != "sobolev":
-            out["cpu_baseline"] = cpu_baseline_hierarchical(64, iters, args.workload != "hier-tik")
-        print(json.dumps(out), flush=True)
+    if args.workload == "hier2d":
+        out["us_per_iteration"] = elapsed / args.steps / (3 * iters) * 1e6
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload not in ("sobolev", "hier2d"):
+        out["cpu_baseline"] = cpu_baseline_hierarchical(64, iters, args.workload != "hier-tik")
     if comm is not None:
         comm.close()
-    if world > 1:
-        dist.destroy_process_group()
+    return out
 
 
 def self_launch(n_ranks):
@@ -283,15 +326,94 @@ def main():
     if args.workload != "killing":
         if world > 1 and args.workload != "multiframe":
             raise SystemExit("--workload %s is a single-GPU measurement" % args.workload)
-        return extra_workload(args, device, world, rank, dist if world > 1 else None)
+        out = extra_workload(args, device, world, rank, dist if world > 1 else None)
+    else:
+        out = killing_workload(args, device, world, rank, local_rank, dist if world > 1 else None)
+        if world == 1 and not args.no_secondary and args.data == "sphere" and \
+                (args.size == 256 or args.secondary_divisor > 1):
+            out["secondary"] = secondary_measurements(args, device)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
 
+
+SECONDARY = (  # (workload, size, steps, warmup, iterations, extra arguments): short runs of BASELINE's other configurations
+    ("killing", 512, 5, 2, 50, {}),
+    ("hier-tik", 256, 3, 1, 50, {}),
+    ("hier-full", 256, 3, 1, 50, {}),
+    ("multiframe", 512, 1, 1, 50, {}),
+    ("sobolev", 256, 5, 2, 50, {}),
+    ("hier2d", 512, 5, 2, 100, {}),
+)
+
+
+def secondary_measurements(args, device):
+    """every other figure the documentation quotes, measured in the SAME run on the SAME box (single GPU, a few steps
+    each, ~15 s together): KillingFusion at 512^3 (the other half of north_star's target), the hierarchical optimizer with
+    and without the 7-tap kernel at 256^3 (BASELINE configs 3 / 2's 3-D counterparts), the 8-frame 512^3 sequence
+    (config 5), the SobolevFusion iteration, and config 2 itself (2-D 512^2; launch-bound: microseconds per iteration).
+    Caller shape: run_hierarchical_optimizer3d_multipair.py:403-432.  A failure of one entry is recorded, not raised:
+    the primary line must still print."""
+    import copy
+    rows = []
+    for workload, size, steps, warmup, iterations, more in SECONDARY:
+        a = copy.copy(args)
+        size = size // max(1, args.secondary_divisor)
+        a.workload, a.size, a.steps, a.warmup, a.iterations = workload, size, steps, warmup, iterations
+        a.no_cpu_baseline, a.frames, a.parallelism, a.halo = True, 8, "replicas", None
+        for k, v in more.items():
+            setattr(a, k, v)
+        row = dict(workload=workload, size=size, steps=steps, iterations=iterations)
+        try:
+            t0 = time.perf_counter()
+            if workload == "killing":
+                d = killing_workload(a, device, 1, 0, device.index or 0, None, dense_walk=False)
+            else:
+                d = extra_workload(a, device, 1, 0, None)
+            r = d["roofline"]
+            row.update(config=d["config"]["workload"], ms_per_step=d["ms_per_step"], value=d["value"],
+                       visited_voxel_updates_per_s=d.get("visited_voxel_updates_per_s", d["value"]),
+                       frac=r["frac"], achieved_gbs=r["achieved"], kernel_ms=r.get("kernel_ms"),
+                       kernel=r.get("kernel"), wall_s=None)
+            if "us_per_iteration" in d:
+                row["us_per_iteration"] = d["us_per_iteration"]
+                row["note"] = r.get("note")
+            row["wall_s"] = time.perf_counter() - t0
+        except Exception as exc:  # noqa: BLE001 -- recorded on the line
+            row["error"] = "%s: %s" % (type(exc).__name__, exc)
+        rows.append(row)
+        gc.enable()
+        gc.collect()
+        torch.cuda.empty_cache()
+    return rows
+
+
+def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=True):
+    """BASELINE config 4 (module docstring); returns the JSON line as a dict"""
     import levelsetfusion_python_amd as lsf
     from levelsetfusion_python_amd import _lib, device as dev
     from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
     from levelsetfusion_python_amd.synthetic import sphere_pair
 
     n, iters = args.size, args.iterations
-    layout = SlabLayout(n * world, rank, world, args.halo if world > 1 else 0)
+    strong = world > 1 and args.scaling == "strong"
+    if strong:
+        # BASELINE config 4 as written: ONE n^3 pair, z-slabbed over the ranks.  The exchange-group depth follows the slab
+        # height: iteration j of a group recomputes h - 1 - j neighbour slices per interior side, (h - 1) / slices-per-rank
+        # of a slab on average (h = 8 on 32-slice slabs would recompute 22 %; slices / 8 keeps it below 10 %)
+        if n % world:
+            raise SystemExit("--scaling strong: --size %d is not divisible by %d ranks" % (n, world))
+        halo = args.halo if args.halo is not None else max(1, min(8, (n // world) // 8))
+        layout = SlabLayout(n, rank, world, halo)
+        pattern, z_shift = "one centred sphere pair, cut into slabs", 0
+    else:
+        halo = (8 if args.halo is None else args.halo) if world > 1 else 0
+        layout = SlabLayout(n * world, rank, world, halo)
+        faces = world > 1 and (args.pattern or "faces") == "faces"
+        pattern = "spheres centred on the slab faces" if faces else "one sphere centred in every slab"
+        z_shift = n // 2 if faces else 0
+    args.halo = halo
     sl = layout.local_slice()
     if args.data == "depth":
         if world > 1:
@@ -299,7 +421,7 @@ def main():
         from levelsetfusion_python_amd.synthetic import depth_pair
         canonical, live0 = depth_pair(n, device)
     else:
-        canonical, live0 = sphere_pair(n, 3, device, (sl.start, sl.stop))
+        canonical, live0 = sphere_pair(n, 3, device, (sl.start, sl.stop), z_shift)
 
     def make_optimizer():
         comm = SlabComm(layout) if world > 1 else None
@@ -361,9 +483,33 @@ def main():
     if world > 1:
         elapsed = max_over_ranks(elapsed)
     assert executed == iters, "expected %d fixed iterations, the gate closed after %d" % (iters, executed)
-    voxels_per_rank = n ** 3
+    voxels_per_rank = n ** 3 // world if strong else n ** 3
     updates = voxels_per_rank * world * iters * args.steps
     value = updates / elapsed
+
+    # ---- what the halo exchange carries (N > 1): the band voxels of the h boundary slices of every interior face, and
+    # the bytes one exchange moves per rank and direction (compact faces: 16 B per band voxel; whole faces otherwise)
+    halo_info = None
+    if world > 1:
+        L, h = layout, layout.halo
+        band = ~((live0.abs() == 1.0) & (canonical.abs() == 1.0))
+        mine = []
+        if L.rank > 0:
+            mine.append(int(band[L.z_begin:L.z_begin + h].sum().item()))
+        if L.rank < world - 1:
+            mine.append(int(band[L.z_end - h:L.z_end].sum().item()))
+        fast = getattr(opt._engine, "_fast", None)
+        compact = fast is not None and getattr(fast, "native", None) is not None and getattr(fast, "faces_ref", None) is not None
+        face_bytes = [16 * v for v in mine] if compact else [16 * h * live0.shape[1] * live0.shape[2]] * len(mine)
+        interval = getattr(fast, "exchange_interval", 1) if fast is not None else 1
+        rows = [None] * world
+        dist.all_gather_object(rows, dict(band_voxels=mine, bytes=face_bytes))
+        per_face = [v for r in rows for v in r["band_voxels"]]
+        halo_info = dict(halo_slices=h, iterations_per_exchange=interval,
+                         exchanges_per_step=len([i for i in range(iters) if i % interval == interval - 1 and i + 1 < iters]),
+                         faces="compact (band voxels only)" if compact else "whole slices",
+                         band_voxels_per_face=per_face, face_voxels=h * live0.shape[1] * live0.shape[2],
+                         bytes_sent_per_exchange_per_rank=[sum(r["bytes"]) for r in rows])
 
     # ---- roofline of the dominant kernel: the fused warp-update kernel alone, HIP events on its stream, over exactly
     # the launch sequence of one step (band lists of the initial pair, `iters` ping-pong launches on the float4 state)
@@ -461,33 +607,38 @@ def main():
     else:
         roofline = roofline_of([None], voxels_per_rank, name % "DENSE", committed_traffic("dense_hbm_bytes_per_launch"))
     roofline_dense = roofline_of([None], voxels_per_rank, name % "DENSE",
-                                 committed_traffic("dense_hbm_bytes_per_launch")) if eng.use_band_list else None
+                                 committed_traffic("dense_hbm_bytes_per_launch")) \
+        if eng.use_band_list and dense_walk else None
 
     out = dict(metric="voxel-warp-updates/sec", value=value, unit="voxel-warp-updates/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               scaling="strong" if strong else "weak", vs_baseline=None, dtype="f32", data="synthetic",
                config=dict(workload="3D %d^3 KillingFusion (Killing + level-set) SlavchevaOptimizer3d, %d fixed "
                                     "iterations per step, %s" % (n, iters, "sphere-pair TSDF" if args.data == "sphere"
                                                                  else "TSDF pair from two synthetic depth frames"),
                            voxels_per_gpu=voxels_per_rank, iterations_per_step=iters,
-                           parallelism=("z-slab x%d, halo %d, %s" % (
-                               world, args.halo, "RCCL send/recv from the library (lsf_slab_state_iteration)"
+                           parallelism=("z-slab x%d (%s: %s), halo %d, %s" % (
+                               world, "strong scaling" if strong else "weak scaling", pattern, args.halo,
+                               "RCCL send/recv from the library (lsf_slab_state_iteration)"
                                if comm.native() is not None else "torch.distributed " + args.backend))
                            if world > 1 else "single GPU"),
                roofline=roofline)
+    if halo_info is not None:
+        out["halo_exchange"] = halo_info
+        # every interior face of the run carries at least this many band voxels / the busiest rank sends this much
+        out["halo_band_voxels_per_face"] = min(halo_info["band_voxels_per_face"])
+        out["halo_bytes_per_exchange"] = max(halo_info["bytes_sent_per_exchange_per_rank"])
     roofline["traffic_source"] = traffic_source
     # the rate over the voxels the launches actually visit (band lists): comparable across inputs and rounds, where
     # `value` (field voxels, as the reference counts its work) grows with the share of the volume outside the band
     out["visited_voxel_updates_per_s"] = roofline["units_per_launch"] * world * iters * args.steps / elapsed
     if roofline_dense is not None:
         out["roofline_dense_walk"] = roofline_dense
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_size, args.cpu_sample_iterations)
-        print(json.dumps(out), flush=True)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_size, args.cpu_sample_iterations)
     if world > 1:
         comm.close()  # the library's own RCCL communicator, before torch tears its process group down
-        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":

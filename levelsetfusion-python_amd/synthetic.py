@@ -8,9 +8,12 @@ anisotropically scaled by (1.05, 0.95, 1.0) along (x, y, z); narrow-band half wi
 import torch
 
 
-def sphere_pair(n, dims=3, device="cuda", z_range=None):
+def sphere_pair(n, dims=3, device="cuda", z_range=None, z_shift=0):
     """returns (canonical, live) float32 tensors of shape (n, n) or (nz, n, n); z_range = (z0, z1) selects the
-    global slices [z0, z1) of a volume whose sphere pattern has period n along z"""
+    global slices [z0, z1) of a volume whose sphere pattern has period n along z; z_shift moves the pattern by that
+    many slices: with z_shift = n / 2 the spheres are centred ON the faces z = 0, n, 2n, ... of a stack of n-slice slabs,
+    so that every slab face cuts a narrow band through its equator (an annulus of ~15 % of the face) and a z-slab run's
+    halo exchange carries data -- bench.py's weak-scaling input"""
     h, r, c = 10.0, 0.3 * n, n / 2.0
     ax = torch.arange(n, dtype=torch.float64, device=device)
     if dims == 2:
@@ -18,7 +21,7 @@ def sphere_pair(n, dims=3, device="cuda", z_range=None):
         coords = [xx, yy]
     else:
         z0, z1 = (0, n) if z_range is None else z_range
-        az = torch.remainder(torch.arange(z0, z1, dtype=torch.float64, device=device), n)
+        az = torch.remainder(torch.arange(z0, z1, dtype=torch.float64, device=device) + float(z_shift), n)
         zz, yy, xx = torch.meshgrid(az, ax, ax, indexing="ij")
         coords = [xx, yy, zz]
 

@@ -24,7 +24,8 @@ def _run(*flags):
 def test_default_workload_line():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    d = _run("--size", "64", "--iterations", "4", "--cpu-sample-size", "16", "--cpu-sample-iterations", "2")
+    d = _run("--size", "64", "--iterations", "4", "--cpu-sample-size", "16", "--cpu-sample-iterations", "2",
+             "--secondary-divisor", "8")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -44,6 +45,26 @@ def test_default_workload_line():
     assert abs(d["visited_voxel_updates_per_s"] - r["units_per_launch"] * 4 * 2 / (d["ms_per_step"] * 2e-3)) \
         < 1e-6 * d["value"]
     assert r["traffic"] is None and r["traffic_source"]["loaded_build_id"]
+    # the other configurations of BASELINE.json ride on the same line (here at 1/8 of their edge lengths)
+    sec = {row["workload"]: row for row in d["secondary"]}
+    assert sorted(sec) == ["hier-full", "hier-tik", "hier2d", "killing", "multiframe", "sobolev"]
+    for name, row in sec.items():
+        assert "error" not in row, row
+        assert row["ms_per_step"] > 0 and row["visited_voxel_updates_per_s"] > 0 and row["frac"] > 0 and row["config"]
+    assert sec["killing"]["size"] == 64 and sec["killing"]["kernel_ms"] > 0
+    assert sec["hier2d"]["size"] == 64 and sec["hier2d"]["us_per_iteration"] > 0 and "LAUNCH-BOUND" in sec["hier2d"]["note"]
+    assert abs(sec["hier2d"]["us_per_iteration"] - sec["hier2d"]["ms_per_step"] * 1e3 / 300) < 1e-6
+
+
+def test_hier2d_workload_line():
+    """BASELINE config 2 as a bench mode: 2-D, 3 levels, microseconds per iteration next to the rate"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    d = _run("--workload", "hier2d", "--size", "128", "--iterations", "10", "--no-cpu-baseline")
+    assert "2D 128^2 HierarchicalOptimizer2d" in d["config"]["workload"] and "secondary" not in d
+    per_pair = 10 * (128 ** 2 + 64 ** 2 + 32 ** 2)
+    assert abs(d["value"] - per_pair * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert abs(d["us_per_iteration"] - d["ms_per_step"] * 1e3 / 30) < 1e-6
 
 
 def test_depth_data_and_other_workloads():
@@ -100,6 +121,20 @@ def test_two_rank_lines():
     d = _run_ranks(2, "--size", "64", "--iterations", "6", "--halo", "2")
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "z-slab x2" in d["config"]["parallelism"]
     assert abs(d["value"] - 2 * 64 ** 3 * 6 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    # the DEFAULT N > 1 input puts narrow bands across every slab face: the halo exchange carries data
+    h = d["halo_exchange"]
+    assert "faces" in d["config"]["parallelism"] and h["halo_slices"] == 2 and h["iterations_per_exchange"] == 2
+    assert h["exchanges_per_step"] == 2 and len(h["band_voxels_per_face"]) == 2      # after iterations 1 and 3 (not the last)
+    assert d["halo_band_voxels_per_face"] > 0.05 * h["face_voxels"] and d["halo_bytes_per_exchange"] > 0
+    # ... where round 3's input (one sphere inside every slab) had nothing to send
+    d = _run_ranks(2, "--size", "96", "--iterations", "4", "--halo", "2", "--pattern", "centered")
+    assert d["halo_band_voxels_per_face"] == 0
+    # strong scaling: BASELINE config 4 as written, ONE pair cut over the ranks; the exchange-group depth follows the slab
+    d = _run_ranks(2, "--size", "64", "--iterations", "6", "--scaling", "strong")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "strong scaling" in d["config"]["parallelism"]
+    assert d["config"]["voxels_per_gpu"] == 64 ** 3 // 2 and d["halo_exchange"]["halo_slices"] == 4
+    assert abs(d["value"] - 64 ** 3 * 6 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert d["halo_band_voxels_per_face"] > 0 and d["halo_bytes_per_exchange"] > 0
     per_pair = 3 * sum((64 >> k) ** 3 for k in range(4))
     d = _run_ranks(2, "--workload", "multiframe", "--size", "64", "--frames", "3", "--iterations", "3")
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "replicas x2" in d["config"]["parallelism"]
