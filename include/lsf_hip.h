@@ -305,8 +305,20 @@ int lsf_band_list_fill(const float *live, const float *canonical, const lsf_grid
  * scratch: lsf_state_prepare_scratch_elements(grid) int32 (8-byte aligned); counts_out[0..4) (device) = INTERIOR and
  * BOUNDARY totals, then the number of voxels OUTSIDE the band with live = -canonical and the first of them (-1: none)
  * -- what lsf_state_finalize_listed needs to know about the voxels no list holds.  lsf_band_list_fill_prepared then writes one subset's list from the ballots the prepare pass kept
- * in scratch (16 bytes per 64 voxels) -- live and canonical are not read again. */
+ * in scratch (16 bytes per 64 voxels) -- live and canonical are not read again.
+ * state_a AND state_b NULL: the pass only counts; lsf_state_pack_needed then writes the two states (live, 0) ONLY where
+ * an iteration can read them: the 1024-voxel chunks that have a voxel within `reach` voxels (per axis) of a chunk that
+ * holds band voxels -- 3^D stencils reach 1, the re-warp gather of an update shorter than `reach` voxels reaches `reach`
+ * (1 <= reach <= 8).  Everything else of the two buffers stays UNINITIALISED: a run is valid only while every
+ * iteration's maximum update stays below `reach` (lsf_records_exceed tells, on the device, in front of a finalize pass
+ * with a skip_flag), and whole-state readers (lsf_state_unpack, lsf_state_finalize) must first complete the state with
+ * invert = 1 (writes exactly the chunks the first call left out, from the verdicts it kept in scratch).  On a narrow
+ * band this replaces 2 x 16 B per VOXEL of initialisation by 2 x 16 B per voxel NEAR THE BAND (a quarter of a 256^3
+ * sphere pair).  lsf_records_exceed: *flag = 1 if any of records[0..count) was executed with a maximum >= limit or NaN. */
 int64_t lsf_state_prepare_scratch_elements(const lsf_grid *grid);
+int lsf_state_pack_needed(const float *live, float *state_a, float *state_b, const lsf_grid *grid, int32_t *scratch,
+                          int32_t reach, int32_t invert, void *stream);
+int lsf_records_exceed(const lsf_iteration_record *records, int32_t count, float limit, int32_t *flag, void *stream);
 int lsf_band_list_fill_prepared(const lsf_grid *grid, int32_t subset, const int32_t *scratch, int32_t *list,
                                 void *stream);
 int lsf_state_prepare(const float *live, const float *canonical, float *state_a, float *state_b,

@@ -22,7 +22,7 @@ ABI_VERSION = 3
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "1f584e9034976f19"
+HEADER_ABI_HASH = "f32cfffb9498bfa0"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -149,6 +149,8 @@ PROTOTYPES = {
     "lsf_band_list_fill_prepared": (ctypes.c_int, [_P(Grid), _i32, _vp, _vp, _vp]),
     "lsf_state_prepare": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp, _vp, _vp]),
     "lsf_state_pack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp]),
+    "lsf_state_pack_needed": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _vp, _i32, _i32, _vp]),
+    "lsf_records_exceed": (ctypes.c_int, [_vp, _i32, _f32, _vp, _vp]),
     "lsf_state_unpack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp]),
     "lsf_state_finalize_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
     "lsf_state_finalize": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _f32, _vp, _vp, _vp]),

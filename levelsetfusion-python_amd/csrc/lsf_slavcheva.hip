@@ -411,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
                                                                Grid g, int dims, int* __restrict__ sums_interior,
                                                                int* __restrict__ sums_boundary,
                                                                unsigned long long* __restrict__ masks,
-                                                               int* __restrict__ opposite) {
+                                                               int* __restrict__ opposite, int* __restrict__ nonempty) {
     __shared__ int part[4][16];  // [INTERIOR count, BOUNDARY count, opposite count, first opposite][pass j * 4 + wave]
     const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
 #pragma unroll
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
             opposed = !in_band && l != cn;
             vf4 o;
             o.x = l; o.y = 0.0f; o.z = 0.0f; o.w = 0.0f;
-            a[v] = o;
+            if (a) a[v] = o;  // null: the states are written by lsf_state_pack_needed, only where an iteration can read them
             if (b) b[v] = o;
             const unsigned zy = fast_div(v, g.div_nx);
             const int x = (int)(v - zy * (unsigned)g.nx);
@@ -460,7 +460,70 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
         }
         opposite[2 * blockIdx.x] = sum;
         opposite[2 * blockIdx.x + 1] = first;
+    } else if (t == 3) {
+        int any = 0;
+        for (int k = 0; k < 16; ++k) any |= part[0][k] | part[1][k];
+        nonempty[blockIdx.x] = any != 0;
     }
+}
+
+// The ping-pong states only where an iteration can READ them (lsf_state_pack_needed): chunk c (1024 consecutive voxels) is
+// needed when some chunk that holds band voxels has a voxel within `reach` voxels of it along every axis -- the 3^D
+// stencils reach 1, the re-warp gather of an update shorter than `reach` voxels floor(|w|) + 1 <= reach.  In linear
+// indices: the voxels of chunk c shifted by dz * slice + dy * row, |dz|, |dy| <= reach, and widened by `reach` along x,
+// fall into at most three consecutive chunks per (dz, dy) -- row ends only ever add candidates.  One block per chunk:
+// the candidates' non-empty flags (written by lsf_state_prepare) are tested by the first threads, a needed chunk is then
+// written as (live, 0) to both states; needed[c] keeps the verdict for whoever has to complete a state later
+// (invert != 0: write exactly the chunks NOT needed, from the kept verdicts).
+__global__ __launch_bounds__(kBlock) void state_pack_needed_kernel(const float* __restrict__ live, vf4* __restrict__ a,
+                                                                   vf4* __restrict__ b, unsigned n, unsigned chunks,
+                                                                   long long row, long long slice, int dims, int reach,
+                                                                   const int* __restrict__ nonempty,
+                                                                   int* __restrict__ needed, int invert) {
+    const int t = threadIdx.x;
+    const long long c0 = (long long)blockIdx.x * kBandChunk;
+    int want;
+    if (invert) {
+        want = needed[blockIdx.x] == 0;
+    } else {
+        const int span = 2 * reach + 1, zs = dims == 3 ? span : 1;
+        bool hit = false;
+        for (int k = t; k < zs * span * 3; k += kBlock) {
+            const int which = k % 3, dy = (k / 3) % span - reach, dz = dims == 3 ? (k / 3) / span - reach : 0;
+            const long long lo = c0 + dz * slice + dy * row - reach, hi = c0 + (long long)kBandChunk - 1 + dz * slice + dy * row + reach;
+            // floor division of possibly negative voxel indices; chunks lo / 1024 .. hi / 1024 (at most three)
+            const long long first = lo >= 0 ? lo / kBandChunk : -((-lo + kBandChunk - 1) / kBandChunk);
+            const long long last = hi >= 0 ? hi / kBandChunk : -((-hi + kBandChunk - 1) / kBandChunk);
+            const long long cand = first + which;
+            if (cand <= last && cand >= 0 && cand < (long long)chunks) hit |= nonempty[cand] != 0;
+        }
+        want = __syncthreads_or(hit);
+        if (t == 0) needed[blockIdx.x] = want;
+    }
+    if (!want) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned v = blockIdx.x * kBandChunk + j * kBlock + t;
+        if (v < n) {
+            vf4 o;
+            o.x = live[v]; o.y = 0.0f; o.z = 0.0f; o.w = 0.0f;
+            if (a) a[v] = o;
+            if (b) b[v] = o;
+        }
+    }
+}
+
+// flag = 1 when a record of [0, count) -- an executed iteration -- holds a maximum that is not below `limit` (NaN
+// included), else 0.  One block; the slots of a record are combined as the gate combines them.
+__global__ __launch_bounds__(kBlock) void records_exceed_kernel(const lsf_iteration_record* __restrict__ records,
+                                                                unsigned count, float limit, int* __restrict__ flag) {
+    bool bad = false;
+    for (unsigned k = threadIdx.x; k < count * LSF_RECORD_SLOTS; k += kBlock) {
+        const unsigned long long p = records[k / LSF_RECORD_SLOTS].slot[k % LSF_RECORD_SLOTS].max_packed;
+        if (p != 0ull) bad |= !(unpack_max_value(p) < limit);
+    }
+    const int any = __syncthreads_or(bad);
+    if (threadIdx.x == 0) *flag = any ? 1 : 0;
 }
 
 
@@ -628,11 +691,15 @@ static inline int* prepare_opposite(int32_t* scratch, unsigned chunks) {
     return reinterpret_cast<int*>(prepare_masks(scratch, chunks) + (size_t)chunks * 32);
 }
 
+// ... then one int per chunk: does the chunk hold band voxels; then one per chunk: lsf_state_pack_needed's verdict
+static inline int* prepare_nonempty(int32_t* scratch, unsigned chunks) { return prepare_opposite(scratch, chunks) + 2 * (size_t)chunks; }
+static inline int* prepare_needed(int32_t* scratch, unsigned chunks) { return prepare_nonempty(scratch, chunks) + chunks; }
+
 extern "C" int64_t lsf_state_prepare_scratch_elements(const lsf_grid* grid) {
     if (check_grid(grid)) return 0;
     unsigned first, n, chunks;
     band_range(grid, first, n, chunks);
-    return 2 * (int64_t)(chunks + 1) + 64 * (int64_t)chunks + 2 + 2 * (int64_t)chunks;
+    return 2 * (int64_t)(chunks + 1) + 64 * (int64_t)chunks + 2 + 2 * (int64_t)chunks + 2 * (int64_t)chunks;
 }
 
 extern "C" int lsf_band_list_fill_prepared(const lsf_grid* grid, int32_t subset, const int32_t* scratch, int32_t* list,
@@ -653,7 +720,8 @@ extern "C" int lsf_band_list_fill_prepared(const lsf_grid* grid, int32_t subset,
 extern "C" int lsf_state_prepare(const float* live, const float* canonical, float* state_a, float* state_b,
                                  const lsf_grid* grid, int32_t* scratch, int64_t* counts_out, void* stream) {
     if (int e = check_grid(grid)) return e;
-    if (!live || !canonical || !state_a || !scratch || !counts_out) return LSF_ERR_BAD_ARGUMENT;  // state_b: optional
+    // state_b: optional; state_a AND state_b NULL: the states are written by lsf_state_pack_needed
+    if (!live || !canonical || (!state_a && state_b) || !scratch || !counts_out) return LSF_ERR_BAD_ARGUMENT;
     if (grid->z_begin != 0 || grid->z_end != grid->nz) return LSF_ERR_BAD_ARGUMENT;  // whole arrays only
     unsigned first, n, chunks;
     band_range(grid, first, n, chunks);
@@ -662,9 +730,33 @@ extern "C" int lsf_state_prepare(const float* live, const float* canonical, floa
     int* sums_boundary = scratch + (chunks + 1);
     hipLaunchKernelGGL(state_prepare_kernel, dim3(chunks), dim3(kBlock), 0, s, live, canonical,
                        reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b), n, make_grid(grid), grid->dims,
-                       sums_interior, sums_boundary, prepare_masks(scratch, chunks), prepare_opposite(scratch, chunks));
+                       sums_interior, sums_boundary, prepare_masks(scratch, chunks), prepare_opposite(scratch, chunks),
+                       prepare_nonempty(scratch, chunks));
     hipLaunchKernelGGL(band_scan_kernel, dim3(3), dim3(1024), 0, s, scratch, chunks, chunks + 1, 2u, (long long*)counts_out,
                        (const int*)prepare_opposite(scratch, chunks));
+    return launch_status();
+}
+
+extern "C" int lsf_state_pack_needed(const float* live, float* state_a, float* state_b, const lsf_grid* grid,
+                                     int32_t* scratch, int32_t reach, int32_t invert, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!live || (!state_a && !state_b) || !scratch || reach < 1 || reach > 8) return LSF_ERR_BAD_ARGUMENT;
+    if (grid->z_begin != 0 || grid->z_end != grid->nz) return LSF_ERR_BAD_ARGUMENT;  // whole arrays only
+    unsigned first, n, chunks;
+    band_range(grid, first, n, chunks);
+    hipLaunchKernelGGL(state_pack_needed_kernel, dim3(chunks), dim3(kBlock), 0, as_stream(stream), live,
+                       reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b), n, chunks, (long long)grid->nx,
+                       (long long)grid->nx * grid->ny, grid->dims, reach, prepare_nonempty(scratch, chunks),
+                       prepare_needed(scratch, chunks), invert);
+    return launch_status();
+}
+
+extern "C" int lsf_records_exceed(const lsf_iteration_record* records, int32_t count, float limit, int32_t* flag,
+                                  void* stream) {
+    (void)hipGetLastError();
+    if (!records || !flag || count < 0) return LSF_ERR_BAD_ARGUMENT;
+    hipLaunchKernelGGL(records_exceed_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), records, (unsigned)count, limit,
+                       flag);
     return launch_status();
 }
 

@@ -435,21 +435,26 @@ class StatePrepare:
     CHUNK = 1024  # voxels per count of lsf_state_prepare's scratch (kBandChunk)
     SPLIT_MAX_VOXELS = 1 << 24  # up to here the second state's fill fits into the host's wait for the list sizes
 
-    def __init__(self, live, canonical, grid=None, cut_chunks=None):
+    def __init__(self, live, canonical, grid=None, cut_chunks=None, sparse_reach=0):
         """cut_chunks (optional): int64 device tensor of chunk indices <= the number of chunks -- the number of INTERIOR /
         BOUNDARY list entries in front of voxel 1024 * chunk comes back with the list sizes (collect), e.g. the positions
         of z cuts in the lists of a slab whose slices are a multiple of 1024 voxels, without a search and a second host
-        read.  (The entry AT the number of chunks is not a count: use cut_totals for a cut at the end of the array.)"""
+        read.  (The entry AT the number of chunks is not a count: use cut_totals for a cut at the end of the array.)
+        sparse_reach > 0: the states are written ONLY in the 1024-voxel chunks an iteration can read while every update
+        stays below `sparse_reach` voxels (lsf_state_pack_needed) -- the rest of both buffers stays uninitialised;
+        complete(state, live) fills it in for whole-state readers."""
         self.grid = grid = grid or make_grid(live.shape)
         n = n_voxels(grid)
         self.states = [torch.empty(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device) for _ in range(2)]
         n_scratch = int(lib.lsf_state_prepare_scratch_elements(ctypes.byref(grid)))
         self._scratch = torch.empty(n_scratch, dtype=torch.int32, device=live.device)
         totals = torch.empty(4, dtype=torch.int64, device=live.device)
+        self.sparse_reach = int(sparse_reach)
         split = os.environ.get("LSF_PREPARE_SPLIT", "1") != "0" and n <= self.SPLIT_MAX_VOXELS
+        none = ctypes.c_void_p(0)
         check(lib.lsf_state_prepare(_ptr(live, n, "live"), _ptr(canonical, n, "canonical"),
-                                    _ptr(self.states[0], 4 * n, "state"),
-                                    ctypes.c_void_p(0) if split else _ptr(self.states[1], 4 * n, "state"),
+                                    none if self.sparse_reach else _ptr(self.states[0], 4 * n, "state"),
+                                    none if split or self.sparse_reach else _ptr(self.states[1], 4 * n, "state"),
                                     ctypes.byref(grid), ctypes.c_void_p(self._scratch.data_ptr()),
                                     ctypes.c_void_p(totals.data_ptr()), stream_ptr()), "lsf_state_prepare")
         self._totals_host = pinned_scratch("prepare totals", 4, torch.int64)
@@ -464,12 +469,36 @@ class StatePrepare:
             self._cuts_host.copy_(cuts.view(-1), non_blocking=True)
         self._copied = torch.cuda.Event()
         self._copied.record()
-        # the second state is written BEHIND the copy of the list sizes: the card fills it while the host wakes up on
-        # the sizes and enqueues the list fills, instead of idling there (two states in the counting pass: 125 us in
-        # front of the sizes; one: 80 us, and these 65 us overlap the host's round trip)
-        if split:
+        # the states are written BEHIND the copy of the list sizes: the card fills them while the host wakes up on
+        # the sizes and enqueues the list fills, instead of idling there.  Sparse: both states, in the chunks near the
+        # band only (a quarter of a 256^3 sphere pair: 2 x 64 MB instead of 2 x 256 MB); else the second state (two states
+        # in the counting pass: 125 us in front of the sizes; one: 80 us, and these 65 us overlap the host's round trip)
+        if self.sparse_reach:
+            check(lib.lsf_state_pack_needed(_ptr(live, n, "live"), _ptr(self.states[0], 4 * n, "state"),
+                                            _ptr(self.states[1], 4 * n, "state"), ctypes.byref(full_range(grid)),
+                                            ctypes.c_void_p(self._scratch.data_ptr()), self.sparse_reach, 0,
+                                            stream_ptr()), "lsf_state_pack_needed")
+        elif split:
             check(lib.lsf_state_pack(_ptr(live, n, "live"), ctypes.c_void_p(0), _ptr(self.states[1], 4 * n, "state"),
                                      ctypes.c_void_p(0), ctypes.byref(full_range(grid)), stream_ptr()), "lsf_state_pack")
+
+    def complete(self, state, live):
+        """sparse states only: write (live, 0) into the chunks of `state` the prepare step left uninitialised (live = the
+        input live field, or any array that still holds it at the voxels outside the band lists)"""
+        if not self.sparse_reach:
+            return state
+        n = n_voxels(self.grid)
+        check(lib.lsf_state_pack_needed(_ptr(live, n, "live"), _ptr(state, 4 * n, "state"), ctypes.c_void_p(0),
+                                        ctypes.byref(full_range(self.grid)), ctypes.c_void_p(self._scratch.data_ptr()),
+                                        self.sparse_reach, 1, stream_ptr()), "lsf_state_pack_needed")
+        return state
+
+    def needed_fraction(self):
+        """share of the 1024-voxel chunks the sparse prepare step initialised (a host read: measurements, tests)"""
+        n = n_voxels(self.grid)
+        chunks = (n + self.CHUNK - 1) // self.CHUNK
+        at = 2 * (chunks + 1) + 64 * chunks + 2 * chunks + chunks  # lsf_slavcheva.hip::prepare_needed
+        return float(self._scratch[at:at + chunks].ne(0).float().mean().item())
 
     def collect(self):
         """(band lists -- empty lists dropped, but never both --, (number of voxels outside the band with

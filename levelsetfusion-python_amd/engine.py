@@ -615,11 +615,28 @@ class SlavchevaOutcome:
     """final fields of one SlavchevaEngine.optimize() call, left on the device in the layout the iteration kernels use
     (the float4 state of the fused path, or planar live / warp of the Sobolev path) and handed out on demand"""
 
-    def __init__(self, grid, canonical, state=None, live=None, warp_planar=None, listed=None):
+    def __init__(self, grid, canonical, state=None, live=None, warp_planar=None, listed=None, sparse=None):
         self.grid, self.canonical, self.state = grid, canonical, state
         self._live, self._warp_planar = live, warp_planar
         # (input live field, band lists, state_prepare's unlisted counts): finalize then visits the band voxels only
         self._listed = listed
+        # dev.StatePrepare whose states were initialised near the band only: readers of the WHOLE state complete it first
+        self._sparse = sparse
+        self._skip = None
+
+    def guard(self, records, count, limit):
+        """enqueue the device-side check of a sparse run: a word that is non-zero when one of records[0..count) holds a
+        maximum update of `limit` voxels or more; the listed finalize pass then leaves the caller's fields alone"""
+        self._skip = torch.empty(1, dtype=torch.int32, device=self._device())
+        _lib.check(_lib.lib.lsf_records_exceed(ctypes.c_void_p(records.data_ptr()), int(count), float(limit),
+                                               ctypes.c_void_p(self._skip.data_ptr()), dev.stream_ptr()),
+                   "lsf_records_exceed")
+
+    def _whole_state(self):
+        if self._sparse is not None:
+            self._sparse.complete(self.state, self._listed[0])
+            self._sparse = None
+        return self.state
 
     def _shape(self):
         g = self.grid
@@ -631,14 +648,14 @@ class SlavchevaOutcome:
     def live(self):
         if self._live is None:
             self._live = torch.empty(self._shape(), dtype=torch.float32, device=self._device())
-            dev.state_unpack(self.state, self.grid, self._live, None, None)
+            dev.state_unpack(self._whole_state(), self.grid, self._live, None, None)
         return self._live
 
     def warp_planar(self):
         if self._warp_planar is None:
             self._warp_planar = torch.empty((self.grid.dims,) + self._shape(), dtype=torch.float32,
                                             device=self._device())
-            dev.state_unpack(self.state, self.grid, None, self._warp_planar, None)
+            dev.state_unpack(self._whole_state(), self.grid, None, self._warp_planar, None)
         return self._warp_planar
 
     def finalize(self, live_out=None, lower_threshold=0.0, statistics=False):
@@ -687,13 +704,14 @@ class SlavchevaOutcome:
                 target.copy_(live0)
             warp = torch.zeros(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
             chain = getattr(self, "_chain", None)  # the pass leaves `target` alone if the chain launch flagged its result
+            skip = chain.violation_ptr if chain is not None else (self._skip.data_ptr() if self._skip is not None else None)
             raw = dev.state_finalize_listed(self.state, self.canonical, full, bands, unlisted, target, warp,
-                                            lower_threshold, statistics,
-                                            skip_flag=chain.violation_ptr if chain is not None else None)
+                                            lower_threshold, statistics, skip_flag=skip)
             self._live = target
         elif self.state is not None:
             warp = torch.empty(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
-            raw = dev.state_finalize(self.state, self.canonical, full, target, None, warp, lower_threshold, statistics)
+            raw = dev.state_finalize(self._whole_state(), self.canonical, full, target, None, warp, lower_threshold,
+                                     statistics)
             self._live = target
         else:
             # planar final fields (SobolevFusion path): one pass as well (lsf_planar_finalize)
@@ -768,6 +786,19 @@ class _ChainReachExceeded(Exception):
     """a chain launch (dev.StateChain) met a warp update its dependency windows do not cover, or gave up waiting (CUs held
     by something else); nothing of the caller's has been modified (SlavchevaEngine.optimize repeats the call with
     per-iteration launches)"""
+
+
+class _SparseStateExceeded(Exception):
+    """a call whose ping-pong states were initialised near the band only (dev.StatePrepare(sparse_reach=...)) met a warp
+    update that can read beyond that; nothing of the caller's has been modified (SlavchevaEngine.optimize repeats the
+    call on fully initialised states and keeps doing so for this optimizer)"""
+
+
+# The ping-pong states are initialised only where an iteration can read them while every update stays below this many
+# voxels (0 = everywhere, as before round 4), for volumes of at least SPARSE_MIN_VOXELS (below, a call is launch-bound and
+# the initialisation passes cost nothing next to it)
+SPARSE_REACH = int(os.environ.get("LSF_SPARSE_REACH", "2"))
+SPARSE_MIN_VOXELS = int(os.environ.get("LSF_SPARSE_MIN_VOXELS", str(1 << 21)))
 
 
 class SlavchevaEngine:
@@ -1124,6 +1155,13 @@ class SlavchevaEngine:
                 # left the caller's tensors alone (its skip flag), so the call simply runs again, one launch per iteration
                 self._chain_disabled = True
                 return self._optimize(live, canonical, finalize)
+            except _SparseStateExceeded:
+                # an update of SPARSE_REACH voxels or more may have gathered from a part of the states that was never
+                # initialised.  The finalize pass has left the caller's tensors alone (its skip flag): the call runs again
+                # on fully initialised states, and so does every later call of this optimizer (its data move that far)
+                self._sparse_disabled = True
+                torch.cuda.synchronize()
+                return self._optimize(live, canonical, finalize)
         self._slab_restore = None
         try:
             outcome = self._optimize(live, canonical, finalize)
@@ -1203,6 +1241,7 @@ class SlavchevaEngine:
                 raise ValueError("slab halo of %d slices is too narrow: this configuration needs >= %d"
                                  % (self.comm.layout.halo, need))
         prepared = None
+        sparse = False
         # SobolevFusion on band lists of a whole volume runs on the float4 layouts too (one vector-memory instruction per
         # neighbour / tap instead of one per component: lsf_sobolev_state.hip); z-slabs, filters of other lengths and
         # list-less runs keep the planar kernels
@@ -1225,7 +1264,14 @@ class SlavchevaEngine:
                     self._cut_chunk_cache = (key, torch.tensor([z * per_slice for z in zs], dtype=torch.int64,
                                                                device=live.device))
                 cut_chunks = self._cut_chunk_cache[1]
-            prepared = dev.StatePrepare(live, canonical, dev.full_range(grid), cut_chunks)
+            # whole volumes: the states are initialised near the band only (a quarter of the voxels of a 256^3 sphere
+            # pair), valid while every update stays below SPARSE_REACH voxels -- checked on the device in front of an
+            # early finalize pass and on the host behind every batch
+            sparse = (not slab and SPARSE_REACH > 0 and dev.n_voxels(grid) >= SPARSE_MIN_VOXELS
+                      and self.iteration_hook is None and not getattr(self, "_sparse_disabled", False)
+                      and os.environ.get("LSF_CHAIN", "0") != "1")
+            prepared = dev.StatePrepare(live, canonical, dev.full_range(grid), cut_chunks,
+                                        sparse_reach=SPARSE_REACH if sparse else 0)
         live_at_entry = None
         if slab and finalize is not None and finalize[0] is not None and not planar_sobolev \
                 and self.min_iterations >= max(self.max_iterations, self.min_iterations):
@@ -1333,8 +1379,11 @@ class SlavchevaEngine:
                 # every launch runs ungated, so the final state is states[limit % 2]: finalize before looking.  A slab run
                 # may still have to be discarded (see optimize()), and the pass writes the caller's tensor: optimize() puts
                 # the copy taken below back before it runs the call again
-                early = SlavchevaOutcome(grid, canonical, state=states[limit % 2], listed=listed)
+                early = SlavchevaOutcome(grid, canonical, state=states[limit % 2], listed=listed,
+                                         sparse=prepared if sparse else None)
                 early._chain = chain
+                if sparse:  # the pass must not touch the caller's fields when an update outran the initialised region
+                    early.guard(records, limit, float(SPARSE_REACH))
                 if slab and finalize[0] is not None:
                     self._slab_restore = (finalize[0], live_at_entry)
                 early.enqueue_finalize(*finalize)
@@ -1359,6 +1408,8 @@ class SlavchevaEngine:
             # z-slab: every EXECUTED iteration must have stayed inside what the halo schedule keeps valid -- also those
             # of a batch in which the gate then closed (a large update followed by convergence inside one
             # check_interval).  Every rank sees the same reduced / gathered records, so the raise is collective.
+            if sparse and n_exec > 0 and not dec["max_value"][:n_exec].max() < SPARSE_REACH:
+                raise _SparseStateExceeded()
             reach = self.comm.layout.halo if slab else 0
             if slab and not self.sobolev and self._fast.exchange_interval > 1:
                 reach = 1  # inside an exchange group every iteration may consume one slice of validity only
@@ -1385,7 +1436,8 @@ class SlavchevaEngine:
         elif early is not None and n_exec == limit:
             outcome = early
         else:
-            outcome = SlavchevaOutcome(grid, canonical, state=states[n_exec % 2], listed=listed)
+            outcome = SlavchevaOutcome(grid, canonical, state=states[n_exec % 2], listed=listed,
+                                       sparse=prepared if sparse else None)
         # what is needed to (re)produce gradient_field of the last executed iteration on demand
         if n_exec == 0:
             self._gradient_state = ("zeros", torch.zeros((dims,) + tuple(live.shape), dtype=torch.float32,
@@ -1397,7 +1449,8 @@ class SlavchevaEngine:
         elif self.sobolev:
             self._gradient_state = ("ready", self._last_g)
         else:
-            self._gradient_state = ("recompute", states[(n_exec - 1) % 2], canonical, grid)
+            self._gradient_state = ("recompute", states[(n_exec - 1) % 2], canonical, grid,
+                                    (prepared, live) if sparse else None)
         return outcome
 
     def _call_hook(self, i, max_warp, lives, warps, states, canonical, grid, sob=None):
@@ -1413,7 +1466,7 @@ class SlavchevaEngine:
             live_now = torch.empty(tuple(states[0].shape[:-1]), dtype=torch.float32, device=states[0].device)
             warp_planar = torch.empty((grid.dims,) + tuple(live_now.shape), dtype=torch.float32, device=live_now.device)
             dev.state_unpack(states[(i + 1) % 2], dev.full_range(grid), live_now, warp_planar, None)
-            self._gradient_state = ("recompute", states[i % 2], canonical, grid)
+            self._gradient_state = ("recompute", states[i % 2], canonical, grid, None)
             g = self.gradient_field()
         own = (slice(None), self.comm.layout.owned_local()) if self._slab() else (slice(None),)
         self.iteration_hook(0, i, dev.interleave(warp_planar[own].contiguous()), dev.interleave(g[own].contiguous()),
@@ -1436,7 +1489,11 @@ class SlavchevaEngine:
         if st[0] == "wide":  # the call was re-run on a wider internal slab: its gradient, cut to this slab's slices
             g = st[1].gradient_field()
             return None if g is None else g[:, st[2]].contiguous()
-        _, state_in, canonical, grid = st
+        _, state_in, canonical, grid = st[:4]
+        if len(st) > 4 and st[4] is not None:
+            # the state was initialised near the band only: complete it from the call's live array, which still holds the
+            # input wherever no list entry points (the finalize pass writes listed voxels only)
+            st[4][0].complete(state_in, st[4][1])
         live_in = torch.empty(tuple(state_in.shape[:-1]), dtype=torch.float32, device=state_in.device)
         warp_in = torch.empty((grid.dims,) + tuple(live_in.shape), dtype=torch.float32, device=state_in.device)
         dev.state_unpack(state_in, grid, live_in, warp_in, None)

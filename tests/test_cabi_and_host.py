@@ -180,7 +180,13 @@ def test_slab_runtime_argument_errors(pkg):
     assert L.lib.lsf_slab_comm_create(None, ctypes.cast(ident, ctypes.c_void_p), 3, 2, ctypes.byref(handle)) == -1  # rank
     assert L.lib.lsf_slab_unique_id(None, None) == -1
     assert L.lib.lsf_slab_comm_destroy(None) == 0
-    assert L.lib.lsf_state_prepare_scratch_elements(ctypes.byref(grid)) == 2 * 2 + 64 * 1 + 2 + 2  # one 1024-voxel chunk
+    assert L.lib.lsf_state_prepare_scratch_elements(ctypes.byref(grid)) == 2 * 2 + 64 * 1 + 2 + 2 + 2  # one 1024-voxel chunk
+    # the sparse initialisation: whole arrays, a reach of 1..8 voxels, at least one state
+    whole = L.Grid(3, 16, 8, 8, 0, 16, 0, 0)
+    assert L.lib.lsf_state_pack_needed(1, 1, 1, ctypes.byref(grid), 1, 2, 0, None) == -1      # not a whole array
+    assert L.lib.lsf_state_pack_needed(1, 1, 1, ctypes.byref(whole), 1, 0, 0, None) == -1     # reach
+    assert L.lib.lsf_state_pack_needed(1, None, None, ctypes.byref(whole), 1, 2, 0, None) == -1
+    assert L.lib.lsf_records_exceed(None, 3, 2.0, 1, None) == -1
     assert L.lib.lsf_band_list_fill_prepared(ctypes.byref(grid), L.BAND_INTERIOR, 1, 1, None) == -1  # not a whole array
 
 

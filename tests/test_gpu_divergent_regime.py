@@ -10,8 +10,7 @@
   vectorised restatement carries the NaNs through, and that is what the kernels are held to: no fault, the same
   iteration counts, the same maxima up to the first non-finite one, the same finite mask and the same finite values.)
 * `SlavchevaOptimizer2d` leaving its loop through the UPPER warp threshold (slavcheva_optimizer2d.py:360-362: the loop
-  runs while lo < max_warp < hi): the iteration that crosses `maximum_warp_length_upper_threshold` is the last one, the
-  convergence report says `is_largest_above_max_threshold`.
+  runs while lo < max_warp < hi): the iteration that crosses `maximum_warp_length_upper_threshold` is the last one.
 """
 import warnings
 
@@ -149,5 +148,9 @@ def test_slavcheva_leaves_through_the_upper_threshold(lsf, ref_slavcheva, tmp_pa
         assert np.array_equal(live, live_ref) and np.array_equal(opt.warp_field, ref.warp_field)
         report = opt.get_convergence_report()
         assert report.iteration_count == k + 1 and not report.iteration_limit_reached
-        assert report.warp_delta_statistics.is_largest_above_max_threshold
-        assert not report.warp_delta_statistics.is_largest_below_min_threshold
+        # the report's statistics are those of the FINAL warp field (slavcheva_optimizer2d.py:393-397), which the re-warp
+        # has zeroed wherever the live field snapped (field_warping.py:138-141): its longest vector need not be the
+        # iteration's maximum that ended the loop
+        lengths = np.linalg.norm(opt.warp_field, axis=-1)
+        assert abs(report.warp_delta_statistics.length_max - float(lengths.max())) <= 1e-5
+        assert report.warp_delta_statistics.is_largest_above_max_threshold == bool(lengths.max() > hi)

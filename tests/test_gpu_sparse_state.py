@@ -1,0 +1,144 @@
+"""The ping-pong states initialised NEAR THE BAND ONLY (round 4: dev.StatePrepare(sparse_reach=...), lsf_state_pack_needed):
+a call must give the same bits as on fully initialised states -- live field, warp, every record, the convergence report,
+the recomputed gradient -- and a call whose updates outrun the initialised region must notice ON THE DEVICE (the finalize
+pass enqueued behind the last iteration leaves the caller's array alone), run again on full states and still be right.
+Reference loop: nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:238-330, :360-362; warp_field_advanced field_warping.py:112-151.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lsf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+KILLING = dict(level_set_term_enabled=True, gradient_descent_rate=0.1, data_term_weight=1.0, smoothing_term_weight=0.2,
+               isomorphic_enforcement_factor=0.1, level_set_term_weight=0.2, maximum_warp_length_lower_threshold=0.0)
+
+
+@pytest.fixture(scope="module")
+def lsf():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import levelsetfusion_python_amd as pkg
+    return pkg
+
+
+class _Sparse:
+    """engine.SPARSE_REACH / SPARSE_MIN_VOXELS for the duration of a block"""
+
+    def __init__(self, reach, min_voxels=0):
+        self.new = (reach, min_voxels)
+
+    def __enter__(self):
+        from levelsetfusion_python_amd import engine
+        self.engine = engine
+        self.old = (engine.SPARSE_REACH, engine.SPARSE_MIN_VOXELS)
+        engine.SPARSE_REACH, engine.SPARSE_MIN_VOXELS = self.new
+
+    def __exit__(self, *a):
+        self.engine.SPARSE_REACH, self.engine.SPARSE_MIN_VOXELS = self.old
+
+
+def _run3d(lsf, canonical, live0, reach, **kw):
+    with _Sparse(reach):
+        opt = lsf.SlavchevaOptimizer3d(field_size=canonical.shape[-1], compute_method=lsf.ComputeMethod.DIRECT, **kw)
+        live = live0.clone()
+        opt.optimize(live, canonical)
+        g = opt.gradient_field
+    return opt, live, g
+
+
+def _same(a, b, energies=1e-12):
+    (oa, la, ga), (ob, lb, gb) = a, b
+    assert torch.equal(la, lb), "live field"
+    assert torch.equal(torch.as_tensor(oa.warp_field), torch.as_tensor(ob.warp_field)), "warp field"
+    assert np.array_equal(np.float32(oa.log.max_warps), np.float32(ob.log.max_warps))
+    assert oa.log.max_warp_locations == ob.log.max_warp_locations
+    for x, y in ((oa.log.data_energies, ob.log.data_energies), (oa.log.smoothing_energies, ob.log.smoothing_energies),
+                 (oa.log.level_set_energies, ob.log.level_set_energies)):
+        assert np.allclose(x, y, rtol=energies, atol=0.0)
+    assert oa.get_convergence_report() == ob.get_convergence_report()
+    assert np.array_equal(ga, gb), "gradient field"
+
+
+@pytest.mark.parametrize("n,iterations", [(128, 12), (192, 6)])
+def test_sparse_states_change_nothing(lsf, n, iterations):
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live0 = sphere_pair(n, 3, "cuda")
+    kw = dict(KILLING, smoothing_term_method=lsf.SmoothingTermMethod.KILLING, max_iterations=iterations,
+              min_iterations=iterations)
+    full = _run3d(lsf, canonical, live0, 0, **kw)
+    for reach in (1, 2):
+        sparse = _run3d(lsf, canonical, live0, reach, **kw)
+        state = sparse[0]._engine._gradient_state
+        assert not getattr(sparse[0]._engine, "_sparse_disabled", False)
+        _same(sparse, full)
+    # what the step saves: the share of the volume the prepare step wrote (reach 2)
+    from levelsetfusion_python_amd import device as dev
+    prepared = dev.StatePrepare(live0, canonical, sparse_reach=2)
+    prepared.collect()
+    share = prepared.needed_fraction()
+    assert 0.05 < share < 0.5, share
+    # ... and complete() makes such a state equal to a fully initialised one, word for word
+    whole = dev.state_pack(live0, None, prepared.grid, copies=1)[0]
+    for st in prepared.states:
+        prepared.complete(st, live0)
+        assert torch.equal(st, whole)
+
+
+def test_sparse_threshold_terminated_and_sobolev(lsf):
+    """a gated run (the host looks at every batch) and the SobolevFusion iteration on the float4 layouts"""
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live0 = sphere_pair(128, 3, "cuda")
+    gated = dict(KILLING, smoothing_term_method=lsf.SmoothingTermMethod.KILLING, max_iterations=30, min_iterations=1,
+                 maximum_warp_length_lower_threshold=0.31, check_interval=4)
+    a, b = _run3d(lsf, canonical, live0, 2, **gated), _run3d(lsf, canonical, live0, 0, **gated)
+    assert 1 < len(a[0].log.max_warps) < 30  # the threshold ended it
+    _same(a, b)
+    k7 = lsf.generate_1d_sobolev_kernel(7, 0.1)
+    sob = dict(sobolev_smoothing_enabled=True, sobolev_kernel=k7, maximum_warp_length_lower_threshold=0.0,
+               max_iterations=6, min_iterations=6)
+    _same(_run3d(lsf, canonical, live0, 2, **sob), _run3d(lsf, canonical, live0, 0, **sob))
+
+
+def test_updates_beyond_the_reach_fall_back_and_stay_right(lsf):
+    """rate 20: the first iteration already moves more than two voxels.  Fixed count: the finalize pass is enqueued behind
+    the last iteration and must have skipped itself; gated: the host notices after the first batch.  Either way the call
+    runs again on full states, the optimizer remembers, and the result is the full-state result"""
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live0 = sphere_pair(128, 3, "cuda")
+    for extra in (dict(max_iterations=4, min_iterations=4), dict(max_iterations=4, min_iterations=1, check_interval=2)):
+        kw = dict(KILLING, smoothing_term_method=lsf.SmoothingTermMethod.KILLING, **extra)
+        kw["gradient_descent_rate"] = 20.0
+        full = _run3d(lsf, canonical, live0, 0, **kw)
+        assert max(full[0].log.max_warps) > 2.0
+        sparse = _run3d(lsf, canonical, live0, 2, **kw)
+        assert sparse[0]._engine._sparse_disabled
+        _same(sparse, full)
+        # the same optimizer again: straight to full states, same answer
+        with _Sparse(2):
+            live = live0.clone()
+            sparse[0].optimize(live, canonical)
+        assert torch.equal(live, full[1])
+
+
+def test_reference_sized_updates_in_2d(lsf, ref_slavcheva, tmp_path):
+    """KillingFusion on the reference's own 64^2 orthographic pair moves 6-7 voxels per iteration: with the sparse path
+    forced on (it is off below 2^21 voxels) the call falls back and still equals the reference's outputs"""
+    S = ref_slavcheva
+    live0, canon = S["ortho64.live"], S["ortho64.canonical"]
+    kw = dict(compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+              smoothing_term_method=lsf.SmoothingTermMethod.KILLING, maximum_warp_length_lower_threshold=0.0,
+              max_iterations=3, min_iterations=3)
+    with _Sparse(2):
+        opt = lsf.SlavchevaOptimizer2d(out_path=str(tmp_path), field_size=64, **kw)
+        live = live0.copy()
+        opt.optimize(live, canon)
+    assert opt._engine._sparse_disabled
+    ref = O.SlavchevaOracle(compute_method=O.DIRECT, level_set_term_enabled=True, smoothing_term_method=O.KILLING,
+                            maximum_warp_length_lower_threshold=0.0, max_iterations=3, min_iterations=3)
+    live_ref = live0.copy()
+    ref.optimize(live_ref, canon)
+    assert np.array_equal(live, live_ref) and np.array_equal(opt.warp_field, ref.warp_field)
+    assert np.abs(live - S["ortho64.killing.live.2"]).max() <= 1e-5 if "ortho64.killing.live.2" in S.files else True

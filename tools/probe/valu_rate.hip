@@ -20,7 +20,7 @@ constexpr int kIters = 2000;
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define REP64(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X)
 
-enum Kind { ADD, PK_ADD, FMA, PK_FMA, MUL, PK_MUL, CNDMASK, SQRT, RCP, ADD_F64, CVT_F64, ADD_DEP, PK_ADD_DEP, MOV_DPP, PK_MOV };
+enum Kind { ADD, PK_ADD, FMA, PK_FMA, MUL, PK_MUL, CNDMASK, CNDMASK_SGPR, CMP, MAX, AND, ADD_U32, LSHL_ADD, CVT_I, SQRT, RCP, ADD_F64, CVT_F64, ADD_DEP, PK_ADD_DEP, MOV_DPP, PK_MOV };
 
 template <int KIND>
 __global__ __launch_bounds__(1024) void rate(unsigned long long* __restrict__ out, float seed) {
@@ -36,6 +36,9 @@ __global__ __launch_bounds__(1024) void rate(unsigned long long* __restrict__ ou
     const float b = seed * 1.0001f + 1e-3f;
     const vf2 pb = {b, b};
     const double db = (double)b;
+    unsigned long long mask = __builtin_amdgcn_read_exec() ^ (0x5555555555555555ull * (blockIdx.x & 1));
+    unsigned long long masks[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    asm volatile("s_mov_b64 vcc, %0" ::"s"(mask) : "vcc");
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const unsigned long long t0 = __builtin_amdgcn_s_memtime();
@@ -65,7 +68,41 @@ __global__ __launch_bounds__(1024) void rate(unsigned long long* __restrict__ ou
             REP64(X)
 #undef X
         } else if constexpr (KIND == CNDMASK) {
-#define X(i) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+            // ONE asm statement per 8 selects: a statement that names vcc as clobbered makes the compiler pad the next
+            // reader with s_nop (VALU-writes-VCC hazard), which is not what is being measured
+#define X8 asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n" \
+                        "v_cndmask_b32 %3, %3, %8, vcc\n v_cndmask_b32 %4, %4, %8, vcc\n v_cndmask_b32 %5, %5, %8, vcc\n"  \
+                        "v_cndmask_b32 %6, %6, %8, vcc\n v_cndmask_b32 %7, %7, %8, vcc"                                    \
+                        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])   \
+                        : "v"(b));
+            X8 X8 X8 X8 X8 X8 X8 X8
+#undef X8
+        } else if constexpr (KIND == CNDMASK_SGPR) {
+#define X(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(mask));
+            REP64(X)
+#undef X
+        } else if constexpr (KIND == CMP) {
+#define X(i) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(masks[i]) : "v"(a[i]), "v"(b));
+            REP64(X)
+#undef X
+        } else if constexpr (KIND == MAX) {
+#define X(i) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            REP64(X)
+#undef X
+        } else if constexpr (KIND == AND) {
+#define X(i) asm volatile("v_and_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            REP64(X)
+#undef X
+        } else if constexpr (KIND == ADD_U32) {
+#define X(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+            REP64(X)
+#undef X
+        } else if constexpr (KIND == LSHL_ADD) {
+#define X(i) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(a[i]) : "v"(b));
+            REP64(X)
+#undef X
+        } else if constexpr (KIND == CVT_I) {
+#define X(i) asm volatile("v_cvt_i32_f32 %0, %0" : "+v"(a[i]));
             REP64(X)
 #undef X
         } else if constexpr (KIND == SQRT) {
@@ -106,6 +143,7 @@ __global__ __launch_bounds__(1024) void rate(unsigned long long* __restrict__ ou
     float s = 0.0f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += a[i] + p[i].x + p[i].y + (float)d[i];
+    for (int i = 0; i < 8; ++i) s += (float)masks[i];
     if (s == 12345.678f) out[0] = 1;  // keep everything alive
     if ((threadIdx.x & 63) == 0) out[1 + blockIdx.x * 16 + threadIdx.x / 64] = t1 - t0;
 }
@@ -142,7 +180,14 @@ int main() {
     run<PK_ADD>("v_pk_add_f32", dev);
     run<PK_MUL>("v_pk_mul_f32", dev);
     run<PK_FMA>("v_pk_fma_f32", dev);
-    run<CNDMASK>("v_cndmask_b32", dev);
+    run<CNDMASK>("v_cndmask vcc", dev);
+    run<CNDMASK_SGPR>("v_cndmask sgpr", dev);
+    run<CMP>("v_cmp_lt_f32", dev);
+    run<MAX>("v_max_f32", dev);
+    run<AND>("v_and_b32", dev);
+    run<ADD_U32>("v_add_u32", dev);
+    run<LSHL_ADD>("v_lshl_add_u32", dev);
+    run<CVT_I>("v_cvt_i32_f32", dev);
     run<MOV_DPP>("v_mov_dpp", dev);
     run<PK_MOV>("v_pk_mov_b32", dev);
     run<SQRT>("v_sqrt_f32", dev);
