@@ -615,7 +615,8 @@ class SlavchevaOutcome:
     """final fields of one SlavchevaEngine.optimize() call, left on the device in the layout the iteration kernels use
     (the float4 state of the fused path, or planar live / warp of the Sobolev path) and handed out on demand"""
 
-    def __init__(self, grid, canonical, state=None, live=None, warp_planar=None, listed=None, sparse=None):
+    def __init__(self, grid, canonical, state=None, live=None, warp_planar=None, listed=None, sparse=None,
+                 warp_zeroed=None):
         self.grid, self.canonical, self.state = grid, canonical, state
         self._live, self._warp_planar = live, warp_planar
         # (input live field, band lists, state_prepare's unlisted counts): finalize then visits the band voxels only
@@ -623,6 +624,7 @@ class SlavchevaOutcome:
         # dev.StatePrepare whose states were initialised near the band only: readers of the WHOLE state complete it first
         self._sparse = sparse
         self._skip = None
+        self._warp_zeroed = warp_zeroed  # a zero-filled API-layout warp tensor made while the card was idle (or None)
 
     def guard(self, records, count, limit):
         """enqueue the device-side check of a sparse run: a word that is non-zero when one of records[0..count) holds a
@@ -702,7 +704,9 @@ class SlavchevaOutcome:
             unlisted = unlisted or (0, -1)
             if target is not live0:
                 target.copy_(live0)
-            warp = torch.zeros(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
+            warp, self._warp_zeroed = self._warp_zeroed, None
+            if warp is None:
+                warp = torch.zeros(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
             chain = getattr(self, "_chain", None)  # the pass leaves `target` alone if the chain launch flagged its result
             skip = chain.violation_ptr if chain is not None else (self._skip.data_ptr() if self._skip is not None else None)
             raw = dev.state_finalize_listed(self.state, self.canonical, full, bands, unlisted, target, warp,
@@ -1242,6 +1246,7 @@ class SlavchevaEngine:
                                  % (self.comm.layout.halo, need))
         prepared = None
         sparse = False
+        warp_zeroed = None
         # SobolevFusion on band lists of a whole volume runs on the float4 layouts too (one vector-memory instruction per
         # neighbour / tap instead of one per component: lsf_sobolev_state.hip); z-slabs, filters of other lengths and
         # list-less runs keep the planar kernels
@@ -1272,6 +1277,10 @@ class SlavchevaEngine:
                       and os.environ.get("LSF_CHAIN", "0") != "1")
             prepared = dev.StatePrepare(live, canonical, dev.full_range(grid), cut_chunks,
                                         sparse_reach=SPARSE_REACH if sparse else 0)
+            if finalize is not None and not slab:
+                # the listed finalize pass wants a zero-filled warp output (192 MB at 256^3, ~29 us): enqueued HERE it runs
+                # while the host waits for the list sizes and the card would idle, instead of behind the last iteration
+                warp_zeroed = torch.zeros(tuple(live.shape) + (dims,), dtype=torch.float32, device=live.device)
         live_at_entry = None
         if slab and finalize is not None and finalize[0] is not None and not planar_sobolev \
                 and self.min_iterations >= max(self.max_iterations, self.min_iterations):
@@ -1380,7 +1389,7 @@ class SlavchevaEngine:
                 # may still have to be discarded (see optimize()), and the pass writes the caller's tensor: optimize() puts
                 # the copy taken below back before it runs the call again
                 early = SlavchevaOutcome(grid, canonical, state=states[limit % 2], listed=listed,
-                                         sparse=prepared if sparse else None)
+                                         sparse=prepared if sparse else None, warp_zeroed=warp_zeroed)
                 early._chain = chain
                 if sparse:  # the pass must not touch the caller's fields when an update outran the initialised region
                     early.guard(records, limit, float(SPARSE_REACH))
@@ -1437,7 +1446,7 @@ class SlavchevaEngine:
             outcome = early
         else:
             outcome = SlavchevaOutcome(grid, canonical, state=states[n_exec % 2], listed=listed,
-                                       sparse=prepared if sparse else None)
+                                       sparse=prepared if sparse else None, warp_zeroed=warp_zeroed)
         # what is needed to (re)produce gradient_field of the last executed iteration on demand
         if n_exec == 0:
             self._gradient_state = ("zeros", torch.zeros((dims,) + tuple(live.shape), dtype=torch.float32,

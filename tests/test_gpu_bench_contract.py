@@ -25,7 +25,7 @@ def test_default_workload_line():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     d = _run("--size", "64", "--iterations", "4", "--cpu-sample-size", "16", "--cpu-sample-iterations", "2",
-             "--secondary-divisor", "8")
+             "--secondary-divisor", "4")
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in d, key
@@ -45,14 +45,14 @@ def test_default_workload_line():
     assert abs(d["visited_voxel_updates_per_s"] - r["units_per_launch"] * 4 * 2 / (d["ms_per_step"] * 2e-3)) \
         < 1e-6 * d["value"]
     assert r["traffic"] is None and r["traffic_source"]["loaded_build_id"]
-    # the other configurations of BASELINE.json ride on the same line (here at 1/8 of their edge lengths)
+    # the other configurations of BASELINE.json ride on the same line (here at 1/4 of their edge lengths)
     sec = {row["workload"]: row for row in d["secondary"]}
     assert sorted(sec) == ["hier-full", "hier-tik", "hier2d", "killing", "multiframe", "sobolev"]
     for name, row in sec.items():
         assert "error" not in row, row
         assert row["ms_per_step"] > 0 and row["visited_voxel_updates_per_s"] > 0 and row["frac"] > 0 and row["config"]
-    assert sec["killing"]["size"] == 64 and sec["killing"]["kernel_ms"] > 0
-    assert sec["hier2d"]["size"] == 64 and sec["hier2d"]["us_per_iteration"] > 0 and "LAUNCH-BOUND" in sec["hier2d"]["note"]
+    assert sec["killing"]["size"] == 128 and sec["killing"]["kernel_ms"] > 0
+    assert sec["hier2d"]["size"] == 128 and sec["hier2d"]["us_per_iteration"] > 0 and "LAUNCH-BOUND" in sec["hier2d"]["note"]
     assert abs(sec["hier2d"]["us_per_iteration"] - sec["hier2d"]["ms_per_step"] * 1e3 / 300) < 1e-6
 
 

@@ -20,7 +20,7 @@ constexpr int kIters = 2000;
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define REP64(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X)
 
-enum Kind { ADD, PK_ADD, FMA, PK_FMA, MUL, PK_MUL, CNDMASK, CNDMASK_SGPR, CMP, MAX, AND, ADD_U32, LSHL_ADD, CVT_I, SQRT, RCP, ADD_F64, CVT_F64, ADD_DEP, PK_ADD_DEP, MOV_DPP, PK_MOV };
+enum Kind { ADD, PK_ADD, FMA, PK_FMA, MUL, PK_MUL, CNDMASK, CNDMASK_SGPR, PAIR_VCC, PAIR_SGPR, PAIR_SGPR_NOP, CMP, MAX, AND, ADD_U32, LSHL_ADD, CVT_I, SQRT, RCP, ADD_F64, CVT_F64, ADD_DEP, PK_ADD_DEP, MOV_DPP, PK_MOV };
 
 template <int KIND>
 __global__ __launch_bounds__(1024) void rate(unsigned long long* __restrict__ out, float seed) {
@@ -33,6 +33,9 @@ __global__ __launch_bounds__(1024) void rate(unsigned long long* __restrict__ ou
         p[i] = vf2{a[i], a[i] * 0.5f};
         d[i] = (double)a[i];
     }
+    float d2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d2[i] = seed * (float)(i + 1) + (float)threadIdx.x * 0.5f;
     const float b = seed * 1.0001f + 1e-3f;
     const vf2 pb = {b, b};
     const double db = (double)b;
@@ -80,6 +83,19 @@ __global__ __launch_bounds__(1024) void rate(unsigned long long* __restrict__ ou
         } else if constexpr (KIND == CNDMASK_SGPR) {
 #define X(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "s"(mask));
             REP64(X)
+#undef X
+        } else if constexpr (KIND == PAIR_VCC) {
+            // the pattern the compiler emits for `x = c < b ? y : x`: compare into vcc, select from vcc (32 pairs = 64 instr)
+#define X(i) asm volatile("v_cmp_lt_f32 vcc, %1, %2\n v_cndmask_b32 %0, %0, %2, vcc" : "+v"(a[i]) : "v"(d2[i]), "v"(b) : "vcc");
+            REP8(X) REP8(X) REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == PAIR_SGPR) {
+#define X(i) asm volatile("v_cmp_lt_f32_e64 %1, %2, %3\n v_cndmask_b32_e64 %0, %0, %3, %1" : "+v"(a[i]), "=&s"(masks[i]) : "v"(d2[i]), "v"(b));
+            REP8(X) REP8(X) REP8(X) REP8(X)
+#undef X
+        } else if constexpr (KIND == PAIR_SGPR_NOP) {
+#define X(i) asm volatile("v_cmp_lt_f32_e64 %1, %2, %3\n s_nop 1\n v_cndmask_b32_e64 %0, %0, %3, %1" : "+v"(a[i]), "=&s"(masks[i]) : "v"(d2[i]), "v"(b));
+            REP8(X) REP8(X) REP8(X) REP8(X)
 #undef X
         } else if constexpr (KIND == CMP) {
 #define X(i) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(masks[i]) : "v"(a[i]), "v"(b));
@@ -182,6 +198,9 @@ int main() {
     run<PK_FMA>("v_pk_fma_f32", dev);
     run<CNDMASK>("v_cndmask vcc", dev);
     run<CNDMASK_SGPR>("v_cndmask sgpr", dev);
+    run<PAIR_VCC>("cmp+cnd vcc", dev);
+    run<PAIR_SGPR>("cmp+cnd sgpr", dev);
+    run<PAIR_SGPR_NOP>("cmp+nop+cnd s", dev);
     run<CMP>("v_cmp_lt_f32", dev);
     run<MAX>("v_max_f32", dev);
     run<AND>("v_and_b32", dev);
