@@ -413,13 +413,23 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
         faces = world > 1 and (args.pattern or "faces") == "faces"
         pattern = "spheres centred on the slab faces" if faces else "one sphere centred in every slab"
         z_shift = n // 2 if faces else 0
+    if args.data == "depth" and world > 1:
+        # north_star's "synthetic depth->TSDF volumes ... at 1, 2, 4 and 8 GPUs": ONE n^3 pair generated from two synthetic
+        # depth frames, cut into slabs along Y -- the camera looks along +z (tsdf/generation.py:356-437), so the narrow band
+        # is a sheet across z that z-slabs would leave to one or two ranks; y-slabs cut it into equal strips
+        if n % world:
+            raise SystemExit("--data depth: --size %d is not divisible by %d ranks" % (n, world))
+        strong = True
+        halo = args.halo if args.halo is not None else max(1, min(8, (n // world) // 8))
+        layout = SlabLayout(n, rank, world, halo, axis=1)
+        pattern = "one depth-frame pair, cut into slabs along y"
     args.halo = halo
     sl = layout.local_slice()
     if args.data == "depth":
-        if world > 1:
-            raise SystemExit("--data depth is a single-GPU measurement (one surface, not one per slab)")
         from levelsetfusion_python_amd.synthetic import depth_pair
         canonical, live0 = depth_pair(n, device)
+        if world > 1:
+            canonical, live0 = layout.cut(canonical), layout.cut(live0)
     else:
         canonical, live0 = sphere_pair(n, 3, device, (sl.start, sl.stop), z_shift)
 
@@ -495,20 +505,23 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
         band = ~((live0.abs() == 1.0) & (canonical.abs() == 1.0))
         mine = []
         if L.rank > 0:
-            mine.append(int(band[L.z_begin:L.z_begin + h].sum().item()))
+            mine.append(int(band.narrow(L.axis, L.begin, h).sum().item()))
         if L.rank < world - 1:
-            mine.append(int(band[L.z_end - h:L.z_end].sum().item()))
+            mine.append(int(band.narrow(L.axis, L.end - h, h).sum().item()))
         fast = getattr(opt._engine, "_fast", None)
         compact = fast is not None and getattr(fast, "native", None) is not None and getattr(fast, "faces_ref", None) is not None
-        face_bytes = [16 * v for v in mine] if compact else [16 * h * live0.shape[1] * live0.shape[2]] * len(mine)
+        face_voxels = h * live0.numel() // live0.shape[L.axis]
+        face_bytes = [16 * v for v in mine] if compact else [16 * face_voxels] * len(mine)
         interval = getattr(fast, "exchange_interval", 1) if fast is not None else 1
         rows = [None] * world
-        dist.all_gather_object(rows, dict(band_voxels=mine, bytes=face_bytes))
+        dist.all_gather_object(rows, dict(band_voxels=mine, bytes=face_bytes,
+                                          band=int(layout.owned_of(band).sum().item())))
         per_face = [v for r in rows for v in r["band_voxels"]]
         halo_info = dict(halo_slices=h, iterations_per_exchange=interval,
                          exchanges_per_step=len([i for i in range(iters) if i % interval == interval - 1 and i + 1 < iters]),
                          faces="compact (band voxels only)" if compact else "whole slices",
-                         band_voxels_per_face=per_face, face_voxels=h * live0.shape[1] * live0.shape[2],
+                         band_voxels_per_face=per_face, face_voxels=face_voxels,
+                         band_voxels_per_rank=[r["band"] for r in rows],
                          bytes_sent_per_exchange_per_rank=[sum(r["bytes"]) for r in rows])
 
     # ---- roofline of the dominant kernel: the fused warp-update kernel alone, HIP events on its stream, over exactly
@@ -617,8 +630,8 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
                                     "iterations per step, %s" % (n, iters, "sphere-pair TSDF" if args.data == "sphere"
                                                                  else "TSDF pair from two synthetic depth frames"),
                            voxels_per_gpu=voxels_per_rank, iterations_per_step=iters,
-                           parallelism=("z-slab x%d (%s: %s), halo %d, %s" % (
-                               world, "strong scaling" if strong else "weak scaling", pattern, args.halo,
+                           parallelism=("%s-slab x%d (%s: %s), halo %d, %s" % (
+                               "zy"[layout.axis], world, "strong scaling" if strong else "weak scaling", pattern, args.halo,
                                "RCCL send/recv from the library (lsf_slab_state_iteration)"
                                if comm.native() is not None else "torch.distributed " + args.backend))
                            if world > 1 else "single GPU"),

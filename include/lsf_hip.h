@@ -50,11 +50,19 @@ typedef struct lsf_grid {
     int32_t nz, ny, nx;      /* allocated extents, nz = 1 when dims == 2 */
     int32_t z_begin, z_end;  /* slices processed by the launch, 0 <= z_begin <= z_end <= nz */
     int32_t z_global_offset; /* global z of local slice 0 (for reported voxel indices) */
-    int32_t reserved;
+    int32_t y_global_offset; /* global y of local row 0: slabs cut along y; 0 otherwise */
     /* lsf_slavcheva_state_iteration only: energies are accumulated for slices in [energy_z_begin, energy_z_end) --
      * a z-slab launch that recomputes halo slices must not count them twice.
      * energy_z_end <= energy_z_begin (e.g. both 0): every slice of the launch counts. */
     int32_t energy_z_begin, energy_z_end;
+    /* Slabs cut along y (lsf_slavcheva_state_iteration on band lists and lsf_state_finalize_listed honour these; every
+     * other entry point requires y_global_offset == 0 and ny_global in {0, ny}): the local array holds rows
+     * [y_global_offset, y_global_offset + ny) of a volume with ny_global rows (0 = ny: not cut along y).  Reported voxel
+     * indices are ((z + z_global_offset) * ny_global + y + y_global_offset) * nx + x, gather positions are formed from the
+     * GLOBAL row (float32(y + y_global_offset) + displacement, as with z), and energies count rows in
+     * [energy_y_begin, energy_y_end) only (energy_y_end <= energy_y_begin: every row). */
+    int32_t ny_global;
+    int32_t energy_y_begin, energy_y_end;
 } lsf_grid;
 
 /* per-iteration reduction record written by the iteration kernels (one record per iteration).
@@ -310,15 +318,15 @@ int lsf_band_list_fill(const float *live, const float *canonical, const lsf_grid
  * an iteration can read them: the 1024-voxel chunks that have a voxel within `reach` voxels (per axis) of a chunk that
  * holds band voxels -- 3^D stencils reach 1, the re-warp gather of an update shorter than `reach` voxels reaches `reach`
  * (1 <= reach <= 8).  Everything else of the two buffers stays UNINITIALISED: a run is valid only while every
- * iteration's maximum update stays below `reach` (lsf_records_exceed tells, on the device, in front of a finalize pass
- * with a skip_flag), and whole-state readers (lsf_state_unpack, lsf_state_finalize) must first complete the state with
+ * iteration's maximum update stays below `reach` (lsf_state_finalize_listed's guard_records check that on the device,
+ * the host on the records it reads), and whole-state readers (lsf_state_unpack, lsf_state_finalize) must first complete the state with
  * invert = 1 (writes exactly the chunks the first call left out, from the verdicts it kept in scratch).  On a narrow
  * band this replaces 2 x 16 B per VOXEL of initialisation by 2 x 16 B per voxel NEAR THE BAND (a quarter of a 256^3
- * sphere pair).  lsf_records_exceed: *flag = 1 if any of records[0..count) was executed with a maximum >= limit or NaN. */
+ * sphere pair). */
 int64_t lsf_state_prepare_scratch_elements(const lsf_grid *grid);
 int lsf_state_pack_needed(const float *live, float *state_a, float *state_b, const lsf_grid *grid, int32_t *scratch,
                           int32_t reach, int32_t invert, void *stream);
-int lsf_records_exceed(const lsf_iteration_record *records, int32_t count, float limit, int32_t *flag, void *stream);
+
 int lsf_band_list_fill_prepared(const lsf_grid *grid, int32_t subset, const int32_t *scratch, int32_t *list,
                                 void *stream);
 int lsf_state_prepare(const float *live, const float *canonical, float *state_a, float *state_b,
@@ -348,11 +356,16 @@ int lsf_planar_finalize(const float *live, const float *warp_planar, const float
  * take the unlisted voxels from lsf_state_prepare's counts_out[2..4): opposite_count of them have
  * |canonical - live| = 2, the first one at voxel first_opposite (-1: none), the others 0.  scratch as lsf_state_finalize.
  * skip_flag (may be NULL): a DEVICE word; when it is non-zero as the pass runs, live_out and warp_interleaved_out are
- * left untouched (and the statistics are meaningless) -- the chain add-on (include/lsf_hip_chain.h) raises such a word. */
+ * left untouched (and the statistics are meaningless) -- the chain add-on (include/lsf_hip_chain.h) raises such a word.
+ * guard_records (may be NULL): the pass also leaves everything untouched when one of guard_records[0..guard_count) was
+ * executed with a maximum update that is not below guard_limit (NaN included): the run's sparsely initialised states
+ * (lsf_state_pack_needed) may then have been read where they were never written. */
 int lsf_state_finalize_listed(const float *state, const float *canonical, float *live_out, float *warp_interleaved_out,
                               const lsf_grid *grid, const int32_t *const *band_lists, const int64_t *band_counts,
                               int32_t n_lists, int64_t opposite_count, int64_t first_opposite, float lower_threshold,
-                              double *statistics16, double *scratch, const int32_t *skip_flag, void *stream);
+                              double *statistics16, double *scratch, const int32_t *skip_flag,
+                              const lsf_iteration_record *guard_records, int32_t guard_count, float guard_limit,
+                              void *stream);
 int lsf_slavcheva_state_iteration(const float *state_in, const float *canonical, float *state_out,
                                   const lsf_grid *grid, const lsf_slavcheva_params *params, const lsf_gate *gate,
                                   lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,

@@ -22,7 +22,7 @@ ABI_VERSION = 3
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "f32cfffb9498bfa0"
+HEADER_ABI_HASH = "b057a086c32c8b57"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -37,7 +37,8 @@ GATE_HIERARCHICAL, GATE_SLAVCHEVA, GATE_OPEN = 0, 1, 2
 class Grid(ctypes.Structure):
     _fields_ = [("dims", ctypes.c_int32), ("nz", ctypes.c_int32), ("ny", ctypes.c_int32), ("nx", ctypes.c_int32),
                 ("z_begin", ctypes.c_int32), ("z_end", ctypes.c_int32), ("z_global_offset", ctypes.c_int32),
-                ("reserved", ctypes.c_int32), ("energy_z_begin", ctypes.c_int32), ("energy_z_end", ctypes.c_int32)]
+                ("y_global_offset", ctypes.c_int32), ("energy_z_begin", ctypes.c_int32), ("energy_z_end", ctypes.c_int32),
+                ("ny_global", ctypes.c_int32), ("energy_y_begin", ctypes.c_int32), ("energy_y_end", ctypes.c_int32)]
 
 
 BAND_ALL, BAND_INTERIOR, BAND_BOUNDARY = 0, 1, 2
@@ -150,13 +151,12 @@ PROTOTYPES = {
     "lsf_state_prepare": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp, _vp, _vp]),
     "lsf_state_pack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp]),
     "lsf_state_pack_needed": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _vp, _i32, _i32, _vp]),
-    "lsf_records_exceed": (ctypes.c_int, [_vp, _i32, _f32, _vp, _vp]),
     "lsf_state_unpack": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _vp]),
     "lsf_state_finalize_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
     "lsf_state_finalize": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _f32, _vp, _vp, _vp]),
     "lsf_planar_finalize": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _f32, _vp, _vp, _vp]),
     "lsf_state_finalize_listed": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _P(ctypes.c_void_p), _P(_i64), _i32,
-                                                 _i64, _i64, _f32, _vp, _vp, _vp, _vp]),
+                                                 _i64, _i64, _f32, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
     "lsf_slavcheva_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp,
                                                      _vp, _i64, _i32, _vp]),
     "lsf_band_scratch_elements": (ctypes.c_int64, [_P(Grid)]),

@@ -50,6 +50,9 @@ struct Grid {
     unsigned index_offset; // linear_index(g, x, y, z) - vidx(g, x, y, z) = z_global_offset * ny * nx
     int gather_nz, gather_z_offset;  // slices / global z of slice 0 of the hierarchical kernel's GATHER operand (the packed
                                      // live field): the grid's own, or a wider / replicated copy (lsf_hier_params::packed_nz)
+    int y_global_offset, ny_global;  // slabs cut along y (lsf_grid::y_global_offset / ny_global); y_cut = either differs
+    int ey_begin, ey_end;            // rows whose energies count (lsf_grid::energy_y_begin / _end; default: all)
+    int y_cut;
 };
 
 __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
@@ -95,10 +98,20 @@ __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
     r.index_offset = (unsigned)((long long)g->z_global_offset * g->ny * g->nx);
     r.gather_nz = g->nz;
     r.gather_z_offset = g->z_global_offset;
+    r.y_global_offset = g->y_global_offset;
+    r.ny_global = g->ny_global > 0 ? g->ny_global : g->ny;
+    r.y_cut = r.y_global_offset != 0 || r.ny_global != g->ny;
+    const bool y_limited = g->energy_y_end > g->energy_y_begin;
+    r.ey_begin = y_limited ? g->energy_y_begin : 0;
+    r.ey_end = y_limited ? g->energy_y_end : g->ny;
     return r;
 }
 
-__host__ inline int check_grid(const lsf_grid* g) {
+__host__ inline bool grid_is_y_cut(const lsf_grid* g) {
+    return g->y_global_offset != 0 || (g->ny_global > 0 && g->ny_global != g->ny);
+}
+
+__host__ inline int check_grid(const lsf_grid* g, bool allow_y_cut = false) {
     // every entry point validates its grid first: also drop any stale (non-sticky) error an earlier, unrelated
     // runtime call of this thread left behind, so that launch_status() reports THIS launch only
     (void)hipGetLastError();
@@ -108,6 +121,10 @@ __host__ inline int check_grid(const lsf_grid* g) {
     if (g->dims == 2 && g->nz != 1) return LSF_ERR_BAD_DIMS;
     if (g->z_begin < 0 || g->z_end > g->nz || g->z_begin > g->z_end) return LSF_ERR_BAD_ARGUMENT;
     if ((long long)g->nz * g->ny * g->nx > 0x7fffffffll) return LSF_ERR_BAD_DIMS;  // 32-bit voxel indices
+    if (g->y_global_offset < 0 || g->ny_global < 0 || (g->ny_global > 0 && g->y_global_offset + g->ny > g->ny_global))
+        return LSF_ERR_BAD_ARGUMENT;
+    // slabs cut along y: only the entry points of the fused path on band lists know about them
+    if (!allow_y_cut && (g->y_global_offset != 0 || (g->ny_global > 0 && g->ny_global != g->ny))) return LSF_ERR_BAD_ARGUMENT;
     return 0;
 }
 
@@ -377,7 +394,7 @@ __device__ inline void decode_voxel(const Grid& g, unsigned i, int& x, int& y, i
 }
 
 __device__ inline unsigned linear_index(const Grid& g, int x, int y, int z) {
-    return (unsigned)(((long long)(z + g.z_global_offset) * g.ny + y) * g.nx + x);
+    return (unsigned)(((long long)(z + g.z_global_offset) * g.ny_global + (y + g.y_global_offset)) * g.nx + x);
 }
 
 // voxel index inside one plane: 32-bit on purpose (check_grid caps a plane at 2^31-1 voxels) so that loads take the

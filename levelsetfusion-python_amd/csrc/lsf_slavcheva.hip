@@ -471,60 +471,62 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
 // needed when some chunk that holds band voxels has a voxel within `reach` voxels of it along every axis -- the 3^D
 // stencils reach 1, the re-warp gather of an update shorter than `reach` voxels floor(|w|) + 1 <= reach.  In linear
 // indices: the voxels of chunk c shifted by dz * slice + dy * row, |dz|, |dy| <= reach, and widened by `reach` along x,
-// fall into at most three consecutive chunks per (dz, dy) -- row ends only ever add candidates.  One block per chunk:
-// the candidates' non-empty flags (written by lsf_state_prepare) are tested by the first threads, a needed chunk is then
-// written as (live, 0) to both states; needed[c] keeps the verdict for whoever has to complete a state later
-// (invert != 0: write exactly the chunks NOT needed, from the kept verdicts).
+// fall into at most three consecutive chunks per (dz, dy) -- row ends only ever add candidates.  Two steps: the verdicts
+// from the chunks' non-empty flags (written by lsf_state_prepare), then the needed chunks written as (live, 0) to both
+// states; needed[c] keeps the verdict for whoever has to complete a state later (invert != 0: write exactly the chunks
+// NOT needed, from the kept verdicts).
+// step 1: the verdicts, one THREAD per chunk (a few dozen flag loads each: microseconds for the whole volume)
+__global__ __launch_bounds__(kBlock) void chunk_needed_kernel(unsigned chunks, long long row, long long slice, int dims,
+                                                              int reach, const int* __restrict__ nonempty,
+                                                              int* __restrict__ needed) {
+    const unsigned c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= chunks) return;
+    const long long c0 = (long long)c * kBandChunk;
+    const int span = 2 * reach + 1, zs = dims == 3 ? span : 1;
+    bool hit = false;
+    for (int k = 0; k < zs * span && !hit; ++k) {
+        const int dy = k % span - reach, dz = dims == 3 ? k / span - reach : 0;
+        const long long lo = c0 + dz * slice + dy * row - reach, hi = c0 + (long long)kBandChunk - 1 + dz * slice + dy * row + reach;
+        // floor division of possibly negative voxel indices; chunks lo / 1024 .. hi / 1024 (at most three)
+        long long first = lo >= 0 ? lo / kBandChunk : -((-lo + kBandChunk - 1) / kBandChunk);
+        long long last = hi >= 0 ? hi / kBandChunk : -((-hi + kBandChunk - 1) / kBandChunk);
+        first = first < 0 ? 0 : first;
+        last = last >= (long long)chunks ? (long long)chunks - 1 : last;
+        for (long long cand = first; cand <= last; ++cand) hit |= nonempty[cand] != 0;
+    }
+    needed[c] = hit ? 1 : 0;
+}
+
+// step 2: (live, 0) into both states for the chunks whose verdict equals `want`; kPackChunks consecutive chunks per block
+// (their verdicts arrive in one load phase; three chunks in four leave at once on a narrow band)
+constexpr int kPackChunks = 4;
 __global__ __launch_bounds__(kBlock) void state_pack_needed_kernel(const float* __restrict__ live, vf4* __restrict__ a,
                                                                    vf4* __restrict__ b, unsigned n, unsigned chunks,
-                                                                   long long row, long long slice, int dims, int reach,
-                                                                   const int* __restrict__ nonempty,
-                                                                   int* __restrict__ needed, int invert) {
+                                                                   const int* __restrict__ needed, int want) {
     const int t = threadIdx.x;
-    const long long c0 = (long long)blockIdx.x * kBandChunk;
-    int want;
-    if (invert) {
-        want = needed[blockIdx.x] == 0;
-    } else {
-        const int span = 2 * reach + 1, zs = dims == 3 ? span : 1;
-        bool hit = false;
-        for (int k = t; k < zs * span * 3; k += kBlock) {
-            const int which = k % 3, dy = (k / 3) % span - reach, dz = dims == 3 ? (k / 3) / span - reach : 0;
-            const long long lo = c0 + dz * slice + dy * row - reach, hi = c0 + (long long)kBandChunk - 1 + dz * slice + dy * row + reach;
-            // floor division of possibly negative voxel indices; chunks lo / 1024 .. hi / 1024 (at most three)
-            const long long first = lo >= 0 ? lo / kBandChunk : -((-lo + kBandChunk - 1) / kBandChunk);
-            const long long last = hi >= 0 ? hi / kBandChunk : -((-hi + kBandChunk - 1) / kBandChunk);
-            const long long cand = first + which;
-            if (cand <= last && cand >= 0 && cand < (long long)chunks) hit |= nonempty[cand] != 0;
-        }
-        want = __syncthreads_or(hit);
-        if (t == 0) needed[blockIdx.x] = want;
-    }
-    if (!want) return;
+    int verdict[kPackChunks];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const unsigned v = blockIdx.x * kBandChunk + j * kBlock + t;
-        if (v < n) {
-            vf4 o;
-            o.x = live[v]; o.y = 0.0f; o.z = 0.0f; o.w = 0.0f;
-            if (a) a[v] = o;
-            if (b) b[v] = o;
+    for (int k = 0; k < kPackChunks; ++k) {
+        const unsigned c = blockIdx.x * kPackChunks + k;
+        verdict[k] = c < chunks ? needed[c] : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < kPackChunks; ++k) {
+        if (verdict[k] != want) continue;
+        const unsigned c = blockIdx.x * kPackChunks + k;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned v = c * kBandChunk + j * kBlock + t;
+            if (v < n) {
+                vf4 o;
+                o.x = live[v]; o.y = 0.0f; o.z = 0.0f; o.w = 0.0f;
+                if (a) a[v] = o;
+                if (b) b[v] = o;
+            }
         }
     }
 }
 
-// flag = 1 when a record of [0, count) -- an executed iteration -- holds a maximum that is not below `limit` (NaN
-// included), else 0.  One block; the slots of a record are combined as the gate combines them.
-__global__ __launch_bounds__(kBlock) void records_exceed_kernel(const lsf_iteration_record* __restrict__ records,
-                                                                unsigned count, float limit, int* __restrict__ flag) {
-    bool bad = false;
-    for (unsigned k = threadIdx.x; k < count * LSF_RECORD_SLOTS; k += kBlock) {
-        const unsigned long long p = records[k / LSF_RECORD_SLOTS].slot[k % LSF_RECORD_SLOTS].max_packed;
-        if (p != 0ull) bad |= !(unpack_max_value(p) < limit);
-    }
-    const int any = __syncthreads_or(bad);
-    if (threadIdx.x == 0) *flag = any ? 1 : 0;
-}
 
 
 // ordered fill of one subset's list from the ballots lsf_state_prepare kept (which = 0 INTERIOR, 1 BOUNDARY).  One WAVE
@@ -696,7 +698,7 @@ static inline int* prepare_nonempty(int32_t* scratch, unsigned chunks) { return 
 static inline int* prepare_needed(int32_t* scratch, unsigned chunks) { return prepare_nonempty(scratch, chunks) + chunks; }
 
 extern "C" int64_t lsf_state_prepare_scratch_elements(const lsf_grid* grid) {
-    if (check_grid(grid)) return 0;
+    if (check_grid(grid, true)) return 0;
     unsigned first, n, chunks;
     band_range(grid, first, n, chunks);
     return 2 * (int64_t)(chunks + 1) + 64 * (int64_t)chunks + 2 + 2 * (int64_t)chunks + 2 * (int64_t)chunks;
@@ -704,7 +706,7 @@ extern "C" int64_t lsf_state_prepare_scratch_elements(const lsf_grid* grid) {
 
 extern "C" int lsf_band_list_fill_prepared(const lsf_grid* grid, int32_t subset, const int32_t* scratch, int32_t* list,
                                            void* stream) {
-    if (int e = check_grid(grid)) return e;
+    if (int e = check_grid(grid, true)) return e;
     if (!scratch || !list || (subset != LSF_BAND_INTERIOR && subset != LSF_BAND_BOUNDARY) || grid->z_begin != 0 ||
         grid->z_end != grid->nz)
         return LSF_ERR_BAD_ARGUMENT;
@@ -719,7 +721,7 @@ extern "C" int lsf_band_list_fill_prepared(const lsf_grid* grid, int32_t subset,
 
 extern "C" int lsf_state_prepare(const float* live, const float* canonical, float* state_a, float* state_b,
                                  const lsf_grid* grid, int32_t* scratch, int64_t* counts_out, void* stream) {
-    if (int e = check_grid(grid)) return e;
+    if (int e = check_grid(grid, true)) return e;
     // state_b: optional; state_a AND state_b NULL: the states are written by lsf_state_pack_needed
     if (!live || !canonical || (!state_a && state_b) || !scratch || !counts_out) return LSF_ERR_BAD_ARGUMENT;
     if (grid->z_begin != 0 || grid->z_end != grid->nz) return LSF_ERR_BAD_ARGUMENT;  // whole arrays only
@@ -744,19 +746,13 @@ extern "C" int lsf_state_pack_needed(const float* live, float* state_a, float* s
     if (grid->z_begin != 0 || grid->z_end != grid->nz) return LSF_ERR_BAD_ARGUMENT;  // whole arrays only
     unsigned first, n, chunks;
     band_range(grid, first, n, chunks);
-    hipLaunchKernelGGL(state_pack_needed_kernel, dim3(chunks), dim3(kBlock), 0, as_stream(stream), live,
-                       reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b), n, chunks, (long long)grid->nx,
-                       (long long)grid->nx * grid->ny, grid->dims, reach, prepare_nonempty(scratch, chunks),
-                       prepare_needed(scratch, chunks), invert);
-    return launch_status();
-}
-
-extern "C" int lsf_records_exceed(const lsf_iteration_record* records, int32_t count, float limit, int32_t* flag,
-                                  void* stream) {
-    (void)hipGetLastError();
-    if (!records || !flag || count < 0) return LSF_ERR_BAD_ARGUMENT;
-    hipLaunchKernelGGL(records_exceed_kernel, dim3(1), dim3(kBlock), 0, as_stream(stream), records, (unsigned)count, limit,
-                       flag);
+    if (!invert)
+        hipLaunchKernelGGL(chunk_needed_kernel, dim3((chunks + kBlock - 1) / kBlock), dim3(kBlock), 0, as_stream(stream),
+                           chunks, (long long)grid->nx, (long long)grid->nx * grid->ny, grid->dims, reach,
+                           prepare_nonempty(scratch, chunks), prepare_needed(scratch, chunks));
+    hipLaunchKernelGGL(state_pack_needed_kernel, dim3((chunks + kPackChunks - 1) / kPackChunks), dim3(kBlock), 0,
+                       as_stream(stream), live, reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b), n, chunks,
+                       prepare_needed(scratch, chunks), invert ? 0 : 1);
     return launch_status();
 }
 

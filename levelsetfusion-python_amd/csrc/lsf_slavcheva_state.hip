@@ -100,7 +100,7 @@ void slavcheva_state_kernel(const vf4* __restrict__ state_in,
                 const NbhState<D> n(state_in, g, x, y, z, sc);
                 band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
             }
-            if (z >= g.e_begin && z < g.e_end) {  // a slab's recomputed halo slices belong to the neighbour's sums
+            if (z >= g.e_begin && z < g.e_end && y >= g.ey_begin && y < g.ey_end) {  // a slab's recomputed halo slices / rows belong to the neighbour's sums
                 en[0] += e[0];
                 en[1] += e[1];
                 en[2] += e[2];
@@ -114,7 +114,7 @@ void slavcheva_state_kernel(const vf4* __restrict__ state_in,
             d.rw.lerp = false;
             d.rw.R = l;
         } else if (!from_taps) {
-            const float px = (float)x + d.wv[0], py = (float)y + d.wv[1];
+            const float px = (float)x + d.wv[0], py = (float)(y + g.y_global_offset) + d.wv[1];
             const float pz = D == 3 ? (float)(z + g.z_global_offset) + d.wv[2] : 0.0f;
             d.rw.lerp = false;
             d.rw.R = state_gather<D>(state_in, g, px, py, pz);
@@ -156,7 +156,7 @@ void slavcheva_state_kernel(const vf4* __restrict__ state_in,
         float gv[3] = {0.0f, 0.0f, 0.0f};
         double e[3] = {0.0, 0.0, 0.0};
         fast_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
-        const bool counted = in_band && z >= g.e_begin && z < g.e_end;
+        const bool counted = in_band && z >= g.e_begin && z < g.e_end && y >= g.ey_begin && y < g.ey_end;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             d.wv[c] = (c < D && in_band) ? (-gv[c]) * p.rate : 0.0f;
@@ -166,14 +166,15 @@ void slavcheva_state_kernel(const vf4* __restrict__ state_in,
         const bool moved = !(d.wv[0] == 0.0f && d.wv[1] == 0.0f && d.wv[2] == 0.0f);
         if (!rewarp_from_taps<D, true>(n, state_in, g, (int)i, x, y, z, d.wv, d.rw)) {
             d.rw.lerp = false;
-            d.rw.R = state_gather<D>(state_in, g, (float)x + d.wv[0], (float)y + d.wv[1],
+            d.rw.R = state_gather<D>(state_in, g, (float)x + d.wv[0], (float)(y + g.y_global_offset) + d.wv[1],
                                      D == 3 ? (float)(z + g.z_global_offset) + d.wv[2] : 0.0f);
         }
         if (!moved) {  // zero displacement: the gather returns live[p] bit for bit (every lerp is a*1 + b*0)
             d.rw.lerp = false;
             d.rw.R = l;
         }
-        const unsigned long long q = listed ? pack_max(len, i + g.index_offset) : 0ull;  // = linear_index(g, x, y, z)
+        // i + index_offset = linear_index(g, x, y, z) unless the slab is cut along y (wave-uniform)
+        const unsigned long long q = listed ? pack_max(len, g.y_cut ? linear_index(g, x, y, z) : i + g.index_offset) : 0ull;
         best = q > best ? q : best;
         LSF_TRACE(4);
         return d;
@@ -445,10 +446,23 @@ __global__ __launch_bounds__(kBlock) void state_finalize_list_kernel(const vf4* 
                                                                      const int* __restrict__ list, unsigned count,
                                                                      int dims, long long index_offset, float lo,
                                                                      double* __restrict__ scratch,
-                                                                     const int* __restrict__ skip_flag) {
+                                                                     const int* __restrict__ skip_flag,
+                                                                     const lsf_iteration_record* __restrict__ guard_records,
+                                                                     unsigned guard_count, float guard_limit) {
     // the chain launch in front of this pass found an update its dependency windows do not cover: the state is not
     // the reference's, the caller's fields stay as they are (lsf_slavcheva_state_chain)
     if (skip_flag && *skip_flag != 0) return;
+    // states initialised near the band only (lsf_state_pack_needed): an executed iteration whose maximum update is not
+    // below the reach may have gathered uninitialised words -- every block looks at the records itself (a few hundred
+    // loads, all blocks at once) instead of a one-block kernel in front of the pass
+    if (guard_records) {
+        bool bad = false;
+        for (unsigned k = threadIdx.x; k < guard_count * LSF_RECORD_SLOTS; k += kBlock) {
+            const unsigned long long p = guard_records[k / LSF_RECORD_SLOTS].slot[k % LSF_RECORD_SLOTS].max_packed;
+            if (p != 0ull) bad |= !(unpack_max_value(p) < guard_limit);
+        }
+        if (__syncthreads_or(bad)) return;
+    }
     FinalizeAccumulator acc;
     for (unsigned k = blockIdx.x * kBlock + threadIdx.x; k < count; k += gridDim.x * kBlock) {
         const long long i = list[k];
@@ -636,7 +650,7 @@ extern "C" int lsf_debug_set_state_trace(void* units, void* waves) {
 
 extern "C" int lsf_state_pack(const float* live, const float* warp_planar, float* state_a, float* state_b,
                               const lsf_grid* grid, void* stream) {
-    if (int e = check_grid(grid)) return e;
+    if (int e = check_grid(grid, true)) return e;
     if (!live || !state_a) return LSF_ERR_BAD_ARGUMENT;
     long long first, n;
     if (!range_of(grid, first, n)) return 0;
@@ -648,7 +662,7 @@ extern "C" int lsf_state_pack(const float* live, const float* warp_planar, float
 
 extern "C" int lsf_state_unpack(const float* state, float* live_out, float* warp_planar_out,
                                 float* warp_interleaved_out, const lsf_grid* grid, void* stream) {
-    if (int e = check_grid(grid)) return e;
+    if (int e = check_grid(grid, true)) return e;
     if (!state) return LSF_ERR_BAD_ARGUMENT;
     long long first, n;
     if (!range_of(grid, first, n)) return 0;
@@ -659,7 +673,7 @@ extern "C" int lsf_state_unpack(const float* state, float* live_out, float* warp
 }
 
 extern "C" int64_t lsf_state_finalize_scratch_elements(const lsf_grid* grid) {
-    if (check_grid(grid)) return 0;
+    if (check_grid(grid, true)) return 0;
     long long first, n;
     range_of(grid, first, n);
     return (int64_t)finalize_blocks(n > 0 ? n : 1) * kFinalizeWords;
@@ -668,8 +682,9 @@ extern "C" int64_t lsf_state_finalize_scratch_elements(const lsf_grid* grid) {
 extern "C" int lsf_state_finalize(const float* state, const float* canonical, float* live_out,
                                   float* warp_planar_out, float* warp_interleaved_out, const lsf_grid* grid,
                                   float lower_threshold, double* statistics16, double* scratch, void* stream) {
-    if (int e = check_grid(grid)) return e;
+    if (int e = check_grid(grid, true)) return e;
     if (!state || (statistics16 && (!canonical || !scratch))) return LSF_ERR_BAD_ARGUMENT;
+    if (statistics16 && grid_is_y_cut(grid)) return LSF_ERR_BAD_ARGUMENT;  // the statistics report z-cut indices only
     long long first, n;
     if (!range_of(grid, first, n)) return statistics16 ? LSF_ERR_BAD_ARGUMENT : 0;
     const unsigned blocks = finalize_blocks(n);
@@ -709,8 +724,10 @@ extern "C" int lsf_state_finalize_listed(const float* state, const float* canoni
                                          const int32_t* const* band_lists, const int64_t* band_counts, int32_t n_lists,
                                          int64_t opposite_count, int64_t first_opposite, float lower_threshold,
                                          double* statistics16, double* scratch, const int32_t* skip_flag,
+                                         const lsf_iteration_record* guard_records, int32_t guard_count, float guard_limit,
                                          void* stream) {
-    if (int e = check_grid(grid)) return e;
+    if (int e = check_grid(grid, true)) return e;
+    if (statistics16 && grid_is_y_cut(grid)) return LSF_ERR_BAD_ARGUMENT;  // the statistics report z-cut indices only
     if (!state || n_lists < 0 || n_lists > 2 || (n_lists && (!band_lists || !band_counts)) ||
         (statistics16 && (!canonical || !scratch)) || grid->z_begin != 0 || grid->z_end != grid->nz)
         return LSF_ERR_BAD_ARGUMENT;
@@ -727,7 +744,7 @@ extern "C" int lsf_state_finalize_listed(const float* state, const float* canoni
                            reinterpret_cast<const vf4*>(state), canonical, live_out, warp_interleaved_out, band_lists[k],
                            (unsigned)band_counts[k], grid->dims, (long long)grid->ny * grid->nx * grid->z_global_offset,
                            lower_threshold, statistics16 ? scratch + (long long)rows * kFinalizeWords : (double*)nullptr,
-                           skip_flag);
+                           skip_flag, guard_records, (unsigned)(guard_records && guard_count > 0 ? guard_count : 0), guard_limit);
         rows += blocks;
         listed += band_counts[k];
     }
@@ -745,9 +762,10 @@ extern "C" int lsf_slavcheva_state_iteration(const float* state_in, const float*
                                              const lsf_gate* gate, lsf_iteration_record* record,
                                              const int32_t* band_list, int64_t band_count, int32_t band_subset,
                                              void* stream) {
-    if (int e = check_grid(grid)) return e;
+    if (int e = check_grid(grid, /*allow_y_cut=*/true)) return e;
     if (!state_in || !canonical || !state_out || state_out == state_in || !params || !record)
         return LSF_ERR_BAD_ARGUMENT;
+    if (grid_is_y_cut(grid) && (!band_list || grid->dims != 3)) return LSF_ERR_BAD_ARGUMENT;  // y-cut slabs: 3-D band lists
     const int tile_y = 4;
     Grid g = make_grid(grid, tile_y);
     g.fast_ok = g.plane * 16 < 0xffffffffll;  // 32-bit byte offsets into the whole float4 state

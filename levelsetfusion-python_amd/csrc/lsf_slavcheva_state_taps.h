@@ -287,7 +287,7 @@ __device__ inline bool wave_span_ok(const Grid& g, int i) {
 // the re-warp's D-linear gather of the live component (OOB -> 1): lerp z, then y, then x as sample_linear does
 template <int D>
 __device__ inline float state_gather(const vf4* __restrict__ s, const Grid& g, float px, float py, float pz) {
-    const AxisTaps ax = axis_taps(px, g.nx, 0), ay = axis_taps(py, g.ny, 0);
+    const AxisTaps ax = axis_taps(px, g.nx, 0), ay = axis_taps(py, g.ny, g.y_global_offset);  // py, pz: GLOBAL positions
     AxisTaps az = ax;
     if (D == 3) az = axis_taps(pz, g.nz, g.z_global_offset);
     const bool cell_inside = ax.v0 && ax.v1 && ay.v0 && ay.v1 && (D == 2 || (az.v0 && az.v1));
@@ -387,7 +387,7 @@ template <int D, bool FAST32>
 __device__ inline bool rewarp_from_taps(const TapsBase<D>& n, const vf4* __restrict__ s, const Grid& g, int i, int x,
                                         int y, int z, const float (&wv)[3], Rewarp& rw) {
     if (D != 3) return false;
-    const NearFar ax((float)x, wv[0]), ay((float)y, wv[1]), az((float)(z + g.z_global_offset), wv[2]);
+    const NearFar ax((float)x, wv[0]), ay((float)(y + g.y_global_offset), wv[1]), az((float)(z + g.z_global_offset), wv[2]);
     const unsigned lowest = min(min((unsigned)x, (unsigned)y), (unsigned)z);
     if (!__all(ax.near && ay.near && az.near && lowest >= 2u)) return false;
     const int slice = g.nx * g.ny;

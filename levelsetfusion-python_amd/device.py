@@ -596,10 +596,12 @@ def planar_finalize(live, warp_planar, canonical, grid, live_out=None, warp_inte
 
 
 def state_finalize_listed(state, canonical, grid, bands, unlisted, live_out=None, warp_interleaved_out=None,
-                          lower_threshold=0.0, statistics=False, skip_flag=None):
+                          lower_threshold=0.0, statistics=False, skip_flag=None, guard=None):
     """state_finalize of whole arrays that visits the voxels of `bands` only (lsf_state_finalize_listed): live_out must
     hold the input live field and warp_interleaved_out zeros already; `unlisted` as state_prepare returned it;
-    skip_flag: device address of a word that turns the pass into a no-op when non-zero (StateChain.violation_ptr)"""
+    skip_flag: device address of a word that turns the pass into a no-op when non-zero (StateChain.violation_ptr);
+    guard = (records, count, limit): the pass is a no-op too when one of the first `count` records holds a maximum update
+    that is not below `limit` (sparsely initialised states, StatePrepare(sparse_reach=...))"""
     n = n_voxels(grid)
     bands = [b for b in bands if b.count]
     stats = scratch = None
@@ -619,7 +621,10 @@ def state_finalize_listed(state, canonical, grid, bands, unlisted, live_out=None
                                         _ptr(stats, 16, "statistics", dtype=torch.float64, allow_none=True),
                                         _ptr(scratch, scratch.numel() if scratch is not None else 0, "scratch",
                                              dtype=torch.float64, allow_none=True),
-                                        ctypes.c_void_p(skip_flag or 0), stream_ptr()),
+                                        ctypes.c_void_p(skip_flag or 0),
+                                        ctypes.c_void_p(guard[0].data_ptr() if guard is not None else 0),
+                                        int(guard[1]) if guard is not None else 0,
+                                        float(guard[2]) if guard is not None else 0.0, stream_ptr()),
           "lsf_state_finalize_listed")
     return stats
 

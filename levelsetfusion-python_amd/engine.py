@@ -623,16 +623,13 @@ class SlavchevaOutcome:
         self._listed = listed
         # dev.StatePrepare whose states were initialised near the band only: readers of the WHOLE state complete it first
         self._sparse = sparse
-        self._skip = None
+        self._guard = None
         self._warp_zeroed = warp_zeroed  # a zero-filled API-layout warp tensor made while the card was idle (or None)
 
     def guard(self, records, count, limit):
-        """enqueue the device-side check of a sparse run: a word that is non-zero when one of records[0..count) holds a
-        maximum update of `limit` voxels or more; the listed finalize pass then leaves the caller's fields alone"""
-        self._skip = torch.empty(1, dtype=torch.int32, device=self._device())
-        _lib.check(_lib.lib.lsf_records_exceed(ctypes.c_void_p(records.data_ptr()), int(count), float(limit),
-                                               ctypes.c_void_p(self._skip.data_ptr()), dev.stream_ptr()),
-                   "lsf_records_exceed")
+        """a sparse run: the listed finalize pass leaves the caller's fields alone when one of records[0..count) holds a
+        maximum update of `limit` voxels or more (it looks at the records itself, on the device)"""
+        self._guard = (records, int(count), float(limit))
 
     def _whole_state(self):
         if self._sparse is not None:
@@ -708,9 +705,10 @@ class SlavchevaOutcome:
             if warp is None:
                 warp = torch.zeros(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
             chain = getattr(self, "_chain", None)  # the pass leaves `target` alone if the chain launch flagged its result
-            skip = chain.violation_ptr if chain is not None else (self._skip.data_ptr() if self._skip is not None else None)
             raw = dev.state_finalize_listed(self.state, self.canonical, full, bands, unlisted, target, warp,
-                                            lower_threshold, statistics, skip_flag=skip)
+                                            lower_threshold, statistics,
+                                            skip_flag=chain.violation_ptr if chain is not None else None,
+                                            guard=self._guard)
             self._live = target
         elif self.state is not None:
             warp = torch.empty(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
@@ -846,6 +844,16 @@ class SlavchevaEngine:
     def _grid(self, live):
         if self.comm is not None and self.comm.active:
             L = self.comm.layout
+            if L.axis == 1:
+                # slabs cut along y: the launches name their voxels by band lists (every z), the grid carries the global
+                # row of local row 0 (gather positions, reported indices) and the owned rows (energies)
+                if live.dim() != 3 or live.shape[1] != L.n_local:
+                    raise ValueError("y-slab runs need a 3-D local field with %d rows, got %r"
+                                     % (L.n_local, tuple(live.shape)))
+                g = dev.make_grid(live.shape)
+                g.y_global_offset, g.ny_global = L.global_offset, L.n_global
+                g.energy_y_begin, g.energy_y_end = L.begin, L.end
+                return g
             if live.dim() != 3 or live.shape[0] != L.nz_local:
                 raise ValueError("slab runs need a 3-D local field with %d slices, got %r"
                                  % (L.nz_local, tuple(live.shape)))
@@ -964,7 +972,7 @@ class SlavchevaEngine:
         if i + 1 < limit and i + 1 >= self.min_iterations:
             self.comm.reduce_max(f.records, i)  # the next iteration's gate tests this record: make it global now
 
-    def _plan_compact_faces(self, f, live, bands, cut, lo, hi, lo_rank, hi_rank):
+    def _plan_compact_faces(self, f, live, bands, cut, lo, hi, lo_rank, hi_rank, faces=None):
         """Only the band voxels of a face travel: every other voxel of the boundary slices never changes (and both ranks
         hold it already).  The sender gathers state[its boundary band voxels], the receiver scatters into its halo band
         voxels -- the same physical voxels in the same ascending order, because both ranks cut their lists out of
@@ -980,8 +988,12 @@ class SlavchevaEngine:
             idx = pieces[0] if len(pieces) == 1 else torch.sort(torch.cat(pieces)).values
             return idx.contiguous(), idx.numel()
         none = (torch.zeros(1, dtype=torch.int32, device=live.device), 0)
-        send = [union(L.z_begin, L.z_begin + h) if lo else none, union(L.z_end - h, L.z_end) if hi else none]
-        recv = [union(L.z_begin - h, L.z_begin) if lo else none, union(L.z_end, L.z_end + h) if hi else none]
+        if faces is not None:  # slabs cut along y: the caller filtered the four lists out by row
+            pad = lambda e: none if e is None or e[1] == 0 else e
+            send, recv = [pad(e) for e in faces["send"]], [pad(e) for e in faces["recv"]]
+        else:
+            send = [union(L.z_begin, L.z_begin + h) if lo else none, union(L.z_end - h, L.z_end) if hi else none]
+            recv = [union(L.z_begin - h, L.z_begin) if lo else none, union(L.z_end, L.z_end + h) if hi else none]
         # A rank's halo holds the neighbour's boundary slices, so what it expects to receive IS what the neighbour sends --
         # if the caller cut consistent slabs.  That contract is cross-checked with the neighbours on EVERY call (a
         # collective and a host read, ~0.2 ms, behind the iterations already queued on the launch stream: the check runs
@@ -1060,6 +1072,8 @@ class SlavchevaEngine:
         boundary slices -> exchange || interior.  Energies count owned slices only (lsf_grid::energy_z_*).  Gated runs
         (the stop test can fire) exchange and reduce every iteration."""
         L = self.comm.layout
+        if L.axis == 1:
+            return self._plan_slab_y(f, live, grid, bands, limit)
         h = L.halo
         lo, hi = L.rank > 0, L.rank < L.world - 1
         _, _, lo_rank, hi_rank = self.comm.native_identity()
@@ -1139,6 +1153,86 @@ class SlavchevaEngine:
             self._comm_stream = torch.cuda.Stream(device=live.device)
             self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
 
+    def _plan_slab_y(self, f, live, grid, bands, limit):
+        """_plan_slab for slabs cut along Y (SlabLayout(axis=1)): the same schedule -- exchange groups of h iterations over
+        row ranges widened by h - 1 - j rows, boundary rows -> exchange || interior rows, deferred waits -- with one
+        difference: a row range is not a contiguous run of the sorted band list, so every part is its own list, filtered
+        out of the lists of the whole local array once per call (y = (index / nx) mod ny: two integer operations and a
+        compaction per part, on the device).  Faces are rows: nz runs of h * nx float4, which only ever travel compacted
+        to their band voxels (gather / scatter by list: a strided face costs nothing extra), or through packed staging
+        buffers on the torch transport."""
+        L = self.comm.layout
+        h = L.halo
+        lo, hi = L.rank > 0, L.rank < L.world - 1
+        _, _, lo_rank, hi_rank = self.comm.native_identity()
+        lo, hi = lo or lo_rank >= 0, hi or hi_rank >= 0
+        own = L.end - L.begin
+        if own < 2 * h:
+            raise ValueError("a slab of %d rows is too thin for a %d-row halo" % (own, h))
+        if bands[0].indices is None:
+            raise ValueError("slabs cut along y run on band lists (use_band_list=True)")
+        fixed = self.min_iterations >= limit
+        f.exchange_interval = h if fixed and not getattr(self, "_exchange_every_iteration", False) else 1
+        nx, ny = grid.nx, grid.ny
+        rows = [((b.indices[:b.count] // nx) % ny) if b.count else None for b in bands]
+
+        def lists_of(ranges):
+            out = []
+            for b, y in zip(bands, rows):
+                if y is None:
+                    continue
+                keep = None
+                for y0, y1 in ranges:
+                    m = (y >= y0) & (y < y1)
+                    keep = m if keep is None else keep | m
+                idx = b.indices[:b.count][keep].contiguous()
+                if idx.numel():
+                    out.append(dev.BandList(idx, idx.numel(), b.subset))
+            return out or [dev.BandList(bands[0].indices[:1], 0, bands[0].subset)]
+
+        def parts(ranges):
+            ranges = [r for r in ranges if r[1] > r[0]]
+            if not ranges:
+                return SlavchevaEngine._Parts([])
+            return SlavchevaEngine._Parts([(grid, lists_of(ranges))])  # the grid already carries the owned rows (energies)
+
+        empty = SlavchevaEngine._Parts([])
+        f.widened_parts = [_Lazy(lambda e=e: (empty, parts([(L.begin - (e if lo else 0), L.end + (e if hi else 0))])))
+                           for e in range(f.exchange_interval)]
+        y_lo, y_hi = L.begin + (h if lo else 0), L.end - (h if hi else 0)
+        f.exchange_parts = _Lazy(lambda: (parts(([(L.begin, y_lo)] if lo else []) + ([(y_hi, L.end)] if hi else [])),
+                                          parts([(y_lo, y_hi)])))
+        e_last = f.exchange_interval - 1
+        in_lo, in_hi = L.begin + (1 if lo else 0), L.end - (1 if hi else 0)
+        f.resume_parts = _Lazy(lambda: (parts([(in_lo, in_hi)]),
+                                        parts(([(L.begin - e_last, in_lo)] if lo else []) +
+                                              ([(in_hi, L.end + e_last)] if hi else []))))
+        self._pending_halos = None
+        f.native = self.comm.native()
+        f.faces_ref = None
+        f.pending_face_plan = None
+        if f.native is not None:
+            # the library's exchange only ever sees compacted faces here; its layout argument is validated, not used
+            f.layout = _lib.SlabLayoutC(grid.ny, grid.nz, grid.nx, L.begin, L.end, h, lo_rank, hi_rank)
+            f.layout_ref = ctypes.byref(f.layout)
+
+            def face(y0, y1):
+                got = lists_of([(y0, y1)])
+                if len(got) == 1:
+                    return got[0].indices[:got[0].count] if got[0].count else got[0].indices[:0], got[0].count
+                idx = torch.sort(torch.cat([g.indices[:g.count] for g in got])).values.contiguous()
+                return idx, idx.numel()
+            self._plan_compact_faces(f, live, None, None, lo, hi, lo_rank, hi_rank,
+                                     faces=dict(send=[face(L.begin, L.begin + h) if lo else None,
+                                                      face(L.end - h, L.end) if hi else None],
+                                                recv=[face(L.begin - h, L.begin) if lo else None,
+                                                      face(L.end, L.end + h) if hi else None]))
+            if f.faces_ref is None:  # the neighbours' lists disagree: rows cannot travel whole through the library
+                f.native = None
+        if f.native is None and not hasattr(self, "_comm_stream"):
+            self._comm_stream = torch.cuda.Stream(device=live.device)
+            self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
+
     def optimize(self, live, canonical, finalize=None):
         """live, canonical: float32 device tensors (z-slab runs: the local slab incl. halos).  Returns a
         SlavchevaOutcome holding the final fields on the device; the caller's tensors are not modified.
@@ -1183,6 +1277,10 @@ class SlavchevaEngine:
         import math
         from .slab import SlabComm, SlabLayout
         L = self.comm.layout
+        if L.axis != 0:
+            raise RuntimeError("a warp update of %.3f voxels outran the %d-row halo of a slab cut along y; the wider "
+                               "re-run exists for z-slabs only: construct the layout with a halo of at least %d rows"
+                               % (max_update, L.halo, int(math.floor(max_update)) + 2))
         per = L.z1 - L.z0
         while True:
             h2 = max(L.halo, int(math.floor(max_update)) + 2)
@@ -1261,7 +1359,7 @@ class SlavchevaEngine:
             # a z-slab run, for the positions of the z cuts in the lists (slices of a multiple of 1024 voxels: the
             # prepare pass's per-chunk prefix counts hold them)
             cut_chunks = None
-            if slab and (grid.ny * grid.nx) % dev.StatePrepare.CHUNK == 0:
+            if slab and self.comm.layout.axis == 0 and (grid.ny * grid.nx) % dev.StatePrepare.CHUNK == 0:
                 zs = self._slab_cut_slices(grid)
                 key = (tuple(zs), grid.ny * grid.nx, live.device)
                 if getattr(self, "_cut_chunk_cache", (None, None))[0] != key:

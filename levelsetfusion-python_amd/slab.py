@@ -30,12 +30,21 @@ def _slot_view(records):
 
 
 class SlabLayout:
-    def __init__(self, nz_global, rank=0, world=1, halo=0):
+    """`world` contiguous slabs of a volume along `axis` (0 = z, the default: a slab and its faces are contiguous runs;
+    1 = y: for volumes whose narrow band is a sheet across z -- a depth frame's surface, tsdf/generation.py:356-437 --,
+    which z-slabs would leave to one or two ranks).  Generic names: `begin` / `end` = owned range inside the local array,
+    `n_local` = local extent incl. halos, `global_offset` = global index of local index 0, `g0` / `g1` = owned range in
+    global indices.  The z-named attributes are the same numbers and are only meaningful for axis 0."""
+
+    def __init__(self, nz_global, rank=0, world=1, halo=0, axis=0):
+        if axis not in (0, 1):
+            raise ValueError("slabs are cut along z (axis 0) or y (axis 1)")
         if nz_global % world != 0:
-            raise ValueError("nz_global=%d is not divisible by the number of slabs %d" % (nz_global, world))
+            raise ValueError("extent %d is not divisible by the number of slabs %d" % (nz_global, world))
         per = nz_global // world
         if world > 1 and halo > per:
             raise ValueError("halo %d wider than a slab of %d slices" % (halo, per))
+        self.axis = axis
         self.nz_global, self.rank, self.world, self.halo = nz_global, rank, world, halo
         self.z0, self.z1 = rank * per, (rank + 1) * per
         self.halo_lo = halo if rank > 0 else 0
@@ -43,13 +52,24 @@ class SlabLayout:
         self.nz_local = per + self.halo_lo + self.halo_hi
         self.z_begin, self.z_end = self.halo_lo, self.halo_lo + per
         self.z_global_offset = self.z0 - self.halo_lo
+        self.n_global, self.g0, self.g1 = self.nz_global, self.z0, self.z1
+        self.n_local, self.begin, self.end, self.global_offset = self.nz_local, self.z_begin, self.z_end, \
+            self.z_global_offset
 
     def local_slice(self):
-        """slice of the GLOBAL z axis held locally (owned slab + halos)"""
+        """slice of the GLOBAL partition axis held locally (owned slab + halos)"""
         return slice(self.z0 - self.halo_lo, self.z1 + self.halo_hi)
 
     def owned_local(self):
         return slice(self.z_begin, self.z_end)
+
+    def cut(self, volume):
+        """the local part (owned slab + halos) of a whole [z][y][x] volume"""
+        return (volume[self.local_slice()] if self.axis == 0 else volume[:, self.local_slice()]).contiguous()
+
+    def owned_of(self, local):
+        """the owned part of a local [z][y][x] (or [z][y][x][c]) array"""
+        return local[self.owned_local()] if self.axis == 0 else local[:, self.owned_local()]
 
 
 class SlabComm:
@@ -124,8 +144,10 @@ class SlabComm:
         self._native = None
 
     def _z_view(self, t, a, b):
-        # scalar field [z,y,x] or planar vector field [c,z,y,x]
-        return t[a:b] if t.dim() == 3 else t[:, a:b]
+        # scalar field [z,y,x] or planar vector field [c,z,y,x]; slices [a, b) along the layout's partition axis
+        if self.layout.axis == 0:
+            return t[a:b] if t.dim() == 3 else t[:, a:b]
+        return t[:, a:b] if t.dim() == 3 else t[:, :, a:b]
 
     def _staging(self, key, shape, like):
         """persistent send / receive staging buffers (allocated once per distinct message shape)"""
@@ -150,8 +172,9 @@ class SlabComm:
         if h > L.halo:
             raise ValueError("requested halo width %d exceeds the layout's halo %d" % (h, L.halo))
         channels = [1 if t.dim() == 3 else t.shape[0] for t in tensors]
-        plane = tuple(tensors[0].shape[-2:])
-        shape = (sum(channels), h) + plane
+        probe = self._z_view(tensors[0], 0, h)
+        plane = tuple(probe.shape[-3:]) if L.axis == 1 else tuple(tensors[0].shape[-2:])  # one message row per channel
+        shape = (sum(channels),) + (plane if L.axis == 1 else (h,) + plane)
         ops, unpack = [], []
         # (neighbour rank, owned slices to send, halo slices to fill)
         sides = []
@@ -212,7 +235,8 @@ class SlabComm:
         L = self.layout
         if not self.active or L.halo == 0:
             return
-        if self.stage_through_host or not state.is_cuda:
+        if self.stage_through_host or not state.is_cuda or L.axis != 0:
+            # y-slabs: a face is nz runs of halo * nx float4 -- packed into / out of persistent staging buffers
             return self.exchange_halos([state.view(state.shape[0], state.shape[1], -1)])
         h = L.halo
         _, _, lo, hi = self.native_identity()

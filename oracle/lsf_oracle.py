@@ -37,22 +37,32 @@ LEVEL_SET_EPS = F32(1e-5)   # level_set_term.py:28
 # =====================================================================================================
 #  a1/a2  D-linear resampling under a warp         (utils/sampling.py:139-175,222-263; field_warping.py:67-109)
 # =====================================================================================================
+def _axis_offsets(axis0_offset, d):
+    """per-axis global offsets of a slab's index 0: an int = a z-slab (axis 0), a tuple = one offset per axis (slabs cut
+    along y carry theirs in position 1)"""
+    if isinstance(axis0_offset, (tuple, list)):
+        return [int(v) for v in axis0_offset] + [0] * (d - len(axis0_offset))
+    return [int(axis0_offset)] + [0] * (d - 1)
+
+
 def _grid_positions(warp, axis0_offset=0):
     """float32 sample positions p + warp[p], one array per spatial axis (axis order), as
     field_warping.py:82  Point2d(x, y) + Point2d(coordinates=warp[y, x])  evaluates them under numpy>=2.
     axis0_offset: the array is a z-slab whose slice 0 is slice `axis0_offset` of the whole volume -- positions along
     axis 0 are formed from the GLOBAL coordinate (float32 rounding of coordinate + displacement depends on the
-    coordinate's magnitude), sample_linear takes the same offset back out of the tap indices."""
+    coordinate's magnitude), sample_linear takes the same offset back out of the tap indices.
+    A tuple gives one offset per axis (slabs cut along y)."""
     shape = warp.shape[:-1]
     d = len(shape)
+    offs = _axis_offsets(axis0_offset, d)
     pos = []
     for axis in range(d):
         c = d - 1 - axis
         idx_shape = [1] * d
         idx_shape[axis] = shape[axis]
         coord = np.arange(shape[axis], dtype=F32).reshape(idx_shape)
-        if axis == 0 and axis0_offset:
-            coord = (coord + F32(axis0_offset)).astype(F32)
+        if offs[axis]:
+            coord = (coord + F32(offs[axis])).astype(F32)
         pos.append((coord + warp[..., c]).astype(F32))
     return pos
 
@@ -66,8 +76,8 @@ def sample_linear(field, pos, oob, axis0_offset=0):
     base = [np.floor(p) for p in pos]
     ratio = [(p - b).astype(F32) for p, b in zip(pos, base)]
     inv = [(F32(1.0) - r).astype(F32) for r in ratio]
-    base_i = [np.clip(b - (axis0_offset if a == 0 else 0), -2, shape[a] + 1).astype(np.int64)
-              for a, b in enumerate(base)]
+    offs = _axis_offsets(axis0_offset, d)
+    base_i = [np.clip(b - offs[a], -2, shape[a] + 1).astype(np.int64) for a, b in enumerate(base)]
     oob_arr = np.broadcast_to(np.asarray(oob, dtype=F32), pos[0].shape)
 
     def tap(offsets):
@@ -652,9 +662,10 @@ class SlavchevaOracle:
             convolve_with_kernel_preserve_zeros(g, self.sobolev_kernel)
         np.copyto(warp, ((-g).astype(F32) * F32(self.gradient_descent_rate)).astype(F32))
         lengths = vector_norm(warp)
-        if self.max_region is not None:
-            _, at = first_argmax(lengths[self.max_region])
-            at = (at[0] + (self.max_region.start or 0),) + tuple(at[1:])
+        if self.max_region is not None:  # a slice along axis 0, or a tuple of slices (slabs cut along another axis)
+            region = self.max_region if isinstance(self.max_region, tuple) else (self.max_region,)
+            _, at = first_argmax(lengths[region])
+            at = tuple(a + ((region[k].start or 0) if k < len(region) else 0) for k, a in enumerate(at))
         else:
             _, at = first_argmax(lengths)
         max_warp = float(lengths[at])

@@ -74,8 +74,8 @@ def test_abi_hash_binds_library_binding_and_header(pkg, tmp_path):
     grown.write_text(text.replace("int32_t packed_nz", "int32_t one_more_member;\n    int32_t packed_nz", 1))
     assert "one_more_member" in grown.read_text() and _build.abi_hash(str(grown)) != _build.abi_hash()
     changed = tmp_path / "changed.h"
-    changed.write_text(text.replace("const int32_t *skip_flag, void *stream);", "void *stream);", 1))
-    assert _build.abi_hash(str(changed)) != _build.abi_hash()
+    changed.write_text(text.replace("const int32_t *skip_flag,", "", 1))
+    assert "skip_flag," not in changed.read_text() and _build.abi_hash(str(changed)) != _build.abi_hash()
 
 
 def test_code_object_targets_gfx950_only(pkg):
@@ -87,8 +87,8 @@ def test_code_object_targets_gfx950_only(pkg):
 
 def test_ctypes_structs_match_header_layout(pkg):
     L = pkg._lib
-    assert ctypes.sizeof(L.Grid) == 40 and L.Grid.energy_z_begin.offset == 32
-    assert ctypes.sizeof(L.SlabLayoutC) == 32 and ctypes.sizeof(L.SlabPart) == 40 + 16 + 16 + 8 + 8
+    assert ctypes.sizeof(L.Grid) == 52 and L.Grid.energy_z_begin.offset == 32 and L.Grid.ny_global.offset == 40
+    assert ctypes.sizeof(L.SlabLayoutC) == 32 and ctypes.sizeof(L.SlabPart) == 56 + 16 + 16 + 8 + 8
     assert ctypes.sizeof(L.IterationRecord) == 32768 == L.RECORD_BYTES and ctypes.sizeof(L.RecordSlot) == 4096
     from levelsetfusion_python_amd import slab
     assert (slab.RECORD_SLOTS, slab.SLOT_WORDS) == (L.RECORD_SLOTS, L.SLOT_WORDS)
@@ -130,13 +130,13 @@ def test_argument_errors_are_reported_not_launched(pkg):
     lists = (ctypes.c_void_p * 2)(1, 1)
     counts = (ctypes.c_int64 * 2)(5, -1)
     assert L.lib.lsf_state_finalize_listed(1, 1, 1, 1, ctypes.byref(ok), lists, counts, 3, 0, -1, 0.0, None, None,
-                                           None, None) == -1                                      # three lists
+                                           None, None, 0, 0.0, None) == -1                        # three lists
     assert L.lib.lsf_state_finalize_listed(1, 1, 1, 1, ctypes.byref(ok), lists, counts, 2, 0, -1, 0.0, None, None,
-                                           None, None) == -1                                      # negative count
+                                           None, None, 0, 0.0, None) == -1                        # negative count
     assert L.lib.lsf_state_finalize_listed(1, None, 1, 1, ctypes.byref(ok), lists, counts, 1, 0, -1, 0.0, 1, 1,
-                                           None, None) == -1                                      # statistics, no canonical
+                                           None, None, 0, 0.0, None) == -1                        # statistics, no canonical
     assert L.lib.lsf_state_finalize_listed(1, 1, 1, 1, ctypes.byref(L.Grid(3, 4, 8, 8, 1, 4, 0, 0)), lists, counts, 1,
-                                           0, -1, 0.0, None, None, None, None) == -1              # not a whole array
+                                           0, -1, 0.0, None, None, None, None, 0, 0.0, None) == -1  # not a whole array
     # the chain kernel: an INTERIOR list of a WHOLE array, distinct states, a scratch block
     sp = L.SlavchevaParams()
     C = L.chain_lib()  # the optional add-on library
@@ -186,7 +186,7 @@ def test_slab_runtime_argument_errors(pkg):
     assert L.lib.lsf_state_pack_needed(1, 1, 1, ctypes.byref(grid), 1, 2, 0, None) == -1      # not a whole array
     assert L.lib.lsf_state_pack_needed(1, 1, 1, ctypes.byref(whole), 1, 0, 0, None) == -1     # reach
     assert L.lib.lsf_state_pack_needed(1, None, None, ctypes.byref(whole), 1, 2, 0, None) == -1
-    assert L.lib.lsf_records_exceed(None, 3, 2.0, 1, None) == -1
+
     assert L.lib.lsf_band_list_fill_prepared(ctypes.byref(grid), L.BAND_INTERIOR, 1, 1, None) == -1  # not a whole array
 
 

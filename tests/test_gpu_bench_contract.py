@@ -135,6 +135,14 @@ def test_two_rank_lines():
     assert d["config"]["voxels_per_gpu"] == 64 ** 3 // 2 and d["halo_exchange"]["halo_slices"] == 4
     assert abs(d["value"] - 64 ** 3 * 6 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     assert d["halo_band_voxels_per_face"] > 0 and d["halo_bytes_per_exchange"] > 0
+    # depth-derived volumes on N > 1: ONE pair from two synthetic depth frames, slabs cut along y (the band is a sheet
+    # across z); band voxels per rank balanced
+    d = _run_ranks(2, "--size", "64", "--iterations", "6", "--data", "depth")
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and "y-slab x2" in d["config"]["parallelism"]
+    assert "depth" in d["config"]["workload"] and d["halo_band_voxels_per_face"] > 0
+    per_rank = d["halo_exchange"]["band_voxels_per_rank"]
+    assert len(per_rank) == 2 and abs(per_rank[0] - per_rank[1]) <= 0.2 * (per_rank[0] + per_rank[1]) / 2
+    assert abs(d["value"] - 64 ** 3 * 6 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
     per_pair = 3 * sum((64 >> k) ** 3 for k in range(4))
     d = _run_ranks(2, "--workload", "multiframe", "--size", "64", "--frames", "3", "--iterations", "3")
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and "replicas x2" in d["config"]["parallelism"]

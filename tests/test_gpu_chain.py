@@ -134,7 +134,7 @@ def test_stages_follow_each_other_through_the_list(lsf):
     a = _run(lsf, canonical, live0, 14, chain=True, stages=4)
     shape = (ctypes.c_int32 * 4)()
     count = a[0]._engine._fast.bands[0].count
-    assert _lib.lib.lsf_state_chain_shape(count, 4, shape) == 0
+    assert _lib.chain_lib().lsf_state_chain_shape(count, 4, shape) == 0
     assert shape[1] == 4 and shape[2] > shape[0], "this list is meant to be long enough for stages: %r" % list(shape)
     b = _run(lsf, canonical, live0, 14, chain=False)
     _same(a, b)

@@ -1,0 +1,105 @@
+"""Slabs cut along Y (SlabLayout(axis=1), round 4) on ONE GPU (gloo, faces staged through the host; at most 4 worker
+processes on the card).  Why y: the camera of tsdf/generation.py:356-437 looks along +z, so the narrow band of a depth
+frame is a SHEET z ~ f(x, y) a few dozen slices thick -- z-slabs leave all of it to one or two ranks, y-slabs cut the sheet
+into equal strips.  The stitched result of 2 and 4 ranks equals the single-process whole-volume run BIT FOR BIT (live field,
+warp, every maximum, energies to 1e-12) on the synthetic depth pair and on the sphere pair, fixed-count (exchange groups
+with widened row ranges) and threshold-terminated (exchange + reduction every iteration); the band voxels per rank of the
+depth pair are balanced to +-20 %, where a z-cut of the same pair is not."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _volume(kind, n):
+    """(canonical, live) float32 device tensors [n, n, n], the same in every process"""
+    sys.path.insert(0, ROOT)
+    from levelsetfusion_python_amd.synthetic import depth_pair, sphere_pair
+    return depth_pair(n, "cuda") if kind == "depth" else sphere_pair(n, 3, "cuda")
+
+
+def _worker(rank, world, port, kind, n, halo, kwargs, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
+    layout = SlabLayout(n, rank, world, halo, axis=1)
+    comm = SlabComm(layout)
+    canonical, live = (layout.cut(v) for v in _volume(kind, n))
+    band = ~((live.abs() == 1.0) & (canonical.abs() == 1.0))
+    opt = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, **kwargs)
+    opt.optimize(live, canonical)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), live=layout.owned_of(live).cpu().numpy(),
+             warp=layout.owned_of(opt.warp_field).cpu().numpy(), max_warps=np.float32(opt.log.max_warps),
+             locations=np.int64(opt.log.max_warp_locations), data=np.float64(opt.log.data_energies),
+             smoothing=np.float64(opt.log.smoothing_energies), level_set=np.float64(opt.log.level_set_energies),
+             band=int(layout.owned_of(band).sum().item()))
+    dist.destroy_process_group()
+
+
+CASES = {
+    # name: (world, volume, halo, fixed iteration count or None for a threshold-terminated run)
+    "depth_two_groups": (2, "depth", 2, 6),
+    "depth_four_groups": (4, "depth", 2, 5),
+    "depth_four_threshold": (4, "depth", 1, None),
+    "sphere_two_groups": (2, "sphere", 4, 9),
+    "sphere_four_every_iteration": (4, "sphere", 1, 4),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_y_slabs_equal_whole_volume(tmp_path, case):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    import levelsetfusion_python_amd as lsf
+    world, kind, halo, fixed = CASES[case]
+    n = 64
+    kwargs = dict(compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                  smoothing_term_method=lsf.SmoothingTermMethod.KILLING, check_interval=4)
+    if fixed is not None:
+        kwargs.update(maximum_warp_length_lower_threshold=0.0, max_iterations=fixed, min_iterations=fixed)
+    else:
+        kwargs.update(maximum_warp_length_lower_threshold=0.05, max_iterations=12, min_iterations=2)
+    canonical, live = _volume(kind, n)
+    ref = lsf.SlavchevaOptimizer3d(field_size=n, **kwargs)
+    ref.optimize(live, canonical)
+    if fixed is None:
+        assert 2 <= len(ref.log.max_warps) <= 12
+    mp.spawn(_worker, args=(world, _free_port(), kind, n, halo, kwargs, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate([p["live"] for p in parts], axis=1), live.cpu().numpy()), "live field"
+    assert np.array_equal(np.concatenate([p["warp"] for p in parts], axis=1), ref.warp_field.cpu().numpy()), "warp field"
+    for p in parts:  # every rank holds the GLOBAL records
+        assert np.array_equal(p["max_warps"], np.float32(ref.log.max_warps))
+        # reported as linear indices of the WHOLE volume in slab runs; (x, y, z) tuples in a whole-volume run
+        where = [(int(i) % n, (int(i) // n) % n, int(i) // (n * n)) for i in p["locations"]]
+        assert where == [tuple(int(v) for v in loc) for loc in ref.log.max_warp_locations]
+        for key, full in (("data", ref.log.data_energies), ("smoothing", ref.log.smoothing_energies),
+                          ("level_set", ref.log.level_set_energies)):
+            assert np.allclose(p[key], full, rtol=1e-12, atol=0.0), key
+    if kind == "depth":
+        counts = np.array([int(p["band"]) for p in parts], dtype=np.float64)
+        assert counts.min() > 0 and np.abs(counts / counts.mean() - 1.0).max() <= 0.2, counts
+        # the same pair cut along z: the sheet lies across z, most slabs are (nearly) empty
+        c0, l0 = _volume(kind, n)
+        band = (~((l0.abs() == 1.0) & (c0.abs() == 1.0))).sum(dim=(1, 2)).cpu().numpy().astype(np.float64)
+        z_counts = band.reshape(world, -1).sum(axis=1)
+        assert np.abs(z_counts / z_counts.mean() - 1.0).max() > 0.2, z_counts

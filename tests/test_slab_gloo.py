@@ -27,7 +27,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, n, nz, halo, iterations, sobolev, out_dir):
+def _worker(rank, world, port, n, nz, halo, iterations, sobolev, out_dir, axis=0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -36,11 +36,11 @@ def _worker(rank, world, port, n, nz, halo, iterations, sobolev, out_dir):
     from levelsetfusion_python_amd.slab import RECORD_SLOTS, SLOT_WORDS, SlabComm, SlabLayout
     from oracle import lsf_oracle as O
     canonical, live = O.sphere_pair(n, d=3, nz=nz)
-    layout = SlabLayout(nz, rank, world, halo)
+    layout = SlabLayout(nz if axis == 0 else n, rank, world, halo, axis=axis)
     comm = SlabComm(layout)
-    sl = layout.local_slice()
-    live_l = torch.from_numpy(live[sl].copy())
-    canon_l = canonical[sl].copy()
+    sl = layout.local_slice() if axis == 0 else (slice(None), layout.local_slice())
+    live_l = torch.from_numpy(np.ascontiguousarray(live[sl]))
+    canon_l = np.ascontiguousarray(canonical[sl])
     warp_l = torch.zeros(live_l.shape + (3,), dtype=torch.float32)
     kernel = O.generate_1d_sobolev_kernel(3, 0.1) if sobolev else None
     opt = O.SlavchevaOracle(compute_method=O.DIRECT, level_set_term_enabled=not sobolev,
@@ -48,16 +48,19 @@ def _worker(rank, world, port, n, nz, halo, iterations, sobolev, out_dir):
                             sobolev_smoothing_enabled=sobolev, sobolev_kernel=kernel)
     records = torch.zeros((iterations, RECORD_SLOTS * SLOT_WORDS), dtype=torch.int64)
     partial = torch.zeros_like(records)  # this rank's records before any reduction
-    own = layout.owned_local()
+    own = layout.owned_local() if axis == 0 else (slice(None), layout.owned_local())
     opt.max_region = own
-    opt.axis0_offset = layout.z_global_offset  # global index of local slice 0
+    # global index of local slice 0 (z-slabs) / of local row 0 (slabs cut along y)
+    opt.axis0_offset = layout.z_global_offset if axis == 0 else (0, layout.global_offset)
     for it in range(iterations):
         lv, wp = live_l.numpy(), warp_l.numpy()
         # the local step: everything the oracle computes within `halo` of a fake (interior) array edge is wrong and
         # is overwritten by the exchange below; owned voxels only read up to one slice into the halo (+ the gather)
         max_warp, at, en = opt.iteration(lv, canon_l, wp)
         m = np.float32(max_warp)
-        flat = int(np.ravel_multi_index((at[0] - layout.z_begin + layout.z0, at[1], at[2]), (nz, n, n)))
+        at_global = (at[0] - layout.z_begin + layout.z0, at[1], at[2]) if axis == 0 else \
+            (at[0], at[1] - layout.begin + layout.g0, at[2])
+        flat = int(np.ravel_multi_index(at_global, (nz, n, n)))
         packed = (np.uint64(m.view(np.uint32)) << np.uint64(32)) | np.uint64((~np.uint32(flat)) & 0xFFFFFFFF)
         records[it, 0] = int(np.array([packed], np.uint64).view(np.int64)[0])
         band = ~(O.is_truncated(lv) & O.is_truncated(canon_l))
@@ -108,6 +111,37 @@ def test_slab_run_matches_whole_volume(tmp_path, world, nz):
     want_idx = [np.ravel_multi_index(at, live.shape) for at in opt.log["max_warp_locations"]]
     assert list(got_idx) == [int(i) for i in want_idx]
     assert np.all(rec[:, 1].view(np.float64) > 0)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_y_slab_run_matches_whole_volume(tmp_path, world):
+    """the same with slabs cut along Y (SlabLayout(axis=1): strided faces through the packed staging buffers, gather
+    positions formed from the GLOBAL row)"""
+    from oracle import lsf_oracle as O
+    n, nz, halo, iterations = 24, 16, 3, 3
+    mp.spawn(_worker, args=(world, _free_port(), n, nz, halo, iterations, False, str(tmp_path), 1), nprocs=world, join=True)
+    canonical, live = O.sphere_pair(n, d=3, nz=nz)
+    opt = O.SlavchevaOracle(compute_method=O.DIRECT, level_set_term_enabled=True, smoothing_term_method=O.KILLING,
+                            maximum_warp_length_lower_threshold=0.0, max_iterations=iterations,
+                            min_iterations=iterations)
+    opt.optimize(live, canonical)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate([p["live"] for p in parts], axis=1), live)
+    assert np.array_equal(np.concatenate([p["warp"] for p in parts], axis=1), opt.warp_field)
+    packed = parts[0]["records"][:, 0].view(np.uint64)
+    assert np.array_equal((packed >> np.uint64(32)).astype(np.uint32).view(np.float32), np.float32(opt.log["max_warps"]))
+    want_idx = [int(np.ravel_multi_index(at, live.shape)) for at in opt.log["max_warp_locations"]]
+    assert list((~packed.astype(np.uint32)).astype(np.int64)) == want_idx
+
+
+def test_y_slab_layout():
+    from levelsetfusion_python_amd.slab import SlabLayout
+    L = SlabLayout(64, 1, 4, 2, axis=1)
+    assert (L.axis, L.n_global, L.g0, L.g1, L.begin, L.end, L.n_local, L.global_offset) == (1, 64, 16, 32, 2, 18, 20, 14)
+    v = torch.arange(4 * 64 * 3, dtype=torch.float32).reshape(4, 64, 3)
+    assert torch.equal(L.cut(v), v[:, 14:34]) and torch.equal(L.owned_of(L.cut(v)), v[:, 16:32])
+    with pytest.raises(ValueError):
+        SlabLayout(64, 0, 4, 2, axis=2)
 
 
 def _gather_worker(rank, world, port, nz, halo, out_dir):
