@@ -1277,17 +1277,14 @@ class SlavchevaEngine:
         import math
         from .slab import SlabComm, SlabLayout
         L = self.comm.layout
-        if L.axis != 0:
-            raise RuntimeError("a warp update of %.3f voxels outran the %d-row halo of a slab cut along y; the wider "
-                               "re-run exists for z-slabs only: construct the layout with a halo of at least %d rows"
-                               % (max_update, L.halo, int(math.floor(max_update)) + 2))
+        ax = L.axis  # 0: z-slabs, 1: slabs cut along y -- the same procedure along that axis
         per = L.z1 - L.z0
         while True:
             h2 = max(L.halo, int(math.floor(max_update)) + 2)
             if 2 * h2 > per:  # the boundary / interior split of a slab iteration needs two disjoint boundary ranges
                 raise RuntimeError("warp update of %.3f voxels needs a %d-slice halo, more than half a slab of %d "
                                    "slices: use fewer, thicker slabs" % (max_update, h2, per))
-            L2 = SlabLayout(L.nz_global, L.rank, L.world, h2)
+            L2 = SlabLayout(L.nz_global, L.rank, L.world, h2, axis=ax)
             # the same kind of communicator on the wider layout; it BORROWS the library-side RCCL communicator (which knows
             # ranks, not layouts: every call names its layout), so the re-run keeps the one-host-call-per-iteration
             # transport instead of ~150 us of torch.distributed point-to-point per iteration
@@ -1295,8 +1292,10 @@ class SlavchevaEngine:
             comm2._native = self.comm.native()
             wide = []
             for t in (live, canonical):
-                w = torch.empty((L2.nz_local,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-                w[L2.z_begin:L2.z_end] = t[L.z_begin:L.z_end]
+                shape = list(t.shape)
+                shape[ax] = L2.n_local
+                w = torch.empty(shape, dtype=t.dtype, device=t.device)
+                w.narrow(ax, L2.begin, L2.end - L2.begin).copy_(t.narrow(ax, L.begin, L.end - L.begin))
                 wide.append(w)
             comm2.exchange_halos(wide)
             clone = copy.copy(self)
@@ -1313,12 +1312,12 @@ class SlavchevaEngine:
         self.iteration_count, self.log = clone.iteration_count, clone.log
         off = L2.halo_lo - L.halo_lo
         window = slice(off, off + L.nz_local)
-        self._gradient_state = ("wide", clone, window)
+        self._gradient_state = ("wide", clone, window, ax)
         grid = self._grid(live)
         if outcome.state is not None:
-            return SlavchevaOutcome(grid, canonical, state=outcome.state[window].contiguous())
-        return SlavchevaOutcome(grid, canonical, live=outcome.live()[window].contiguous(),
-                                warp_planar=outcome.warp_planar()[:, window].contiguous())
+            return SlavchevaOutcome(grid, canonical, state=outcome.state.narrow(ax, off, L.n_local).contiguous())
+        return SlavchevaOutcome(grid, canonical, live=outcome.live().narrow(ax, off, L.n_local).contiguous(),
+                                warp_planar=outcome.warp_planar().narrow(1 + ax, off, L.n_local).contiguous())
 
     def _optimize(self, live, canonical, finalize=None):
         """one attempt of optimize() (see there)
@@ -1595,7 +1594,8 @@ class SlavchevaEngine:
             return g
         if st[0] == "wide":  # the call was re-run on a wider internal slab: its gradient, cut to this slab's slices
             g = st[1].gradient_field()
-            return None if g is None else g[:, st[2]].contiguous()
+            ax = st[3] if len(st) > 3 else 0
+            return None if g is None else g.narrow(1 + ax, st[2].start, st[2].stop - st[2].start).contiguous()
         _, state_in, canonical, grid = st[:4]
         if len(st) > 4 and st[4] is not None:
             # the state was initialised near the band only: complete it from the call's live array, which still holds the

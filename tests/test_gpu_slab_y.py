@@ -55,12 +55,15 @@ def _worker(rank, world, port, kind, n, halo, kwargs, out_dir):
 
 
 CASES = {
-    # name: (world, volume, halo, fixed iteration count or None for a threshold-terminated run)
-    "depth_two_groups": (2, "depth", 2, 6),
-    "depth_four_groups": (4, "depth", 2, 5),
-    "depth_four_threshold": (4, "depth", 1, None),
-    "sphere_two_groups": (2, "sphere", 4, 9),
-    "sphere_four_every_iteration": (4, "sphere", 1, 4),
+    # name: (world, volume, edge, halo, fixed iteration count or None for a threshold-terminated run).  The depth pair's
+    # updates are SEVERAL VOXELS long at the rims of its band (10.9 voxels in the first iteration at 64^3): those runs
+    # outgrow any exchange group and are re-run on a wider internal slab with an exchange per iteration
+    # (SlavchevaEngine._optimize_widened along y) -- which needs slabs of at least twice that halo
+    "depth_two_ranks": (2, "depth", 64, 2, 5),
+    "depth_four_ranks": (4, "depth", 128, 2, 3),
+    "depth_two_threshold": (2, "depth", 64, 1, None),
+    "sphere_two_groups": (2, "sphere", 64, 4, 9),
+    "sphere_four_every_iteration": (4, "sphere", 64, 1, 4),
 }
 
 
@@ -70,19 +73,21 @@ def test_y_slabs_equal_whole_volume(tmp_path, case):
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
     import levelsetfusion_python_amd as lsf
-    world, kind, halo, fixed = CASES[case]
-    n = 64
+    world, kind, n, halo, fixed = CASES[case]
     kwargs = dict(compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING, check_interval=4)
     if fixed is not None:
         kwargs.update(maximum_warp_length_lower_threshold=0.0, max_iterations=fixed, min_iterations=fixed)
     else:
-        kwargs.update(maximum_warp_length_lower_threshold=0.05, max_iterations=12, min_iterations=2)
+        kwargs.update(maximum_warp_length_lower_threshold=0.05, maximum_warp_length_upper_threshold=8.0,
+                      max_iterations=12, min_iterations=2)
     canonical, live = _volume(kind, n)
     ref = lsf.SlavchevaOptimizer3d(field_size=n, **kwargs)
     ref.optimize(live, canonical)
     if fixed is None:
         assert 2 <= len(ref.log.max_warps) <= 12
+    if kind == "sphere":
+        assert max(ref.log.max_warps) < 1.0  # exchange groups run as planned
     mp.spawn(_worker, args=(world, _free_port(), kind, n, halo, kwargs, str(tmp_path)), nprocs=world, join=True)
     parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     assert np.array_equal(np.concatenate([p["live"] for p in parts], axis=1), live.cpu().numpy()), "live field"
