@@ -107,7 +107,18 @@ __global__ __launch_bounds__(kBlock) void convolve_list4_kernel(const vf4* __res
                                                                 TapsN<NT> taps, int axis, const int* __restrict__ list,
                                                                 unsigned count, lsf_gate gate) {
     if (gate_closed(gate)) return;
-    const unsigned k = blockIdx.x * kBlock + threadIdx.x;
+    // XCD-aware tile order (blocks b, b + 8, ... share an XCD under round-robin dispatch): XCD k takes the k-th eighth of
+    // the list -- a contiguous z-range --, so that the y -/+ 3 rows a block reads are rows its own XCD's other blocks read
+    // or wrote into the same L2.  In plain block order the seven rows of the y pass came from seven other XCDs' L2s, i.e.
+    // through the fabric: 143 MB per launch against 79 MB for the x pass (profiles/r04_sobolev_pmc_hbm_traffic.csv)
+    unsigned tile = blockIdx.x;
+    const unsigned tiles = gridDim.x;
+    if (tiles >= 64u) {
+        const unsigned per_xcd = (tiles + kXcds - 1) / kXcds, xcd = blockIdx.x % kXcds;
+        tile = xcd * per_xcd + blockIdx.x / kXcds;
+        if (tile >= tiles || blockIdx.x / kXcds >= per_xcd) return;  // grid padded to a multiple of 8 (see launch_pass4)
+    }
+    const unsigned k = tile * kBlock + threadIdx.x;
     if (k >= count) return;
     const unsigned i = (unsigned)list[k];
     int x, y, z;
@@ -247,7 +258,9 @@ void launch_pass4(const vf4* in, vf4* out, const vf4* mask, const Grid& g, int a
                   const int* list, unsigned count, const lsf_gate& gt, hipStream_t s) {
     TapsN<NT> taps;
     for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
-    const dim3 grid((count + kBlock - 1) / kBlock);
+    unsigned tiles = (count + kBlock - 1) / kBlock;
+    if (tiles >= 64u) tiles = (tiles + kXcds - 1) / kXcds * kXcds;  // every XCD the same number of blocks (the kernel's tile order)
+    const dim3 grid(tiles);
     if (taps_are_float32(taps_host, NT))
         hipLaunchKernelGGL((convolve_list4_kernel<NT, true>), grid, dim3(kBlock), 0, s, in, out, mask, g, taps, axis, list,
                            count, gt);

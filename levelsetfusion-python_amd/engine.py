@@ -741,7 +741,7 @@ class _SobolevStatePlan:
     buffer B] (float4, zero-initialised: unlisted voxels are never written).  3-D: gradient -> raw, x pass raw -> A,
     y pass A -> B, z pass + update + re-warp B -> final gradient in A; 2-D: y pass raw -> A, x pass + update A -> B."""
 
-    def __init__(self, launcher, states, canonical, grid, params, bands, g4, taps, min_iterations):
+    def __init__(self, launcher, states, canonical, grid, params, bands, g4, taps, min_iterations, iterations_hint=0):
         f = self.f = launcher
         n = dev.n_voxels(grid)
         self.p_state = [f.pointer(t, 4 * n, "state") for t in states]
@@ -757,6 +757,24 @@ class _SobolevStatePlan:
         self.stream = dev.stream_ptr()
         self.axes = _conv_axis_order(grid.dims)
         self.final = 1 if grid.dims == 3 else 2  # index of the buffer that holds the final gradient
+        # The LAST pass runs along z: its seven taps lie in seven slices.  In list order an XCD sweeps a z-range with a
+        # window of ~2 slices of the band in flight, its 4 MB L2 cannot keep seven slices of five streams, and every tap
+        # comes through the fabric (237 MB per launch at 256^3 against 130 MB of compulsory traffic: the kernel ran at the
+        # Infinity Cache's 5.5 TB/s, profiles/r04_sobolev_pmc_hbm_traffic.csv).  In STRIP-major order -- eight strips of rows,
+        # each swept through z -- an XCD's window spans ~19 slices of ITS strip, so the z -/+ 3 taps are lines its own CUs
+        # have just read.  Results do not depend on the order (every listed voxel is written by its index); one sort per
+        # call, worth it from a handful of iterations on.
+        self.bands_last = self.bands
+        if grid.dims == 3 and iterations_hint >= 8 and os.environ.get("LSF_SOBOLEV_STRIPS", "1") != "0":
+            self.bands_last = [self._strip_major(b, grid) if b.count >= (1 << 17) else b for b in self.bands]
+
+    @staticmethod
+    def _strip_major(band, grid, strips=8):
+        idx = band.indices[:band.count].long()
+        rows = max(1, (grid.ny + strips - 1) // strips)
+        key = ((idx // grid.nx) % grid.ny // rows) * (grid.nz * grid.ny * grid.nx) + idx
+        ordered = (torch.sort(key).values % (grid.nz * grid.ny * grid.nx)).to(torch.int32)
+        return dev.BandList(ordered, band.count, band.subset)
 
     def enqueue(self, i):
         f, lib, check = self.f, _lib.lib, _lib.check
@@ -773,7 +791,7 @@ class _SobolevStatePlan:
                 check(lib.lsf_convolve_axis_listed4(src, dst, raw, f.grid_ref, axis, self.p_taps, self.n_taps, gate,
                                                     band.pointer, band.count, self.stream), "lsf_convolve_axis_listed4")
             src, dst = dst, (b if dst is a else a)
-        for k, band in enumerate(self.bands):
+        for k, band in enumerate(self.bands_last):
             check(lib.lsf_sobolev_state_update(src, raw, s_in, s_out, dst, f.grid_ref, self.params_ref, self.axes[-1],
                                                self.p_taps, self.n_taps, gate, rec, band.pointer, band.count,
                                                int(k == 0), self.stream), "lsf_sobolev_state_update")
@@ -1434,7 +1452,7 @@ class SlavchevaEngine:
             if sob_state:
                 g4 = [torch.zeros(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device) for _ in range(3)]
                 sob = _SobolevStatePlan(f, states, canonical, grid, self.params, bands, g4, self.sobolev_kernel,
-                                        self.min_iterations)
+                                        self.min_iterations, max(self.max_iterations, self.min_iterations))
                 self._sobolev_band = _Counted(sum(b.count for b in bands))  # what bench.py prices this path over
             # Fixed-count runs on ONE interior list MAY run K iterations per launch (lsf_slavcheva_state_chain) instead of K
             # launches -- the stop test cannot fire in between.  Opt-in (LSF_CHAIN=1): bit-identical, but measured 4 %
