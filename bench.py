@@ -604,7 +604,18 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
     # that is bound by HBM rather than by the per-band-voxel arithmetic.
     name = "slavcheva_state_kernel<3,KILLING,LEVELSET,BASIC,DIRECT,%s>"
     if eng.use_band_list:
-        bands = dev.band_lists(live0, canonical, grid)
+        if world > 1 and layout.axis == 1:
+            # slabs cut along y: the lists of the whole local array, reduced to the owned rows (a row range is not a
+            # contiguous run of a sorted list)
+            bands = []
+            for b in dev.band_lists(live0, canonical, dev.make_grid(live0.shape)):
+                idx = b.indices[:b.count]
+                rows = (idx // live0.shape[2]) % live0.shape[1]
+                own = idx[(rows >= layout.begin) & (rows < layout.end)].contiguous()
+                if own.numel():
+                    bands.append(dev.BandList(own, own.numel(), b.subset))
+        else:
+            bands = dev.band_lists(live0, canonical, grid)
         # what the timed steps launched: the chain kernel (all iterations of a call in one launch) when the engine took
         # it -- one INTERIOR list, single GPU --, else one launch per iteration and list
         chained = world == 1 and getattr(eng, "_chain_used", False) and len(bands) == 1

@@ -765,8 +765,9 @@ class _SobolevStatePlan:
         # have just read.  Results do not depend on the order (every listed voxel is written by its index); one sort per
         # call, worth it from a handful of iterations on.
         self.bands_last = self.bands
-        if grid.dims == 3 and iterations_hint >= 8 and os.environ.get("LSF_SOBOLEV_STRIPS", "1") != "0":
-            self.bands_last = [self._strip_major(b, grid) if b.count >= (1 << 17) else b for b in self.bands]
+        strips = int(os.environ.get("LSF_SOBOLEV_STRIPS", "8"))  # 0: list order (measurements)
+        if grid.dims == 3 and iterations_hint >= 8 and strips > 0:
+            self.bands_last = [self._strip_major(b, grid, strips) if b.count >= (1 << 17) else b for b in self.bands]
 
     @staticmethod
     def _strip_major(band, grid, strips=8):
@@ -951,10 +952,9 @@ class SlavchevaEngine:
             mode, (boundary, interior) = _lib.SLAB_RESUME, f.resume_parts.get()
         else:
             mode, (boundary, interior) = _lib.SLAB_LAUNCH, f.widened_parts[0 if j == k - 1 else k - 1 - j].get()
+        if f.native is not None and exchange and f.pending_face_plan is not None:
+            self._finish_compact_faces(f)  # may fall back to the torch transport (slabs cut along y, neighbours disagree)
         if f.native is not None:  # the whole iteration in one host call (lsf_slab.hip): RCCL on the library's stream
-            if exchange and f.pending_face_plan is not None:
-                plan, f.pending_face_plan = f.pending_face_plan, None
-                self._plan_compact_faces(f, *plan)
             status = _lib.lib.lsf_slab_state_iteration(f.native, s_in, f.p_canon, s_out, f.layout_ref, boundary.array,
                                                        boundary.n, interior.array, interior.n, f.params_ref, gate_ref,
                                                        f.record_ptrs[i], mode, f.faces_ref, f.stream)
@@ -1013,21 +1013,51 @@ class SlavchevaEngine:
             send = [union(L.z_begin, L.z_begin + h) if lo else none, union(L.z_end - h, L.z_end) if hi else none]
             recv = [union(L.z_begin - h, L.z_begin) if lo else none, union(L.z_end, L.z_end + h) if hi else none]
         # A rank's halo holds the neighbour's boundary slices, so what it expects to receive IS what the neighbour sends --
-        # if the caller cut consistent slabs.  That contract is cross-checked with the neighbours on EVERY call (a
-        # collective and a host read, ~0.2 ms, behind the iterations already queued on the launch stream: the check runs
-        # on a stream of its own): mismatched message sizes would hang or corrupt the transport, and whether to check
-        # cannot depend on anything one rank alone sees (a rank whose data changed would enter the collective alone).
-        # LSF_SLAB_VERIFY_FACES=first: only on an optimizer's first call (measurements).
-        ok = True
+        # if the caller cut consistent slabs.  That contract is cross-checked with the neighbours on EVERY call:
+        # mismatched message sizes would hang or corrupt the transport, and whether to check cannot depend on anything
+        # one rank alone sees (a rank whose data changed would enter the collective alone).  The counts are host numbers
+        # as soon as the list sizes are (they are cut positions), so the collective is STARTED here, when the launch plan is
+        # made, on a stream of its own, and its result is READ when the first exchange is enqueued -- h - 1 iterations of
+        # host work later (round 4: read where it was started, the 0.4 ms of collective + host read starved the card of
+        # launches, 0.29 ms of a 2.5 ms slab call in the loop-back).  LSF_SLAB_VERIFY_FACES=first: only on an optimizer's
+        # first call (measurements).
+        check = None
         if not getattr(self, "_faces_verified", False) or os.environ.get("LSF_SLAB_VERIFY_FACES", "always") != "first":
-            if getattr(self, "_plan_stream", None) is None or self._plan_stream.device != live.device:
-                self._plan_stream = torch.cuda.Stream(device=live.device)
-            with torch.cuda.stream(self._plan_stream):
-                mine = torch.tensor([send[0][1], send[1][1], recv[0][1], recv[1][1]], dtype=torch.int64,
-                                    device=live.device)
-                rows = [torch.zeros_like(mine) for _ in range(torch.distributed.get_world_size(self.comm.group))]
+            counts = [send[0][1], send[1][1], recv[0][1], recv[1][1]]
+            world = torch.distributed.get_world_size(self.comm.group)
+            if self.comm.stage_through_host:  # gloo (tests): a host collective, done at once
+                mine = torch.tensor(counts, dtype=torch.int64)
+                rows = [torch.zeros_like(mine) for _ in range(world)]
                 torch.distributed.all_gather(rows, mine, group=self.comm.group)
-                rows = [r.tolist() for r in rows]
+                check = (torch.stack(rows), None)
+            else:
+                if getattr(self, "_plan_stream", None) is None or self._plan_stream.device != live.device:
+                    self._plan_stream = torch.cuda.Stream(device=live.device)
+                with torch.cuda.stream(self._plan_stream):
+                    staged = dev.pinned_scratch("face counts out", 4, torch.int64)
+                    staged.copy_(torch.tensor(counts, dtype=torch.int64))
+                    mine = staged.to(live.device, non_blocking=True)
+                    rows = [torch.empty_like(mine) for _ in range(world)]
+                    torch.distributed.all_gather(rows, mine, group=self.comm.group)
+                    landed = dev.pinned_scratch("face counts in", 4 * world, torch.int64)
+                    landed.copy_(torch.cat(rows), non_blocking=True)
+                    done = torch.cuda.Event()
+                    done.record()
+                check = (landed.view(world, 4), done)
+        f.pending_face_plan = (send, recv, check, live.device)
+
+    def _finish_compact_faces(self, f):
+        """second half of _plan_compact_faces, when the first exchange is enqueued: the neighbours' counts (the collective
+        started with the launch plan has long finished), then the lsf_slab_faces descriptor -- or, if a neighbour
+        disagrees, whole faces (z-slabs) / the torch transport with its packed staging buffers (slabs cut along y)"""
+        send, recv, check, device = f.pending_face_plan
+        f.pending_face_plan = None
+        ok = True
+        if check is not None:
+            table, done = check
+            if done is not None:
+                done.synchronize()
+            rows = table.tolist()
             # every rank sees every row, so all ranks reach the same verdict without a second collective: a rank's lower
             # boundary lands in its lower neighbour's UPPER halo, its upper boundary in the upper neighbour's LOWER halo
             if len(rows) == 1:  # the one-GPU loop-back: this rank is its own neighbour on both sides
@@ -1038,14 +1068,22 @@ class SlavchevaEngine:
             self._faces_verified = ok
         if not ok:
             import warnings
-            warnings.warn("slab halos are not consistent with the neighbours' slabs (band voxel counts differ): whole "
-                          "slices are exchanged")
+            if self.comm.layout.axis == 1:
+                warnings.warn("slab halos are not consistent with the neighbours' slabs (band voxel counts differ): the "
+                              "rows travel whole through torch.distributed")
+                f.native = None
+                if not hasattr(self, "_comm_stream"):
+                    self._comm_stream = torch.cuda.Stream(device=device)
+                    self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
+            else:
+                warnings.warn("slab halos are not consistent with the neighbours' slabs (band voxel counts differ): whole "
+                              "slices are exchanged")
             return
         faces = _lib.SlabFaces()
         f.face_tensors = []
         for side in range(2):
             for name, (idx, count) in (("send", send[side]), ("recv", recv[side])):
-                msg = torch.empty(max(count, 1) * 4, dtype=torch.float32, device=live.device)
+                msg = torch.empty(max(count, 1) * 4, dtype=torch.float32, device=device)
                 f.face_tensors += [idx, msg]
                 getattr(faces, name + "_list")[side] = idx.data_ptr()
                 getattr(faces, name + "_msg")[side] = msg.data_ptr()
@@ -1166,7 +1204,7 @@ class SlavchevaEngine:
             # collective and a host read (~0.2 ms) that then wait behind the iterations already queued, not in front of them
             f.pending_face_plan = None
             if listed and os.environ.get("LSF_SLAB_FACES", "compact") != "full":
-                f.pending_face_plan = (live, bands, cut, lo, hi, lo_rank, hi_rank)
+                self._plan_compact_faces(f, live, bands, cut, lo, hi, lo_rank, hi_rank)
         elif not hasattr(self, "_comm_stream"):
             self._comm_stream = torch.cuda.Stream(device=live.device)
             self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
@@ -1245,8 +1283,6 @@ class SlavchevaEngine:
                                                       face(L.end - h, L.end) if hi else None],
                                                 recv=[face(L.begin - h, L.begin) if lo else None,
                                                       face(L.end, L.end + h) if hi else None]))
-            if f.faces_ref is None:  # the neighbours' lists disagree: rows cannot travel whole through the library
-                f.native = None
         if f.native is None and not hasattr(self, "_comm_stream"):
             self._comm_stream = torch.cuda.Stream(device=live.device)
             self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]

@@ -93,10 +93,16 @@ def test_sparse_threshold_terminated_and_sobolev(lsf):
     """a gated run (the host looks at every batch) and the SobolevFusion iteration on the float4 layouts"""
     from levelsetfusion_python_amd.synthetic import sphere_pair
     canonical, live0 = sphere_pair(128, 3, "cuda")
+    probe = _run3d(lsf, canonical, live0, 0, **dict(KILLING, smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
+                                                    max_iterations=12, min_iterations=12))
+    m = np.float32(probe[0].log.max_warps)
+    # the first iteration k >= 2 whose maximum falls below every earlier one: a lower threshold between ends the loop there
+    k = next(i for i in range(2, len(m)) if m[i] < m[:i].min())
     gated = dict(KILLING, smoothing_term_method=lsf.SmoothingTermMethod.KILLING, max_iterations=30, min_iterations=1,
-                 maximum_warp_length_lower_threshold=0.31, check_interval=4)
+                 check_interval=4)
+    gated["maximum_warp_length_lower_threshold"] = float((m[:k].min() + m[k]) / 2)
     a, b = _run3d(lsf, canonical, live0, 2, **gated), _run3d(lsf, canonical, live0, 0, **gated)
-    assert 1 < len(a[0].log.max_warps) < 30  # the threshold ended it
+    assert len(a[0].log.max_warps) == k + 1 < 30  # the threshold ended it
     _same(a, b)
     k7 = lsf.generate_1d_sobolev_kernel(7, 0.1)
     sob = dict(sobolev_smoothing_enabled=True, sobolev_kernel=k7, maximum_warp_length_lower_threshold=0.0,

@@ -2,8 +2,11 @@
 on ONE GPU: a world of size 1 whose rank plays the middle slab of three and sends both halo faces to ITSELF (RCCL
 allows self send / recv inside a group).  The received data are meaningless; what is exercised and timed is the exact
 call sequence of the N > 1 path on device tensors.
-Usage: [HALO=8] [ITERS=50] [FIXED_ONLY=1] [LB_TIMELINE=1] [LB_PROFILE=1] slab_nccl_loopback.py [n]
-n = edge of the slab (default 32: a tiny volume, wall time per iteration = host time; 256 = the bench's slab)."""
+Usage: [HALO=8] [ITERS=50] [FIXED_ONLY=1] [LB_TIMELINE=1] [LB_PROFILE=1] [PATTERN=faces|centered] slab_nccl_loopback.py [n]
+n = edge of the slab (default 32: a tiny volume, wall time per iteration = host time; 256 = the bench's slab).
+PATTERN (round 4): faces (default) = the bench's weak-scaling input, spheres centred ON the slab faces, so that the compact
+faces carry their band voxels (~15 % of a face); centered = round 3's input, one sphere inside the slab, whose compact
+faces are EMPTY (what profiles/r01g / r01h / r03_slab_rccl_loopback.txt measured: sending nothing)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -29,7 +32,14 @@ layout = SlabLayout(3 * n, 1, 3, int(os.environ.get("HALO", "4")))
 comm = SelfComm(layout)
 assert comm.active and not comm.stage_through_host
 sl = layout.local_slice()
-canonical, live0 = sphere_pair(n, 3, "cuda", (sl.start, sl.stop))
+pattern = os.environ.get("PATTERN", "faces")
+canonical, live0 = sphere_pair(n, 3, "cuda", (sl.start, sl.stop), n // 2 if pattern == "faces" else 0)
+_band = ~((live0.abs() == 1.0) & (canonical.abs() == 1.0))
+_h = layout.halo
+print("pattern %s: band voxels in the %d boundary slices of the lower / upper face: %d / %d of %d (%.1f %% / %.1f %%)"
+      % (pattern, _h, int(_band[layout.z_begin:layout.z_begin + _h].sum()), int(_band[layout.z_end - _h:layout.z_end].sum()),
+         _h * n * n, 100.0 * float(_band[layout.z_begin:layout.z_begin + _h].float().mean()),
+         100.0 * float(_band[layout.z_end - _h:layout.z_end].float().mean())), flush=True)
 print("transport:", "native RCCL (lsf_slab_state_iteration)" if comm.native() is not None else "torch.distributed",
       flush=True)
 from levelsetfusion_python_amd.engine import SlavchevaEngine
@@ -93,6 +103,13 @@ for fixed in ((True,) if os.environ.get("FIXED_ONLY") == "1" else (True, False))
                                             _plan.get("_plan_compact_faces", 0.0) * 1e6))
         _host[0], _host[1] = 0.0, 0
         _plan.clear()
+        _f = getattr(opt._engine, "_fast", None)
+        if rep == 0 and _f is not None and getattr(_f, "faces", None) is not None:
+            print("    compact faces: send %s / recv %s band voxels = %s / %s bytes per exchange (whole faces: 2 x %d bytes)"
+                  % (list(_f.faces.send_count), list(_f.faces.recv_count), [16 * int(c) for c in _f.faces.send_count],
+                     [16 * int(c) for c in _f.faces.recv_count], 16 * _h * n * n), flush=True)
+        elif rep == 0 and _f is not None:
+            print("    whole faces travel: 2 x %d bytes per exchange" % (16 * _h * n * n), flush=True)
 if os.environ.get("LB_PROFILE") == "1":
     import cProfile, pstats
     live = live0.clone()
