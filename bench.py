@@ -632,7 +632,7 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
         roofline = roofline_of([None], voxels_per_rank, name % "DENSE", committed_traffic("dense_hbm_bytes_per_launch"))
     roofline_dense = roofline_of([None], voxels_per_rank, name % "DENSE",
                                  committed_traffic("dense_hbm_bytes_per_launch")) \
-        if eng.use_band_list and dense_walk else None
+        if eng.use_band_list and dense_walk and not (world > 1 and layout.axis == 1) else None  # y-cut grids: lists only
 
     out = dict(metric="voxel-warp-updates/sec", value=value, unit="voxel-warp-updates/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,

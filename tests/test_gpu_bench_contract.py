@@ -108,7 +108,8 @@ def _run_ranks(world, *flags):
                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                           "--gpus", str(world), "--steps", "2", "--warmup", "1", "--backend", "gloo", "--share-device",
                           "--no-cpu-baseline", *flags], capture_output=True, text=True, timeout=900, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
+    # the ranks' own tracebacks, not the launcher's summary of them
+    assert out.returncode == 0, "\n".join(ln for ln in out.stderr.splitlines() if ln.startswith("[rank"))[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout  # rank 0 alone prints the JSON line
     return json.loads(lines[0])
