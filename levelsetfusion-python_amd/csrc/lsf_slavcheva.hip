@@ -497,9 +497,10 @@ __global__ __launch_bounds__(kBlock) void chunk_needed_kernel(unsigned chunks, l
     needed[c] = hit ? 1 : 0;
 }
 
-// step 2: (live, 0) into both states for the chunks whose verdict equals `want`; kPackChunks consecutive chunks per block
-// (their verdicts arrive in one load phase; three chunks in four leave at once on a narrow band)
-constexpr int kPackChunks = 4;
+// step 2: (live, 0) into both states for the chunks whose verdict equals `want`: one chunk per block (four per block
+// measured slower, 58 against 46 us at 256^3: the needed chunks come in runs, and a block that draws four of them keeps
+// its CU's other slots waiting), two chunks in three leave after one load on a narrow band
+constexpr int kPackChunks = 1;
 __global__ __launch_bounds__(kBlock) void state_pack_needed_kernel(const float* __restrict__ live, vf4* __restrict__ a,
                                                                    vf4* __restrict__ b, unsigned n, unsigned chunks,
                                                                    const int* __restrict__ needed, int want) {
