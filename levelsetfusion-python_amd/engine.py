@@ -952,6 +952,11 @@ class SlavchevaEngine:
             mode, (boundary, interior) = _lib.SLAB_RESUME, f.resume_parts.get()
         else:
             mode, (boundary, interior) = _lib.SLAB_LAUNCH, f.widened_parts[0 if j == k - 1 else k - 1 - j].get()
+        if f.native is not None and getattr(f, "face_plan_args", None) is not None and (exchange or i >= 1):
+            # the neighbours' face counts: the collective is started BEHIND the first iteration's launches (its ~0.2 ms of
+            # host calls then run while the card works) -- at once if the first iteration already exchanges
+            (args, kwargs), f.face_plan_args = f.face_plan_args, None
+            self._plan_compact_faces(f, *args, **kwargs)
         if f.native is not None and exchange and f.pending_face_plan is not None:
             self._finish_compact_faces(f)  # may fall back to the torch transport (slabs cut along y, neighbours disagree)
         if f.native is not None:  # the whole iteration in one host call (lsf_slab.hip): RCCL on the library's stream
@@ -1202,9 +1207,9 @@ class SlavchevaEngine:
             f.layout_ref = ctypes.byref(f.layout)
             # compact faces are planned when the first exchange is enqueued (_enqueue_state_iteration): the plan costs a
             # collective and a host read (~0.2 ms) that then wait behind the iterations already queued, not in front of them
-            f.pending_face_plan = None
+            f.pending_face_plan = f.face_plan_args = None
             if listed and os.environ.get("LSF_SLAB_FACES", "compact") != "full":
-                self._plan_compact_faces(f, live, bands, cut, lo, hi, lo_rank, hi_rank)
+                f.face_plan_args = ((live, bands, cut, lo, hi, lo_rank, hi_rank), {})
         elif not hasattr(self, "_comm_stream"):
             self._comm_stream = torch.cuda.Stream(device=live.device)
             self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
@@ -1266,7 +1271,7 @@ class SlavchevaEngine:
         self._pending_halos = None
         f.native = self.comm.native()
         f.faces_ref = None
-        f.pending_face_plan = None
+        f.pending_face_plan = f.face_plan_args = None
         if f.native is not None:
             # the library's exchange only ever sees compacted faces here; its layout argument is validated, not used
             f.layout = _lib.SlabLayoutC(grid.ny, grid.nz, grid.nx, L.begin, L.end, h, lo_rank, hi_rank)
@@ -1278,11 +1283,11 @@ class SlavchevaEngine:
                     return got[0].indices[:got[0].count] if got[0].count else got[0].indices[:0], got[0].count
                 idx = torch.sort(torch.cat([g.indices[:g.count] for g in got])).values.contiguous()
                 return idx, idx.numel()
-            self._plan_compact_faces(f, live, None, None, lo, hi, lo_rank, hi_rank,
-                                     faces=dict(send=[face(L.begin, L.begin + h) if lo else None,
+            f.face_plan_args = ((live, None, None, lo, hi, lo_rank, hi_rank),
+                                dict(faces=dict(send=[face(L.begin, L.begin + h) if lo else None,
                                                       face(L.end - h, L.end) if hi else None],
                                                 recv=[face(L.begin - h, L.begin) if lo else None,
-                                                      face(L.end, L.end + h) if hi else None]))
+                                                      face(L.end, L.end + h) if hi else None])))
         if f.native is None and not hasattr(self, "_comm_stream"):
             self._comm_stream = torch.cuda.Stream(device=live.device)
             self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
