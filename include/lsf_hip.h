@@ -377,12 +377,16 @@ int lsf_slavcheva_state_iteration(const float *state_in, const float *canonical,
  * fields -- same results -- with one vector-memory instruction per neighbour / tap instead of one per component:
  *   state  float4 [z][y][x] = (live, u, v, w)        as lsf_slavcheva_state_iteration (two ping-pong copies, both
  *                                                    (live, 0) at unlisted voxels: lsf_state_prepare / lsf_state_pack)
- *   g4     float4 [z][y][x] = (g_x, g_y, g_z, 0)     raw gradient, filter intermediates, final gradient; the caller
+ *   g4     float4 [z][y][x] = (g_x, g_y, g_z, m)     raw gradient (m = 0), filter intermediates (m = mask bits), final gradient; the caller
  *                                                    zero-initialises them once (unlisted voxels are never written)
  * One iteration = lsf_sobolev_state_gradient, lsf_convolve_axis_listed4 for every axis but the last (3-D: x, y; 2-D: y),
  * lsf_sobolev_state_update for the last (3-D: z, 2-D: x) -- each once per band list (ascending voxel indices of any
  * LSF_BAND_* subset; first_list != 0 on the call that stands for the unlisted voxels' zero update in the arg-max).
- * 3 / 5 / 7 / 9 taps (LSF_ERR_KERNEL_TOO_LONG otherwise); 16 * nz * ny * nx need not fit 32 bits. */
+ * 3 / 5 / 7 / 9 taps (LSF_ERR_KERNEL_TOO_LONG otherwise); 16 * nz * ny * nx need not fit 32 bits.
+ * zero_mask_source4: the RAW gradient for the FIRST pass (its own input: math_utils/convolution.py:118 computes the mask
+ * before filtering) -- that pass leaves the three verdicts as bits in the fourth component of out4 --, NULL for every
+ * later pass (and for lsf_sobolev_state_update behind at least one pass): the mask is then read from the fourth
+ * component of in4's centre tap and handed on, one 16-byte load per voxel and pass less. */
 int lsf_sobolev_state_gradient(const float *state, const float *canonical, float *g_raw4, const lsf_grid *grid,
                                const lsf_slavcheva_params *params, const lsf_gate *gate, lsf_iteration_record *record,
                                const int32_t *band_list, int64_t band_count, void *stream);

@@ -64,11 +64,16 @@ __global__ __launch_bounds__(kBlock) void sobolev_state_gradient_kernel(const vf
 
 // out[a] = sum_j k[j] * in[a + c - j] per component, zero outside [0, len), float64 in tap order, one float32 rounding,
 // forced to 0 where the RAW gradient's component is below 1e-6 (math_utils/convolution.py:118,123,127)
+// The mask travels WITH the data from the second pass on: the first pass (mask_src = the raw gradient, which is also its
+// input) leaves the three verdicts as bits in the unused fourth component of its output, every later pass (mask_src ==
+// nullptr) finds them in the centre tap it loads anyway and hands them on -- one 16-byte load per voxel and pass less, and
+// 26 MB per pass at 256^3 that no longer come through the fabric (profiles/r04_sobolev_pmc_hbm_traffic.csv).
 template <int NT, bool FMA>
 __device__ inline vf4 filtered_at(const vf4* __restrict__ in, const vf4* __restrict__ mask_src, const TapsN<NT>& taps,
                                   unsigned i, int a, int len, int stride) {
     constexpr int c = NT / 2;
-    const vf4 m = mask_src[i];
+    vf4 m = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (mask_src) m = mask_src[i];
     vf4 v[NT];
     const vf4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -85,11 +90,14 @@ __device__ inline vf4 filtered_at(const vf4* __restrict__ in, const vf4* __restr
         acc[1] = mac<FMA>(acc[1], taps.k[j], (double)v[j].y);
         acc[2] = mac<FMA>(acc[2], taps.k[j], (double)v[j].z);
     }
+    unsigned bits;
+    if (mask_src) bits = (fabsf(m.x) < 1e-6f ? 1u : 0u) | (fabsf(m.y) < 1e-6f ? 2u : 0u) | (fabsf(m.z) < 1e-6f ? 4u : 0u);
+    else bits = __float_as_uint(v[c].w);  // the centre tap of the previous pass's output
     vf4 o;
-    o.x = fabsf(m.x) < 1e-6f ? 0.0f : (float)acc[0];
-    o.y = fabsf(m.y) < 1e-6f ? 0.0f : (float)acc[1];
-    o.z = fabsf(m.z) < 1e-6f ? 0.0f : (float)acc[2];
-    o.w = 0.0f;
+    o.x = (bits & 1u) ? 0.0f : (float)acc[0];
+    o.y = (bits & 2u) ? 0.0f : (float)acc[1];
+    o.z = (bits & 4u) ? 0.0f : (float)acc[2];
+    o.w = __uint_as_float(bits);
     return o;
 }
 
@@ -309,7 +317,8 @@ extern "C" int lsf_convolve_axis_listed4(const float* in4, float* out4, const fl
                                          const lsf_gate* gate, const int32_t* band_list, int64_t band_count,
                                          void* stream) {
     if (int e = check_grid(grid)) return e;
-    if (!in4 || !out4 || in4 == out4 || !zero_mask_source4 || !taps_host || !band_list || band_count < 0 ||
+    // zero_mask_source4 == NULL: the mask bits are in in4's fourth component (a pass behind the first one)
+    if (!in4 || !out4 || in4 == out4 || !taps_host || !band_list || band_count < 0 ||
         band_count > 0x7fffffffll || axis < 0 || axis >= grid->dims)
         return LSF_ERR_BAD_ARGUMENT;
     if (!taps_ok(n_taps)) return LSF_ERR_KERNEL_TOO_LONG;
@@ -336,7 +345,7 @@ extern "C" int lsf_sobolev_state_update(const float* in4, const float* zero_mask
                                         int32_t n_taps, const lsf_gate* gate, lsf_iteration_record* record,
                                         const int32_t* band_list, int64_t band_count, int32_t first_list, void* stream) {
     if (int e = check_grid(grid)) return e;
-    if (!in4 || !zero_mask_source4 || !state_in || !state_out || state_out == state_in || !g_out4 || g_out4 == in4 ||
+    if (!in4 || !state_in || !state_out || state_out == state_in || !g_out4 || g_out4 == in4 ||
         !params || !record || !taps_host || !band_list || band_count < 0 || band_count > 0x7fffffffll || axis < 0 ||
         axis >= grid->dims)
         return LSF_ERR_BAD_ARGUMENT;

@@ -787,13 +787,18 @@ class _SobolevStatePlan:
             check(lib.lsf_sobolev_state_gradient(s_in, self.p_canon, raw, f.grid_ref, self.params_ref, gate, rec,
                                                  band.pointer, band.count, self.stream), "lsf_sobolev_state_gradient")
         src, dst = raw, a
+        # the FIRST pass takes the zero-preserving mask from the raw gradient (its own input) and leaves it as bits in its
+        # output's fourth component; every later pass reads it there (no mask source: one load per voxel less)
+        none = ctypes.c_void_p(0)
         for axis in self.axes[:-1]:
             for band in self.bands:
-                check(lib.lsf_convolve_axis_listed4(src, dst, raw, f.grid_ref, axis, self.p_taps, self.n_taps, gate,
-                                                    band.pointer, band.count, self.stream), "lsf_convolve_axis_listed4")
+                check(lib.lsf_convolve_axis_listed4(src, dst, raw if src is raw else none, f.grid_ref, axis, self.p_taps,
+                                                    self.n_taps, gate, band.pointer, band.count, self.stream),
+                      "lsf_convolve_axis_listed4")
             src, dst = dst, (b if dst is a else a)
         for k, band in enumerate(self.bands_last):
-            check(lib.lsf_sobolev_state_update(src, raw, s_in, s_out, dst, f.grid_ref, self.params_ref, self.axes[-1],
+            check(lib.lsf_sobolev_state_update(src, raw if src is raw else none, s_in, s_out, dst, f.grid_ref,
+                                               self.params_ref, self.axes[-1],
                                                self.p_taps, self.n_taps, gate, rec, band.pointer, band.count,
                                                int(k == 0), self.stream), "lsf_sobolev_state_update")
 
@@ -952,7 +957,8 @@ class SlavchevaEngine:
             mode, (boundary, interior) = _lib.SLAB_RESUME, f.resume_parts.get()
         else:
             mode, (boundary, interior) = _lib.SLAB_LAUNCH, f.widened_parts[0 if j == k - 1 else k - 1 - j].get()
-        if f.native is not None and getattr(f, "face_plan_args", None) is not None and (exchange or i >= 1):
+        if f.native is not None and getattr(f, "face_plan_args", None) is not None and \
+                (exchange or i >= 1 or os.environ.get("LSF_SLAB_FACE_CHECK_AT", "first") == "plan"):
             # the neighbours' face counts: the collective is started BEHIND the first iteration's launches (its ~0.2 ms of
             # host calls then run while the card works) -- at once if the first iteration already exchanges
             (args, kwargs), f.face_plan_args = f.face_plan_args, None
