@@ -443,6 +443,11 @@ typedef struct lsf_slab_faces {
     float *send_msg[2], *recv_msg[2];
     int64_t send_count[2], recv_count[2];
 } lsf_slab_faces;
+/* helper of the compact-face plan: out[f] = the ascending merge of the ascending runs a[f] (n_a[f] entries) and b[f]
+ * (n_b[f]), all entries distinct, for f < pairs <= 4, in ONE launch (a face's band voxels are the face slices' entries
+ * of the INTERIOR and of the BOUNDARY list: both ranks must enumerate them in the same -- ascending -- order). */
+int lsf_merge_sorted_runs(const int32_t *const *a, const int64_t *n_a, const int32_t *const *b, const int64_t *n_b,
+                          int32_t *const *out, int32_t pairs, void *stream);
 int lsf_slab_unique_id(const char *rccl_library_path, uint8_t *id_out128);
 int lsf_slab_comm_create(const char *rccl_library_path, const uint8_t *id128, int32_t rank, int32_t world,
                          lsf_slab_comm **out);

@@ -958,9 +958,11 @@ class SlavchevaEngine:
         else:
             mode, (boundary, interior) = _lib.SLAB_LAUNCH, f.widened_parts[0 if j == k - 1 else k - 1 - j].get()
         if f.native is not None and getattr(f, "face_plan_args", None) is not None and \
-                (exchange or i >= 1 or os.environ.get("LSF_SLAB_FACE_CHECK_AT", "first") == "plan"):
-            # the neighbours' face counts: the collective is started BEHIND the first iteration's launches (its ~0.2 ms of
-            # host calls then run while the card works) -- at once if the first iteration already exchanges
+                (exchange or j >= k - 2 or os.environ.get("LSF_SLAB_FACE_CHECK_AT", "late") == "plan"):
+            # the face lists and the neighbours' face counts: made ONE iteration before the first exchange -- the host
+            # enqueues an iteration in ~20 us, the card takes ~30, so that is where the host's lead over the card is
+            # largest and the ~0.15 ms of host calls (a collective) starve it least (kernel trace of the loop-back,
+            # round 4: planned behind the first iteration, with torch.sort for the merges, the card idled 0.4 ms there)
             (args, kwargs), f.face_plan_args = f.face_plan_args, None
             self._plan_compact_faces(f, *args, **kwargs)
         if f.native is not None and exchange and f.pending_face_plan is not None:
@@ -1010,12 +1012,17 @@ class SlavchevaEngine:
         L = self.comm.layout
         h = L.halo
 
+        merges = []  # (run a, run b, out): the faces that have entries in both lists, merged in ONE launch below
+
         def union(z0, z1):
             pieces = [b.indices[c[z0]:c[z1]] for b, c in zip(bands, cut) if c[z1] > c[z0]]
             if not pieces:
                 return torch.zeros(1, dtype=torch.int32, device=live.device), 0
-            idx = pieces[0] if len(pieces) == 1 else torch.sort(torch.cat(pieces)).values
-            return idx.contiguous(), idx.numel()
+            if len(pieces) == 1:
+                return pieces[0].contiguous(), pieces[0].numel()
+            out = torch.empty(pieces[0].numel() + pieces[1].numel(), dtype=torch.int32, device=live.device)
+            merges.append((pieces[0], pieces[1], out))
+            return out, out.numel()
         none = (torch.zeros(1, dtype=torch.int32, device=live.device), 0)
         if faces is not None:  # slabs cut along y: the caller filtered the four lists out by row
             pad = lambda e: none if e is None or e[1] == 0 else e
@@ -1023,6 +1030,12 @@ class SlavchevaEngine:
         else:
             send = [union(L.z_begin, L.z_begin + h) if lo else none, union(L.z_end - h, L.z_end) if hi else none]
             recv = [union(L.z_begin - h, L.z_begin) if lo else none, union(L.z_end, L.z_end + h) if hi else none]
+            if merges:  # ascending merge of the INTERIOR and the BOUNDARY entries of a face (lsf_merge_sorted_runs)
+                n = len(merges)
+                arr = lambda k: (ctypes.c_void_p * n)(*[m[k].data_ptr() for m in merges])
+                cnt = lambda k: (ctypes.c_int64 * n)(*[m[k].numel() for m in merges])
+                _lib.check(_lib.lib.lsf_merge_sorted_runs(arr(0), cnt(0), arr(1), cnt(1), arr(2), n, dev.stream_ptr()),
+                           "lsf_merge_sorted_runs")
         # A rank's halo holds the neighbour's boundary slices, so what it expects to receive IS what the neighbour sends --
         # if the caller cut consistent slabs.  That contract is cross-checked with the neighbours on EVERY call:
         # mismatched message sizes would hang or corrupt the transport, and whether to check cannot depend on anything
