@@ -1209,8 +1209,13 @@ class SlavchevaEngine:
         f.widened_parts = [_Lazy(lambda e=e: (empty, parts([(L.z_begin - (e if lo else 0), L.z_end + (e if hi else 0))])))
                            for e in range(f.exchange_interval)]
         z_lo, z_hi = L.z_begin + (h if lo else 0), L.z_end - (h if hi else 0)
-        f.exchange_parts = _Lazy(lambda: (parts(([(L.z_begin, z_lo)] if lo else []) + ([(z_hi, L.z_end)] if hi else [])),
-                                          parts([(z_lo, z_hi)])))
+        if f.exchange_interval > 1 and os.environ.get("LSF_SLAB_SPLIT", "1") == "0":
+            # measurement: no boundary-first split -- the whole owned range in one launch, the exchange behind it and
+            # hidden behind the NEXT iteration's halo-independent part only (the deferred wait)
+            f.exchange_parts = _Lazy(lambda: (parts([(L.z_begin, L.z_end)]), empty))
+        else:
+            f.exchange_parts = _Lazy(lambda: (parts(([(L.z_begin, z_lo)] if lo else []) +
+                                                    ([(z_hi, L.z_end)] if hi else [])), parts([(z_lo, z_hi)])))
         # first iteration of a group, while the previous group's exchange may still be in flight: the owned slices that
         # do not touch a halo slice first, the rest (the widened range's outer slices) after the halos have arrived
         e_last = f.exchange_interval - 1
