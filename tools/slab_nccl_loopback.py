@@ -110,6 +110,22 @@ for fixed in ((True,) if os.environ.get("FIXED_ONLY") == "1" else (True, False))
                      [16 * int(c) for c in _f.faces.recv_count], 16 * _h * n * n), flush=True)
         elif rep == 0 and _f is not None:
             print("    whole faces travel: 2 x %d bytes per exchange" % (16 * _h * n * n), flush=True)
+if os.environ.get("LB_SINGLE", "1") == "1":
+    # the same box's single-GPU call for the ratio: one n^3 sphere pair (as many band voxels as the slab owns), no comm
+    c1, l1 = sphere_pair(n, 3, "cuda")
+    single = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                                      smoothing_term_method=lsf.SmoothingTermMethod.KILLING, check_interval=50,
+                                      maximum_warp_length_lower_threshold=0.0, max_iterations=iters, min_iterations=iters)
+    for rep in range(4):
+        live = l1.clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        single.optimize(live, c1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if rep:
+            print("single GPU, the same box: %d iterations, %.1f us per iteration (whole optimize %.2f ms)"
+                  % (iters, dt / iters * 1e6, dt * 1e3), flush=True)
 if os.environ.get("LB_PROFILE") == "1":
     import cProfile, pstats
     live = live0.clone()
