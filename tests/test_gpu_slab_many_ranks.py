@@ -30,6 +30,18 @@ def _volume(kind, n, nz):
         from oracle import lsf_oracle as O
         c, l = O.sphere_pair(n, d=3, nz=nz, z_total=nz)
         return c, l
+    if kind == "island":
+        # ONE sphere pair in the middle third of the stack, free space (+1) everywhere else: the end slabs hold no band
+        # voxel at all -- what the end ranks of bench.py --scaling strong see at N = 8 (the 256^3 sphere spans z 41..217)
+        from oracle import lsf_oracle as O
+        assert nz == 3 * n
+        c1, l1 = O.sphere_pair(n, d=3)
+        out = []
+        for f in (c1, l1):
+            vol = np.ones((nz, n, n), np.float32)
+            vol[n:2 * n] = f
+            out.append(vol)
+        return out[0], out[1]
     # the reference's orthographic 2-D pair (tests/golden: generate_initial_orthographic_2d_tsdf_fields, 64 x 64) laid
     # into the (z, x) plane and swept along y with a slow shear: default KillingFusion weights move it by several voxels
     # per iteration, along z -- across the slab faces -- as much as along x
@@ -69,6 +81,7 @@ def _worker(rank, world, port, kind, n, nz, halo, kwargs, out_dir):
 CASES = {
     # name: (world, volume, halo, fixed iteration count or None for a threshold-terminated run, sobolev)
     "three_slabs_groups": (3, "sphere", 2, 6, False),
+    "three_slabs_empty_end_ranks": (3, "island", 2, 6, False),
     "four_slabs_groups": (4, "sphere", 4, 9, False),
     "four_slabs_threshold": (4, "sphere", 1, None, False),
     "three_slabs_sobolev_lists": (3, "sphere", 3, 4, True),
@@ -89,6 +102,8 @@ def test_slab_ranks_equal_whole_volume(tmp_path, case):
     world, kind, halo, fixed, sobolev = CASES[case]
     n = 64
     nz = 96 if (world == 3 and kind == "sphere") else (128 if (kind == "sphere" or world == 4) else 64)
+    if kind == "island":
+        nz = 3 * n
     if sobolev:
         kwargs = dict(compute_method=lsf.ComputeMethod.DIRECT, sobolev_smoothing_enabled=True,
                       sobolev_kernel=lsf.generate_1d_sobolev_kernel(7, 0.1), check_interval=3)
