@@ -452,6 +452,13 @@ int lsf_slab_unique_id(const char *rccl_library_path, uint8_t *id_out128);
 int lsf_slab_comm_create(const char *rccl_library_path, const uint8_t *id128, int32_t rank, int32_t world,
                          lsf_slab_comm **out);
 int lsf_slab_comm_destroy(lsf_slab_comm *comm);
+/* The cross-check of a call's compact faces ("the caller verifies that the counts agree"), without a host round trip in
+ * front of the launches: _begin hands this rank's four counts (send lower, send upper, recv lower, recv upper) to an
+ * ncclAllGather on the communicator's stream and returns at once; _end waits for it and copies every rank's four counts,
+ * rank-major, into table[4 * world].  Every rank sees every row and so reaches the same verdict.  Every rank of the
+ * communicator must call the pair at the same point of its call sequence (it is a collective). */
+int lsf_slab_face_counts_begin(lsf_slab_comm *comm, const int64_t *counts4);
+int lsf_slab_face_counts_end(lsf_slab_comm *comm, int64_t *table);
 int lsf_slab_state_iteration(lsf_slab_comm *comm, const float *state_in, const float *canonical, float *state_out,
                              const lsf_slab_layout *layout, const lsf_slab_part *boundary_parts, int32_t n_boundary,
                              const lsf_slab_part *interior_parts, int32_t n_interior,

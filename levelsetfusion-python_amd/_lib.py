@@ -22,7 +22,7 @@ ABI_VERSION = 3
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "6b12c2f962f12492"
+HEADER_ABI_HASH = "30c08fae8c3ad80b"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -166,6 +166,8 @@ PROTOTYPES = {
     "lsf_slab_unique_id": (ctypes.c_int, [ctypes.c_char_p, _vp]),
     "lsf_slab_comm_create": (ctypes.c_int, [ctypes.c_char_p, _vp, _i32, _i32, _P(_vp)]),
     "lsf_slab_comm_destroy": (ctypes.c_int, [_vp]),
+    "lsf_slab_face_counts_begin": (ctypes.c_int, [_vp, _P(_i64)]),
+    "lsf_slab_face_counts_end": (ctypes.c_int, [_vp, _P(_i64)]),
     "lsf_slab_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(SlabLayoutC), _P(SlabPart), _i32, _P(SlabPart),
                                                 _i32, _P(SlavchevaParams), _P(Gate), _vp, _i32, _P(SlabFaces), _vp]),
     "lsf_slavcheva_filter_update_rewarp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),

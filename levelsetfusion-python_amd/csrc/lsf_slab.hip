@@ -11,6 +11,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -29,6 +30,7 @@ struct RcclApi {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -61,7 +63,8 @@ int load_rccl(const char* path) {
     const bool ok = bind(api.GetUniqueId, "ncclGetUniqueId") && bind(api.CommInitRank, "ncclCommInitRank") &&
                     bind(api.CommDestroy, "ncclCommDestroy") && bind(api.GroupStart, "ncclGroupStart") &&
                     bind(api.GroupEnd, "ncclGroupEnd") && bind(api.Send, "ncclSend") &&
-                    bind(api.Recv, "ncclRecv") && bind(api.GetErrorString, "ncclGetErrorString");
+                    bind(api.Recv, "ncclRecv") && bind(api.AllGather, "ncclAllGather") &&
+                    bind(api.GetErrorString, "ncclGetErrorString");
     if (!ok) return LSF_ERR_RCCL_UNAVAILABLE;
     g_rccl = api;  // the handle is stored last of all members' owner: readers test it first
     return 0;
@@ -76,6 +79,12 @@ struct lsf_slab_comm {
     hipEvent_t boundary_done[2], halos_done[2];
     unsigned parity;
     int pending;  // index of the halos_done event a LSF_SLAB_EXCHANGE_DEFERRED call left for the next call, or -1
+    // face counts of the current call (lsf_slab_face_counts_*): [0, 4) this rank's, [4, 4 + 4 * world) every rank's
+    long long* counts_dev;
+    long long* counts_host;  // pinned
+    hipEvent_t counts_done;
+    bool counts_in_flight;
+    bool gather_on_main;  // the face gather behind the boundary launches on the launch stream (default), not on comm_stream
 };
 
 #define LSF_RCCL_CHECK(call)                                                                       \
@@ -119,12 +128,22 @@ extern "C" int lsf_slab_comm_create(const char* rccl_library_path, const uint8_t
     c->world = world;
     c->parity = 0;
     c->pending = -1;
+    c->counts_dev = c->counts_host = nullptr;
+    c->counts_in_flight = false;
+    const char* where = getenv("LSF_SLAB_GATHER_STREAM");
+    c->gather_on_main = !(where && strcmp(where, "comm") == 0);
     hipError_t e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
         e = hipEventCreateWithFlags(&c->boundary_done[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->halos_done[k], hipEventDisableTiming);
     }
+    const size_t words = 4u + 4u * (size_t)world;
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->counts_done, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->counts_dev), words * sizeof(long long));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->counts_host), words * sizeof(long long), 0);
     if (e != hipSuccess) {
+        if (c->counts_dev) (void)hipFree(c->counts_dev);
+        if (c->counts_host) (void)hipHostFree(c->counts_host);
         g_rccl.CommDestroy(c->comm);
         delete c;
         return (int)e;
@@ -140,9 +159,32 @@ extern "C" int lsf_slab_comm_destroy(lsf_slab_comm* c) {
         (void)hipEventDestroy(c->boundary_done[k]);
         (void)hipEventDestroy(c->halos_done[k]);
     }
+    (void)hipEventDestroy(c->counts_done);
+    (void)hipFree(c->counts_dev);
+    (void)hipHostFree(c->counts_host);
     (void)hipStreamDestroy(c->comm_stream);
     if (g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     delete c;
+    return 0;
+}
+
+extern "C" int lsf_slab_face_counts_begin(lsf_slab_comm* c, const int64_t* counts4) {
+    if (!c || !counts4 || c->counts_in_flight) return LSF_ERR_BAD_ARGUMENT;
+    for (int k = 0; k < 4; ++k) c->counts_host[k] = counts4[k];
+    LSF_HIP_CHECK(hipMemcpyAsync(c->counts_dev, c->counts_host, 4 * sizeof(long long), hipMemcpyHostToDevice, c->comm_stream));
+    LSF_RCCL_CHECK(g_rccl.AllGather(c->counts_dev, c->counts_dev + 4, 4, ncclInt64, c->comm, c->comm_stream));
+    LSF_HIP_CHECK(hipMemcpyAsync(c->counts_host + 4, c->counts_dev + 4, 4 * (size_t)c->world * sizeof(long long),
+                                 hipMemcpyDeviceToHost, c->comm_stream));
+    LSF_HIP_CHECK(hipEventRecord(c->counts_done, c->comm_stream));
+    c->counts_in_flight = true;
+    return 0;
+}
+
+extern "C" int lsf_slab_face_counts_end(lsf_slab_comm* c, int64_t* table) {
+    if (!c || !table || !c->counts_in_flight) return LSF_ERR_BAD_ARGUMENT;
+    c->counts_in_flight = false;
+    LSF_HIP_CHECK(hipEventSynchronize(c->counts_done));
+    for (int k = 0; k < 4 * c->world; ++k) table[k] = c->counts_host[4 + k];
     return 0;
 }
 
@@ -208,16 +250,23 @@ __global__ __launch_bounds__(256) void merge_runs_kernel(MergePairs m, int pairs
 // halo <- lower neighbour.  Between distinct peers the order inside a group is irrelevant; when a rank is its own
 // neighbour (the one-GPU loop-back of a z-periodic stack) sends and receives pair up in order, and this order pairs the
 // lower boundary with the upper halo -- the same voxels of a periodic stack -- so counts match and the physics is right.
-static int exchange_compact(lsf_slab_comm* c, float* state, const lsf_slab_layout* L, const lsf_slab_faces* F,
-                            hipStream_t s) {
+static int gather_faces(const float* state, const lsf_slab_layout* L, const lsf_slab_faces* F, hipStream_t s) {
     const bool lo = L->lo_rank >= 0, hi = L->hi_rank >= 0;
     const unsigned n_slo = lo ? (unsigned)F->send_count[0] : 0u, n_shi = hi ? (unsigned)F->send_count[1] : 0u;
-    const unsigned n_rlo = lo ? (unsigned)F->recv_count[0] : 0u, n_rhi = hi ? (unsigned)F->recv_count[1] : 0u;
     if (n_slo + n_shi > 0)
         hipLaunchKernelGGL(face_gather_kernel, dim3((n_slo + n_shi + 255) / 256), dim3(256), 0, s,
                            reinterpret_cast<const vf4*>(state), F->send_list[0], n_slo,
                            reinterpret_cast<vf4*>(F->send_msg[0]), F->send_list[1], n_shi,
                            reinterpret_cast<vf4*>(F->send_msg[1]));
+    return (int)hipGetLastError();
+}
+
+// the messages are gathered already (gather_faces): wire + scatter on s
+static int exchange_compact(lsf_slab_comm* c, float* state, const lsf_slab_layout* L, const lsf_slab_faces* F,
+                            hipStream_t s) {
+    const bool lo = L->lo_rank >= 0, hi = L->hi_rank >= 0;
+    const unsigned n_slo = lo ? (unsigned)F->send_count[0] : 0u, n_shi = hi ? (unsigned)F->send_count[1] : 0u;
+    const unsigned n_rlo = lo ? (unsigned)F->recv_count[0] : 0u, n_rhi = hi ? (unsigned)F->recv_count[1] : 0u;
     LSF_RCCL_CHECK(g_rccl.GroupStart());
     if (lo && n_slo) LSF_RCCL_CHECK(g_rccl.Send(F->send_msg[0], (size_t)n_slo * 4, ncclFloat, L->lo_rank, c->comm, s));
     if (hi && n_rhi) LSF_RCCL_CHECK(g_rccl.Recv(F->recv_msg[1], (size_t)n_rhi * 4, ncclFloat, L->hi_rank, c->comm, s));
@@ -318,9 +367,16 @@ extern "C" int lsf_slab_state_iteration(lsf_slab_comm* comm, const float* state_
     // 1. the slices the neighbours are waiting for
     if (int e = launch_parts(state_in, canonical, state_out, boundary_parts, n_boundary, params, gate, record, stream))
         return e;
-    // 2. their exchange on the communication stream, while ...
+    // 2. their exchange on the communication stream, while ...  (compact faces: the messages are gathered on the LAUNCH
+    //    stream, right behind the boundary parts -- 4 us there; on the communication stream the gather started ~13 us
+    //    after the boundary parts ended and took 21 us squeezed in beside the interior part's one-workgroup-per-CU grid:
+    //    kernel trace of the loop-back, profiles/r04_slab_rccl_loopback.txt)
+    if (faces && comm->gather_on_main)
+        if (int e = gather_faces(state_out, layout, faces, main)) return e;
     LSF_HIP_CHECK(hipEventRecord(comm->boundary_done[k], main));
     LSF_HIP_CHECK(hipStreamWaitEvent(comm->comm_stream, comm->boundary_done[k], 0));
+    if (faces && !comm->gather_on_main)
+        if (int e = gather_faces(state_out, layout, faces, comm->comm_stream)) return e;
     if (int e = faces ? exchange_compact(comm, state_out, layout, faces, comm->comm_stream)
                       : exchange_state(comm, state_out, layout, comm->comm_stream))
         return e;

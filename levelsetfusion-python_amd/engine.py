@@ -1011,45 +1011,68 @@ class SlavchevaEngine:
         rank disagrees (a caller that hands inconsistent halos)."""
         L = self.comm.layout
         h = L.halo
-
-        merges = []  # (run a, run b, out): the faces that have entries in both lists, merged in ONE launch below
-
-        def union(z0, z1):
-            pieces = [b.indices[c[z0]:c[z1]] for b, c in zip(bands, cut) if c[z1] > c[z0]]
-            if not pieces:
-                return torch.zeros(1, dtype=torch.int32, device=live.device), 0
-            if len(pieces) == 1:
-                return pieces[0].contiguous(), pieces[0].numel()
-            out = torch.empty(pieces[0].numel() + pieces[1].numel(), dtype=torch.int32, device=live.device)
-            merges.append((pieces[0], pieces[1], out))
-            return out, out.numel()
-        none = (torch.zeros(1, dtype=torch.int32, device=live.device), 0)
+        # Host work between two launches (the card waits for it: kernel trace of the loop-back, DESIGN section 6): a face
+        # is (device pointer, count) -- a run of a sorted list is pointer arithmetic, no tensor views -- and the faces
+        # that have entries in both lists are merged in ONE launch into ONE buffer
+        if getattr(self, "_no_face", None) is None or self._no_face.device != live.device:
+            self._no_face = torch.zeros(4, dtype=torch.int32, device=live.device)  # a valid address for an empty face
+        none = (self._no_face.data_ptr(), 0)
+        keep = [self._no_face]
         if faces is not None:  # slabs cut along y: the caller filtered the four lists out by row
-            pad = lambda e: none if e is None or e[1] == 0 else e
+            def pad(e):
+                if e is None or e[1] == 0:
+                    return none
+                keep.append(e[0])
+                return e[0].data_ptr(), int(e[1])
             send, recv = [pad(e) for e in faces["send"]], [pad(e) for e in faces["recv"]]
         else:
-            send = [union(L.z_begin, L.z_begin + h) if lo else none, union(L.z_end - h, L.z_end) if hi else none]
-            recv = [union(L.z_begin - h, L.z_begin) if lo else none, union(L.z_end, L.z_end + h) if hi else none]
-            if merges:  # ascending merge of the INTERIOR and the BOUNDARY entries of a face (lsf_merge_sorted_runs)
+            base = [b.indices.data_ptr() for b in bands]
+            merges = []  # (run a, run b, offset into the merged buffer): ascending merge of the INTERIOR and the BOUNDARY
+                         # entries of a face (lsf_merge_sorted_runs)
+            merged_words = 0
+
+            def union(z0, z1):
+                nonlocal merged_words
+                runs = [(p + 4 * c[z0], c[z1] - c[z0]) for p, c in zip(base, cut) if c[z1] > c[z0]]
+                if not runs:
+                    return none
+                if len(runs) == 1:
+                    return runs[0]
+                merges.append((runs[0], runs[1], merged_words))
+                merged_words += runs[0][1] + runs[1][1]
+                return None, runs[0][1] + runs[1][1], len(merges) - 1  # its address follows below
+            plan = [union(L.z_begin, L.z_begin + h) if lo else none, union(L.z_end - h, L.z_end) if hi else none,
+                    union(L.z_begin - h, L.z_begin) if lo else none, union(L.z_end, L.z_end + h) if hi else none]
+            keep += [b.indices for b in bands]
+            if merges:
                 n = len(merges)
-                arr = lambda k: (ctypes.c_void_p * n)(*[m[k].data_ptr() for m in merges])
-                cnt = lambda k: (ctypes.c_int64 * n)(*[m[k].numel() for m in merges])
-                _lib.check(_lib.lib.lsf_merge_sorted_runs(arr(0), cnt(0), arr(1), cnt(1), arr(2), n, dev.stream_ptr()),
-                           "lsf_merge_sorted_runs")
+                merged = torch.empty(merged_words, dtype=torch.int32, device=live.device)
+                keep.append(merged)
+                out = [merged.data_ptr() + 4 * m[2] for m in merges]
+                plan = [e if e[0] is not None else (out[e[2]], e[1]) for e in plan]
+                vp, i64 = ctypes.c_void_p * n, ctypes.c_int64 * n
+                _lib.check(_lib.lib.lsf_merge_sorted_runs(vp(*[m[0][0] for m in merges]), i64(*[m[0][1] for m in merges]),
+                                                          vp(*[m[1][0] for m in merges]), i64(*[m[1][1] for m in merges]),
+                                                          vp(*out), n, dev.stream_ptr()), "lsf_merge_sorted_runs")
+            send, recv = plan[:2], plan[2:]
         # A rank's halo holds the neighbour's boundary slices, so what it expects to receive IS what the neighbour sends --
         # if the caller cut consistent slabs.  That contract is cross-checked with the neighbours on EVERY call:
         # mismatched message sizes would hang or corrupt the transport, and whether to check cannot depend on anything
         # one rank alone sees (a rank whose data changed would enter the collective alone).  The counts are host numbers
-        # as soon as the list sizes are (they are cut positions), so the collective is STARTED here, when the launch plan is
-        # made, on a stream of its own, and its result is READ when the first exchange is enqueued -- h - 1 iterations of
-        # host work later (round 4: read where it was started, the 0.4 ms of collective + host read starved the card of
-        # launches, 0.29 ms of a 2.5 ms slab call in the loop-back).  LSF_SLAB_VERIFY_FACES=first: only on an optimizer's
-        # first call (measurements).
+        # (cut positions), so the collective is STARTED here and its result is READ when the first exchange is enqueued.
+        # On the native transport it is the library's own (lsf_slab_face_counts_begin / _end: an ncclAllGather on the
+        # communicator's stream, ~15 us of host time; through torch.distributed the pinned copies, the collective and
+        # the event cost ~0.15 ms of host calls, which the card spent idle).  LSF_SLAB_VERIFY_FACES=first: only on an
+        # optimizer's first call (measurements).
         check = None
         if not getattr(self, "_faces_verified", False) or os.environ.get("LSF_SLAB_VERIFY_FACES", "always") != "first":
             counts = [send[0][1], send[1][1], recv[0][1], recv[1][1]]
             world = torch.distributed.get_world_size(self.comm.group)
-            if self.comm.stage_through_host:  # gloo (tests): a host collective, done at once
+            if f.native is not None and not self.comm.stage_through_host:
+                _lib.check(_lib.lib.lsf_slab_face_counts_begin(f.native, (ctypes.c_int64 * 4)(*counts)),
+                           "lsf_slab_face_counts_begin")
+                check = ("native", None)
+            elif self.comm.stage_through_host:  # gloo (tests): a host collective, done at once
                 mine = torch.tensor(counts, dtype=torch.int64)
                 rows = [torch.zeros_like(mine) for _ in range(world)]
                 torch.distributed.all_gather(rows, mine, group=self.comm.group)
@@ -1068,20 +1091,26 @@ class SlavchevaEngine:
                     done = torch.cuda.Event()
                     done.record()
                 check = (landed.view(world, 4), done)
-        f.pending_face_plan = (send, recv, check, live.device)
+        f.pending_face_plan = (send, recv, check, live.device, keep)
 
     def _finish_compact_faces(self, f):
         """second half of _plan_compact_faces, when the first exchange is enqueued: the neighbours' counts (the collective
         started with the launch plan has long finished), then the lsf_slab_faces descriptor -- or, if a neighbour
         disagrees, whole faces (z-slabs) / the torch transport with its packed staging buffers (slabs cut along y)"""
-        send, recv, check, device = f.pending_face_plan
+        send, recv, check, device, keep = f.pending_face_plan
         f.pending_face_plan = None
         ok = True
         if check is not None:
             table, done = check
             if done is not None:
                 done.synchronize()
-            rows = table.tolist()
+            if isinstance(table, str):  # the library's collective
+                world = self.comm.native_identity()[1]
+                flat = (ctypes.c_int64 * (4 * world))()
+                _lib.check(_lib.lib.lsf_slab_face_counts_end(f.native, flat), "lsf_slab_face_counts_end")
+                rows = [list(flat[4 * r:4 * r + 4]) for r in range(world)]
+            else:
+                rows = table.tolist()
             # every rank sees every row, so all ranks reach the same verdict without a second collective: a rank's lower
             # boundary lands in its lower neighbour's UPPER halo, its upper boundary in the upper neighbour's LOWER halo
             if len(rows) == 1:  # the one-GPU loop-back: this rank is its own neighbour on both sides
@@ -1104,14 +1133,15 @@ class SlavchevaEngine:
                               "slices are exchanged")
             return
         faces = _lib.SlabFaces()
-        f.face_tensors = []
-        for side in range(2):
-            for name, (idx, count) in (("send", send[side]), ("recv", recv[side])):
-                msg = torch.empty(max(count, 1) * 4, dtype=torch.float32, device=device)
-                f.face_tensors += [idx, msg]
-                getattr(faces, name + "_list")[side] = idx.data_ptr()
-                getattr(faces, name + "_msg")[side] = msg.data_ptr()
-                getattr(faces, name + "_count")[side] = count
+        entries = [(name, side, e) for side in range(2) for name, e in (("send", send[side]), ("recv", recv[side]))]
+        msgs = torch.empty(4 * sum(max(e[1], 1) for _, _, e in entries), dtype=torch.float32, device=device)  # all four
+        f.face_tensors = keep + [msgs]
+        at = msgs.data_ptr()
+        for name, side, (pointer, count) in entries:
+            getattr(faces, name + "_list")[side] = pointer
+            getattr(faces, name + "_msg")[side] = at
+            getattr(faces, name + "_count")[side] = count
+            at += 16 * max(count, 1)
         f.faces = faces
         f.faces_ref = ctypes.byref(faces)
 
@@ -1452,7 +1482,15 @@ class SlavchevaEngine:
             # whole volumes: the states are initialised near the band only (a quarter of the voxels of a 256^3 sphere
             # pair), valid while every update stays below SPARSE_REACH voxels -- checked on the device in front of an
             # early finalize pass and on the host behind every batch
-            sparse = (not slab and SPARSE_REACH > 0 and dev.n_voxels(grid) >= SPARSE_MIN_VOXELS
+            # Slabs: in exchange groups only (a fixed iteration count; an update of one voxel or more already sends the
+            # call to _optimize_widened, which exchanges every iteration and runs on full states), with a halo of at
+            # least SPARSE_REACH slices: then every chunk a rank reads in its halo is one the owner initialises too (the
+            # band voxel that makes it needed lies inside the owner's halo), so even whole faces carry valid data
+            slab_groups = (slab and self.min_iterations >= max(self.max_iterations, self.min_iterations)
+                           and not getattr(self, "_exchange_every_iteration", False)
+                           and self.comm.layout.halo >= max(SPARSE_REACH, 2)
+                           and os.environ.get("LSF_SPARSE_SLABS", "1") != "0")
+            sparse = ((not slab or slab_groups) and SPARSE_REACH > 0 and dev.n_voxels(grid) >= SPARSE_MIN_VOXELS
                       and self.iteration_hook is None and not getattr(self, "_sparse_disabled", False)
                       and os.environ.get("LSF_CHAIN", "0") != "1")
             prepared = dev.StatePrepare(live, canonical, dev.full_range(grid), cut_chunks,
@@ -1597,8 +1635,8 @@ class SlavchevaEngine:
             # z-slab: every EXECUTED iteration must have stayed inside what the halo schedule keeps valid -- also those
             # of a batch in which the gate then closed (a large update followed by convergence inside one
             # check_interval).  Every rank sees the same reduced / gathered records, so the raise is collective.
-            if sparse and n_exec > 0 and not dec["max_value"][:n_exec].max() < SPARSE_REACH:
-                raise _SparseStateExceeded()
+            if sparse and not slab and n_exec > 0 and not dec["max_value"][:n_exec].max() < SPARSE_REACH:
+                raise _SparseStateExceeded()  # (a slab's exchange groups stop at one voxel: _HaloTooNarrow below)
             reach = self.comm.layout.halo if slab else 0
             if slab and not self.sobolev and self._fast.exchange_interval > 1:
                 reach = 1  # inside an exchange group every iteration may consume one slice of validity only

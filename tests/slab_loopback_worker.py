@@ -36,9 +36,14 @@ def main(out_path, port):
                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING, maximum_warp_length_lower_threshold=0.0,
                   max_iterations=12, min_iterations=12, check_interval=5)
     results = {}
-    for tag, transport, faces in (("rccl", "rccl", "compact"), ("rccl_full", "rccl", "full"), ("torch", "torch", "full")):
+    from levelsetfusion_python_amd import engine
+    full_states_below = engine.SPARSE_MIN_VOXELS
+    # ..._sparse: the ping-pong states initialised near the band only (by default from 2^21 voxels on; here at 48^2 x 52)
+    for tag, transport, faces in (("rccl", "rccl", "compact"), ("rccl_full", "rccl", "full"), ("torch", "torch", "full"),
+                                  ("rccl_sparse", "rccl", "compact"), ("rccl_full_sparse", "rccl", "full")):
         os.environ["LSF_SLAB_TRANSPORT"] = transport
         os.environ["LSF_SLAB_FACES"] = faces
+        engine.SPARSE_MIN_VOXELS = 0 if tag.endswith("_sparse") else full_states_below
         comm = SelfComm(layout)
         used = "rccl" if comm.native() is not None else "torch"
         opt = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, **kwargs)
@@ -62,7 +67,11 @@ def main(out_path, port):
     ref.optimize(whole_l, whole_c)
     ref_live, ref_warp = whole_l[n:2 * n].cpu().numpy(), ref.warp_field[n:2 * n].cpu().numpy()
     a, b, c = results["rccl"], results["rccl_full"], results["torch"]
-    np.savez(out_path, used_rccl=a["used"], used_torch=c["used"],
+    sparse_differs = [t + ":" + k for t in ("rccl_sparse", "rccl_full_sparse") for k in ("live", "warp", "max_warps")
+                      if not np.array_equal(a[k], results[t][k])]
+    sparse_differs += [t + ":data" for t in ("rccl_sparse", "rccl_full_sparse")  # float64 sums by atomics: order varies
+                       if not np.allclose(a["data"], results[t]["data"], rtol=1e-10)]
+    np.savez(out_path, used_rccl=a["used"], used_torch=c["used"], sparse_differs=",".join(sparse_differs),
              live_equal=np.array_equal(a["live"], c["live"]) and np.array_equal(a["live"], b["live"]),
              warp_equal=np.array_equal(a["warp"], c["warp"]) and np.array_equal(a["warp"], b["warp"]),
              max_equal=np.array_equal(a["max_warps"], c["max_warps"]) and np.array_equal(a["max_warps"], b["max_warps"]),

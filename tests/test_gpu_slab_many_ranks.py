@@ -59,6 +59,8 @@ def _volume(kind, n, nz):
 
 def _worker(rank, world, port, kind, n, nz, halo, kwargs, out_dir):
     sys.path.insert(0, ROOT)
+    kwargs = dict(kwargs)
+    os.environ.update(kwargs.pop("_env", {}))  # read when the package is imported, below
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -82,6 +84,10 @@ CASES = {
     # name: (world, volume, halo, fixed iteration count or None for a threshold-terminated run, sobolev)
     "three_slabs_groups": (3, "sphere", 2, 6, False),
     "three_slabs_empty_end_ranks": (3, "island", 2, 6, False),
+    # the ping-pong states initialised near the band only (engine.SPARSE_REACH; volumes of 2^21 voxels and more by
+    # default, every volume here): whole faces travel on this transport, i.e. also voxels a rank never initialised
+    "three_slabs_groups_sparse_states": (3, "sphere", 2, 6, "sparse"),
+    "two_slabs_large_updates_sparse_states": (2, "ortho", 2, 5, "sparse"),
     "four_slabs_groups": (4, "sphere", 4, 9, False),
     "four_slabs_threshold": (4, "sphere", 1, None, False),
     "three_slabs_sobolev_lists": (3, "sphere", 3, 4, True),
@@ -100,6 +106,8 @@ def test_slab_ranks_equal_whole_volume(tmp_path, case):
     import torch.multiprocessing as mp
     import levelsetfusion_python_amd as lsf
     world, kind, halo, fixed, sobolev = CASES[case]
+    env = {"LSF_SPARSE_MIN_VOXELS": "0"} if sobolev == "sparse" else {}
+    sobolev = sobolev is True
     n = 64
     nz = 96 if (world == 3 and kind == "sphere") else (128 if (kind == "sphere" or world == 4) else 64)
     if kind == "island":
@@ -126,7 +134,8 @@ def test_slab_ranks_equal_whole_volume(tmp_path, case):
         kwargs.update(maximum_warp_length_lower_threshold=0.0, max_iterations=fixed, min_iterations=fixed)
     else:
         kwargs.update(maximum_warp_length_lower_threshold=0.0319, max_iterations=30, min_iterations=2)
-    mp.spawn(_worker, args=(world, _free_port(), kind, n, nz, halo, kwargs, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), kind, n, nz, halo, dict(kwargs, _env=env), str(tmp_path)),
+             nprocs=world, join=True)
     canonical, live = (torch.from_numpy(v).cuda() for v in _volume(kind, n, nz))
     ref = lsf.SlavchevaOptimizer3d(field_size=n, **kwargs)
     ref._run_checks = lambda *a: None  # the stacked volume is not a cube
