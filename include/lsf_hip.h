@@ -390,6 +390,14 @@ int lsf_slavcheva_state_iteration(const float *state_in, const float *canonical,
 int lsf_sobolev_state_gradient(const float *state, const float *canonical, float *g_raw4, const lsf_grid *grid,
                                const lsf_slavcheva_params *params, const lsf_gate *gate, lsf_iteration_record *record,
                                const int32_t *band_list, int64_t band_count, void *stream);
+/* 3-D: lsf_sobolev_state_gradient and the x pass (the FIRST pass of a volume, math_utils/convolution.py:94-105) in ONE
+ * launch: out4 = what lsf_convolve_axis_listed4(raw, out4, raw, axis 0) would hold, bit for bit, mask bits included; the
+ * raw gradient is never stored.  band_list must then hold EVERY band voxel whose gradient can be non-zero (one
+ * ascending list of the whole band, e.g. LSF_BAND_ALL): a tap at a voxel that is not in THIS list counts as zero. */
+int lsf_sobolev_state_gradient_x(const float *state, const float *canonical, float *out4, const lsf_grid *grid,
+                                 const lsf_slavcheva_params *params, const double *taps_host, int32_t n_taps,
+                                 const lsf_gate *gate, lsf_iteration_record *record, const int32_t *band_list,
+                                 int64_t band_count, void *stream);
 int lsf_convolve_axis_listed4(const float *in4, float *out4, const float *zero_mask_source4, const lsf_grid *grid,
                               int32_t axis, const double *taps_host, int32_t n_taps, const lsf_gate *gate,
                               const int32_t *band_list, int64_t band_count, void *stream);

@@ -18,6 +18,36 @@ using namespace lsf::slav;
 
 namespace {
 
+__device__ inline void decode_listed(const Grid& g, unsigned i, int& x, int& y, int& z) {
+    const unsigned zy = fast_div(i, g.div_nx);
+    x = (int)(i - zy * (unsigned)g.nx);
+    z = (int)fast_div(zy, g.div_ny);
+    y = (int)zy - z * g.ny;
+}
+
+// raw gradient (and energy terms) of ONE listed voxel; zero where the voxel has left the narrow-band union
+// (tsdf_set_routines.py:19-52: a listed voxel may have snapped to +-1)
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
+__device__ inline void listed_voxel_gradient(const vf4* __restrict__ state, const float* __restrict__ canonical,
+                                             const Grid& g, const Params& p, int i, int x, int y, int z, float (&gv)[3],
+                                             double (&e)[3]) {
+    const vf4 sc = state[i];
+    const float l = sc.x, cn = canonical[i];
+    gv[0] = gv[1] = gv[2] = 0.0f;
+    e[0] = e[1] = e[2] = 0.0;
+    if (!(fabsf(l) == 1.0f && fabsf(cn) == 1.0f)) {
+        const bool interior = x > 0 && x < g.nx - 1 && y > 0 && y < g.ny - 1 && (D == 2 || (z > 0 && z < g.nz - 1));
+        if (g.wide_ok && __all(interior) && wave_span_ok(g, i)) {
+            NbhStateFast<D> n;
+            n.load(state, g, (unsigned)i, sc, !g.fast_ok);
+            band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
+        } else {
+            const NbhState<D> n(state, g, x, y, z, sc);
+            band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
+        }
+    }
+}
+
 // gradient (+ energies) of the listed voxels -> g_raw4; everything else in g_raw4 keeps the caller's zeros
 template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
 __global__ __launch_bounds__(kBlock) void sobolev_state_gradient_kernel(const vf4* __restrict__ state,
@@ -30,31 +60,119 @@ __global__ __launch_bounds__(kBlock) void sobolev_state_gradient_kernel(const vf
     double en[3] = {0.0, 0.0, 0.0};
     for_each_listed_voxel(g, band_list, band_count, [&](int x, int y, int z) {
         const int i = vidx(g, x, y, z);
-        const vf4 sc = state[i];
-        const float l = sc.x, cn = canonical[i];
-        float gv[3] = {0.0f, 0.0f, 0.0f};
-        // outside the narrow-band union (tsdf_set_routines.py:19-52): a listed voxel may have left it by snapping to +-1
-        if (!(fabsf(l) == 1.0f && fabsf(cn) == 1.0f)) {
-            double e[3] = {0.0, 0.0, 0.0};
-            const bool interior = x > 0 && x < g.nx - 1 && y > 0 && y < g.ny - 1 && (D == 2 || (z > 0 && z < g.nz - 1));
-            if (g.wide_ok && __all(interior) && wave_span_ok(g, i)) {
-                NbhStateFast<D> n;
-                n.load(state, g, (unsigned)i, sc, !g.fast_ok);
-                band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
-            } else {
-                const NbhState<D> n(state, g, x, y, z, sc);
-                band_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(n, p, l, cn, gv, e);
-            }
-            if (z >= g.e_begin && z < g.e_end) {
-                en[0] += e[0];
-                en[1] += e[1];
-                en[2] += e[2];
-            }
+        float gv[3];
+        double e[3];
+        listed_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(state, canonical, g, p, i, x, y, z, gv, e);
+        if (z >= g.e_begin && z < g.e_end) {
+            en[0] += e[0];
+            en[1] += e[1];
+            en[2] += e[2];
         }
         vf4 o;
         o.x = gv[0]; o.y = gv[1]; o.z = D == 3 ? gv[2] : 0.0f; o.w = 0.0f;
         g_raw[i] = o;
     });
+    if (ENERGY != LSF_ENERGY_NONE) {
+        double* dst[3] = {&record_slot(record)->data_energy, &record_slot(record)->smoothing_energy,
+                          &record_slot(record)->level_set_energy};
+        block_reduce_commit<3>(0ull, en, nullptr, dst);
+    }
+}
+
+// Gradient AND the first filter pass (along x, 3-D: math_utils/convolution.py:94-105 filters x first) in one launch: the
+// raw gradient never goes to memory.  Why this is possible on a band list: the raw gradient is ZERO at every voxel that
+// is not listed (the filter's input buffers are zero-initialised and only listed voxels are ever written), so the x -/+ d
+// taps of a listed voxel are either entries of the same ascending list a few positions away -- same row, consecutive x --
+// or zero.  A workgroup takes 256 consecutive entries, every thread computes its entry's raw gradient into LDS, and the
+// threads c = n_taps / 2 entries away from either end of the tile filter theirs (tiles overlap by 2c entries: 2.4 % of
+// the gradient work twice, for a 7-tap filter).  Same float64 sums in the same tap order as filtered_at (a missing
+// tap adds k * 0 exactly as a stored zero does), same mask bits in the fourth component: bit-identical to gradient ->
+// raw -> lsf_convolve_axis_listed4(axis 0).  Saves per listed voxel and iteration one 16-byte store, eight 16-byte loads
+// and a launch (21.4 + 15.9 us of kernels at 256^3, profiles/r04_sobolev_pmc_hbm_traffic.csv), and per call one
+// zero-filled gradient buffer.
+constexpr int kMaxTaps = 9;
+
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, bool FMA>
+__global__ __launch_bounds__(kBlock) void sobolev_state_gradient_x_kernel(const vf4* __restrict__ state,
+                                                                          const float* __restrict__ canonical,
+                                                                          vf4* __restrict__ out, Grid g, Params p,
+                                                                          TapsN<kMaxTaps> taps, int n_taps, lsf_gate gate,
+                                                                          lsf_iteration_record* record,
+                                                                          const int* __restrict__ band_list,
+                                                                          unsigned band_count) {
+    if (gate_closed(gate)) return;
+    __shared__ int s_index[kBlock];
+    __shared__ vf4 s_raw[kBlock];
+    const int c = n_taps / 2, t = (int)threadIdx.x;
+    const unsigned per_tile = (unsigned)(kBlock - 2 * c);  // entries a tile FILTERS; it computes c more on either side
+    const unsigned tiles = (band_count + per_tile - 1) / per_tile;
+    // the list walk of for_each_listed_voxel: XCD k owns the k-th eighth of the tiles (blocks b, b + 8, ... share an XCD)
+    unsigned first = blockIdx.x, step = gridDim.x, end = tiles;
+    if (gridDim.x % kXcds == 0) {
+        const unsigned per_xcd = (tiles + kXcds - 1) / kXcds, xcd = blockIdx.x % kXcds;
+        first = xcd * per_xcd + blockIdx.x / kXcds;
+        step = gridDim.x / kXcds;
+        end = (xcd + 1) * per_xcd < tiles ? (xcd + 1) * per_xcd : tiles;
+    }
+    double en[3] = {0.0, 0.0, 0.0};
+    for (unsigned u = first; u < end; u += step) {  // block-uniform bounds: every thread meets every barrier
+        const long long k = (long long)u * per_tile - c + t;
+        const bool valid = k >= 0 && k < (long long)band_count;
+        const bool owner = valid && t >= c && t < kBlock - c;
+        int i = -0x40000000, x = 0, y = 0, z = 0;  // an index no tap address (i + d >= -kMaxTaps / 2) can equal
+        vf4 raw = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (valid) {
+            i = band_list[k];
+            decode_listed(g, (unsigned)i, x, y, z);
+            float gv[3];
+            double e[3];
+            listed_voxel_gradient<D, SMOOTH, LEVELSET, DATA, ENERGY>(state, canonical, g, p, i, x, y, z, gv, e);
+            if (owner && z >= g.e_begin && z < g.e_end) {
+                en[0] += e[0];
+                en[1] += e[1];
+                en[2] += e[2];
+            }
+            raw.x = gv[0]; raw.y = gv[1]; raw.z = D == 3 ? gv[2] : 0.0f;
+        }
+        s_index[t] = i;
+        s_raw[t] = raw;
+        __syncthreads();
+        if (owner) {
+            double acc[3] = {0.0, 0.0, 0.0};
+            // tap j = c - d reads voxel i + d: j ascending = d from +c down to -c (filtered_at's order)
+#pragma unroll
+            for (int d = kMaxTaps / 2; d >= -(kMaxTaps / 2); --d) {
+                if (d <= c && d >= -c) {
+                    const int q = x + d;
+                    vf4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (d == 0) {
+                        v = raw;
+                    } else if (q >= 0 && q < g.nx) {
+                        // voxel i + d of the same row, if listed, sits 1 .. |d| entries away (the list ascends)
+                        const int sign = d > 0 ? 1 : -1, reach = d > 0 ? d : -d;
+                        int at = -1;
+#pragma unroll
+                        for (int s = 1; s <= reach; ++s)
+                            if (s_index[t + sign * s] == i + d) at = t + sign * s;
+                        if (at >= 0) v = s_raw[at];
+                    }
+                    const double k = taps.k[c - d];
+                    acc[0] = mac<FMA>(acc[0], k, (double)v.x);
+                    acc[1] = mac<FMA>(acc[1], k, (double)v.y);
+                    acc[2] = mac<FMA>(acc[2], k, (double)v.z);
+                }
+            }
+            const unsigned bits = (fabsf(raw.x) < 1e-6f ? 1u : 0u) | (fabsf(raw.y) < 1e-6f ? 2u : 0u) |
+                                  (fabsf(raw.z) < 1e-6f ? 4u : 0u);
+            vf4 o;
+            o.x = (bits & 1u) ? 0.0f : (float)acc[0];
+            o.y = (bits & 2u) ? 0.0f : (float)acc[1];
+            o.z = (bits & 4u) ? 0.0f : (float)acc[2];
+            o.w = __uint_as_float(bits);
+            out[i] = o;
+        }
+        __syncthreads();  // the next tile overwrites the LDS arrays
+    }
     if (ENERGY != LSF_ENERGY_NONE) {
         double* dst[3] = {&record_slot(record)->data_energy, &record_slot(record)->smoothing_energy,
                           &record_slot(record)->level_set_energy};
@@ -101,12 +219,6 @@ __device__ inline vf4 filtered_at(const vf4* __restrict__ in, const vf4* __restr
     return o;
 }
 
-__device__ inline void decode_listed(const Grid& g, unsigned i, int& x, int& y, int& z) {
-    const unsigned zy = fast_div(i, g.div_nx);
-    x = (int)(i - zy * (unsigned)g.nx);
-    z = (int)fast_div(zy, g.div_ny);
-    y = (int)zy - z * g.ny;
-}
 
 // one zero-preserving pass at listed voxels (one thread per voxel; convolve_list_kernel on the float4 layout)
 template <int NT, bool FMA>
@@ -218,19 +330,35 @@ struct GradArgs {
     hipStream_t s;
     const vf4* state;
     const float* canonical;
-    vf4* g_raw;
+    vf4* g_raw;  // the raw gradient -- or, with n_taps > 0, the gradient after the x pass (sobolev_state_gradient_x_kernel)
     Grid g;
     Params p;
     lsf_gate gate;
     lsf_iteration_record* record;
     const int* list;
     unsigned count;
+    TapsN<kMaxTaps> taps;
+    int n_taps;  // 0: gradient only
+    bool fma;
 };
 
 template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
 void grad_one(const GradArgs& a) {
-    hipLaunchKernelGGL((sobolev_state_gradient_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY>), dim3(a.blocks), dim3(kBlock),
-                       0, a.s, a.state, a.canonical, a.g_raw, a.g, a.p, a.gate, a.record, a.list, a.count);
+    if (a.n_taps == 0) {
+        hipLaunchKernelGGL((sobolev_state_gradient_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY>), dim3(a.blocks), dim3(kBlock),
+                           0, a.s, a.state, a.canonical, a.g_raw, a.g, a.p, a.gate, a.record, a.list, a.count);
+        return;
+    }
+    if constexpr (D == 3) {
+        if (a.fma)
+            hipLaunchKernelGGL((sobolev_state_gradient_x_kernel<3, SMOOTH, LEVELSET, DATA, ENERGY, true>), dim3(a.blocks),
+                               dim3(kBlock), 0, a.s, a.state, a.canonical, a.g_raw, a.g, a.p, a.taps, a.n_taps, a.gate,
+                               a.record, a.list, a.count);
+        else
+            hipLaunchKernelGGL((sobolev_state_gradient_x_kernel<3, SMOOTH, LEVELSET, DATA, ENERGY, false>), dim3(a.blocks),
+                               dim3(kBlock), 0, a.s, a.state, a.canonical, a.g_raw, a.g, a.p, a.taps, a.n_taps, a.gate,
+                               a.record, a.list, a.count);
+    }
 }
 
 template <int D, int SMOOTH, bool LEVELSET, int DATA>
@@ -306,9 +434,28 @@ extern "C" int lsf_sobolev_state_gradient(const float* state, const float* canon
     if (g.z_end == g.z_begin || band_count == 0) return 0;
     GradArgs a{band_list_blocks((unsigned)band_count), as_stream(stream), reinterpret_cast<const vf4*>(state), canonical,
                reinterpret_cast<vf4*>(g_raw4), g, params_of(params), gate_or_open(gate), record, band_list,
-               (unsigned)band_count};
+               (unsigned)band_count, TapsN<kMaxTaps>(), 0, false};
     if (grid->dims == 2) grad_terms<2>(params, a);
     else grad_terms<3>(params, a);
+    return launch_status();
+}
+
+extern "C" int lsf_sobolev_state_gradient_x(const float* state, const float* canonical, float* out4, const lsf_grid* grid,
+                                            const lsf_slavcheva_params* params, const double* taps_host, int32_t n_taps,
+                                            const lsf_gate* gate, lsf_iteration_record* record, const int32_t* band_list,
+                                            int64_t band_count, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!state || !canonical || !out4 || !params || !record || !band_list || !taps_host || band_count < 0 ||
+        band_count > 0x7fffffffll || grid->dims != 3)
+        return LSF_ERR_BAD_ARGUMENT;
+    if (!taps_ok(n_taps)) return LSF_ERR_KERNEL_TOO_LONG;
+    const Grid g = state_grid(grid);
+    if (g.z_end == g.z_begin || band_count == 0) return 0;
+    GradArgs a{band_list_blocks((unsigned)band_count), as_stream(stream), reinterpret_cast<const vf4*>(state), canonical,
+               reinterpret_cast<vf4*>(out4), g, params_of(params), gate_or_open(gate), record, band_list,
+               (unsigned)band_count, TapsN<kMaxTaps>(), n_taps, taps_are_float32(taps_host, n_taps)};
+    for (int j = 0; j < kMaxTaps; ++j) a.taps.k[j] = j < n_taps ? taps_host[j] : 0.0;
+    grad_terms<3>(params, a);
     return launch_status();
 }
 

@@ -756,7 +756,20 @@ class _SobolevStatePlan:
         self.min_iterations = min_iterations
         self.stream = dev.stream_ptr()
         self.axes = _conv_axis_order(grid.dims)
-        self.final = 1 if grid.dims == 3 else 2  # index of the buffer that holds the final gradient
+        # 3-D: the gradient and the x pass in ONE launch (lsf_sobolev_state_gradient_x: the raw gradient never reaches
+        # memory), over ONE list of the whole band -- a tap at a voxel of another list would count as zero
+        self.fused_x = self.fuses_x(grid) and len(g4) == 2
+        self.bands_first = self.bands
+        if self.fused_x and len(self.bands) == 2:
+            lo, hi = self.bands
+            merged = torch.empty(lo.count + hi.count, dtype=torch.int32, device=states[0].device)
+            vp, i64 = ctypes.c_void_p * 1, ctypes.c_int64 * 1
+            _lib.check(_lib.lib.lsf_merge_sorted_runs(vp(lo.pointer.value), i64(lo.count), vp(hi.pointer.value),
+                                                      i64(hi.count), vp(merged.data_ptr()), 1, self.stream),
+                       "lsf_merge_sorted_runs")
+            self.bands_first = [dev.BandList(merged, merged.numel(), _lib.BAND_ALL)]
+        # index of the buffer that holds the final gradient
+        self.final = (0 if self.fused_x else 1) if grid.dims == 3 else 2
         # The LAST pass runs along z: its seven taps lie in seven slices.  In list order an XCD sweeps a z-range with a
         # window of ~2 slices of the band in flight, its 4 MB L2 cannot keep seven slices of five streams, and every tap
         # comes through the fabric (237 MB per launch at 256^3 against 130 MB of compulsory traffic: the kernel ran at the
@@ -768,6 +781,11 @@ class _SobolevStatePlan:
         strips = int(os.environ.get("LSF_SOBOLEV_STRIPS", "8"))  # 0: list order (measurements)
         if grid.dims == 3 and iterations_hint >= 8 and strips > 0:
             self.bands_last = [self._strip_major(b, grid, strips) if b.count >= (1 << 17) else b for b in self.bands]
+
+    @staticmethod
+    def fuses_x(grid):
+        """does the iteration take the fused gradient + x pass (then two gradient buffers suffice instead of three)?"""
+        return grid.dims == 3 and os.environ.get("LSF_SOBOLEV_FUSE_X", "1") != "0"
 
     @staticmethod
     def _strip_major(band, grid, strips=8):
@@ -782,15 +800,24 @@ class _SobolevStatePlan:
         s_in, s_out = self.p_state[i % 2], self.p_state[(i + 1) % 2]
         gate = None if i < self.min_iterations else f.gate_ref(i - 1)
         rec = f.record_ptrs[i]
-        raw, a, b = self.p_g
-        for band in self.bands:
-            check(lib.lsf_sobolev_state_gradient(s_in, self.p_canon, raw, f.grid_ref, self.params_ref, gate, rec,
-                                                 band.pointer, band.count, self.stream), "lsf_sobolev_state_gradient")
-        src, dst = raw, a
+        none = ctypes.c_void_p(0)
+        if self.fused_x:
+            a, b = self.p_g
+            raw = None
+            for band in self.bands_first:
+                check(lib.lsf_sobolev_state_gradient_x(s_in, self.p_canon, a, f.grid_ref, self.params_ref, self.p_taps,
+                                                       self.n_taps, gate, rec, band.pointer, band.count, self.stream),
+                      "lsf_sobolev_state_gradient_x")
+            src, dst, axes = a, b, self.axes[1:-1]
+        else:
+            raw, a, b = self.p_g
+            for band in self.bands:
+                check(lib.lsf_sobolev_state_gradient(s_in, self.p_canon, raw, f.grid_ref, self.params_ref, gate, rec,
+                                                     band.pointer, band.count, self.stream), "lsf_sobolev_state_gradient")
+            src, dst, axes = raw, a, self.axes[:-1]
         # the FIRST pass takes the zero-preserving mask from the raw gradient (its own input) and leaves it as bits in its
         # output's fourth component; every later pass reads it there (no mask source: one load per voxel less)
-        none = ctypes.c_void_p(0)
-        for axis in self.axes[:-1]:
+        for axis in axes:
             for band in self.bands:
                 check(lib.lsf_convolve_axis_listed4(src, dst, raw if src is raw else none, f.grid_ref, axis, self.p_taps,
                                                     self.n_taps, gate, band.pointer, band.count, self.stream),
@@ -1553,7 +1580,8 @@ class SlavchevaEngine:
             f.bands = bands
             self._fast = f
             if sob_state:
-                g4 = [torch.zeros(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device) for _ in range(3)]
+                g4 = [torch.zeros(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device)
+                      for _ in range(2 if _SobolevStatePlan.fuses_x(grid) else 3)]
                 sob = _SobolevStatePlan(f, states, canonical, grid, self.params, bands, g4, self.sobolev_kernel,
                                         self.min_iterations, max(self.max_iterations, self.min_iterations))
                 self._sobolev_band = _Counted(sum(b.count for b in bands))  # what bench.py prices this path over

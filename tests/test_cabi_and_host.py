@@ -180,6 +180,10 @@ def test_slab_runtime_argument_errors(pkg):
     assert L.lib.lsf_slab_comm_create(None, ctypes.cast(ident, ctypes.c_void_p), 3, 2, ctypes.byref(handle)) == -1  # rank
     assert L.lib.lsf_slab_unique_id(None, None) == -1
     assert L.lib.lsf_slab_comm_destroy(None) == 0
+    # the face counts' collective: a communicator, four counts in, a table out
+    four = (ctypes.c_int64 * 4)(1, 2, 3, 4)
+    assert L.lib.lsf_slab_face_counts_begin(None, four) == -1
+    assert L.lib.lsf_slab_face_counts_end(None, four) == -1
     assert L.lib.lsf_state_prepare_scratch_elements(ctypes.byref(grid)) == 2 * 2 + 64 * 1 + 2 + 2 + 2  # one 1024-voxel chunk
     # the sparse initialisation: whole arrays, a reach of 1..8 voxels, at least one state
     whole = L.Grid(3, 16, 8, 8, 0, 16, 0, 0)

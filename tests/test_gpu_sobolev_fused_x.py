@@ -1,0 +1,108 @@
+"""lsf_sobolev_state_gradient_x (round 4): the raw gradient and the x pass of the SobolevFusion iteration in ONE launch
+must leave exactly what lsf_sobolev_state_gradient -> lsf_convolve_axis_listed4(axis 0, mask = the raw gradient) leave --
+every bit of every listed voxel, mask bits in the fourth component included, and the same energies -- on bands with holes
+(listed voxels whose x-neighbours are not listed), on bands that touch the volume's faces (rows that start at x = 0), at
+the ends of the list and across the tile overlap, for 3 / 5 / 7 / 9 taps, float32-valued and arbitrary float64 taps.
+Through the C ABI, as the engine calls it.  Reference arithmetic: nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:238-330,
+math_utils/convolution.py:94-132."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lsf():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import levelsetfusion_python_amd as pkg
+    return pkg
+
+
+def _fields(kind, n):
+    """(canonical, live, planar warp) float32 device tensors"""
+    from levelsetfusion_python_amd.synthetic import depth_pair, sphere_pair
+    g = torch.Generator(device="cuda").manual_seed(5)
+    if kind == "sphere":
+        canonical, live = sphere_pair(n, 3, "cuda")
+    elif kind == "depth":  # the band is a sheet that reaches the x and y faces: INTERIOR and BOUNDARY lists
+        canonical, live = depth_pair(n, "cuda")
+    else:  # "holes": a truncated random field -- isolated band voxels, short runs, gaps of one and two voxels in a row
+        canonical = torch.rand((n, n, n), device="cuda", generator=g) * 4.0 - 2.0
+        live = torch.rand((n, n, n), device="cuda", generator=g) * 4.0 - 2.0
+        canonical, live = canonical.clamp(-1.0, 1.0), live.clamp(-1.0, 1.0)
+    warp = (torch.rand((3, n, n, n), device="cuda", generator=g) - 0.5) * 0.6
+    return canonical.contiguous(), live.contiguous(), warp.contiguous()
+
+
+def _taps(n_taps, float32_valued):
+    k = np.exp(-0.5 * (np.arange(n_taps) - n_taps // 2) ** 2 / 1.7) * (1.0 + 0.07 * np.arange(n_taps))  # not symmetric
+    k = k / k.sum()
+    return np.ascontiguousarray(k.astype(np.float32).astype(np.float64) if float32_valued else k + 1e-11)
+
+
+@pytest.mark.parametrize("kind,n", [("sphere", 64), ("depth", 64), ("holes", 40)])
+@pytest.mark.parametrize("n_taps,float32_valued", [(7, True), (7, False), (3, True), (5, False), (9, True)])
+def test_fused_gradient_x_equals_gradient_then_x_pass(lsf, kind, n, n_taps, float32_valued):
+    from levelsetfusion_python_amd import _lib, device as dev
+    canonical, live, warp = _fields(kind, n)
+    grid = dev.make_grid(live.shape)
+    nvox = dev.n_voxels(grid)
+    state = dev.state_pack(live, warp, grid, copies=1)[0]
+    bands = [b for b in dev.band_lists(live, canonical, dev.full_range(grid)) if b.count]
+    assert bands
+    if kind == "depth":
+        assert len(bands) == 2, "this pair is meant to have band voxels on the volume's faces"
+    # ONE ascending list of the whole band for the fused kernel
+    whole = torch.sort(torch.cat([b.indices[:b.count] for b in bands])).values.contiguous()
+    if kind == "holes":
+        idx = whole.long()
+        gaps = (idx[1:] - idx[:-1])
+        assert int((gaps == 2).sum()) > 100 and int((gaps == 3).sum()) > 100  # listed voxels around unlisted ones
+    taps = _taps(n_taps, float32_valued)
+    p_taps = taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, sobolev_smoothing_enabled=True,
+                                   sobolev_kernel=lsf.generate_1d_sobolev_kernel(7, 0.1), level_set_term_enabled=True,
+                                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING)
+    params = ctypes.byref(opt._engine.params)
+    records = dev.new_records(2, live.device)
+    rec = [ctypes.c_void_p(records.data_ptr() + i * _lib.RECORD_BYTES) for i in range(2)]
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())
+    stream = dev.stream_ptr()
+    raw, ref, fused = (torch.zeros((n, n, n, 4), dtype=torch.float32, device="cuda") for _ in range(3))
+    for b in bands:
+        _lib.check(_lib.lib.lsf_sobolev_state_gradient(ptr(state), ptr(canonical), ptr(raw), ctypes.byref(grid), params,
+                                                       None, rec[0], b.pointer, b.count, stream), "gradient")
+    for b in bands:
+        _lib.check(_lib.lib.lsf_convolve_axis_listed4(ptr(raw), ptr(ref), ptr(raw), ctypes.byref(grid), 0, p_taps, n_taps,
+                                                      None, b.pointer, b.count, stream), "x pass")
+    _lib.check(_lib.lib.lsf_sobolev_state_gradient_x(ptr(state), ptr(canonical), ptr(fused), ctypes.byref(grid), params,
+                                                     p_taps, n_taps, None, rec[1], ptr(whole), whole.numel(), stream),
+               "fused")
+    torch.cuda.synchronize()
+    assert float(raw[..., :3].abs().max()) > 1e-3 and float(ref[..., :3].abs().max()) > 1e-3
+    # every bit, the mask bits in the fourth component included (compare as integers: the bits are not a float value)
+    assert torch.equal(fused.view(torch.int32), ref.view(torch.int32))
+    dec = dev.decode_records(dev.records_to_host(records))
+    for key in ("data_energy", "smoothing_energy", "level_set_energy"):
+        assert np.isclose(dec[key][0], dec[key][1], rtol=1e-12, atol=0.0), key  # float64 sums by atomics: order varies
+    assert dec["data_energy"][0] > 0.0
+
+
+def test_fused_entry_rejects_what_it_cannot_do(lsf):
+    from levelsetfusion_python_amd import _lib, device as dev
+    n = 16
+    grid3, grid2 = dev.make_grid((n, n, n)), dev.make_grid((n, n))
+    opt = lsf.SlavchevaOptimizer3d(field_size=n, sobolev_smoothing_enabled=True,
+                                   sobolev_kernel=lsf.generate_1d_sobolev_kernel(7, 0.1))
+    params = ctypes.byref(opt._engine.params)
+    taps = np.ones(11, dtype=np.float64)
+    p_taps = taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    one = ctypes.c_void_p(1)
+    call = _lib.lib.lsf_sobolev_state_gradient_x
+    assert call(one, one, one, ctypes.byref(grid2), params, p_taps, 7, None, one, one, 1, None) == -1  # 2-D filters y first
+    assert call(one, one, one, ctypes.byref(grid3), params, p_taps, 11, None, one, one, 1, None) != 0  # 3 / 5 / 7 / 9 taps
+    assert call(one, one, None, ctypes.byref(grid3), params, p_taps, 7, None, one, one, 1, None) == -1
