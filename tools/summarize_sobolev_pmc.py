@@ -44,6 +44,7 @@ write, _ = means("pmc_write")
 # algorithmic bytes per band voxel and launch (fp32, D = 3; SURVEY 8d's S-sobolev 76 B = 20 + 12 | 12 + 12 | 12 + 12 ...
 # on the float4 layouts the kernels move 16-byte gradients: both figures are listed)
 ALG = {"sobolev_state_gradient_kernel": (20 + 12, "R state 16 + canonical 4, W raw gradient 12 (16 on the float4 layout)"),
+       "sobolev_state_gradient_x_kernel": (20 + 12, "gradient AND x pass in one launch (round 4): R state 16 + canonical 4, W the x-filtered gradient 12 (16 on the float4 layout); the raw gradient stays in LDS"),
        "convolve_list4_kernel": (12 + 12, "R gradient 12 (+ mask 12 from L2), W 12 (16 + 16 on the float4 layout)"),
        "sobolev_state_update_kernel": (12 + 4 + 12 + 4, "R gradient 12 + live 4 (gathered), W warp 12 + live 4 (+ final gradient)")}
 out = os.path.join(ROOT, "profiles", tag + "_sobolev_pmc_hbm_traffic.csv")
@@ -59,12 +60,13 @@ with open(out, "w") as f:
             continue
         hbm = (fk * fetch_corr + wk * write_corr) * 1024 / 1e6
         alg = ALG[base][0] * band / 1e6
-        per_iter = 2 if base == "convolve_list4_kernel" else 1
+        fused = any(k.startswith("sobolev_state_gradient_x_kernel") for k in dur)
+        per_iter = (1 if fused else 2) if base == "convolve_list4_kernel" else 1
         total_us += dur[kernel][0] * per_iter
         total_hbm += hbm * per_iter
         f.write('"%s",%d,%.2f,%.1f,%.1f,%.1f,%.1f,"%s"\n' % (kernel, n_f[(kernel, "FETCH_SIZE")], dur[kernel][0], fk, wk, hbm, alg,
                                                          ALG[base][1]))
-    f.write('"one iteration (gradient + 2 passes + update)",,%.2f,,,%.1f,%.1f,"76 B x %d band voxels; fetch correction %.4f '
+    f.write('"one iteration (gradient, filter passes, update)",,%.2f,,,%.1f,%.1f,"76 B x %d band voxels; fetch correction %.4f '
             'write correction %.4f (16-byte-per-lane calibration launches)"\n'
             % (total_us, total_hbm, 76 * band / 1e6, band, fetch_corr, write_corr))
 print(open(out).read())
