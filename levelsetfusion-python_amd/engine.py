@@ -1520,11 +1520,19 @@ class SlavchevaEngine:
             sparse = ((not slab or slab_groups) and SPARSE_REACH > 0 and dev.n_voxels(grid) >= SPARSE_MIN_VOXELS
                       and self.iteration_hook is None and not getattr(self, "_sparse_disabled", False)
                       and os.environ.get("LSF_CHAIN", "0") != "1")
+            # the listed finalize pass wants a zero-filled warp output (192 MB at 256^3, 26 us): filled in the call's
+            # prologue, where the card waits for the host, instead of behind the last iteration.  Up to 256^3 IN FRONT of
+            # the counting pass: the states written behind it are then the last thing to pass through the 256 MB Infinity
+            # Cache before the first two iterations read them (filled behind the states it evicted them: 1.846-1.858
+            # against 1.817-1.825 ms per step, three alternating runs on one box); a larger volume's fill (1.6 GB at
+            # 512^3) would only keep the list sizes from the host (8.67 against 8.53 ms)
+            fill_first = os.environ.get("LSF_WARP_FILL", "auto") == "first" or \
+                (os.environ.get("LSF_WARP_FILL", "auto") == "auto" and dev.n_voxels(grid) <= (1 << 24))
+            if finalize is not None and not slab and fill_first:
+                warp_zeroed = torch.zeros(tuple(live.shape) + (dims,), dtype=torch.float32, device=live.device)
             prepared = dev.StatePrepare(live, canonical, dev.full_range(grid), cut_chunks,
                                         sparse_reach=SPARSE_REACH if sparse else 0)
-            if finalize is not None and not slab:
-                # the listed finalize pass wants a zero-filled warp output (192 MB at 256^3, ~29 us): enqueued HERE it runs
-                # while the host waits for the list sizes and the card would idle, instead of behind the last iteration
+            if finalize is not None and not slab and not fill_first:
                 warp_zeroed = torch.zeros(tuple(live.shape) + (dims,), dtype=torch.float32, device=live.device)
         live_at_entry = None
         if slab and finalize is not None and finalize[0] is not None and not planar_sobolev \
