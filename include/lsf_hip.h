@@ -87,6 +87,15 @@ typedef struct lsf_iteration_record {
     lsf_record_slot slot[LSF_RECORD_SLOTS];
 } lsf_iteration_record; /* 32 KiB */
 
+/* HOST-side reading of records that have been copied to the host (no device involved): the value of each of n records,
+ * combined over its partial slots as above.  slots = n x n_slots x slot_words int64 words, the first four words of every
+ * slot being max_packed and the three energies (slot_words >= 4: 512 for whole records, 4 when only the used words were
+ * copied; n_slots = LSF_RECORD_SLOTS, or a multiple of it when the slots of several ranks' records stand side by side).
+ * Out, n entries each (energies3: n x 3): the maximum as a float, the voxel index it was found at, the energy sums
+ * (slots added in ascending order), executed = 1 where the record's maximum word is non-zero. */
+int lsf_records_decode(const int64_t *slots, int32_t n, int32_t n_slots, int32_t slot_words, float *max_value,
+                       int64_t *argmax, double *energies3, uint8_t *executed);
+
 /* Device-side convergence gate.  The reference tests its stop condition on the host after every iteration
  * (hierarchical_optimizer2d.py:169-171, slavcheva_optimizer2d.py:360-362); here every kernel of iteration i
  * looks at the record of iteration i-1 and turns itself into a no-op when that iteration already met the

@@ -22,7 +22,7 @@ ABI_VERSION = 3
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "74e2a319488f2b4a"
+HEADER_ABI_HASH = "eeeaee6f97c85c9f"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -162,6 +162,7 @@ PROTOTYPES = {
     "lsf_band_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
     "lsf_band_count": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),
     "lsf_band_list_fill": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),
+    "lsf_records_decode": (ctypes.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "lsf_merge_sorted_runs": (ctypes.c_int, [_P(_vp), _P(_i64), _P(_vp), _P(_i64), _P(_vp), _i32, _vp]),
     "lsf_slab_unique_id": (ctypes.c_int, [ctypes.c_char_p, _vp]),
     "lsf_slab_comm_create": (ctypes.c_int, [ctypes.c_char_p, _vp, _i32, _i32, _P(_vp)]),

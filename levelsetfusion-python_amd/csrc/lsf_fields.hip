@@ -1,6 +1,8 @@
 // Field utilities of liblsf_hip.so: layout conversion, resampling under a warp (a1-a3), np.gradient packing
 // (a4), pyramid restrict / prolong (a5, a6), separable convolution passes (a9, a10), convergence statistics
 // (a20).  Reference citations are in include/lsf_hip.h next to each entry point.
+#include <cstring>
+
 #include "lsf_device.h"
 
 using namespace lsf;
@@ -1079,3 +1081,34 @@ extern "C" const char* lsf_build_id(void) { return LSF_BUILD_ID; }
 #define LSF_ABI_HASH "unknown"
 #endif
 extern "C" const char* lsf_abi_hash(void) { return LSF_ABI_HASH; }
+
+// records on the HOST -> their values (max over the slots' packed maxima, slot-ordered sum of the energies): what
+// device.decode_records did with a dozen numpy calls (~30 us at the end of every optimize() call)
+extern "C" int lsf_records_decode(const int64_t* slots, int32_t n, int32_t n_slots, int32_t slot_words, float* max_value,
+                                  int64_t* argmax, double* energies3, uint8_t* executed) {
+    if (n < 0 || n_slots < 1 || slot_words < 4 || (n > 0 && (!slots || !max_value || !argmax || !energies3 || !executed)))
+        return LSF_ERR_BAD_ARGUMENT;
+    for (int32_t r = 0; r < n; ++r) {
+        const int64_t* rec = slots + (size_t)r * n_slots * slot_words;
+        uint64_t packed = 0;
+        double e[3] = {0.0, 0.0, 0.0};
+        for (int32_t k = 0; k < n_slots; ++k) {
+            const int64_t* w = rec + (size_t)k * slot_words;
+            const uint64_t p = (uint64_t)w[0];
+            packed = p > packed ? p : packed;
+            for (int c = 0; c < 3; ++c) {
+                double v;
+                memcpy(&v, &w[1 + c], sizeof(v));
+                e[c] += v;
+            }
+        }
+        const uint32_t bits = (uint32_t)(packed >> 32), inverted = (uint32_t)packed;
+        memcpy(&max_value[r], &bits, sizeof(float));
+        argmax[r] = (int64_t)(uint32_t)~inverted;
+        energies3[3 * r + 0] = e[0];
+        energies3[3 * r + 1] = e[1];
+        energies3[3 * r + 2] = e[2];
+        executed[r] = packed != 0;
+    }
+    return 0;
+}

@@ -142,6 +142,15 @@ def decode_records(records_host):
     raw = records_host
     if raw.ndim == 2:
         raw = slot_view(np.ascontiguousarray(raw))
+    if raw.dtype == np.int64 and raw.ndim == 3 and raw.shape[2] >= USED_SLOT_WORDS and raw.flags.c_contiguous:
+        # one host call into the library (lsf_records_decode) instead of a dozen numpy calls: ~30 -> ~8 us per optimize()
+        n = raw.shape[0]
+        max_value, index = np.empty(n, np.float32), np.empty(n, np.int64)
+        energies, executed = np.empty((n, 3), np.float64), np.empty(n, np.bool_)
+        check(lib.lsf_records_decode(raw.ctypes.data, n, raw.shape[1], raw.shape[2], max_value.ctypes.data,
+                                     index.ctypes.data, energies.ctypes.data, executed.ctypes.data), "lsf_records_decode")
+        return dict(executed=executed, max_value=max_value, argmax=index, data_energy=energies[:, 0],
+                    smoothing_energy=energies[:, 1], level_set_energy=energies[:, 2])
     words = raw.view(np.uint64)  # same item size: no copy, strides kept
     packed = words[:, :, 0].max(axis=1)
     energies = np.ascontiguousarray(raw[:, :, 1:4]).view(np.float64).sum(axis=1)

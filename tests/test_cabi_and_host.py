@@ -276,6 +276,24 @@ def test_record_decoding(pkg):
     assert list(d["executed"]) == [True, False, False]
     assert d["max_value"][0] == np.float32(0.125) and d["argmax"][0] == 12
     assert (d["data_energy"][0], d["smoothing_energy"][0], d["level_set_energy"][0]) == (1.75, 3.0, 4.5)
+    # contiguous records go through the library (lsf_records_decode, a host function), anything else through numpy: the same
+    # values from both, on random records, for 8 slots (one rank) and 24 (three ranks' slots side by side), 4 and 512 words
+    rng = np.random.default_rng(3)
+    for n_slots, words in ((8, 4), (24, 4), (8, 512)):
+        wide = np.zeros((7, n_slots, words + 2), np.int64)
+        wide[:, :, 0] = [[pack(v, i) for v, i in zip(rng.random(n_slots) * (rng.random(n_slots) > 0.3),
+                                                     rng.integers(0, 2 ** 31, n_slots))] for _ in range(7)]
+        wide[:, :, 1:4] = rng.standard_normal((7, n_slots, 3)).view(np.int64)
+        wide[3] = 0  # a record that was never executed
+        through_numpy = dev.decode_records(wide[:, :, :words])       # a strided view: not contiguous
+        through_library = dev.decode_records(np.ascontiguousarray(wide[:, :, :words]))
+        assert set(through_numpy) == set(through_library)
+        for key in through_numpy:
+            a, b = through_numpy[key], through_library[key]
+            assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(a, b), key
+        assert not through_library["executed"][3] and through_library["executed"][0]
+    assert pkg._lib.lib.lsf_records_decode(None, 1, 8, 4, None, None, None, None) == -1
+    assert pkg._lib.lib.lsf_records_decode(1, 1, 8, 3, 1, 1, 1, 1) == -1  # a slot has at least its four used words
 
 
 def test_slab_layout(pkg):
