@@ -410,6 +410,8 @@ int lsf_sobolev_state_gradient_x(const float *state, const float *canonical, flo
 int lsf_convolve_axis_listed4(const float *in4, float *out4, const float *zero_mask_source4, const lsf_grid *grid,
                               int32_t axis, const double *taps_host, int32_t n_taps, const lsf_gate *gate,
                               const int32_t *band_list, int64_t band_count, void *stream);
+/* g_out4 of lsf_sobolev_state_update may be NULL: the iteration's filtered gradient is then not stored (a caller that
+ * knows which iteration is the last one -- a fixed iteration count -- only needs that one's). */
 int lsf_sobolev_state_update(const float *in4, const float *zero_mask_source4, const float *state_in, float *state_out,
                              float *g_out4, const lsf_grid *grid, const lsf_slavcheva_params *params, int32_t axis,
                              const double *taps_host, int32_t n_taps, const lsf_gate *gate,

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kBlock) void sobolev_state_update_kernel(const vf4*
         o.x = v; o.y = wv[0]; o.z = wv[1]; o.w = wv[2];
         go.x = gv[0]; go.y = gv[1]; go.z = gv[2]; go.w = 0.0f;
         state_out[i] = o;
-        g_out[i] = go;
+        if (g_out) g_out[i] = go;  // null: nobody will read this iteration's gradient (16 B per voxel less to write)
         const unsigned long long q = pack_max(len_w, linear_index(g, x, y, z));
         best = q > best ? q : best;
     });
@@ -492,7 +492,7 @@ extern "C" int lsf_sobolev_state_update(const float* in4, const float* zero_mask
                                         int32_t n_taps, const lsf_gate* gate, lsf_iteration_record* record,
                                         const int32_t* band_list, int64_t band_count, int32_t first_list, void* stream) {
     if (int e = check_grid(grid)) return e;
-    if (!in4 || !state_in || !state_out || state_out == state_in || !g_out4 || g_out4 == in4 ||
+    if (!in4 || !state_in || !state_out || state_out == state_in || g_out4 == in4 ||
         !params || !record || !taps_host || !band_list || band_count < 0 || band_count > 0x7fffffffll || axis < 0 ||
         axis >= grid->dims)
         return LSF_ERR_BAD_ARGUMENT;

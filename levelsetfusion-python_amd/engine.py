@@ -741,7 +741,8 @@ class _SobolevStatePlan:
     buffer B] (float4, zero-initialised: unlisted voxels are never written).  3-D: gradient -> raw, x pass raw -> A,
     y pass A -> B, z pass + update + re-warp B -> final gradient in A; 2-D: y pass raw -> A, x pass + update A -> B."""
 
-    def __init__(self, launcher, states, canonical, grid, params, bands, g4, taps, min_iterations, iterations_hint=0):
+    def __init__(self, launcher, states, canonical, grid, params, bands, g4, taps, min_iterations, iterations_hint=0,
+                 gradient_every_iteration=True):
         f = self.f = launcher
         n = dev.n_voxels(grid)
         self.p_state = [f.pointer(t, 4 * n, "state") for t in states]
@@ -754,6 +755,9 @@ class _SobolevStatePlan:
         self.p_taps = self.taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         self.n_taps = int(self.taps.size)
         self.min_iterations = min_iterations
+        # the filtered gradient is an OUTPUT of the last executed iteration only (gradient_field, the reference's attribute
+        # of that name): a run whose iteration count is fixed stores just that one (16 B per voxel and iteration less)
+        self.last_iteration = None if gradient_every_iteration else iterations_hint - 1
         self.stream = dev.stream_ptr()
         self.axes = _conv_axis_order(grid.dims)
         # 3-D: the gradient and the x pass in ONE launch (lsf_sobolev_state_gradient_x: the raw gradient never reaches
@@ -823,6 +827,8 @@ class _SobolevStatePlan:
                                                     self.n_taps, gate, band.pointer, band.count, self.stream),
                       "lsf_convolve_axis_listed4")
             src, dst = dst, (b if dst is a else a)
+        if self.last_iteration is not None and i != self.last_iteration:
+            dst = none
         for k, band in enumerate(self.bands_last):
             check(lib.lsf_sobolev_state_update(src, raw if src is raw else none, s_in, s_out, dst, f.grid_ref,
                                                self.params_ref, self.axes[-1],
@@ -1590,8 +1596,11 @@ class SlavchevaEngine:
             if sob_state:
                 g4 = [torch.zeros(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device)
                       for _ in range(2 if _SobolevStatePlan.fuses_x(grid) else 3)]
+                n_max = max(self.max_iterations, self.min_iterations)
+                every = (self.iteration_hook is not None or self.min_iterations < n_max
+                         or os.environ.get("LSF_SOBOLEV_GRADIENT", "last") == "every")
                 sob = _SobolevStatePlan(f, states, canonical, grid, self.params, bands, g4, self.sobolev_kernel,
-                                        self.min_iterations, max(self.max_iterations, self.min_iterations))
+                                        self.min_iterations, n_max, gradient_every_iteration=every)
                 self._sobolev_band = _Counted(sum(b.count for b in bands))  # what bench.py prices this path over
             # Fixed-count runs on ONE interior list MAY run K iterations per launch (lsf_slavcheva_state_chain) instead of K
             # launches -- the stop test cannot fire in between.  Opt-in (LSF_CHAIN=1): bit-identical, but measured 4 %
