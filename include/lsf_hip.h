@@ -410,6 +410,12 @@ int lsf_sobolev_state_gradient_x(const float *state, const float *canonical, flo
 int lsf_convolve_axis_listed4(const float *in4, float *out4, const float *zero_mask_source4, const lsf_grid *grid,
                               int32_t axis, const double *taps_host, int32_t n_taps, const lsf_gate *gate,
                               const int32_t *band_list, int64_t band_count, void *stream);
+/* Walk order of the LAST pass of a volume (along z): the ascending band list regrouped strip by strip -- `strips` strips of
+ * ceil(ny / strips) rows, each swept through all slices, ascending inside a strip -- so that the z -/+ taps of a workgroup
+ * are lines its own XCD has just read (results do not depend on the order).  out: band_count
+ * entries; scratch: 3 * n_strips * nz int32 with n_strips = ceil(ny / ceil(ny / strips)) <= strips. */
+int lsf_band_list_strip_major(const int32_t *band_list, int64_t band_count, const lsf_grid *grid, int32_t strips,
+                              int32_t *out, int32_t *scratch, void *stream);
 /* g_out4 of lsf_sobolev_state_update may be NULL: the iteration's filtered gradient is then not stored (a caller that
  * knows which iteration is the last one -- a fixed iteration count -- only needs that one's). */
 int lsf_sobolev_state_update(const float *in4, const float *zero_mask_source4, const float *state_in, float *state_out,

@@ -422,6 +422,92 @@ void launch_update4(const vf4* in, const vf4* mask, const vf4* state_in, vf4* st
 
 }  // namespace
 
+// ---- the ascending band list regrouped STRIP by strip (the z pass's walk order, see lsf_band_list_strip_major) ----------
+// In the ascending list the entries of one (slice z, strip of rows s) are ONE run (rows ascend inside a slice): run
+// boundaries by binary search, an exclusive scan of the run lengths in strip-major order, and a gather.
+__device__ inline int first_not_below(const int* __restrict__ list, unsigned count, long long key) {
+    unsigned lo = 0u, hi = count;
+    while (lo < hi) {
+        const unsigned mid = (lo + hi) >> 1;
+        if ((long long)list[mid] < key) lo = mid + 1u;
+        else hi = mid;
+    }
+    return (int)lo;
+}
+
+__global__ __launch_bounds__(kBlock) void strip_runs_kernel(const int* __restrict__ list, unsigned count, int nx, int ny,
+                                                            int nz, int rows, int n_strips, int* __restrict__ start,
+                                                            int* __restrict__ length) {
+    const int r = blockIdx.x * kBlock + threadIdx.x;  // run index in strip-major order: r = s * nz + z
+    if (r >= n_strips * nz) return;
+    const int s = r / nz, z = r - s * nz;
+    const int row0 = min(s * rows, ny), row1 = min((s + 1) * rows, ny);
+    const int lo = first_not_below(list, count, ((long long)z * ny + row0) * nx);
+    const int hi = first_not_below(list, count, ((long long)z * ny + row1) * nx);
+    start[r] = lo;
+    length[r] = hi - lo;
+}
+
+// exclusive scan of m run lengths by ONE workgroup (m = strips * nz: a few thousand)
+__global__ __launch_bounds__(1024) void strip_scan_kernel(const int* __restrict__ length, int* __restrict__ first, int m) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x, per = (m + 1023) / 1024;
+    int sum = 0;
+    for (int k = t * per; k < min((t + 1) * per, m); ++k) sum += length[k];
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {  // Hillis-Steele over the 1024 partial sums
+        const int v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int at = t ? part[t - 1] : 0;
+    for (int k = t * per; k < min((t + 1) * per, m); ++k) {
+        first[k] = at;
+        at += length[k];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void strip_gather_kernel(const int* __restrict__ list, const int* __restrict__ start,
+                                                              const int* __restrict__ first, int m, unsigned count,
+                                                              int* __restrict__ out) {
+    const unsigned p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= count) return;
+    // the LAST run whose first output position is <= p (empty runs share their successor's position and are skipped)
+    int lo = 0, hi = m;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (first[mid] <= (int)p) lo = mid + 1;
+        else hi = mid;
+    }
+    const int r = lo - 1;
+    out[p] = list[start[r] + ((int)p - first[r])];
+}
+
+extern "C" int lsf_band_list_strip_major(const int32_t* band_list, int64_t band_count, const lsf_grid* grid, int32_t strips,
+                                         int32_t* out, int32_t* scratch, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!band_list || !out || !scratch || out == band_list || band_count < 0 || band_count > 0x7fffffffll || strips < 1 ||
+        strips > 64 || grid->dims != 3)
+        return LSF_ERR_BAD_ARGUMENT;
+    if (band_count == 0) return 0;
+    const int rows = (grid->ny + strips - 1) / strips, n_strips = (grid->ny + rows - 1) / rows;
+    const long long m = (long long)n_strips * grid->nz;
+    if (m > (1 << 20)) return LSF_ERR_BAD_ARGUMENT;
+    int* start = scratch;
+    int* length = scratch + m;
+    int* first = scratch + 2 * m;
+    hipStream_t s = as_stream(stream);
+    const unsigned count = (unsigned)band_count;
+    hipLaunchKernelGGL(strip_runs_kernel, dim3((unsigned)((m + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, band_list, count,
+                       grid->nx, grid->ny, grid->nz, rows, n_strips, start, length);
+    hipLaunchKernelGGL(strip_scan_kernel, dim3(1), dim3(1024), 0, s, length, first, (int)m);
+    hipLaunchKernelGGL(strip_gather_kernel, dim3((count + kBlock - 1) / kBlock), dim3(kBlock), 0, s, band_list, start, first,
+                       (int)m, count, out);
+    return launch_status();
+}
+
 extern "C" int lsf_sobolev_state_gradient(const float* state, const float* canonical, float* g_raw4,
                                           const lsf_grid* grid, const lsf_slavcheva_params* params, const lsf_gate* gate,
                                           lsf_iteration_record* record, const int32_t* band_list, int64_t band_count,

@@ -373,25 +373,6 @@ def test_bench_plain_form_starts_its_own_launcher(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
-def test_strip_major_list_is_a_permutation_sorted_by_strip(pkg):
-    """host logic of the SobolevFusion z pass (engine._SobolevStatePlan._strip_major): the same voxels, strip by strip
-    (eight strips of rows), ascending inside a strip -- so that an XCD's window spans many slices of ITS strip"""
-    import torch
-    from levelsetfusion_python_amd import device as dev, engine
-    grid = dev.make_grid((12, 40, 16))
-    g = torch.Generator().manual_seed(3)
-    idx = torch.sort(torch.randperm(12 * 40 * 16, generator=g)[:3000]).values.to(torch.int32)
-    band = dev.BandList(idx, idx.numel(), pkg._lib.BAND_ALL)
-    out = engine._SobolevStatePlan._strip_major(band, grid, strips=8)
-    got = out.indices[:out.count].long()
-    assert out.count == band.count and out.subset == band.subset
-    assert torch.equal(torch.sort(got).values, idx.long())
-    strip = (got // 16) % 40 // 5  # rows per strip = ceil(40 / 8)
-    assert bool((strip[1:] >= strip[:-1]).all())
-    same = strip[1:] == strip[:-1]
-    assert bool((got[1:][same] > got[:-1][same]).all())
-
-
 def test_bench_scaling_modes_parse():
     """bench.py's N > 1 modes exist and default as documented (no GPU needed to parse)"""
     import importlib.util

@@ -106,3 +106,31 @@ def test_fused_entry_rejects_what_it_cannot_do(lsf):
     assert call(one, one, one, ctypes.byref(grid2), params, p_taps, 7, None, one, one, 1, None) == -1  # 2-D filters y first
     assert call(one, one, one, ctypes.byref(grid3), params, p_taps, 11, None, one, one, 1, None) != 0  # 3 / 5 / 7 / 9 taps
     assert call(one, one, None, ctypes.byref(grid3), params, p_taps, 7, None, one, one, 1, None) == -1
+
+
+@pytest.mark.parametrize("shape,limit,strips", [((12, 40, 16), 12 * 40 * 16, 8), ((64, 64, 64), 64 ** 3, 8),
+                                                ((5, 7, 9), 5 * 7 * 9, 8), ((1024, 1024, 1024), 7 * 1024 * 1024, 8),
+                                                ((33, 50, 20), 33 * 50 * 20, 3)])
+def test_strip_major_list(lsf, shape, limit, strips):
+    """lsf_band_list_strip_major (the walk order of the SobolevFusion z pass): the same voxels, strip by strip (strips of
+    ceil(ny / strips) rows), ascending inside a strip -- equal to a sort by (strip, index)"""
+    from levelsetfusion_python_amd import _lib, device as dev, engine
+    grid = dev.make_grid(shape)
+    g = torch.Generator().manual_seed(3)
+    for take in (min(3000, limit), 1, limit if limit <= 40000 else 20000):
+        idx = torch.sort(torch.randperm(limit, generator=g)[:take]).values.to(torch.int32).cuda()
+        band = dev.BandList(idx, idx.numel(), _lib.BAND_ALL)
+        out = engine._SobolevStatePlan._strip_major(band, grid, strips=strips)
+        torch.cuda.synchronize()
+        assert out.indices.dtype == torch.int32 and out.count == band.count and out.subset == band.subset
+        got = out.indices[:out.count].long()
+        rows = (shape[1] + strips - 1) // strips
+        wide = idx.long()
+        key = ((wide // shape[2]) % shape[1] // rows) * (shape[0] * shape[1] * shape[2]) + wide
+        expected = wide[torch.argsort(key)]
+        assert torch.equal(got, expected)
+    one = ctypes.c_void_p(1)
+    call = _lib.lib.lsf_band_list_strip_major
+    assert call(one, 5, ctypes.byref(grid), 0, one, one, None) == -1          # at least one strip
+    assert call(one, 5, ctypes.byref(grid), 8, None, one, None) == -1
+    assert call(one, 5, ctypes.byref(dev.make_grid((8, 8))), 8, one, one, None) == -1   # volumes only
