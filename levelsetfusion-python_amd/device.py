@@ -22,8 +22,26 @@ def require_gpu():
                            "There is no CPU execution path in this package.")
 
 
+# torch.cuda.current_stream() / current_device() walk half a dozen Python frames each (device-type look-up, availability
+# check, an environment read): ~4 us per call, a dozen calls per optimize() -- cProfile of one call, tools/host_profile.py.
+# The two raw queries behind them are single C calls.
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def current_device_index():
+    return _raw_device() if _raw_device is not None else torch.cuda.current_device()
+
+
+def current_stream_handle():
+    """the current HIP stream of the current device as an integer (hipStream_t)"""
+    if _raw_stream is not None and _raw_device is not None:
+        return _raw_stream(_raw_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
 def stream_ptr():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return ctypes.c_void_p(current_stream_handle())
 
 
 _PINNED = {}
@@ -36,7 +54,7 @@ def pinned_scratch(name, numel, dtype):
     again -- and optimizers that run side by side (experiment/multipair.py: pairs in flight, one thread and one stream
     each) never share one."""
     # one buffer per purpose, grown to the largest length asked for
-    key = (torch.cuda.current_device(), torch.cuda.current_stream().cuda_stream, name, dtype)
+    key = (current_device_index(), current_stream_handle(), name, dtype)
     buf = _PINNED.get(key)
     if buf is None or buf.numel() < int(numel):
         buf = _PINNED[key] = torch.empty(max(int(numel), 2 * buf.numel() if buf is not None else 0), dtype=dtype,
@@ -70,7 +88,7 @@ def _ptr(t, numel, name, dtype=torch.float32, allow_none=False):
         raise ValueError("%s: tensor required" % name)
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise ValueError("%s: expected a CUDA/ROCm tensor" % name)
-    if t.device.index != torch.cuda.current_device():
+    if t.device.index != current_device_index():
         # kernels are launched on the CURRENT device's current stream (stream_ptr): a tensor that lives elsewhere
         # would be reached through a peer mapping at best
         raise ValueError("%s is on %s but the current device is cuda:%d (torch.cuda.set_device / torch.cuda.device)"
