@@ -169,7 +169,13 @@ extern "C" int lsf_slab_comm_destroy(lsf_slab_comm* c) {
 }
 
 extern "C" int lsf_slab_face_counts_begin(lsf_slab_comm* c, const int64_t* counts4) {
-    if (!c || !counts4 || c->counts_in_flight) return LSF_ERR_BAD_ARGUMENT;
+    if (!c || !counts4) return LSF_ERR_BAD_ARGUMENT;
+    if (c->counts_in_flight) {
+        // a call that planned its faces but never exchanged them (fewer iterations than one exchange group) never asked
+        // for the table: every rank is in that position together, so the stale collective is simply waited for and dropped
+        LSF_HIP_CHECK(hipEventSynchronize(c->counts_done));
+        c->counts_in_flight = false;
+    }
     for (int k = 0; k < 4; ++k) c->counts_host[k] = counts4[k];
     LSF_HIP_CHECK(hipMemcpyAsync(c->counts_dev, c->counts_host, 4 * sizeof(long long), hipMemcpyHostToDevice, c->comm_stream));
     LSF_RCCL_CHECK(g_rccl.AllGather(c->counts_dev, c->counts_dev + 4, 4, ncclInt64, c->comm, c->comm_stream));

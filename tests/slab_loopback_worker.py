@@ -46,6 +46,12 @@ def main(out_path, port):
         engine.SPARSE_MIN_VOXELS = 0 if tag.endswith("_sparse") else full_states_below
         comm = SelfComm(layout)
         used = "rccl" if comm.native() is not None else "torch"
+        if tag == "rccl":
+            # a call of exactly one exchange group plans its faces (and starts the count collective) but never exchanges:
+            # the next call on the same communicator must not trip over the collective left in flight
+            short = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, **dict(kwargs, max_iterations=halo, min_iterations=halo))
+            short.optimize(live0.clone(), canonical)
+            assert len(short.log.max_warps) == halo
         opt = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, **kwargs)
         live = live0.clone()
         opt.optimize(live, canonical)
