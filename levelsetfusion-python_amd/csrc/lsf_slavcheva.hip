@@ -742,7 +742,7 @@ extern "C" int lsf_state_prepare(const float* live, const float* canonical, floa
 
 extern "C" int lsf_state_pack_needed(const float* live, float* state_a, float* state_b, const lsf_grid* grid,
                                      int32_t* scratch, int32_t reach, int32_t invert, void* stream) {
-    if (int e = check_grid(grid)) return e;
+    if (int e = check_grid(grid, true)) return e;  // whole local arrays, also of slabs cut along y (as lsf_state_prepare)
     if (!live || (!state_a && !state_b) || !scratch || reach < 1 || reach > 8) return LSF_ERR_BAD_ARGUMENT;
     if (grid->z_begin != 0 || grid->z_end != grid->nz) return LSF_ERR_BAD_ARGUMENT;  // whole arrays only
     unsigned first, n, chunks;

@@ -1545,6 +1545,7 @@ class SlavchevaEngine:
                 (os.environ.get("LSF_WARP_FILL", "auto") == "auto" and dev.n_voxels(grid) <= (1 << 24))
             if finalize is not None and not slab and fill_first:
                 warp_zeroed = torch.zeros(tuple(live.shape) + (dims,), dtype=torch.float32, device=live.device)
+            self._sparse_used = sparse  # (tests and measurements look at this)
             prepared = dev.StatePrepare(live, canonical, dev.full_range(grid), cut_chunks,
                                         sparse_reach=SPARSE_REACH if sparse else 0)
             if finalize is not None and not slab and not fill_first:

@@ -60,19 +60,24 @@ def _volume(kind, n, nz):
 def _worker(rank, world, port, kind, n, nz, halo, kwargs, out_dir):
     sys.path.insert(0, ROOT)
     kwargs = dict(kwargs)
-    os.environ.update(kwargs.pop("_env", {}))  # read when the package is imported, below
+    env = kwargs.pop("_env", {})
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd import engine
     from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
+    if "LSF_SPARSE_MIN_VOXELS" in env:  # (the package is imported already: the enum members among the arguments brought it in)
+        engine.SPARSE_MIN_VOXELS = int(env["LSF_SPARSE_MIN_VOXELS"])
     layout = SlabLayout(nz, rank, world, halo)
     comm = SlabComm(layout)
     sl = layout.local_slice()
     canonical, live = (torch.from_numpy(np.ascontiguousarray(v[sl])).cuda() for v in _volume(kind, n, nz))
     opt = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, **kwargs)
     opt.optimize(live, canonical)
+    if env.get("LSF_SPARSE_MIN_VOXELS") == "0" and max(opt.log.max_warps) < 1.0:
+        assert opt._engine._sparse_used, "this case is meant to run on states initialised near the band only"
     own = layout.owned_local()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), live=live[own].cpu().numpy(),
              warp=opt.warp_field[own].cpu().numpy(), max_warps=np.float32(opt.log.max_warps),

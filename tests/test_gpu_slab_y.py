@@ -34,18 +34,25 @@ def _volume(kind, n):
 
 def _worker(rank, world, port, kind, n, halo, kwargs, out_dir):
     sys.path.insert(0, ROOT)
+    kwargs = dict(kwargs)
+    env = kwargs.pop("_env", {})
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd import engine
     from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
+    if "LSF_SPARSE_MIN_VOXELS" in env:  # (the package is imported already: the enum members among the arguments brought it in)
+        engine.SPARSE_MIN_VOXELS = int(env["LSF_SPARSE_MIN_VOXELS"])
     layout = SlabLayout(n, rank, world, halo, axis=1)
     comm = SlabComm(layout)
     canonical, live = (layout.cut(v) for v in _volume(kind, n))
     band = ~((live.abs() == 1.0) & (canonical.abs() == 1.0))
     opt = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, **kwargs)
     opt.optimize(live, canonical)
+    if env.get("LSF_SPARSE_MIN_VOXELS") == "0" and max(opt.log.max_warps) < 1.0:
+        assert opt._engine._sparse_used, "this case is meant to run on states initialised near the band only"
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), live=layout.owned_of(live).cpu().numpy(),
              warp=layout.owned_of(opt.warp_field).cpu().numpy(), max_warps=np.float32(opt.log.max_warps),
              locations=np.int64(opt.log.max_warp_locations), data=np.float64(opt.log.data_energies),
@@ -64,6 +71,9 @@ CASES = {
     "depth_two_threshold": (2, "depth", 64, 1, None),
     "sphere_two_groups": (2, "sphere", 64, 4, 9),
     "sphere_four_every_iteration": (4, "sphere", 64, 1, 4),
+    # the ping-pong states initialised near the band only (by default from 2^21 voxels on; forced here): exchange groups,
+    # whole rows travel on this transport -- also voxels a rank never initialised
+    "sphere_two_groups_sparse_states": (2, "sphere", 64, 4, 9),
 }
 
 
@@ -88,7 +98,9 @@ def test_y_slabs_equal_whole_volume(tmp_path, case):
         assert 2 <= len(ref.log.max_warps) <= 12
     if kind == "sphere":
         assert max(ref.log.max_warps) < 1.0  # exchange groups run as planned
-    mp.spawn(_worker, args=(world, _free_port(), kind, n, halo, kwargs, str(tmp_path)), nprocs=world, join=True)
+    env = {"LSF_SPARSE_MIN_VOXELS": "0"} if case.endswith("sparse_states") else {}
+    mp.spawn(_worker, args=(world, _free_port(), kind, n, halo, dict(kwargs, _env=env), str(tmp_path)), nprocs=world,
+             join=True)
     parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     assert np.array_equal(np.concatenate([p["live"] for p in parts], axis=1), live.cpu().numpy()), "live field"
     assert np.array_equal(np.concatenate([p["warp"] for p in parts], axis=1), ref.warp_field.cpu().numpy()), "warp field"
