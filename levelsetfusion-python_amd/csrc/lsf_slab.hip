@@ -141,9 +141,15 @@ extern "C" int lsf_slab_comm_create(const char* rccl_library_path, const uint8_t
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->counts_done, hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->counts_dev), words * sizeof(long long));
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->counts_host), words * sizeof(long long), 0);
-    if (e != hipSuccess) {
+    if (e != hipSuccess) {  // (the struct was value-initialised: whatever is still null was never created)
         if (c->counts_dev) (void)hipFree(c->counts_dev);
         if (c->counts_host) (void)hipHostFree(c->counts_host);
+        if (c->counts_done) (void)hipEventDestroy(c->counts_done);
+        for (int k = 0; k < 2; ++k) {
+            if (c->boundary_done[k]) (void)hipEventDestroy(c->boundary_done[k]);
+            if (c->halos_done[k]) (void)hipEventDestroy(c->halos_done[k]);
+        }
+        if (c->comm_stream) (void)hipStreamDestroy(c->comm_stream);
         g_rccl.CommDestroy(c->comm);
         delete c;
         return (int)e;
