@@ -100,8 +100,9 @@ __host__ inline Grid make_grid(const lsf_grid* g, int tile_y = 4) {
     r.gather_z_offset = g->z_global_offset;
     r.y_global_offset = g->y_global_offset;
     r.ny_global = g->ny_global > 0 ? g->ny_global : g->ny;
-    r.y_cut = r.y_global_offset != 0 || r.ny_global != g->ny;
     const bool y_limited = g->energy_y_end > g->energy_y_begin;
+    // (a limited energy row range counts as "cut along y" too: kernels specialised for y_cut == 0 ignore all four fields)
+    r.y_cut = r.y_global_offset != 0 || r.ny_global != g->ny || y_limited;
     r.ey_begin = y_limited ? g->energy_y_begin : 0;
     r.ey_end = y_limited ? g->energy_y_end : g->ny;
     return r;

@@ -29,21 +29,36 @@ constexpr unsigned kTraceBlocks = 64, kTraceUnits = 16, kTraceStamps = 8;
 #define LSF_TRACE(slot) do {} while (0)
 #endif
 
-// WALK: the dense tile walk over every voxel, a band list (ALL or BOUNDARY subset), an INTERIOR band list
-constexpr int kWalkDense = 0, kWalkList = 1, kWalkListInterior = 2;
+// WALK: the dense tile walk over every voxel, a band list (ALL or BOUNDARY subset), an INTERIOR band list -- and the two
+// list walks once more for slabs cut along y (lsf_grid::y_global_offset / ny_global / energy_y_*).  Whole volumes and
+// z-slabs run instantiations that know those fields to be trivial: carried as live scalars they cost the INTERIOR walk
+// 19 VALU instructions per 64 voxels, six more scalar spills into vector lanes and a 16-byte scratch frame (ISA of round
+// 3's kernel against round 4's with the y fields added).
+constexpr int kWalkDense = 0, kWalkList = 1, kWalkListInterior = 2, kWalkListYCut = 3, kWalkListInteriorYCut = 4;
+constexpr int walk_of(int walk_code) {
+    return walk_code == kWalkListYCut ? kWalkList : (walk_code == kWalkListInteriorYCut ? kWalkListInterior : walk_code);
+}
 
-template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, int WALK>
-__global__ __launch_bounds__(WALK == kWalkListInterior ? kCuBlock : kBlock)
+template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, int WALK_CODE>
+__global__ __launch_bounds__(walk_of(WALK_CODE) == kWalkListInterior ? kCuBlock : kBlock)
 // <= 128 VGPRs for the dense walk (at 132 = 3 waves per SIMD it streamed 20 % slower) and the CU-sized workgroups; the
 // general list walk (voxels on a face, arrays of 4 GiB and more) may take 3 waves' worth instead of spilling -- a list
 // walk runs as fast with 3 waves per SIMD as with 4 (measured with 768-thread workgroups)
-__attribute__((amdgpu_waves_per_eu(WALK == kWalkList ? 3 : 4, 4)))
+__attribute__((amdgpu_waves_per_eu(walk_of(WALK_CODE) == kWalkList ? 3 : 4, 4)))
 void slavcheva_state_kernel(const vf4* __restrict__ state_in,
                                                                  const float* __restrict__ canonical,
                                                                  vf4* __restrict__ state_out, Grid g, Params p,
                                                                  lsf_gate gate, lsf_iteration_record* record,
                                                                  const int* __restrict__ band_list,
                                                                  unsigned band_count) {
+    constexpr int WALK = walk_of(WALK_CODE);
+    if (WALK_CODE == WALK) {  // not cut along y: every row is a row of the volume, every row's energies count
+        g.y_global_offset = 0;
+        g.ny_global = g.ny;
+        g.ey_begin = -0x7fffffff - 1;
+        g.ey_end = 0x7fffffff;
+        g.y_cut = 0;
+    }
 #ifdef LSF_STATE_TRACE
     unsigned long long* wave_row = (g_state_waves && WALK == kWalkListInterior)
                                        ? g_state_waves + ((unsigned long long)blockIdx.x * kMaxBlockWaves + threadIdx.x / 64) * 8 : nullptr;
@@ -563,6 +578,15 @@ struct LaunchArgs {
 
 template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, int WALK>
 void launch_one(const LaunchArgs& a) {
+    if constexpr (D == 3 && (WALK == kWalkList || WALK == kWalkListInterior)) {
+        if (a.g.y_cut) {
+            hipLaunchKernelGGL((slavcheva_state_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY,
+                                                       WALK == kWalkList ? kWalkListYCut : kWalkListInteriorYCut>),
+                               dim3(a.blocks), dim3(a.threads), 0, a.s, a.state_in, a.canonical, a.state_out, a.g, a.p, a.gate,
+                               a.record, a.band_list, a.band_count);
+            return;
+        }
+    }
     hipLaunchKernelGGL((slavcheva_state_kernel<D, SMOOTH, LEVELSET, DATA, ENERGY, WALK>), dim3(a.blocks),
                        dim3(a.threads), 0, a.s, a.state_in, a.canonical, a.state_out, a.g, a.p, a.gate,
                        a.record, a.band_list, a.band_count);
