@@ -45,8 +45,9 @@ HBM_PEAK_GBS = 8000.0                    # MI355X HBM3E spec peak (MI355X_MICROA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=None,
+                    help="timed steps (default: 100 for the millisecond-scale steps -- killing, sobolev, hier2d --, else 20)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps in front (default: 10 resp. 5)")
     ap.add_argument("--size", type=int, default=None,
                     help="edge of the per-GPU volume (default 256 = BASELINE config 4; multiframe: 512 = config 5)")
     ap.add_argument("--iterations", type=int, default=50)
@@ -92,6 +93,13 @@ def parse():
     args = ap.parse_args()
     if args.size is None:
         args.size = 512 if args.workload in ("multiframe", "hier2d") else 256
+    # a step of a few milliseconds: 20 of them are over before the card's clocks have settled (20 timed steps 1.74-1.75 ms
+    # each at 256^3, 200: 1.71-1.72) -- the default run times 100 (0.2 s at 256^3, 0.8 s at 512^3)
+    short_steps = args.workload in ("killing", "sobolev", "hier2d") and args.size <= 512
+    if args.steps is None:
+        args.steps = 100 if short_steps else 20
+    if args.warmup is None:
+        args.warmup = 10 if short_steps else 5
     return args
 
 
@@ -133,11 +141,14 @@ def cpu_baseline_hierarchical(size, iterations, full):
 def timed_steps(step, args, fence, max_over_ranks=None):
     """W untimed + K timed steps between fences (barrier + synchronize on both sides), cyclic GC parked as in main();
     returns (sum of what step() returns over the timed steps, seconds)"""
-    for _ in range(args.warmup):
+    late = min(3, args.warmup)  # the last warm-up steps run BEHIND the collection (see main())
+    for _ in range(args.warmup - late):
         step()
     gc.collect()
     gc.freeze()  # keep torch's objects out of the cyclic collector's full passes
     gc.disable()
+    for _ in range(late):
+        step()
     fence()
     t0 = time.perf_counter()
     total = None
@@ -339,12 +350,12 @@ def main():
 
 
 SECONDARY = (  # (workload, size, steps, warmup, iterations, extra arguments): short runs of BASELINE's other configurations
-    ("killing", 512, 5, 2, 50, {}),
+    ("killing", 512, 20, 4, 50, {}),
     ("hier-tik", 256, 3, 1, 50, {}),
     ("hier-full", 256, 3, 1, 50, {}),
     ("multiframe", 512, 1, 1, 50, {}),
-    ("sobolev", 256, 5, 2, 50, {}),
-    ("hier2d", 512, 5, 2, 100, {}),
+    ("sobolev", 256, 20, 4, 50, {}),
+    ("hier2d", 512, 20, 4, 100, {}),
 )
 
 
@@ -473,16 +484,22 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
         return float(t.item())
 
     executed = 0
-    for _ in range(args.warmup):
+    late = min(3, args.warmup)  # warm-up steps that run behind the collection below
+    for _ in range(args.warmup - late):
         executed = step()
     # Python's cyclic collector walks every object torch has created (~40 ms per full collection, measured with
     # tools/step_times.py: one 2.5 ms step in ~25 took 40 ms): park the existing objects in the permanent generation,
     # as a serving loop would, and keep the cyclic collector out of the timed steps altogether (with few warm-up steps the
     # objects of the first timed steps would otherwise be walked in a full pass: one 60 ms pause seen in a 5-step
     # 512^3 run); reference counting still frees every tensor of a step as the step ends.
+    # The collection takes ~40 ms during which the card sits idle and drops its clocks: timed straight behind it, the
+    # first steps ran slow (20 timed steps: 1.78-1.80 ms each, 200: 1.72-1.73, 400: 1.71 -- a one-off of ~1.4 ms whatever
+    # K), so the last warm-up steps run between the collection and the timed region.  Still W untimed steps in all.
     gc.collect()
     gc.freeze()
     gc.disable()
+    for _ in range(late):
+        executed = step()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
