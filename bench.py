@@ -510,6 +510,22 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
     if world > 1:
         elapsed = max_over_ranks(elapsed)
     assert executed == iters, "expected %d fixed iterations, the gate closed after %d" % (iters, executed)
+    # The same K steps under the conditions of the PRODUCT's pair loop (experiment/multipair.run_pairs ->
+    # hostloop.parked_collector(): torch's objects parked, the cyclic collector left ON; caller shape
+    # run_hierarchical_optimizer3d_multipair.py:403-432) -- reported next to ms_per_step as ms_per_step_gc_on
+    from levelsetfusion_python_amd.hostloop import parked_collector
+    gc.unfreeze()
+    with parked_collector():
+        for _ in range(late):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        elapsed_gc_on = time.perf_counter() - t0
+    if world > 1:
+        elapsed_gc_on = max_over_ranks(elapsed_gc_on)
     voxels_per_rank = n ** 3 // world if strong else n ** 3
     updates = voxels_per_rank * world * iters * args.steps
     value = updates / elapsed
@@ -654,7 +670,8 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
         if eng.use_band_list and dense_walk and not (world > 1 and layout.axis == 1) else None  # y-cut grids: lists only
 
     out = dict(metric="voxel-warp-updates/sec", value=value, unit="voxel-warp-updates/s", n_gpus=world,
-               steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3, higher_is_better=True,
+               steps=args.steps, warmup=args.warmup, ms_per_step=elapsed / args.steps * 1e3,
+               ms_per_step_gc_on=elapsed_gc_on / args.steps * 1e3, higher_is_better=True,
                scaling="strong" if strong else "weak", vs_baseline=None, dtype="f32", data="synthetic",
                config=dict(workload="3D %d^3 KillingFusion (Killing + level-set) SlavchevaOptimizer3d, %d fixed "
                                     "iterations per step, %s" % (n, iters, "sphere-pair TSDF" if args.data == "sphere"

@@ -13,6 +13,8 @@ import re
 import numpy as np
 import pandas as pd
 
+from ..hostloop import parked_collector
+
 LEVEL_COLUMNS = ["iter_count", "iter_lim_reached", "warp_delta_amt_ratio", "warp_delta_min", "warp_delta_max",
                  "warp_delta_mean", "warp_delta_std", "warp_delta_max_x", "warp_delta_max_y",
                  "warps_below_min_thresh", "warps_above_max_thresh", "diff_delta_min", "diff_delta_max",
@@ -51,7 +53,15 @@ def run_pairs(optimizer, pairs, progress=None):
     at every launch boundary of the fine ones, and another pair's kernels move into those gaps (tools/pairs_in_flight.py
     at 256^3: the Tikhonov-only hierarchical optimizer 21.1 -> 18.0 ms per pair with two in flight; with the 7-tap kernel
     and for the Slavcheva optimizer the gain stays inside the run-to-run spread -- one host thread at a time holds the
-    interpreter)."""
+    interpreter).
+
+    The loop runs under `hostloop.parked_collector()`: a full pass of Python's cyclic collector over torch's objects
+    costs as much as twenty KillingFusion calls at 256^3, and bench.py's timed steps run without it too."""
+    with parked_collector():
+        return _run_pairs(optimizer, pairs, progress)
+
+
+def _run_pairs(optimizer, pairs, progress):
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
     rank = dist.get_rank() if world > 1 else 0

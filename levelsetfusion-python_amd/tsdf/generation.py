@@ -10,6 +10,9 @@ import torch
 
 from .. import _lib, device as dev
 from ..engine import as_device_field  # noqa: F401  (require_gpu side effect lives in device.require_gpu)
+# the hard-coded piecewise-linear pairs of tsdf/generation.py:238-353 (host numpy; BASELINE config 1's input)
+from .orthographic import (Point2d, add_surface_to_2d_tsdf_field_sample,  # noqa: F401
+                           generate_initial_orthographic_2d_tsdf_fields, generate_sample_orthographic_2d_tsdf_field)
 
 
 class FilteringMethod(Enum):

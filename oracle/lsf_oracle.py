@@ -1039,3 +1039,50 @@ def downsample2x_linear(field):
                 wgt = DOWNSAMPLE_WEIGHTS[inner[dz] + inner[dy] + inner[dx]]
                 out += wgt * p[dz:dz + 2 * nz:2, dy:dy + 2 * ny:2, dx:dx + 2 * nx:2]
     return out
+
+
+# =====================================================================================================
+#  BASELINE config 1's input: the hand-made orthographic 2-D pair   (tsdf/generation.py:238-353)
+# =====================================================================================================
+ORTHOGRAPHIC_SURFACE = ((9, 56), (14, 66), (23, 72), (35, 72), (44, 65), (54, 60), (63, 60), (69, 64), (76, 71),
+                        (84, 73), (91, 72), (106, 63), (109, 57))   # (x, y), tsdf/generation.py:289-301
+ORTHOGRAPHIC_DETAIL = ((32, 65), (36, 65), (41, 61))                # tsdf/generation.py:303-305
+
+
+def orthographic_surface_fill(field, points, narrow_band_width_voxels=20, back_cutoff_voxels=math.inf):
+    """One polyline into `field`, column by column, scalar float32 arithmetic (tsdf/generation.py:238-265): rows above
+    the band <- 1, band rows <- clip((surface_y - y) / half_width), rows behind <- -1 unless a back cut-off ends the
+    band early.  `points` are (x, y) float32 pairs."""
+    half = narrow_band_width_voxels // 2
+    behind = min(half, back_cutoff_voxels)
+    for (ax, ay), (bx, by) in zip(points[:-1], points[1:]):
+        run = F32(bx) - F32(ax)
+        for x in range(int(ax), int(bx)):
+            t = F32(F32(x) - F32(ax)) / run
+            sy = F32(F32(ay) * F32(F32(1.0) - t)) + F32(F32(by) * t)
+            if F32(sy - F32(narrow_band_width_voxels)) < 0:
+                raise ValueError("Surface is too close to 0 in the y dimension for a full narrow band representation")
+            first = int(F32(sy - F32(half)))
+            last = int(F32(F32(sy + F32(behind)) + F32(1)))
+            field[0:first, x] = 1.0
+            for y in range(first, last):
+                field[y, x] = min(max(F32(F32(sy - F32(y)) / F32(half)), F32(-1.0)), F32(1.0))
+            if last < field.shape[0] and last < back_cutoff_voxels:
+                field[last:, x] = -1.0
+    return field
+
+
+def orthographic_pair(field_size=128, narrow_band_width_voxels=20, mimic_eta=False, default_value=1):
+    """(live, canonical) of generate_initial_orthographic_2d_tsdf_fields (tsdf/generation.py:282-353): surface and
+    detail polylines lowered by 0.23 rows (float32), canonical = the same 5 rows further down, cut off 3 voxels behind
+    the surface when `mimic_eta`."""
+    lower = lambda pts, by: [(F32(x), F32(F32(y) + F32(by))) for x, y in pts]  # noqa: E731
+    live_surface, live_detail = lower(ORTHOGRAPHIC_SURFACE, -0.23), lower(ORTHOGRAPHIC_DETAIL, -0.23)
+    live = np.full((field_size, field_size), default_value, dtype=F32)
+    orthographic_surface_fill(live, live_surface, narrow_band_width_voxels)
+    orthographic_surface_fill(live, live_detail, narrow_band_width_voxels)
+    cutoff = 3 if mimic_eta else math.inf
+    canonical = np.full((field_size, field_size), default_value, dtype=F32)
+    orthographic_surface_fill(canonical, lower(live_surface, 5.0), narrow_band_width_voxels, cutoff)
+    orthographic_surface_fill(canonical, lower(live_detail, 5.0), narrow_band_width_voxels, cutoff)
+    return live, canonical

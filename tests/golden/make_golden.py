@@ -10,6 +10,8 @@ Outputs
   ref_hierarchical.npz    HierarchicalOptimizer2d runs (per-iteration warp fields)
   ref_slavcheva.npz       SlavchevaOptimizer2d runs (per-iteration live / warp / gradient / energies)
   ref_config1.npz         BASELINE config 1 at full length: the 64 x 64 orthographic pair, 100 fixed iterations
+  ref_orthographic.npz    the hand-made orthographic 2-D pairs themselves (tsdf/generation.py:238-353) and the errors
+                          the generator raises for fields that cannot hold them
 """
 import ast
 import contextlib
@@ -319,6 +321,50 @@ def config1():
     print("ref_config1.npz:", len(out), "arrays")
 
 
+def orthographic():
+    """BASELINE config 1's INPUT generator: generate_initial_orthographic_2d_tsdf_fields with and without mimic_eta,
+    other band widths / default values, a free-standing polyline through generate_sample_orthographic_2d_tsdf_field,
+    and which exception a field that cannot hold the surface raises (stored as a code: 1 IndexError, 2 ValueError)"""
+    from utils.point2d import Point2d
+    out = {}
+    for tag, kw in (("size128", dict(field_size=128)),
+                    ("size128.eta", dict(field_size=128, mimic_eta=True)),
+                    ("size160.band12.default0", dict(field_size=160, narrow_band_width_voxels=12, default_value=0)),
+                    ("size128.band30.eta.default_half", dict(field_size=128, narrow_band_width_voxels=30,
+                                                             mimic_eta=True, default_value=0.5)),
+                    ("size110.band7", dict(field_size=110, narrow_band_width_voxels=7))):
+        live, canonical = tsdf_gen.generate_initial_orthographic_2d_tsdf_fields(**kw)
+        out[tag + ".live"], out[tag + ".canonical"] = live, canonical
+    codes = {IndexError: 1, ValueError: 2}
+    for tag, kw in (("size64", dict(field_size=64)), ("size100.eta", dict(field_size=100, mimic_eta=True)),
+                    ("size128.band60", dict(field_size=128, narrow_band_width_voxels=60)),
+                    ("size128.smoothing", dict(field_size=128, live_smoothing_kernel_size=3))):
+        try:
+            tsdf_gen.generate_initial_orthographic_2d_tsdf_fields(**kw)
+            code = 0
+        except NameError:
+            code = 3
+        except (IndexError, ValueError) as e:
+            code = codes[type(e)]
+        out[tag + ".raises"] = np.array(code)
+    points = np.array([[3.5, 30.25], [10.0, 41.5], [17.25, 33.0], [40.0, 52.125]], dtype=np.float32)
+    out["polyline.points"] = points
+    for tag, kw in (("polyline.size80", dict(size=80)), ("polyline.size80.cut5", dict(size=80, back_cutoff_voxels=5)),
+                    ("polyline.size72.band8.default_m1", dict(size=72, narrow_band_width_voxels=8,
+                                                              default_value=-1))):
+        out[tag] = tsdf_gen.generate_sample_orthographic_2d_tsdf_field([Point2d(x, y) for x, y in points], **kw)
+    # a band that runs past the last row: the rows that exist are written, then IndexError
+    field = np.full((40, 48), 0.25, dtype=np.float32)
+    try:
+        tsdf_gen.add_surface_to_2d_tsdf_field_sample(field, [Point2d(x, y) for x, y in points])
+        out["polyline.rows40.raises"] = np.array(0)
+    except IndexError:
+        out["polyline.rows40.raises"] = np.array(1)
+    out["polyline.rows40.partial"] = field
+    np.savez_compressed(os.path.join(HERE, "ref_orthographic.npz"), **out)
+    print("ref_orthographic.npz:", len(out), "arrays")
+
+
 def slavcheva():
     out = {}
     sampling.set_focus_coordinates(0, 0)
@@ -518,11 +564,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "config1":
         config1()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "orthographic":
+        orthographic()
+        sys.exit(0)
     literals()
     leaf()
     hierarchical()
     slavcheva()
     config1()
+    orthographic()
     tsdf()
     ewa()
     for f in sorted(os.listdir(HERE)):
