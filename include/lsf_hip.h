@@ -380,6 +380,49 @@ int lsf_slavcheva_state_iteration(const float *state_in, const float *canonical,
                                   lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,
                                   int32_t band_subset, void *stream);
 
+/* ---- a whole fixed-count call of the fused path, enqueued by the library in two host calls ---------------------------
+ * replaces the LOOP of slavcheva_optimizer2d.py:354-388 (min_iterations == max_iterations: its stop test :360-362 cannot
+ * fire) around the calls above, for whole volumes on band lists: lsf_state_run_begin launches lsf_state_prepare and the
+ * initialisation of the two states (sparse_reach > 0: lsf_state_pack_needed with that reach, else both states in full,
+ * the second one behind the copy of the list sizes when second_state_late != 0) and RETURNS when the four totals of
+ * lsf_state_prepare are in totals_host; the caller sizes the two lists from them (totals_host[0] INTERIOR, [1] BOUNDARY
+ * entries) and calls lsf_state_run_finish, which launches the list fills, `iterations` x lsf_slavcheva_state_iteration
+ * per non-empty list (ungated; iteration i reads state[i % 2], writes the other, reduces into records[i], which the
+ * caller has zeroed) and lsf_state_finalize_listed of the final state into live_out (which must hold the input live field:
+ * the pass writes listed voxels only; statistics16 / finalize_scratch as there, may be NULL; with sparse states the pass
+ * guards itself with the records), copies the records' used words and the statistics to the host and RETURNS when the
+ * stream has drained, the records decoded into `result` (lsf_records_decode).  The same launches in the same order as the
+ * calls made one by one: identical results.  Both functions block the calling thread only (no device-wide
+ * synchronisation); totals_host, words_host (iterations x LSF_RECORD_SLOTS x 4 int64) and statistics_host (16 doubles)
+ * must be page-locked host memory, words_device as many int64 of device memory. */
+typedef struct lsf_state_run {
+    const float *live;        /* the input live field; read again by the sparse initialisation */
+    const float *canonical;
+    float *state[2];          /* the two ping-pong states, nz * ny * nx float4 each, contents undefined on entry */
+    int32_t *prepare_scratch; /* lsf_state_prepare_scratch_elements(grid) int32 */
+    int64_t *totals_device;   /* 4 int64 */
+    int64_t *totals_host;     /* 4 int64, page-locked */
+    lsf_grid grid;            /* a whole volume: z_begin = 0, z_end = nz, no offsets */
+    int32_t sparse_reach;     /* 0: both states are written in full */
+    int32_t second_state_late;
+} lsf_state_run;
+typedef struct lsf_state_run_result {
+    float *max_value;    /* host arrays of `iterations` entries (energies3: 3 per iteration), as lsf_records_decode */
+    int64_t *argmax;
+    double *energies3;
+    uint8_t *executed;
+    int32_t final_state;    /* out: index of the state that holds the result (iterations % 2) */
+    int32_t n_lists;        /* out: launches per iteration */
+    int32_t reach_exceeded; /* out: sparse states and an update of sparse_reach voxels or more -- live_out was left alone
+                               (the finalize pass's guard) and the call has to be repeated on full states */
+    int32_t reserved;
+} lsf_state_run_result;
+int lsf_state_run_begin(const lsf_state_run *run, void *stream);
+int lsf_state_run_finish(const lsf_state_run *run, const lsf_slavcheva_params *params, int32_t *list_interior,
+                         int32_t *list_boundary, lsf_iteration_record *records, int32_t iterations, float *live_out,
+                         float lower_threshold, double *statistics16, double *finalize_scratch, int64_t *words_device,
+                         int64_t *words_host, double *statistics_host, lsf_state_run_result *result, void *stream);
+
 /* ---- the SobolevFusion iteration on the float4 layouts (band lists) ------------------------------
  * replaces one pass of slavcheva_optimizer2d.py:163-236 / :238-330 WITH a Sobolev filter (math_utils/convolution.py:
  * 114-132) exactly as lsf_slavcheva_gradient + lsf_convolve_axis_listed x D + lsf_slavcheva_update_rewarp do on planar

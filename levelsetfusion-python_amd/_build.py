@@ -9,7 +9,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "liblsf_hip.so")
 SOURCES = ["lsf_fields.hip", "lsf_hierarchical.hip", "lsf_slavcheva.hip", "lsf_slavcheva_state.hip",
-           "lsf_sobolev_state.hip", "lsf_slab.hip", "lsf_tsdf.hip"]
+           "lsf_slavcheva_run.hip", "lsf_sobolev_state.hip", "lsf_slab.hip", "lsf_tsdf.hip"]
 HEADERS = ["lsf_device.h", "lsf_slavcheva_terms.h", "lsf_slavcheva_state_taps.h",
            os.path.join("..", "..", "include", "lsf_hip.h")]
 # the chain kernel (K fused iterations per launch; measured 4 % slower) is an OPTIONAL add-on

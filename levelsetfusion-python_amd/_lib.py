@@ -22,7 +22,7 @@ ABI_VERSION = 3
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "0e1986b407e4aecc"
+HEADER_ABI_HASH = "91d3771e5af36db6"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -84,6 +84,20 @@ class SlabFaces(ctypes.Structure):
     _fields_ = [("send_list", ctypes.c_void_p * 2), ("recv_list", ctypes.c_void_p * 2),
                 ("send_msg", ctypes.c_void_p * 2), ("recv_msg", ctypes.c_void_p * 2),
                 ("send_count", ctypes.c_int64 * 2), ("recv_count", ctypes.c_int64 * 2)]
+
+
+class StateRun(ctypes.Structure):
+    """lsf_state_run: the buffers of a whole fixed-count call enqueued by the library (lsf_state_run_begin / _finish)"""
+    _fields_ = [("live", ctypes.c_void_p), ("canonical", ctypes.c_void_p), ("state", ctypes.c_void_p * 2),
+                ("prepare_scratch", ctypes.c_void_p), ("totals_device", ctypes.c_void_p),
+                ("totals_host", ctypes.c_void_p), ("grid", Grid), ("sparse_reach", ctypes.c_int32),
+                ("second_state_late", ctypes.c_int32)]
+
+
+class StateRunResult(ctypes.Structure):
+    _fields_ = [("max_value", ctypes.c_void_p), ("argmax", ctypes.c_void_p), ("energies3", ctypes.c_void_p),
+                ("executed", ctypes.c_void_p), ("final_state", ctypes.c_int32), ("n_lists", ctypes.c_int32),
+                ("reach_exceeded", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class HierParams(ctypes.Structure):
@@ -159,6 +173,9 @@ PROTOTYPES = {
                                                  _i64, _i64, _f32, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
     "lsf_slavcheva_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp,
                                                      _vp, _i64, _i32, _vp]),
+    "lsf_state_run_begin": (ctypes.c_int, [_P(StateRun), _vp]),
+    "lsf_state_run_finish": (ctypes.c_int, [_P(StateRun), _P(SlavchevaParams), _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp,
+                                            _vp, _vp, _vp, _P(StateRunResult), _vp]),
     "lsf_band_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
     "lsf_band_count": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),
     "lsf_band_list_fill": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),

@@ -1,0 +1,145 @@
+// A whole fixed-count KillingFusion-style optimize() call of a whole volume, enqueued by the LIBRARY in two host calls
+// (include/lsf_hip.h: lsf_state_run_begin / lsf_state_run_finish).  Reference loop: nonrigid_opt/slavcheva/
+// slavcheva_optimizer2d.py:354-388 -- one Python iteration of which is ONE kernel launch here; caller shape
+// run_hierarchical_optimizer3d_multipair.py:403-432 (a loop of such calls over independent pairs).
+//
+// Nothing new runs on the device: the two functions issue the launches of lsf_state_prepare, lsf_state_pack_needed /
+// lsf_state_pack, lsf_band_list_fill_prepared, lsf_slavcheva_state_iteration x K and lsf_state_finalize_listed in the order
+// the Python engine issues them, on the caller's stream -- results are those launches' results, bit for bit.  What changes
+// is the host side: K + 8 foreign calls, their argument marshalling and three tensor-level read-backs become two calls
+// that run without the interpreter lock (ctypes releases it), so that a second pair's call can be enqueued by another
+// host thread meanwhile (experiment/multipair.run_pairs with several optimizers).
+#include "lsf_device.h"
+
+#include <cstring>
+
+using namespace lsf;
+
+namespace {
+
+// the four used words of every slot of every record, gathered for ONE copy to the host (a record is 8 slots 4 KiB apart)
+__global__ __launch_bounds__(kBlock) void records_used_words_kernel(const long long* __restrict__ records,
+                                                                    long long* __restrict__ out, int n_slots) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;  // (slot, word)
+    if (k >= n_slots * 4) return;
+    out[k] = records[(long long)(k >> 2) * (sizeof(lsf_record_slot) / 8) + (k & 3)];
+}
+
+// one timing-less event per host thread and device, created on first use (an event per call costs a create / destroy pair)
+inline hipEvent_t thread_event() {
+    thread_local hipEvent_t events[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!events[dev] && hipEventCreateWithFlags(&events[dev], hipEventDisableTiming) != hipSuccess) events[dev] = nullptr;
+    return events[dev];
+}
+
+inline bool run_ok(const lsf_state_run* r) {
+    return r && r->live && r->canonical && r->state[0] && r->state[1] && r->state[0] != r->state[1] && r->prepare_scratch &&
+           r->totals_device && r->totals_host && r->sparse_reach >= 0 && r->sparse_reach <= 8;
+}
+
+}  // namespace
+
+extern "C" int lsf_state_run_begin(const lsf_state_run* run, void* stream) {
+    if (!run_ok(run)) return LSF_ERR_BAD_ARGUMENT;
+    const lsf_grid* g = &run->grid;
+    if (int e = check_grid(g)) return e;
+    if (g->z_begin != 0 || g->z_end != g->nz) return LSF_ERR_BAD_ARGUMENT;  // whole volumes
+    hipStream_t s = as_stream(stream);
+    const bool sparse = run->sparse_reach > 0;
+    // the counting pass; it also writes the states unless they are initialised near the band only (below).  With
+    // second_state_late the second state is written behind the copy of the list sizes, where it overlaps the host's wait
+    float* b_in_pass = (sparse || run->second_state_late) ? nullptr : run->state[1];
+    if (int e = lsf_state_prepare(run->live, run->canonical, sparse ? nullptr : run->state[0], b_in_pass, g,
+                                  run->prepare_scratch, run->totals_device, stream))
+        return e;
+    if (hipMemcpyAsync(run->totals_host, run->totals_device, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess)
+        return (int)hipGetLastError();
+    hipEvent_t sizes = thread_event();
+    if (!sizes) return (int)hipGetLastError();
+    int status = 0;
+    if (hipEventRecord(sizes, s) != hipSuccess) status = (int)hipGetLastError();
+    if (!status && sparse)
+        status = lsf_state_pack_needed(run->live, run->state[0], run->state[1], g, run->prepare_scratch, run->sparse_reach, 0,
+                                       stream);
+    else if (!status && run->second_state_late)
+        status = lsf_state_pack(run->live, nullptr, run->state[1], nullptr, g, stream);
+    if (!status && hipEventSynchronize(sizes) != hipSuccess) status = (int)hipGetLastError();
+    return status;
+}
+
+extern "C" int lsf_state_run_finish(const lsf_state_run* run, const lsf_slavcheva_params* params, int32_t* list_interior,
+                                    int32_t* list_boundary, lsf_iteration_record* records, int32_t iterations,
+                                    float* live_out, float lower_threshold, double* statistics16,
+                                    double* finalize_scratch, int64_t* words_device, int64_t* words_host,
+                                    double* statistics_host, lsf_state_run_result* result, void* stream) {
+    if (!run_ok(run) || !params || !records || iterations < 1 || !live_out || !words_device || !words_host || !result ||
+        (statistics16 && (!finalize_scratch || !statistics_host)) || !result->max_value || !result->argmax ||
+        !result->energies3 || !result->executed)
+        return LSF_ERR_BAD_ARGUMENT;
+    const lsf_grid* g = &run->grid;
+    if (int e = check_grid(g)) return e;
+    const int64_t n_interior = run->totals_host[0], n_boundary = run->totals_host[1];
+    if (n_interior < 0 || n_boundary < 0 || n_interior > 0x7fffffffll || n_boundary > 0x7fffffffll ||
+        (n_interior && !list_interior) || (n_boundary && !list_boundary))
+        return LSF_ERR_BAD_ARGUMENT;
+    hipStream_t s = as_stream(stream);
+    // the lists, from the ballots the counting pass kept; an empty list is dropped -- but never both (a launch over an
+    // empty BOUNDARY list still contributes the arg-max of an all-zero update)
+    const int32_t* lists[2];
+    int64_t counts[2];
+    int32_t subsets[2];
+    int n_lists = 0;
+    if (n_interior) {
+        if (int e = lsf_band_list_fill_prepared(g, LSF_BAND_INTERIOR, run->prepare_scratch, list_interior, stream)) return e;
+        lists[n_lists] = list_interior; counts[n_lists] = n_interior; subsets[n_lists++] = LSF_BAND_INTERIOR;
+    }
+    if (n_boundary || !n_lists) {
+        if (n_boundary)
+            if (int e = lsf_band_list_fill_prepared(g, LSF_BAND_BOUNDARY, run->prepare_scratch, list_boundary, stream)) return e;
+        // (an empty list is never dereferenced; the pointer only has to be non-NULL to mean "a list walk")
+        lists[n_lists] = n_boundary ? list_boundary : reinterpret_cast<const int32_t*>(run->prepare_scratch);
+        counts[n_lists] = n_boundary; subsets[n_lists++] = LSF_BAND_BOUNDARY;
+    }
+    // the iterations: ungated (a fixed count), iteration i reads state[i % 2] and writes the other
+    for (int32_t i = 0; i < iterations; ++i)
+        for (int k = 0; k < n_lists; ++k)
+            if (int e = lsf_slavcheva_state_iteration(run->state[i % 2], run->canonical, run->state[(i + 1) % 2], g, params,
+                                                      nullptr, records + i, lists[k], counts[k], subsets[k], stream))
+                return e;
+    // the end of the call behind the last iteration: the listed voxels' live values into the caller's array (which holds
+    // the input everywhere else) and the convergence statistics; with sparsely initialised states the pass looks at the
+    // records first and leaves everything alone when an update outran what was initialised
+    const float* final_state = run->state[iterations % 2];
+    int64_t listed_counts[2] = {0, 0};
+    const int32_t* listed[2] = {nullptr, nullptr};
+    int n_listed = 0;
+    for (int k = 0; k < n_lists; ++k)
+        if (counts[k]) { listed[n_listed] = lists[k]; listed_counts[n_listed++] = counts[k]; }
+    const bool sparse = run->sparse_reach > 0;
+    if (int e = lsf_state_finalize_listed(final_state, run->canonical, live_out, nullptr, g, listed, listed_counts, n_listed,
+                                          run->totals_host[2], run->totals_host[3], lower_threshold, statistics16,
+                                          finalize_scratch, nullptr, sparse ? records : nullptr, sparse ? iterations : 0,
+                                          (float)run->sparse_reach, stream))
+        return e;
+    const int n_slots = iterations * LSF_RECORD_SLOTS;
+    hipLaunchKernelGGL(records_used_words_kernel, dim3((n_slots * 4 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                       reinterpret_cast<const long long*>(records), reinterpret_cast<long long*>(words_device), n_slots);
+    if (int e = launch_status()) return e;
+    if (hipMemcpyAsync(words_host, words_device, (size_t)n_slots * 4 * sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess)
+        return (int)hipGetLastError();
+    if (statistics16 &&
+        hipMemcpyAsync(statistics_host, statistics16, 16 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess)
+        return (int)hipGetLastError();
+    if (hipStreamSynchronize(s) != hipSuccess) return (int)hipGetLastError();
+    if (int e = lsf_records_decode(words_host, iterations, LSF_RECORD_SLOTS, 4, result->max_value, result->argmax,
+                                   result->energies3, result->executed))
+        return e;
+    result->final_state = iterations % 2;
+    result->n_lists = n_lists;
+    result->reach_exceeded = 0;
+    for (int32_t i = 0; i < iterations && sparse; ++i)
+        if (result->executed[i] && !(result->max_value[i] < (float)run->sparse_reach)) result->reach_exceeded = 1;
+    return 0;
+}

@@ -727,6 +727,40 @@ class SlavchevaOutcome:
         return target, warp, (raw.cpu().numpy() if raw is not None else None)
 
 
+class _RunOutcome(SlavchevaOutcome):
+    """the final fields of a call the LIBRARY enqueued in one piece (SlavchevaEngine._optimize_run): the live field is
+    already in the caller's array and the statistics are on the host; the dense API-layout warp is only built when somebody
+    asks for it (the reference's optimize() does not hand its warp field out at all, slavcheva_optimizer2d.py:332-408) --
+    from the final state's LISTED voxels, so that states initialised near the band only need no completion and nothing here
+    depends on the caller's tensor staying as the call left it"""
+
+    def __init__(self, grid, canonical, state, target, bands, raw):
+        super().__init__(grid, canonical, state=state)
+        self._live, self._bands, self._raw, self._warp = target, bands, raw, None
+
+    def live(self):
+        return self._live
+
+    def warp_interleaved(self):
+        if self._warp is None:
+            warp = torch.zeros(self._shape() + (self.grid.dims,), dtype=torch.float32, device=self._device())
+            dev.state_finalize_listed(self.state, self.canonical, dev.full_range(self.grid), self._bands, (0, -1), None,
+                                      warp, 0.0, False)
+            self._warp = warp
+        return self._warp
+
+    def warp_planar(self):
+        if self._warp_planar is None:
+            self._warp_planar = dev.deinterleave(self.warp_interleaved(), self.grid.dims)
+        return self._warp_planar
+
+    def finalize(self, live_out=None, lower_threshold=0.0, statistics=False):
+        """(live, a callable that builds the interleaved warp, raw statistics): everything was produced by the call"""
+        if live_out is not None and live_out is not self._live:
+            live_out.copy_(self._live)
+        return self._live, self.warp_interleaved, (self._raw if statistics else None)
+
+
 class _HaloTooNarrow(Exception):
     """a z-slab run met a warp update its halo schedule cannot carry (SlavchevaEngine.optimize re-runs it wider)"""
 
@@ -900,6 +934,9 @@ class SlavchevaEngine:
         self.check_interval = max(1, int(check_interval))
         self.comm = comm
         self.use_band_list = bool(use_band_list)  # False: the fused kernel walks every voxel (measurements, tests)
+        # whole-volume fixed-count calls are enqueued by the library in one piece (_optimize_run); False: the general path,
+        # one foreign call per launch (tests hold the two against each other)
+        self.library_run = True
         self.iteration_count = 0
         self.log = None
         self._gradient_state = None
@@ -1491,6 +1528,13 @@ class SlavchevaEngine:
         dims = grid.dims
         n_rec = max(self.max_iterations, self.min_iterations, 1)
         slab = self._slab()
+        if (self.library_run and finalize is not None and not slab and not self.sobolev and self.use_band_list
+                and self.iteration_hook is None
+                and self.min_iterations > 0 and self.min_iterations >= self.max_iterations
+                and dev.buffer_addressing_ok(grid) and os.environ.get("LSF_CHAIN", "0") != "1"):
+            # a whole volume, a fixed iteration count, no Sobolev filter, nobody watching the iterations: the whole call is
+            # enqueued by the library (two host calls; slavcheva_optimizer2d.py:354-388's loop without a Python iteration)
+            return self._optimize_run(live, canonical, grid, finalize)
         if slab:
             need = 1 if not self.sobolev else max(1, len(self.sobolev_kernel) // 2)
             if self.comm.layout.halo < need:
@@ -1735,6 +1779,85 @@ class SlavchevaEngine:
                                     (prepared, live) if sparse else None)
         return outcome
 
+    def _optimize_run(self, live, canonical, grid, finalize):
+        """_optimize for the case the library enqueues in one piece (lsf_state_run_begin / _finish): prepare pass, (sparse)
+        states, band lists, all iterations, the listed finalize pass and the read-backs -- the same launches in the same
+        order as the general path below makes one by one, hence the same results, in two foreign calls that run without the
+        interpreter lock."""
+        live_out, lower_threshold, statistics = finalize
+        iterations = self.min_iterations
+        device = live.device
+        n = dev.n_voxels(grid)
+        whole = dev.full_range(grid)
+        sparse = (SPARSE_REACH > 0 and n >= SPARSE_MIN_VOXELS and not getattr(self, "_sparse_disabled", False))
+        self._sparse_used = sparse
+        usable = (live_out is not None and live_out.is_cuda and live_out.dtype == torch.float32
+                  and live_out.is_contiguous() and tuple(live_out.shape) == tuple(live.shape))
+        target = live_out if usable else torch.empty_like(live)
+        if target is not live:
+            target.copy_(live)  # the finalize pass writes listed voxels only
+        states = [torch.empty(tuple(live.shape) + (4,), dtype=torch.float32, device=device) for _ in range(2)]
+        scratch = torch.empty(int(_lib.lib.lsf_state_prepare_scratch_elements(ctypes.byref(whole))), dtype=torch.int32,
+                              device=device)
+        totals = torch.empty(4, dtype=torch.int64, device=device)
+        totals_host = dev.pinned_scratch("run totals", 4, torch.int64)
+        run = _lib.StateRun()
+        run.live, run.canonical = dev._ptr(live, n, "live"), dev._ptr(canonical, n, "canonical")
+        run.state[0], run.state[1] = states[0].data_ptr(), states[1].data_ptr()
+        run.prepare_scratch, run.totals_device, run.totals_host = scratch.data_ptr(), totals.data_ptr(), totals_host.data_ptr()
+        run.grid = whole
+        run.sparse_reach = SPARSE_REACH if sparse else 0
+        run.second_state_late = int(not sparse and n <= dev.StatePrepare.SPLIT_MAX_VOXELS)
+        stream = dev.stream_ptr()
+        _lib.check(_lib.lib.lsf_state_run_begin(ctypes.byref(run), stream), "lsf_state_run_begin")
+        # (the card is writing the states now; the lists are sized from the totals the call waited for)
+        n_interior, n_boundary, opposite, first_opposite = totals_host.tolist()
+        lists = torch.empty(max(n_interior + n_boundary, 1), dtype=torch.int32, device=device)
+        records = dev.new_records(iterations, device)
+        words = torch.empty(iterations * _lib.RECORD_SLOTS * dev.USED_SLOT_WORDS, dtype=torch.int64, device=device)
+        words_host = dev.pinned_scratch("run records", words.numel(), torch.int64)
+        stats = stats_host = stats_scratch = None
+        if statistics:
+            stats = torch.empty(16, dtype=torch.float64, device=device)
+            stats_scratch = torch.empty(2 * int(_lib.lib.lsf_state_finalize_scratch_elements(ctypes.byref(whole))),
+                                        dtype=torch.float64, device=device)
+            stats_host = dev.pinned_scratch("run statistics", 16, torch.float64)
+        max_value, argmax = np.empty(iterations, np.float32), np.empty(iterations, np.int64)
+        energies, executed = np.empty((iterations, 3), np.float64), np.empty(iterations, np.bool_)
+        result = _lib.StateRunResult(max_value.ctypes.data, argmax.ctypes.data, energies.ctypes.data, executed.ctypes.data)
+        none = ctypes.c_void_p(0)
+        p_lists = lists.data_ptr()
+        _lib.check(_lib.lib.lsf_state_run_finish(
+            ctypes.byref(run), ctypes.byref(self.params), ctypes.c_void_p(p_lists),
+            ctypes.c_void_p(p_lists + 4 * n_interior), ctypes.c_void_p(records.data_ptr()), iterations,
+            dev._ptr(target, n, "live_out"), float(lower_threshold),
+            ctypes.c_void_p(stats.data_ptr()) if statistics else none,
+            ctypes.c_void_p(stats_scratch.data_ptr()) if statistics else none, ctypes.c_void_p(words.data_ptr()),
+            ctypes.c_void_p(words_host.data_ptr()), ctypes.c_void_p(stats_host.data_ptr()) if statistics else none,
+            ctypes.byref(result), stream), "lsf_state_run_finish")
+        if result.reach_exceeded:
+            raise _SparseStateExceeded()  # the pass has left the caller's array alone (its guard); optimize() repeats
+        n_exec = int(executed.sum())
+        bands = []
+        if n_interior:
+            bands.append(dev.BandList(lists[:n_interior], n_interior, _lib.BAND_INTERIOR))
+        if n_boundary or not bands:
+            bands.append(dev.BandList(lists[n_interior:] if n_boundary else lists[:1], n_boundary, _lib.BAND_BOUNDARY))
+        f = _Counted(sum(b.count for b in bands))
+        f.bands, f.records = bands, records
+        self._fast = f
+        self._chain_used = False
+        self.iteration_count = n_exec
+        wd, ws, wl = self.weights
+        self.log = dict(max_warps=max_value[:n_exec].tolist(), max_warp_indices=argmax[:n_exec].tolist(),
+                        data_energies=(wd * energies[:n_exec, 0]).tolist(),
+                        smoothing_energies=(ws * energies[:n_exec, 1]).tolist(),
+                        level_set_energies=(wl * energies[:n_exec, 2]).tolist())
+        # gradient_field() recomputes the last iteration's gradient on demand from its INPUT state, at the listed voxels
+        self._gradient_state = ("recompute_listed", states[(n_exec - 1) % 2], canonical, grid, bands)
+        return _RunOutcome(grid, canonical, states[n_exec % 2], target, bands,
+                           stats_host.numpy().copy() if statistics else None)
+
     def _call_hook(self, i, max_warp, lives, warps, states, canonical, grid, sob=None):
         """iteration i has run: hand its warp and gradient to the hook in the API layout (owned slices of a slab)"""
         if self.sobolev and sob is None:
@@ -1772,6 +1895,28 @@ class SlavchevaEngine:
             g = st[1].gradient_field()
             ax = st[3] if len(st) > 3 else 0
             return None if g is None else g.narrow(1 + ax, st[2].start, st[2].stop - st[2].start).contiguous()
+        if st[0] == "recompute_listed":
+            # the unfused kernels at the voxels of the call's band lists (the gradient is zero everywhere else): of the
+            # input state only the listed voxels' neighbourhoods and re-warp cells are read, so a state that was initialised
+            # near the band only (lsf_state_pack_needed) serves as it stands, and nothing of the caller's is touched
+            _, state_in, canonical, grid, bands = st
+            live_in = torch.empty(tuple(state_in.shape[:-1]), dtype=torch.float32, device=state_in.device)
+            warp_in = torch.empty((grid.dims,) + tuple(live_in.shape), dtype=torch.float32, device=state_in.device)
+            dev.state_unpack(state_in, grid, live_in, warp_in, None)
+            g = torch.zeros_like(warp_in)
+            scratch_records = dev.new_records(1, live_in.device)
+            params = _lib.SlavchevaParams.from_buffer_copy(self.params)
+            params.energy_mode = _lib.ENERGY_NONE
+            warp_out, live_scratch = torch.empty_like(warp_in), torch.empty_like(live_in)
+            for band in bands:
+                if band.count:
+                    dev.slavcheva_gradient(live_in, canonical, warp_in, g, grid, params, None, scratch_records, 0, band)
+            for band in bands:
+                if band.count:
+                    dev.slavcheva_update_rewarp(live_in, canonical, g, warp_out, live_scratch, grid, params, None,
+                                                scratch_records, 0, band)
+            self._gradient_state = ("ready", g)
+            return g
         _, state_in, canonical, grid = st[:4]
         if len(st) > 4 and st[4] is not None:
             # the state was initialised near the band only: complete it from the call's live array, which still holds the

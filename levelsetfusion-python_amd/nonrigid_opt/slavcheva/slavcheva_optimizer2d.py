@@ -78,7 +78,7 @@ class _SlavchevaOptimizerBase:
         self.enable_convergence_status_logging = enable_convergence_status_logging
         self.verbose = verbose
         self.log = None
-        self.warp_field = None
+        self._warp_field = None
         self._engine = SlavchevaEngine(
             direct=compute_method == ComputeMethod.DIRECT, level_set_term_enabled=level_set_term_enabled,
             sobolev_smoothing_enabled=sobolev_smoothing_enabled,
@@ -113,6 +113,21 @@ class _SlavchevaOptimizerBase:
     @iteration_hook.setter
     def iteration_hook(self, hook):
         self._engine.iteration_hook = hook
+
+    @property
+    def warp_field(self):
+        """the last call's final warp field [..., D] (numpy for numpy inputs, a device tensor for device inputs).  The
+        reference's optimize() keeps its warp field to itself (slavcheva_optimizer2d.py:332-408: a local); here it is an
+        attribute that is BUILT WHEN READ -- the iterations keep the warp packed with the live field, and a dense
+        [..., D] copy costs a pass over the volume nobody may ever look at"""
+        w = self._warp_field
+        if callable(w):
+            w = self._warp_field = w()
+        return w
+
+    @warp_field.setter
+    def warp_field(self, value):
+        self._warp_field = value
 
     @property
     def gradient_field(self):
@@ -161,10 +176,10 @@ class _SlavchevaOptimizerBase:
             ds = tsdf_difference_statistics_from_raw(raw[8:], shape)
             self.log.convergence_report = ConvergenceReport(n, n >= self.max_iterations, ws, ds)
         if on_device:
-            self.warp_field = warp
+            self.warp_field = warp  # a tensor, or a callable that builds it on first access (the warp_field property)
         else:
             np.copyto(live_field, final_live.cpu().numpy())
-            self.warp_field = warp.cpu().numpy()
+            self.warp_field = (lambda: warp().cpu().numpy()) if callable(warp) else warp.cpu().numpy()
         return live_field
 
     def get_convergence_report(self):

@@ -1,0 +1,163 @@
+"""A whole fixed-count call enqueued by the LIBRARY (lsf_state_run_begin / lsf_state_run_finish, engine._optimize_run;
+round 5) against the same call made launch by launch from Python (engine.library_run = False) and against the oracle:
+live field, every record, the convergence report, the warp field and the gradient field -- bit for bit, on fully and on
+sparsely initialised states, in 2-D and 3-D, with voxels on the array's faces and with an empty band.  And what the
+call leaves behind (warp_field / gradient_field, both built on demand) does not depend on the caller's tensor staying
+as the call left it.
+Reference loop: nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:354-388; report :393-404."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lsf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+KILLING = dict(level_set_term_enabled=True, gradient_descent_rate=0.1, data_term_weight=1.0, smoothing_term_weight=0.2,
+               isomorphic_enforcement_factor=0.1, level_set_term_weight=0.2, maximum_warp_length_lower_threshold=0.0)
+
+
+@pytest.fixture(scope="module")
+def lsf():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import levelsetfusion_python_amd as pkg
+    return pkg
+
+
+class _Sparse:
+    def __init__(self, reach, min_voxels=0):
+        self.new = (reach, min_voxels)
+
+    def __enter__(self):
+        from levelsetfusion_python_amd import engine
+        self.engine = engine
+        self.old = (engine.SPARSE_REACH, engine.SPARSE_MIN_VOXELS)
+        engine.SPARSE_REACH, engine.SPARSE_MIN_VOXELS = self.new
+
+    def __exit__(self, *a):
+        self.engine.SPARSE_REACH, self.engine.SPARSE_MIN_VOXELS = self.old
+
+
+def _optimizer(lsf, shape, iterations, library_run, smoothing="killing"):
+    cls = lsf.SlavchevaOptimizer3d if len(shape) == 3 else lsf.SlavchevaOptimizer2d
+    kw = dict(KILLING)
+    kw["smoothing_term_method"] = lsf.SmoothingTermMethod.KILLING if smoothing == "killing" else \
+        lsf.SmoothingTermMethod.TIKHONOV
+    opt = cls(field_size=shape[-1], compute_method=lsf.ComputeMethod.DIRECT, max_iterations=iterations,
+              min_iterations=iterations, **kw)
+    opt._engine.library_run = library_run
+    return opt
+
+
+def _call(lsf, canonical, live0, iterations, library_run, reach=0, **kw):
+    with _Sparse(reach):
+        opt = _optimizer(lsf, tuple(live0.shape), iterations, library_run, **kw)
+        live = live0.clone()
+        out = opt.optimize(live, canonical)
+        assert out is live
+        took_run = type(opt._engine._fast).__name__ == "_Counted"
+        assert took_run == library_run, "the call took the other path"
+        return opt, live
+
+
+def _same(a, b):
+    (oa, la), (ob, lb) = a, b
+    assert torch.equal(la, lb), "live field"
+    assert np.array_equal(np.float32(oa.log.max_warps), np.float32(ob.log.max_warps))
+    assert oa.log.max_warp_locations == ob.log.max_warp_locations
+    assert oa.log.data_energies == ob.log.data_energies and oa.log.smoothing_energies == ob.log.smoothing_energies
+    assert oa.log.level_set_energies == ob.log.level_set_energies
+    ra, rb = oa.get_convergence_report(), ob.get_convergence_report()
+    assert ra.iteration_count == rb.iteration_count and ra.iteration_limit_reached == rb.iteration_limit_reached
+    # the same pass over the same lists in the same launch geometry: the float64 partial sums agree to the last bit
+    assert vars(ra.warp_delta_statistics) == vars(rb.warp_delta_statistics)
+    assert vars(ra.tsdf_difference_statistics) == vars(rb.tsdf_difference_statistics)
+    assert torch.equal(torch.as_tensor(oa.warp_field), torch.as_tensor(ob.warp_field)), "warp field"
+    assert np.array_equal(oa.gradient_field, ob.gradient_field), "gradient field"
+
+
+@pytest.mark.parametrize("n,reach", [(48, 0), (64, 2), (96, 2)])
+def test_library_run_equals_launch_by_launch_3d(lsf, n, reach):
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live0 = sphere_pair(n, 3, "cuda")
+    a = _call(lsf, canonical, live0, 12, True, reach)
+    b = _call(lsf, canonical, live0, 12, False, reach)
+    assert a[0]._engine._sparse_used == bool(reach)
+    _same(a, b)
+
+
+def test_library_run_equals_the_oracle(lsf):
+    canonical, live0 = O.sphere_pair(40, d=3)
+    opt, live = _call(lsf, torch.from_numpy(canonical).cuda(), torch.from_numpy(live0).cuda(), 6, True, 2)
+    ref = O.SlavchevaOracle(compute_method=O.DIRECT, smoothing_term_method=O.KILLING, max_iterations=6, min_iterations=6,
+                            **KILLING)
+    live_ref = live0.copy()
+    ref.optimize(live_ref, canonical)
+    assert np.array_equal(live.cpu().numpy(), live_ref)
+    assert np.array_equal(opt.warp_field.cpu().numpy(), ref.warp_field)
+    assert np.array_equal(np.float32(opt.log.max_warps), np.float32(ref.log.max_warps))
+
+
+@pytest.mark.parametrize("smoothing", ["killing", "tikhonov"])
+def test_library_run_2d_with_voxels_on_the_faces(lsf, ref_slavcheva, smoothing):
+    """the reference's 64 x 64 orthographic pair: its band runs into the array's faces (a BOUNDARY list beside the INTERIOR
+    one: two launches per iteration) and its updates are several voxels long"""
+    canonical = torch.from_numpy(ref_slavcheva["ortho64.canonical"]).cuda()
+    live0 = torch.from_numpy(ref_slavcheva["ortho64.live"]).cuda()
+    a = _call(lsf, canonical, live0, 5, True, smoothing=smoothing)
+    b = _call(lsf, canonical, live0, 5, False, smoothing=smoothing)
+    assert len(a[0]._engine._fast.bands) == 2 and all(band.count for band in a[0]._engine._fast.bands)
+    _same(a, b)
+
+
+def test_library_run_with_an_empty_band(lsf):
+    """both fields truncated everywhere: no list entry, every update zero -- the arg-max of an all-zero update is voxel 0"""
+    canonical = torch.ones((32, 32, 32), device="cuda")
+    live0 = -torch.ones((32, 32, 32), device="cuda")
+    a = _call(lsf, canonical, live0, 3, True)
+    b = _call(lsf, canonical, live0, 3, False)
+    assert a[0].log.max_warps == [0.0, 0.0, 0.0]
+    _same(a, b)
+
+
+def test_large_updates_on_sparse_states_fall_back_and_stay_right(lsf, ref_slavcheva):
+    """the orthographic pair embedded in a 3-D volume moves several voxels per iteration: on states initialised within two
+    voxels of the band the finalize pass must leave the caller's array alone (its guard), the call runs again on full
+    states -- same result as the launch-by-launch path that never used sparse states"""
+    c2, l2 = ref_slavcheva["ortho64.canonical"], ref_slavcheva["ortho64.live"]
+    canonical = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(c2, (16, 64, 64)))).cuda()
+    live0 = torch.from_numpy(np.ascontiguousarray(np.broadcast_to(l2, (16, 64, 64)))).cuda()
+    # field_size is the cube's side in the reference's check (slavcheva_optimizer2d.py:157-161); this volume is a slab of
+    # the extruded 2-D pair, so the engine is driven directly
+    from levelsetfusion_python_amd import _lib, engine
+
+    def run(library_run, reach):
+        with _Sparse(reach):
+            eng = engine.SlavchevaEngine(True, True, False, _lib.DATA_BASIC, _lib.SMOOTHING_KILLING, 0.1, 1.0, 0.2, 0.1, 0.2,
+                                         0.0, 10000.0, 3, 3, None)
+            eng.library_run = library_run
+            live = live0.clone()
+            outcome = eng.optimize(live, canonical, finalize=(live, 0.0, True))
+            final, warp, raw = outcome.finalize(live, 0.0, True)
+            return eng, live, (warp() if callable(warp) else warp), raw
+    ea, la, wa, ra = run(True, 2)
+    eb, lb, wb, rb = run(False, 0)
+    assert getattr(ea, "_sparse_disabled", False), "the sparse attempt must have been abandoned"
+    assert max(ea.log["max_warps"]) >= 2.0
+    assert torch.equal(la, lb) and torch.equal(wa, wb) and np.array_equal(ra, rb)
+    assert ea.log == eb.log
+
+
+def test_what_the_call_leaves_behind_does_not_depend_on_the_caller_s_tensor(lsf):
+    """warp_field and gradient_field are built when read -- from the call's own states and lists, also when the states were
+    initialised near the band only: overwriting the live tensor (the next frame arrives) changes neither"""
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live0 = sphere_pair(64, 3, "cuda")
+    a = _call(lsf, canonical, live0, 8, True, 2)
+    b = _call(lsf, canonical, live0, 8, False, 0)
+    assert a[0]._engine._sparse_used
+    a[1].fill_(float("nan"))  # the caller reuses its buffer before looking at anything
+    assert torch.equal(torch.as_tensor(a[0].warp_field), torch.as_tensor(b[0].warp_field))
+    assert np.array_equal(a[0].gradient_field, b[0].gradient_field)
+    assert not np.isnan(a[0].gradient_field).any()
