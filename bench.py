@@ -5,9 +5,9 @@ Workload (BASELINE.json config 4, the configuration the metric is quoted on): 3-
 optimizer -- SlavchevaOptimizer3d, DIRECT, Killing regulariser (lambda 0.1, weight 0.2) + level-set term
 (weight 0.2), no Sobolev filter, rate 0.1, FIXED 50 iterations -- on the synthetic "sphere pair" of SURVEY.md
 section 8(d), fp32.  One *step* = one optimize(live, canonical) call = 50 iterations of the fused warp-update kernel
-over one 256^3 pair: one launch of lsf_slavcheva_state_iteration per iteration and band list (the chain add-on, K
-iterations per launch, only with LSF_CHAIN=1 -- the roofline block then reports the chain launch) -- plus the
-prepare / finalize passes and the convergence-statistics reductions the reference also runs per call.
+over one 256^3 pair: one launch of lsf_slavcheva_state_iteration per iteration and band list, all of them enqueued by the
+library (lsf_state_run_begin / lsf_state_run_finish) -- plus the prepare / finalize passes and the convergence-statistics
+reductions the reference also runs per call.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU; `python bench.py --gpus N` starts it itself):
   --scaling weak (default): every rank owns a 256^3 z-slab of a 256 x 256 x (256 N) volume whose spheres are centred ON
@@ -163,6 +163,48 @@ def timed_steps(step, args, fence, max_over_ranks=None):
     return total, elapsed
 
 
+def hier_finest_level_kernels(n, full, taps, device, reps=20):
+    """HIP events around the launches ONE finest-level iteration of the hierarchical optimizer makes, on buffers of the
+    level's size (the engine's own launches carry the same kernels plus the record bookkeeping): hier_iteration_kernel
+    (Tikhonov; with the in-kernel update when no filter follows) and, with a gradient kernel, convolve_xyz_kernel (x, y, z
+    passes + warp update in one launch).  Loop body: hierarchical_optimizer2d.py:184-225.  Returns per-launch milliseconds."""
+    from levelsetfusion_python_amd import _lib, device as dev
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live = sphere_pair(n, 3, device)
+    packed = dev.pack_live_gradient(live)
+    grid = dev.make_grid((n, n, n))
+    warp = torch.zeros((3, n, n, n), device=device)
+    F = [torch.zeros_like(warp) for _ in range(2)]
+    raw = torch.zeros_like(warp) if full else None
+    rec = dev.new_records(2, device)
+    params = _lib.HierParams(1.0, 0.05, 0.1, 1, 0 if full else 1, 0)
+
+    def iteration(k):
+        dev.hier_iteration(packed, canonical, warp, F[k % 2], raw if full else F[(k + 1) % 2], grid, params, None, rec, 0)
+
+    def filter_pass(k):
+        dev.convolve_xyz(raw, F[(k + 1) % 2], grid, taps, None, warp, 0.1)
+
+    def timed(*launchers):
+        for k in range(3):
+            for f in launchers:
+                f(k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for k in range(reps):
+            for f in launchers:
+                f(k)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    out = {"hier_iteration_kernel<3,TIK%s>" % ("" if full else ",UPDATE"): timed(iteration)}
+    if full:
+        out["convolve_xyz_kernel<7 taps, warp update>"] = timed(filter_pass)
+        out["both, back to back"] = timed(iteration, filter_pass)
+    return out
+
+
 def extra_workload(args, device, world, rank, dist):
     """the other iteration kernels: SobolevFusion-style Slavcheva, hierarchical Tikhonov (+ 7-tap kernel), and
     BASELINE config 5 -- the multi-frame sequence (`multiframe`): F synthetic frames, frame k against k + 1 as
@@ -286,6 +328,17 @@ def extra_workload(args, device, world, rank, dist):
         out["roofline"]["dense_equivalent_gbs"] = value * b_alg / 1e9 / world
     if args.workload == "hier2d":
         out["us_per_iteration"] = elapsed / args.steps / (3 * iters) * 1e6
+    if args.workload in ("hier-tik", "hier-full", "multiframe") and comm is None:
+        # the dominant kernels of this workload: the finest level's launches alone (87.5 % of a step's voxel-updates),
+        # HIP events on their stream; kernel_ms = one finest-level iteration, frac = B_alg x n^3 / kernel_ms
+        opt = frames = canonical = live0 = None  # noqa: F841  (the level's buffers: 4 vector fields at n^3)
+        gc.collect()
+        torch.cuda.empty_cache()
+        full = args.workload != "hier-tik"
+        kernels = hier_finest_level_kernels(n, full, k7, device)
+        per_iteration = kernels["both, back to back"] if full else next(iter(kernels.values()))
+        out["roofline"].update(kernel=" + ".join(k for k in kernels if not k.startswith("both")), kernel_ms=per_iteration,
+                               kernels_ms=kernels, finest_level_frac=b_alg * n ** 3 / (per_iteration * 1e-3) / 1e9 / HBM_PEAK_GBS)
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload not in ("sobolev", "hier2d"):
         out["cpu_baseline"] = cpu_baseline_hierarchical(64, iters, args.workload != "hier-tik")
     if comm is not None:
@@ -351,6 +404,7 @@ def main():
 
 SECONDARY = (  # (workload, size, steps, warmup, iterations, extra arguments): short runs of BASELINE's other configurations
     ("killing", 512, 20, 4, 50, {}),
+    ("killing-pairs", 256, 60, 4, 50, {}),
     ("hier-tik", 256, 3, 1, 50, {}),
     ("hier-full", 256, 3, 1, 50, {}),
     ("multiframe", 512, 1, 1, 50, {}),
@@ -378,6 +432,11 @@ def secondary_measurements(args, device):
         row = dict(workload=workload, size=size, steps=steps, iterations=iterations)
         try:
             t0 = time.perf_counter()
+            if workload == "killing-pairs":
+                row.update(pairs_in_flight(a, device))
+                row["wall_s"] = time.perf_counter() - t0
+                rows.append(row)
+                continue
             if workload == "killing":
                 d = killing_workload(a, device, 1, 0, device.index or 0, None, dense_walk=False)
             else:
@@ -387,6 +446,9 @@ def secondary_measurements(args, device):
                        visited_voxel_updates_per_s=d.get("visited_voxel_updates_per_s", d["value"]),
                        frac=r["frac"], achieved_gbs=r["achieved"], kernel_ms=r.get("kernel_ms"),
                        kernel=r.get("kernel"), wall_s=None)
+            for key in ("kernels_ms", "finest_level_frac"):
+                if key in r:
+                    row[key] = r[key]
             if "us_per_iteration" in d:
                 row["us_per_iteration"] = d["us_per_iteration"]
                 row["note"] = r.get("note")
@@ -398,6 +460,63 @@ def secondary_measurements(args, device):
         gc.collect()
         torch.cuda.empty_cache()
     return rows
+
+
+def pairs_in_flight(args, device, lanes=2):
+    """The caller loop of the reference's multi-pair scripts (run_hierarchical_optimizer3d_multipair.py:403-432: independent
+    pairs, one optimize() each) with TWO pairs in flight: two optimizers, a host thread and a HIP stream each -- what
+    experiment/multipair.run_pairs does with a sequence of optimizers.  A whole call is two foreign calls that run without
+    the interpreter lock (lsf_state_run_begin / _finish), so one pair's launches fill the other's ramp, drain and host gaps.
+    BASELINE config 4 per pair; reports milliseconds per PAIR (wall time / pairs) next to the one-pair-at-a-time figure."""
+    import threading
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd.hostloop import parked_collector
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    n, iters, steps = args.size, args.iterations, args.steps
+    canonical, live0 = sphere_pair(n, 3, device)
+
+    def optimizer():
+        return lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                                        smoothing_term_method=lsf.SmoothingTermMethod.KILLING, gradient_descent_rate=0.1,
+                                        data_term_weight=1.0, smoothing_term_weight=0.2, isomorphic_enforcement_factor=0.1,
+                                        level_set_term_weight=0.2, maximum_warp_length_lower_threshold=0.0,
+                                        max_iterations=iters, min_iterations=iters, check_interval=iters)
+
+    def run(p):
+        streams = [torch.cuda.Stream(device=device) for _ in range(p)]
+        barrier = threading.Barrier(p + 1)
+        sums = [None] * p
+
+        def lane(k):
+            torch.cuda.set_device(device)
+            with torch.cuda.stream(streams[k]):
+                opt, live = optimizer(), torch.empty_like(live0)
+                for _ in range(args.warmup):
+                    live.copy_(live0)
+                    opt.optimize(live, canonical)
+                streams[k].synchronize()
+                barrier.wait()
+                for _ in range(steps):
+                    live.copy_(live0)
+                    opt.optimize(live, canonical)
+                streams[k].synchronize()
+                sums[k] = float(live.double().sum().item())
+        threads = [threading.Thread(target=lane, args=(k,)) for k in range(p)]
+        for t in threads:
+            t.start()
+        with parked_collector():
+            barrier.wait()
+            t0 = time.perf_counter()
+            for t in threads:
+                t.join()
+            dt = time.perf_counter() - t0
+        return dt / (p * steps) * 1e3, sums
+    one, s1 = run(1)
+    two, s2 = run(lanes)
+    return dict(config="3D %d^3 KillingFusion, %d fixed iterations per pair, %d independent pairs in flight (a host thread and "
+                       "a HIP stream each)" % (n, iters, lanes),
+                ms_per_pair=two, ms_per_pair_one_in_flight=one, ms_per_step=two, value=n ** 3 * iters / (two * 1e-3),
+                results_equal=len(set(s1 + s2)) == 1, pairs_in_flight=lanes)
 
 
 def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=True):
@@ -576,43 +695,16 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters
 
-    def chain_launch(band):
-        """the launch a fixed-count step really makes: ONE chain launch for all `iters` iterations
-        (lsf_slavcheva_state_chain); per-iteration time = its duration / iters, HIP events on its stream"""
-        states = dev.state_pack(live0, None, grid, copies=2)
-        records = dev.new_records(iters, device)
-        stages = int(os.environ.get("LSF_CHAIN_STAGES", "1"))
-        chain = dev.StateChain(states, canonical, grid, eng.params, records, band, stages)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        ok = chain.launch(0, iters)
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / iters if ok else None
-
-    def roofline_of(bands, units, kernel_name, traffic, chained=False):
-        per_launch_ms = None
-        if chained:
-            chain_launch(bands[0])
-            kernel_ms = min(chain_launch(bands[0]) for _ in range(3))
-            launches(bands)
-            per_launch_ms = launches(bands)
-        else:
-            launches(bands)
-            # the median of five measurements of the step's launch sequence: one 1.4 ms sample can catch a clock ramp or
-            # a neighbour's burst (seen once: 34.3 us on a box whose other runs gave 28.2)
-            kernel_ms = sorted(launches(bands) for _ in range(5))[2]
+    def roofline_of(bands, units, kernel_name, traffic):
+        launches(bands)
+        # the median of five measurements of the step's launch sequence: one 1.4 ms sample can catch a clock ramp or
+        # a neighbour's burst (seen once: 34.3 us on a box whose other runs gave 28.2)
+        kernel_ms = sorted(launches(bands) for _ in range(5))[2]
         alg_bytes = B_ALG["killing"] * units
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
         out = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
                    traffic=traffic, kernel=kernel_name, kernel_ms=kernel_ms, units_per_launch=units,
                    algorithmic_bytes_per_launch=alg_bytes, voxels_per_launch=voxels_per_rank)
-        if chained:
-            # kernel_ms = duration of the ONE chain launch / its iterations; "launch" in the keys above = one iteration
-            out.update(iterations_per_launch=iters, launch_ms=kernel_ms * iters,
-                       per_iteration_launch_kernel_ms=per_launch_ms,
-                       per_iteration_launch_frac=alg_bytes / (per_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
         return out
 
     build_id = _lib.lib.lsf_build_id().decode()
@@ -651,17 +743,8 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
                     bands.append(dev.BandList(own, own.numel(), b.subset))
         else:
             bands = dev.band_lists(live0, canonical, grid)
-        # what the timed steps launched: the chain kernel (all iterations of a call in one launch) when the engine took
-        # it -- one INTERIOR list, single GPU --, else one launch per iteration and list
-        chained = world == 1 and getattr(eng, "_chain_used", False) and len(bands) == 1
-        if chained:
-            name = "slavcheva_state_chain_kernel<3,KILLING,LEVELSET,BASIC,DIRECT> (%d iterations per launch)" % iters
-            roofline = roofline_of(bands, bands[0].count, name, committed_traffic("chain_hbm_bytes_per_iteration"),
-                                   chained=True)
-            name = "slavcheva_state_kernel<3,KILLING,LEVELSET,BASIC,DIRECT,%s>"
-        else:
-            roofline = roofline_of(bands, sum(b.count for b in bands), name % "LIST",
-                                   committed_traffic("hbm_bytes_per_launch"))
+        # what the timed steps launched: one launch per iteration and list
+        roofline = roofline_of(bands, sum(b.count for b in bands), name % "LIST", committed_traffic("hbm_bytes_per_launch"))
         roofline["dense_equivalent_gbs"] = B_ALG["killing"] * voxels_per_rank / (roofline["kernel_ms"] * 1e-3) / 1e9
     else:
         roofline = roofline_of([None], voxels_per_rank, name % "DENSE", committed_traffic("dense_hbm_bytes_per_launch"))

@@ -11,10 +11,14 @@
  * Rules of the ABI
  *   - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns 0 on success or a
  *     hipError_t value; nothing throws.  LSF_ERR_* (negative) flag argument errors detected on the host.
- *   - The library owns no memory.  Its only process-wide state is read-only after first use: the table of RCCL entry
- *     points the z-slab runtime binds once (under a mutex) and per-device cached device attributes.  All pointers are
+ *   - The library owns no FIELD memory: every field, state, list, record and scratch buffer is the caller's.  What it
+ *     does own: per slab communicator (lsf_slab_comm_create ... _destroy) a HIP stream, a few events and two small
+ *     face-count buffers (one hipMalloc, one hipHostMalloc); per host thread and device one timing-less event
+ *     (lsf_state_run_begin).  Its only process-wide state is read-only after first use: the table of RCCL entry points
+ *     the z-slab runtime binds once (under a mutex) and per-device cached device attributes.  All field pointers are
  *     DEVICE pointers supplied by the caller (e.g. torch.Tensor.data_ptr()), all launches are asynchronous on `stream`
- *     (a hipStream_t passed as void*; NULL = the default stream).  Re-entrant across streams and devices.
+ *     (a hipStream_t passed as void*; NULL = the default stream); the functions that also WAIT say so
+ *     (lsf_state_run_begin / _finish, lsf_slab_face_counts_end).  Re-entrant across streams, devices and host threads.
  *   - Layouts (MI355X-first):
  *       scalar fields      float32 [z][y][x]            (nz = 1 for 2-D)
  *       vector fields      float32 PLANAR [c][z][y][x]  c = 0:x(u) 1:y(v) 2:z(w); `dims` planes
@@ -390,11 +394,12 @@ int lsf_slavcheva_state_iteration(const float *state_in, const float *canonical,
  * per non-empty list (ungated; iteration i reads state[i % 2], writes the other, reduces into records[i], which the
  * caller has zeroed) and lsf_state_finalize_listed of the final state into live_out (which must hold the input live field:
  * the pass writes listed voxels only; statistics16 / finalize_scratch as there, may be NULL; with sparse states the pass
- * guards itself with the records), copies the records' used words and the statistics to the host and RETURNS when the
- * stream has drained, the records decoded into `result` (lsf_records_decode).  The same launches in the same order as the
- * calls made one by one: identical results.  Both functions block the calling thread only (no device-wide
- * synchronisation); totals_host, words_host (iterations x LSF_RECORD_SLOTS x 4 int64) and statistics_host (16 doubles)
- * must be page-locked host memory, words_device as many int64 of device memory. */
+ * guards itself with the records), copies the records' used words and the statistics to the host in ONE transfer and
+ * RETURNS when the stream has drained, the records decoded into `result` (lsf_records_decode).  The same launches in the
+ * same order as the calls made one by one: identical results.  Both functions block the calling thread only (no
+ * device-wide synchronisation); totals_host and words_host must be page-locked host memory; words_host and words_device
+ * hold iterations x LSF_RECORD_SLOTS x 4 + 16 int64: the used words of every record slot, then the 16 statistics (as
+ * doubles; zeros without statistics16). */
 typedef struct lsf_state_run {
     const float *live;        /* the input live field; read again by the sparse initialisation */
     const float *canonical;
@@ -421,7 +426,7 @@ int lsf_state_run_begin(const lsf_state_run *run, void *stream);
 int lsf_state_run_finish(const lsf_state_run *run, const lsf_slavcheva_params *params, int32_t *list_interior,
                          int32_t *list_boundary, lsf_iteration_record *records, int32_t iterations, float *live_out,
                          float lower_threshold, double *statistics16, double *finalize_scratch, int64_t *words_device,
-                         int64_t *words_host, double *statistics_host, lsf_state_run_result *result, void *stream);
+                         int64_t *words_host, lsf_state_run_result *result, void *stream);
 
 /* ---- the SobolevFusion iteration on the float4 layouts (band lists) ------------------------------
  * replaces one pass of slavcheva_optimizer2d.py:163-236 / :238-330 WITH a Sobolev filter (math_utils/convolution.py:

@@ -12,12 +12,6 @@ SOURCES = ["lsf_fields.hip", "lsf_hierarchical.hip", "lsf_slavcheva.hip", "lsf_s
            "lsf_slavcheva_run.hip", "lsf_sobolev_state.hip", "lsf_slab.hip", "lsf_tsdf.hip"]
 HEADERS = ["lsf_device.h", "lsf_slavcheva_terms.h", "lsf_slavcheva_state_taps.h",
            os.path.join("..", "..", "include", "lsf_hip.h")]
-# the chain kernel (K fused iterations per launch; measured 4 % slower) is an OPTIONAL add-on
-# library of its own: the product library carries only what the product runs (include/lsf_hip_chain.h)
-CHAIN_SOURCES = ["lsf_slavcheva_chain.hip"]
-CHAIN_HEADERS = HEADERS + [os.path.join("..", "..", "include", "lsf_hip_chain.h")]
-CHAIN_LIB_PATH = os.path.join(LIB_DIR, "liblsf_chain.so")
-CHAIN_ID_PATH = os.path.join(LIB_DIR, "chain_build_id.txt")
 ABI_HEADER = os.path.join(PKG_DIR, "..", "include", "lsf_hip.h")
 # -ffp-contract=off: multiply and add stay separately rounded so that results are bit-identical to the numpy
 # oracle (numpy never fuses); the path is HBM/L1-bound, the lost FMAs do not show.
@@ -113,13 +107,5 @@ def build(force=False, verbose=True):
     return _compile_and_link(None, None, LIB_PATH, ID_PATH, verbose)
 
 
-def build_chain(force=False, verbose=True):
-    """the optional chain add-on (include/lsf_hip_chain.h): liblsf_chain.so from lsf_slavcheva_chain.hip alone"""
-    if not force and not is_stale(CHAIN_LIB_PATH, CHAIN_ID_PATH, CHAIN_SOURCES, CHAIN_HEADERS):
-        return CHAIN_LIB_PATH
-    return _compile_and_link(CHAIN_SOURCES, CHAIN_HEADERS, CHAIN_LIB_PATH, CHAIN_ID_PATH, verbose)
-
-
 if __name__ == "__main__":
     print(build(force=True))
-    print(build_chain(force=True))

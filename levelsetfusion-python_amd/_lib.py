@@ -11,7 +11,7 @@ import os
 # with hipErrorNoDevice.
 import torch  # noqa: F401
 
-from ._build import CHAIN_LIB_PATH, LIB_PATH
+from ._build import LIB_PATH
 
 c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -22,11 +22,10 @@ ABI_VERSION = 3
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "91d3771e5af36db6"
+HEADER_ABI_HASH = "5c706a274c6e4af5"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
-ERR_NOT_RESIDENT = -6
 
 SMOOTHING_TIKHONOV, SMOOTHING_KILLING = 0, 1
 DATA_BASIC, DATA_THRESHOLDED_FDM = 0, 2
@@ -175,7 +174,7 @@ PROTOTYPES = {
                                                      _vp, _i64, _i32, _vp]),
     "lsf_state_run_begin": (ctypes.c_int, [_P(StateRun), _vp]),
     "lsf_state_run_finish": (ctypes.c_int, [_P(StateRun), _P(SlavchevaParams), _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp,
-                                            _vp, _vp, _vp, _P(StateRunResult), _vp]),
+                                            _vp, _vp, _P(StateRunResult), _vp]),
     "lsf_band_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
     "lsf_band_count": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),
     "lsf_band_list_fill": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),
@@ -210,16 +209,6 @@ PROTOTYPES = {
 }
 
 
-# the optional chain add-on liblsf_chain.so: every symbol include/lsf_hip_chain.h declares
-CHAIN_PROTOTYPES = {
-    "lsf_state_chain_scratch_elements": (ctypes.c_int64, [_i64, _i32]),
-    "lsf_state_chain_shape": (ctypes.c_int, [_i64, _i32, _P(_i32)]),
-    "lsf_state_chain_plan": (ctypes.c_int, [_P(Grid), _vp, _i64, _i32, _vp, _vp]),
-    "lsf_slavcheva_state_chain": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _vp, _vp, _i64, _i32,
-                                                 _i32, _vp, _vp]),
-}
-
-
 class LsfHipError(RuntimeError):
     pass
 
@@ -251,27 +240,6 @@ def _load():
 
 
 lib = _load()
-
-_chain = None
-
-
-def chain_lib():
-    """the optional chain add-on (include/lsf_hip_chain.h; LSF_CHAIN=1, tests/test_gpu_chain.py), loaded on first use.
-    Not part of the product library: the chain kernel measured 4 % slower than one launch per iteration."""
-    global _chain
-    if _chain is None:
-        path = os.environ.get("LSF_CHAIN_LIBRARY") or CHAIN_LIB_PATH
-        if not os.path.exists(path):
-            raise ImportError("liblsf_chain.so is missing (%s): build the add-on with\n"
-                              "    python -c 'import __graft_entry__ as g; g.build()'" % path)
-        handle = ctypes.CDLL(path)
-        for name, (restype, argtypes) in CHAIN_PROTOTYPES.items():
-            fn = getattr(handle, name)
-            fn.restype = restype
-            fn.argtypes = argtypes
-        _chain = handle
-    return _chain
-
 
 def check(status, what):
     if status == 0:

@@ -166,15 +166,13 @@ constexpr unsigned kXcds = 8;
 // blocks whose position lies in the narrow band would do all the work (measured: 0.21 ms vs 0.13 ms at 256^3).
 constexpr unsigned kBlocksPerXcd = 251;
 
-// tuning knob for measurements (tools/kernel_cases.py): LSF_BLOCKS_PER_XCD overrides the persistent-grid size of the
-// Slavcheva iteration kernel; read once per process
+// persistent-grid size of the tile walks (measured 64 ... 256 blocks per XCD in rounds 1-2: DESIGN.md section 7; a
+// variant build -- tools/build_variant.sh NAME - -DLSF_BLOCKS_PER_XCD=n -- overrides it for measurements)
+#ifndef LSF_BLOCKS_PER_XCD
+#define LSF_BLOCKS_PER_XCD 0
+#endif
 __host__ inline unsigned blocks_per_xcd(unsigned fallback = kBlocksPerXcd) {
-    static const unsigned v = [] {
-        const char* e = getenv("LSF_BLOCKS_PER_XCD");
-        const int n = e ? atoi(e) : 0;
-        return n > 0 ? (unsigned)n : 0u;
-    }();
-    return v ? v : fallback;
+    return LSF_BLOCKS_PER_XCD > 0 ? (unsigned)LSF_BLOCKS_PER_XCD : fallback;
 }
 
 __host__ inline unsigned launch_blocks(unsigned total_tiles, unsigned per_xcd = kBlocksPerXcd) {
@@ -365,12 +363,7 @@ __host__ inline unsigned band_list_blocks(unsigned count, unsigned default_per_x
     const unsigned units = (count + kBlock - 1) / kBlock;
     if (units <= kXcds) return units < 1 ? 1 : units;
     const unsigned per_xcd = (units + kXcds - 1) / kXcds;
-    static const unsigned override_cap = [] {
-        const char* e = getenv("LSF_LIST_BLOCKS_PER_XCD");  // measurement knob, see blocks_per_xcd()
-        const int n = e ? atoi(e) : 0;
-        return n > 0 ? (unsigned)n : 0u;
-    }();
-    const unsigned cap = override_cap ? override_cap : default_per_xcd;
+    const unsigned cap = default_per_xcd;
     const unsigned rounds = (per_xcd + cap - 1) / cap;
     return kXcds * ((per_xcd + rounds - 1) / rounds);
 }

@@ -130,8 +130,10 @@ extern "C" int lsf_slab_comm_create(const char* rccl_library_path, const uint8_t
     c->pending = -1;
     c->counts_dev = c->counts_host = nullptr;
     c->counts_in_flight = false;
-    const char* where = getenv("LSF_SLAB_GATHER_STREAM");
-    c->gather_on_main = !(where && strcmp(where, "comm") == 0);
+    // the face gather runs on the launch stream, right behind the boundary launches (on the communication stream it
+    // started 13 us late and took 21 us beside the interior launch: 2.36-2.40 against 2.29-2.39 ms per slab call,
+    // profiles/r04_slab_rccl_loopback.txt)
+    c->gather_on_main = true;
     hipError_t e = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking);
     for (int k = 0; k < 2 && e == hipSuccess; ++k) {
         e = hipEventCreateWithFlags(&c->boundary_done[k], hipEventDisableTiming);

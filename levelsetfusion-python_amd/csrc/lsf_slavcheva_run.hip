@@ -17,12 +17,14 @@ using namespace lsf;
 
 namespace {
 
-// the four used words of every slot of every record, gathered for ONE copy to the host (a record is 8 slots 4 KiB apart)
+// the four used words of every slot of every record (a record is 8 slots 4 KiB apart) and, behind them, the 16 doubles of
+// the convergence statistics, gathered for ONE copy to the host
 __global__ __launch_bounds__(kBlock) void records_used_words_kernel(const long long* __restrict__ records,
+                                                                    const long long* __restrict__ statistics16,
                                                                     long long* __restrict__ out, int n_slots) {
-    const int k = blockIdx.x * kBlock + threadIdx.x;  // (slot, word)
-    if (k >= n_slots * 4) return;
-    out[k] = records[(long long)(k >> 2) * (sizeof(lsf_record_slot) / 8) + (k & 3)];
+    const int k = blockIdx.x * kBlock + threadIdx.x;  // (slot, word), then the statistics
+    if (k < n_slots * 4) out[k] = records[(long long)(k >> 2) * (sizeof(lsf_record_slot) / 8) + (k & 3)];
+    else if (k < n_slots * 4 + 16) out[k] = statistics16 ? statistics16[k - n_slots * 4] : 0ll;
 }
 
 // one timing-less event per host thread and device, created on first use (an event per call costs a create / destroy pair)
@@ -73,9 +75,9 @@ extern "C" int lsf_state_run_finish(const lsf_state_run* run, const lsf_slavchev
                                     int32_t* list_boundary, lsf_iteration_record* records, int32_t iterations,
                                     float* live_out, float lower_threshold, double* statistics16,
                                     double* finalize_scratch, int64_t* words_device, int64_t* words_host,
-                                    double* statistics_host, lsf_state_run_result* result, void* stream) {
+                                    lsf_state_run_result* result, void* stream) {
     if (!run_ok(run) || !params || !records || iterations < 1 || !live_out || !words_device || !words_host || !result ||
-        (statistics16 && (!finalize_scratch || !statistics_host)) || !result->max_value || !result->argmax ||
+        (statistics16 && !finalize_scratch) || !result->max_value || !result->argmax ||
         !result->energies3 || !result->executed)
         return LSF_ERR_BAD_ARGUMENT;
     const lsf_grid* g = &run->grid;
@@ -124,13 +126,12 @@ extern "C" int lsf_state_run_finish(const lsf_state_run* run, const lsf_slavchev
                                           (float)run->sparse_reach, stream))
         return e;
     const int n_slots = iterations * LSF_RECORD_SLOTS;
-    hipLaunchKernelGGL(records_used_words_kernel, dim3((n_slots * 4 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
-                       reinterpret_cast<const long long*>(records), reinterpret_cast<long long*>(words_device), n_slots);
+    hipLaunchKernelGGL(records_used_words_kernel, dim3((n_slots * 4 + 16 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                       reinterpret_cast<const long long*>(records), reinterpret_cast<const long long*>(statistics16),
+                       reinterpret_cast<long long*>(words_device), n_slots);
     if (int e = launch_status()) return e;
-    if (hipMemcpyAsync(words_host, words_device, (size_t)n_slots * 4 * sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess)
-        return (int)hipGetLastError();
-    if (statistics16 &&
-        hipMemcpyAsync(statistics_host, statistics16, 16 * sizeof(double), hipMemcpyDeviceToHost, s) != hipSuccess)
+    if (hipMemcpyAsync(words_host, words_device, ((size_t)n_slots * 4 + 16) * sizeof(int64_t), hipMemcpyDeviceToHost, s) !=
+        hipSuccess)
         return (int)hipGetLastError();
     if (hipStreamSynchronize(s) != hipSuccess) return (int)hipGetLastError();
     if (int e = lsf_records_decode(words_host, iterations, LSF_RECORD_SLOTS, 4, result->max_value, result->argmax,

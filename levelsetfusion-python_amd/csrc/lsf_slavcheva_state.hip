@@ -639,10 +639,6 @@ inline unsigned compute_units() {
     if (!cached[dev]) {
         int n = 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        if (const char* e = getenv("LSF_LIST_BLOCKS")) {  // measurement knob
-            const int v = atoi(e);
-            if (v > 0) n = v;
-        }
         cached[dev] = n;
     }
     return (unsigned)cached[dev];
@@ -811,17 +807,17 @@ extern "C" int lsf_slavcheva_state_iteration(const float* state_in, const float*
     const unsigned blocks = all_interior ? cu_list_blocks((unsigned)band_count, compute_units())
                             : listed     ? band_list_blocks((unsigned)band_count, 128u)
                                          : launch_blocks(t.total, blocks_per_xcd());
-    static const unsigned list_threads = [] {  // measurement knob: waves per CU of the INTERIOR list walk
-        const char* e = getenv("LSF_LIST_THREADS");
-        const int v = e ? atoi(e) : 0;
-        return (v >= 64 && v <= kCuBlock && v % 64 == 0) ? (unsigned)v : (unsigned)kCuBlock;
-    }();
-    static const unsigned list_group = [] {  // measurement knob: wave-units per group of the list walk
-        const char* e = getenv("LSF_LIST_GROUP");
-        const int v = e ? atoi(e) : 0;
-        return v > 0 ? (unsigned)v : 0u;
-    }();
-    if (list_group) g.list_group = list_group;
+    // waves per CU of the INTERIOR list walk (2, 3 or 4 per SIMD run equally fast: 33.0 / 31.6 / 31.5 us) and wave-units per
+    // group (1 ... 16 within 3 %, 32 is 8 % slower): measured in round 2; variant builds
+    // (tools/build_variant.sh NAME - -DLSF_LIST_THREADS=n -DLSF_LIST_GROUP=n) override them for measurements
+#ifdef LSF_LIST_THREADS
+    const unsigned list_threads = LSF_LIST_THREADS;
+#else
+    const unsigned list_threads = kCuBlock;
+#endif
+#ifdef LSF_LIST_GROUP
+    g.list_group = LSF_LIST_GROUP;
+#endif
     g.list_store_nt = listed && band_count * 32ll > 200ll * 1000 * 1000;
     LaunchArgs a{blocks, all_interior ? list_threads : (unsigned)(kTileX * tile_y), as_stream(stream), reinterpret_cast<const vf4*>(state_in), canonical,
                  reinterpret_cast<vf4*>(state_out), g, make_params(params), gate_or_open(gate), record, band_list,

@@ -5,7 +5,6 @@ contiguity and element counts on the host BEFORE the launch (a hand-written kern
 take the whole GPU down), then passes raw device pointers + the current HIP stream to the library.
 """
 import ctypes
-import os
 
 import numpy as np
 import torch
@@ -27,14 +26,34 @@ def require_gpu():
 # The two raw queries behind them are single C calls.
 _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_checked = False
+
+
+def _check_raw_queries():
+    """the two queries are private to torch: the first time a GPU is used they are held against the public calls, and
+    dropped for good if they are missing, raise, or answer differently (another torch release)"""
+    global _raw_device, _raw_stream, _raw_checked
+    _raw_checked = True
+    try:
+        ok = (_raw_device is not None and _raw_stream is not None
+              and _raw_device() == torch.cuda.current_device()
+              and _raw_stream(_raw_device()) == torch.cuda.current_stream().cuda_stream)
+    except Exception:  # noqa: BLE001 -- any failure means: use the public calls
+        ok = False
+    if not ok:
+        _raw_device = _raw_stream = None
 
 
 def current_device_index():
+    if not _raw_checked:
+        _check_raw_queries()
     return _raw_device() if _raw_device is not None else torch.cuda.current_device()
 
 
 def current_stream_handle():
     """the current HIP stream of the current device as an integer (hipStream_t)"""
+    if not _raw_checked:
+        _check_raw_queries()
     if _raw_stream is not None and _raw_device is not None:
         return _raw_stream(_raw_device())
     return torch.cuda.current_stream().cuda_stream
@@ -477,7 +496,7 @@ class StatePrepare:
         self._scratch = torch.empty(n_scratch, dtype=torch.int32, device=live.device)
         totals = torch.empty(4, dtype=torch.int64, device=live.device)
         self.sparse_reach = int(sparse_reach)
-        split = os.environ.get("LSF_PREPARE_SPLIT", "1") != "0" and n <= self.SPLIT_MAX_VOXELS
+        split = n <= self.SPLIT_MAX_VOXELS
         none = ctypes.c_void_p(0)
         check(lib.lsf_state_prepare(_ptr(live, n, "live"), _ptr(canonical, n, "canonical"),
                                     none if self.sparse_reach else _ptr(self.states[0], 4 * n, "state"),
@@ -626,7 +645,8 @@ def state_finalize_listed(state, canonical, grid, bands, unlisted, live_out=None
                           lower_threshold=0.0, statistics=False, skip_flag=None, guard=None):
     """state_finalize of whole arrays that visits the voxels of `bands` only (lsf_state_finalize_listed): live_out must
     hold the input live field and warp_interleaved_out zeros already; `unlisted` as state_prepare returned it;
-    skip_flag: device address of a word that turns the pass into a no-op when non-zero (StateChain.violation_ptr);
+    skip_flag: device address of a word that turns the pass into a no-op when non-zero (tools/chain: the chain kernel's
+    violation word);
     guard = (records, count, limit): the pass is a no-op too when one of the first `count` records holds a maximum update
     that is not below `limit` (sparsely initialised states, StatePrepare(sparse_reach=...))"""
     n = n_voxels(grid)
@@ -654,54 +674,6 @@ def state_finalize_listed(state, canonical, grid, bands, unlisted, live_out=None
                                         float(guard[2]) if guard is not None else 0.0, stream_ptr()),
           "lsf_state_finalize_listed")
     return stats
-
-
-class StateChain:
-    """K fused iterations of an INTERIOR band list per launch (lsf_slavcheva_state_chain): the dependency windows of the
-    list are planned once (lsf_state_chain_plan), every launch(first, count) then runs iterations first .. first + count - 1
-    of the call -- iteration j reads states[j % 2], writes the other, reduces into records[j].
-    REACH_LIMIT: update length from which the windows no longer cover the re-warp gather (the launch then raises its
-    violation word, which a finalize pass given violation_ptr honours, and the records' maxima tell the host)."""
-
-    REACH_LIMIT = 2.0
-
-    def __init__(self, states, canonical, grid, params, records, band, stages=1):
-        if band.subset != _lib.BAND_INTERIOR or not band.count:
-            raise ValueError("the chain kernel walks a non-empty INTERIOR band list")
-        self.grid = full_range(grid)
-        n = n_voxels(grid)
-        self.stages = int(stages)
-        self._keep = (states, canonical, records, band, params)
-        self._states = [_ptr(t, 4 * n, "state") for t in states]
-        self._canonical = _ptr(canonical, n, "canonical")
-        self._params = ctypes.byref(params)
-        self._records = records
-        self._band = band
-        self._lib = clib = _lib.chain_lib()  # the optional add-on library (include/lsf_hip_chain.h)
-        words = int(clib.lsf_state_chain_scratch_elements(band.count, self.stages))
-        self.scratch = torch.empty(words, dtype=torch.int32, device=states[0].device)
-        self._scratch = ctypes.c_void_p(self.scratch.data_ptr())
-        self.violation_ptr = self.scratch.data_ptr() + 4
-        shape = (ctypes.c_int32 * 4)()
-        check(clib.lsf_state_chain_shape(band.count, self.stages, shape), "lsf_state_chain_shape")
-        self.workgroups, self.stages_used, self.chunks, self.units = (int(v) for v in shape)
-        check(clib.lsf_state_chain_plan(ctypes.byref(self.grid), band.pointer, band.count, self.stages, self._scratch,
-                                       stream_ptr()), "lsf_state_chain_plan")
-
-    def launch(self, first, count):
-        """False: the kernel's workgroups cannot all be resident on this device (nothing was launched)"""
-        a, b = self._states[first % 2], self._states[(first + 1) % 2]
-        status = self._lib.lsf_slavcheva_state_chain(a, b, self._canonical, ctypes.byref(self.grid), self._params,
-                                               _record_ptr(self._records, first), self._band.pointer, self._band.count,
-                                               int(count), self.stages, self._scratch, stream_ptr())
-        if status == _lib.ERR_NOT_RESIDENT:
-            return False
-        check(status, "lsf_slavcheva_state_chain")
-        return True
-
-    def aborted(self):
-        """True when a wait of the last launch timed out (control word 0; a host read: call it behind the records)"""
-        return bool(int(self.scratch[0].item()))
 
 
 def full_range(grid):

@@ -123,7 +123,7 @@ class HierarchicalEngine:
         # False: levels without a captured graph run eagerly (same results) -- set while optimizers work side by side in
         # several host threads: HIP refuses ordinary calls of OTHER threads while a capture is in progress
         self.allow_graph_capture = True
-        self.graph_max_voxels = int(os.environ.get("LSF_GRAPH_MAX_VOXELS", graph_max_voxels))  # ... i.e. levels of at most this many voxels (the variable: a measurement knob)
+        self.graph_max_voxels = int(graph_max_voxels)  # ... i.e. levels of at most this many voxels
         self._graphs = {}
         self.linear_resampling = linear_resampling  # ResamplingStrategy.LINEAR (3-D): math_utils/resampling.py
         self.collect_reports = collect_reports
@@ -157,8 +157,9 @@ class HierarchicalEngine:
         self.level_results = []
         # 3-D levels from 2^23 voxels up: lsf_convolve_xyz instead of three passes (0.21 against 0.25 ms at 256^3, 1.29
         # against 1.9 ms at 512^3; below that its 64 x 16-column blocks are too few to fill the GPU: 0.045 / 0.035 ms at 128^3)
-        self.fused_filter = os.environ.get("LSF_FUSED_FILTER", "1") != "0"
+        self.fused_filter = True  # (False: three convolve_axis passes -- measurements, tests)
         self.fused_filter_min_voxels = 1 << 23
+        self.defer_maximum = True  # (False: every iteration keeps its own maximum pass -- tests hold the two against each other)
         self.last_gradient = None  # planar gradient of the finest level after the last iteration
 
     # ------------------------------------------------------------------------------------------------
@@ -318,7 +319,7 @@ class HierarchicalEngine:
         lv.defer_max = (dims == 3 and tik and ker and float(self.maximum_warp_update_threshold) <= 0.0
                         and self.fused_filter and n >= self.fused_filter_min_voxels
                         and dev.convolve_xyz_ok(grid, self.gradient_kernel)
-                        and os.environ.get("LSF_HIER_DEFER_MAX", "1") != "0")
+                        and self.defer_maximum)
         if lv.defer_max:
             lv.params_prevmax = _lib.HierParams.from_buffer_copy(lv.params)
             lv.params_prevmax.previous_max = 1
@@ -704,11 +705,8 @@ class SlavchevaOutcome:
             warp, self._warp_zeroed = self._warp_zeroed, None
             if warp is None:
                 warp = torch.zeros(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
-            chain = getattr(self, "_chain", None)  # the pass leaves `target` alone if the chain launch flagged its result
             raw = dev.state_finalize_listed(self.state, self.canonical, full, bands, unlisted, target, warp,
-                                            lower_threshold, statistics,
-                                            skip_flag=chain.violation_ptr if chain is not None else None,
-                                            guard=self._guard)
+                                            lower_threshold, statistics, guard=self._guard)
             self._live = target
         elif self.state is not None:
             warp = torch.empty(self._shape() + (g.dims,), dtype=torch.float32, device=self._device())
@@ -775,6 +773,8 @@ class _SobolevStatePlan:
     buffer B] (float4, zero-initialised: unlisted voxels are never written).  3-D: gradient -> raw, x pass raw -> A,
     y pass A -> B, z pass + update + re-warp B -> final gradient in A; 2-D: y pass raw -> A, x pass + update A -> B."""
 
+    STRIPS = 8  # row bands of the strip-major list the z pass walks (8 / 16 / 32 measured: profiles/r04_probe_sobolev_sweep.txt)
+
     def __init__(self, launcher, states, canonical, grid, params, bands, g4, taps, min_iterations, iterations_hint=0,
                  gradient_every_iteration=True):
         f = self.f = launcher
@@ -816,14 +816,14 @@ class _SobolevStatePlan:
         # have just read.  Results do not depend on the order (every listed voxel is written by its index); one sort per
         # call, worth it from a handful of iterations on.
         self.bands_last = self.bands
-        strips = int(os.environ.get("LSF_SOBOLEV_STRIPS", "8"))  # 0: list order (measurements)
+        strips = self.STRIPS
         if grid.dims == 3 and iterations_hint >= 8 and strips > 0:
             self.bands_last = [self._strip_major(b, grid, strips) if b.count >= (1 << 17) else b for b in self.bands]
 
     @staticmethod
     def fuses_x(grid):
         """does the iteration take the fused gradient + x pass (then two gradient buffers suffice instead of three)?"""
-        return grid.dims == 3 and os.environ.get("LSF_SOBOLEV_FUSE_X", "1") != "0"
+        return grid.dims == 3
 
     @staticmethod
     def _strip_major(band, grid, strips=8):
@@ -882,12 +882,6 @@ class _SobolevStatePlan:
         """[c][z,]y,x float32 from the float4 buffer of the last executed iteration (API edge only)"""
         g4 = self.g4[self.final]
         return g4[..., :dims].movedim(-1, 0).contiguous()
-
-
-class _ChainReachExceeded(Exception):
-    """a chain launch (dev.StateChain) met a warp update its dependency windows do not cover, or gave up waiting (CUs held
-    by something else); nothing of the caller's has been modified (SlavchevaEngine.optimize repeats the call with
-    per-iteration launches)"""
 
 
 class _SparseStateExceeded(Exception):
@@ -992,7 +986,7 @@ class SlavchevaEngine:
         axes = _conv_axis_order(grid.dims)
         # on a band list the LAST pass runs in the launch of the update and the re-warp (the filtered gradient of a voxel is
         # all its update needs): four launches per iteration instead of five
-        fuse_last = band is not None and os.environ.get("LSF_SOBOLEV_FUSE_LAST", "1") != "0"
+        fuse_last = band is not None
         for axis in axes[:-1] if fuse_last else axes:
             dev.convolve_axis(src, dst, g0, grid if axis == 2 else in_plane_grid, axis, self.sobolev_kernel,
                               gate, band_own if axis == 2 else band)
@@ -1037,7 +1031,7 @@ class SlavchevaEngine:
         else:
             mode, (boundary, interior) = _lib.SLAB_LAUNCH, f.widened_parts[0 if j == k - 1 else k - 1 - j].get()
         if f.native is not None and getattr(f, "face_plan_args", None) is not None and \
-                (exchange or j >= k - 2 or os.environ.get("LSF_SLAB_FACE_CHECK_AT", "late") == "plan"):
+                (exchange or j >= k - 2):
             # the face lists and the neighbours' face counts: made ONE iteration before the first exchange -- the host
             # enqueues an iteration in ~20 us, the card takes ~30, so that is where the host's lead over the card is
             # largest and the ~0.15 ms of host calls (a collective) starve it least (kernel trace of the loop-back,
@@ -1141,35 +1135,34 @@ class SlavchevaEngine:
         # (cut positions), so the collective is STARTED here and its result is READ when the first exchange is enqueued.
         # On the native transport it is the library's own (lsf_slab_face_counts_begin / _end: an ncclAllGather on the
         # communicator's stream, ~15 us of host time; through torch.distributed the pinned copies, the collective and
-        # the event cost ~0.15 ms of host calls, which the card spent idle).  LSF_SLAB_VERIFY_FACES=first: only on an
-        # optimizer's first call (measurements).
+        # the event cost ~0.15 ms of host calls, which the card spent idle).  (Checking on an optimizer's first call only
+        # measured 2.47 against 2.55 ms per slab call, profiles/r04_slab_rccl_loopback.txt: a hang is worse.)
         check = None
-        if not getattr(self, "_faces_verified", False) or os.environ.get("LSF_SLAB_VERIFY_FACES", "always") != "first":
-            counts = [send[0][1], send[1][1], recv[0][1], recv[1][1]]
-            world = torch.distributed.get_world_size(self.comm.group)
-            if f.native is not None and not self.comm.stage_through_host:
-                _lib.check(_lib.lib.lsf_slab_face_counts_begin(f.native, (ctypes.c_int64 * 4)(*counts)),
-                           "lsf_slab_face_counts_begin")
-                check = ("native", None)
-            elif self.comm.stage_through_host:  # gloo (tests): a host collective, done at once
-                mine = torch.tensor(counts, dtype=torch.int64)
-                rows = [torch.zeros_like(mine) for _ in range(world)]
+        counts = [send[0][1], send[1][1], recv[0][1], recv[1][1]]
+        world = torch.distributed.get_world_size(self.comm.group)
+        if f.native is not None and not self.comm.stage_through_host:
+            _lib.check(_lib.lib.lsf_slab_face_counts_begin(f.native, (ctypes.c_int64 * 4)(*counts)),
+                       "lsf_slab_face_counts_begin")
+            check = ("native", None)
+        elif self.comm.stage_through_host:  # gloo (tests): a host collective, done at once
+            mine = torch.tensor(counts, dtype=torch.int64)
+            rows = [torch.zeros_like(mine) for _ in range(world)]
+            torch.distributed.all_gather(rows, mine, group=self.comm.group)
+            check = (torch.stack(rows), None)
+        else:
+            if getattr(self, "_plan_stream", None) is None or self._plan_stream.device != live.device:
+                self._plan_stream = torch.cuda.Stream(device=live.device)
+            with torch.cuda.stream(self._plan_stream):
+                staged = dev.pinned_scratch("face counts out", 4, torch.int64)
+                staged.copy_(torch.tensor(counts, dtype=torch.int64))
+                mine = staged.to(live.device, non_blocking=True)
+                rows = [torch.empty_like(mine) for _ in range(world)]
                 torch.distributed.all_gather(rows, mine, group=self.comm.group)
-                check = (torch.stack(rows), None)
-            else:
-                if getattr(self, "_plan_stream", None) is None or self._plan_stream.device != live.device:
-                    self._plan_stream = torch.cuda.Stream(device=live.device)
-                with torch.cuda.stream(self._plan_stream):
-                    staged = dev.pinned_scratch("face counts out", 4, torch.int64)
-                    staged.copy_(torch.tensor(counts, dtype=torch.int64))
-                    mine = staged.to(live.device, non_blocking=True)
-                    rows = [torch.empty_like(mine) for _ in range(world)]
-                    torch.distributed.all_gather(rows, mine, group=self.comm.group)
-                    landed = dev.pinned_scratch("face counts in", 4 * world, torch.int64)
-                    landed.copy_(torch.cat(rows), non_blocking=True)
-                    done = torch.cuda.Event()
-                    done.record()
-                check = (landed.view(world, 4), done)
+                landed = dev.pinned_scratch("face counts in", 4 * world, torch.int64)
+                landed.copy_(torch.cat(rows), non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+            check = (landed.view(world, 4), done)
         f.pending_face_plan = (send, recv, check, live.device, keep)
 
     def _finish_compact_faces(self, f):
@@ -1318,13 +1311,10 @@ class SlavchevaEngine:
         f.widened_parts = [_Lazy(lambda e=e: (empty, parts([(L.z_begin - (e if lo else 0), L.z_end + (e if hi else 0))])))
                            for e in range(f.exchange_interval)]
         z_lo, z_hi = L.z_begin + (h if lo else 0), L.z_end - (h if hi else 0)
-        if f.exchange_interval > 1 and os.environ.get("LSF_SLAB_SPLIT", "1") == "0":
-            # measurement: no boundary-first split -- the whole owned range in one launch, the exchange behind it and
-            # hidden behind the NEXT iteration's halo-independent part only (the deferred wait)
-            f.exchange_parts = _Lazy(lambda: (parts([(L.z_begin, L.z_end)]), empty))
-        else:
-            f.exchange_parts = _Lazy(lambda: (parts(([(L.z_begin, z_lo)] if lo else []) +
-                                                    ([(z_hi, L.z_end)] if hi else [])), parts([(z_lo, z_hi)])))
+        # (measured and left alone, profiles/r04_slab_rccl_loopback.txt: no boundary-first split -- the whole owned range in
+        # one launch, the exchange hidden behind the next iteration's halo-independent part only -- is within 2 %)
+        f.exchange_parts = _Lazy(lambda: (parts(([(L.z_begin, z_lo)] if lo else []) +
+                                                ([(z_hi, L.z_end)] if hi else [])), parts([(z_lo, z_hi)])))
         # first iteration of a group, while the previous group's exchange may still be in flight: the owned slices that
         # do not touch a halo slice first, the rest (the widened range's outer slices) after the halos have arrived
         e_last = f.exchange_interval - 1
@@ -1440,11 +1430,6 @@ class SlavchevaEngine:
         if not self._slab():
             try:
                 return self._optimize(live, canonical, finalize)
-            except _ChainReachExceeded:
-                # an update of two voxels or more: beyond the chain kernel's dependency windows.  The finalize pass has
-                # left the caller's tensors alone (its skip flag), so the call simply runs again, one launch per iteration
-                self._chain_disabled = True
-                return self._optimize(live, canonical, finalize)
             except _SparseStateExceeded:
                 # an update of SPARSE_REACH voxels or more may have gathered from a part of the states that was never
                 # initialised.  The finalize pass has left the caller's tensors alone (its skip flag): the call runs again
@@ -1531,7 +1516,7 @@ class SlavchevaEngine:
         if (self.library_run and finalize is not None and not slab and not self.sobolev and self.use_band_list
                 and self.iteration_hook is None
                 and self.min_iterations > 0 and self.min_iterations >= self.max_iterations
-                and dev.buffer_addressing_ok(grid) and os.environ.get("LSF_CHAIN", "0") != "1"):
+                and dev.buffer_addressing_ok(grid)):
             # a whole volume, a fixed iteration count, no Sobolev filter, nobody watching the iterations: the whole call is
             # enqueued by the library (two host calls; slavcheva_optimizer2d.py:354-388's loop without a Python iteration)
             return self._optimize_run(live, canonical, grid, finalize)
@@ -1547,8 +1532,7 @@ class SlavchevaEngine:
         # neighbour / tap instead of one per component: lsf_sobolev_state.hip); z-slabs, filters of other lengths and
         # list-less runs keep the planar kernels
         sob_state = (self.sobolev and self.use_band_list and not slab and dev.buffer_addressing_ok(grid)
-                     and len(self.sobolev_kernel) in dev.LISTED_TAP_COUNTS
-                     and os.environ.get("LSF_SOBOLEV_STATE", "1") != "0")
+                     and len(self.sobolev_kernel) in dev.LISTED_TAP_COUNTS)
         planar_sobolev = self.sobolev and not sob_state
         fused_prepare = not planar_sobolev and self.use_band_list and dev.buffer_addressing_ok(grid)
         if fused_prepare:
@@ -1574,19 +1558,16 @@ class SlavchevaEngine:
             # band voxel that makes it needed lies inside the owner's halo), so even whole faces carry valid data
             slab_groups = (slab and self.min_iterations >= max(self.max_iterations, self.min_iterations)
                            and not getattr(self, "_exchange_every_iteration", False)
-                           and self.comm.layout.halo >= max(SPARSE_REACH, 2)
-                           and os.environ.get("LSF_SPARSE_SLABS", "1") != "0")
+                           and self.comm.layout.halo >= max(SPARSE_REACH, 2))
             sparse = ((not slab or slab_groups) and SPARSE_REACH > 0 and dev.n_voxels(grid) >= SPARSE_MIN_VOXELS
-                      and self.iteration_hook is None and not getattr(self, "_sparse_disabled", False)
-                      and os.environ.get("LSF_CHAIN", "0") != "1")
+                      and self.iteration_hook is None and not getattr(self, "_sparse_disabled", False))
             # the listed finalize pass wants a zero-filled warp output (192 MB at 256^3, 26 us): filled in the call's
             # prologue, where the card waits for the host, instead of behind the last iteration.  Up to 256^3 IN FRONT of
             # the counting pass: the states written behind it are then the last thing to pass through the 256 MB Infinity
             # Cache before the first two iterations read them (filled behind the states it evicted them: 1.846-1.858
             # against 1.817-1.825 ms per step, three alternating runs on one box); a larger volume's fill (1.6 GB at
             # 512^3) would only keep the list sizes from the host (8.67 against 8.53 ms)
-            fill_first = os.environ.get("LSF_WARP_FILL", "auto") == "first" or \
-                (os.environ.get("LSF_WARP_FILL", "auto") == "auto" and dev.n_voxels(grid) <= (1 << 24))
+            fill_first = dev.n_voxels(grid) <= (1 << 24)
             if finalize is not None and not slab and fill_first:
                 warp_zeroed = torch.zeros(tuple(live.shape) + (dims,), dtype=torch.float32, device=live.device)
             self._sparse_used = sparse  # (tests and measurements look at this)
@@ -1603,7 +1584,7 @@ class SlavchevaEngine:
             live_at_entry = finalize[0].clone()
         records = dev.new_records(n_rec, live.device)
         self._last_g = None
-        lives = warps = gbufs = states = chain = sob = None
+        lives = warps = gbufs = states = sob = None
         if planar_sobolev:
             lives = [live.clone(), live.clone()]
             warps = [torch.zeros((dims,) + tuple(live.shape), dtype=torch.float32, device=live.device)
@@ -1651,23 +1632,10 @@ class SlavchevaEngine:
                 g4 = [torch.zeros(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device)
                       for _ in range(2 if _SobolevStatePlan.fuses_x(grid) else 3)]
                 n_max = max(self.max_iterations, self.min_iterations)
-                every = (self.iteration_hook is not None or self.min_iterations < n_max
-                         or os.environ.get("LSF_SOBOLEV_GRADIENT", "last") == "every")
+                every = self.iteration_hook is not None or self.min_iterations < n_max
                 sob = _SobolevStatePlan(f, states, canonical, grid, self.params, bands, g4, self.sobolev_kernel,
                                         self.min_iterations, n_max, gradient_every_iteration=every)
                 self._sobolev_band = _Counted(sum(b.count for b in bands))  # what bench.py prices this path over
-            # Fixed-count runs on ONE interior list MAY run K iterations per launch (lsf_slavcheva_state_chain) instead of K
-            # launches -- the stop test cannot fire in between.  Opt-in (LSF_CHAIN=1): bit-identical, but measured 4 %
-            # SLOWER than one launch per iteration at 256^3 and 512^3: what a launch
-            # boundary costs (~3.5 us) the chain pays again as wait + acquire + publish, and the rest of a launch's
-            # "fixed" time is the drain of each wave's last unit, which a resident workgroup has as well
-            if (not slab and not self.sobolev and listed is not None
-                    and self.min_iterations >= max(self.max_iterations, self.min_iterations)
-                    and self.min_iterations > 0 and self.iteration_hook is None and len(bands) == 1
-                    and bands[0].subset == _lib.BAND_INTERIOR and bands[0].count > 0 and 16 * n < 0xffffffff
-                    and not getattr(self, "_chain_disabled", False) and os.environ.get("LSF_CHAIN", "0") == "1"):
-                stages = int(os.environ.get("LSF_CHAIN_STAGES", "1"))
-                chain = dev.StateChain(states, canonical, grid, self.params, records, bands[0], stages)
             if slab:
                 self._plan_slab(f, live, grid, bands, 0 if self.min_iterations == 0
                                 else max(self.max_iterations, self.min_iterations),
@@ -1680,13 +1648,9 @@ class SlavchevaEngine:
         hooked = self.iteration_hook is not None
         while it < limit:
             # a run whose stop test cannot fire (min_iterations == max_iterations) has nothing to look at in between: all of
-            # it is enqueued at once, whatever check_interval says (the chain kernel keeps its batches: a launch per batch)
-            batch = 1 if hooked else (limit - it if self.min_iterations >= limit and chain is None
-                                      else min(self.check_interval, limit - it))
-            if chain is not None and not chain.launch(it, batch):
-                chain = None  # a CU cannot hold the kernel's workgroup on this device: one launch per iteration
-            self._chain_used = chain is not None
-            for i in range(it, it + batch) if chain is None else ():
+            # it is enqueued at once, whatever check_interval says
+            batch = 1 if hooked else (limit - it if self.min_iterations >= limit else min(self.check_interval, limit - it))
+            for i in range(it, it + batch):
                 if planar_sobolev:
                     self._enqueue_iteration(i, lives[i % 2], lives[(i + 1) % 2], warps[i % 2], warps[(i + 1) % 2],
                                             canonical, grid, records, gbufs, limit)
@@ -1707,7 +1671,6 @@ class SlavchevaEngine:
                 # the copy taken below back before it runs the call again
                 early = SlavchevaOutcome(grid, canonical, state=states[limit % 2], listed=listed,
                                          sparse=prepared if sparse else None, warp_zeroed=warp_zeroed)
-                early._chain = chain
                 if sparse:  # the pass must not touch the caller's fields when an update outran the initialised region
                     early.guard(records, limit, float(SPARSE_REACH))
                 if slab and finalize[0] is not None:
@@ -1716,21 +1679,6 @@ class SlavchevaEngine:
             dec = dev.decode_records(self.comm.gather_records(records, 0, it) if slab and ungated
                                      else dev.records_to_host(records[:it]))
             n_exec = int(dec["executed"].sum())
-            if chain is not None:
-                # A wait that timed out poisons the LAST record of the launch (an all-ones maximum decodes as NaN) and every
-                # workgroup leaves: records in between may never have been written, so `executed` is not a prefix then --
-                # look at every record of the launch, and at the launch's own abort word.  The finalize pass behind an
-                # aborted launch has left the caller's fields alone (the kernel raises its skip word on abort too), so the
-                # call can simply run again with one launch per iteration.
-                aborted = bool(np.isnan(dec["max_value"][:it]).any()) or chain.aborted()
-                if aborted or n_exec < it:
-                    import warnings
-                    warnings.warn("lsf_slavcheva_state_chain: a workgroup waited for its neighbours longer than the launch "
-                                  "allows and the launch gave up (is something else holding CUs of this GPU?); the call "
-                                  "is repeated with one launch per iteration")
-                    raise _ChainReachExceeded()
-                if n_exec > 0 and not dec["max_value"][:n_exec].max() < dev.StateChain.REACH_LIMIT:
-                    raise _ChainReachExceeded()
             # z-slab: every EXECUTED iteration must have stayed inside what the halo schedule keeps valid -- also those
             # of a batch in which the gate then closed (a large update followed by convergence inside one
             # check_interval).  Every rank sees the same reduced / gathered records, so the raise is collective.
@@ -1814,14 +1762,14 @@ class SlavchevaEngine:
         n_interior, n_boundary, opposite, first_opposite = totals_host.tolist()
         lists = torch.empty(max(n_interior + n_boundary, 1), dtype=torch.int32, device=device)
         records = dev.new_records(iterations, device)
-        words = torch.empty(iterations * _lib.RECORD_SLOTS * dev.USED_SLOT_WORDS, dtype=torch.int64, device=device)
+        n_words = iterations * _lib.RECORD_SLOTS * dev.USED_SLOT_WORDS
+        words = torch.empty(n_words + 16, dtype=torch.int64, device=device)  # the records' used words, then the statistics
         words_host = dev.pinned_scratch("run records", words.numel(), torch.int64)
-        stats = stats_host = stats_scratch = None
+        stats = stats_scratch = None
         if statistics:
             stats = torch.empty(16, dtype=torch.float64, device=device)
             stats_scratch = torch.empty(2 * int(_lib.lib.lsf_state_finalize_scratch_elements(ctypes.byref(whole))),
                                         dtype=torch.float64, device=device)
-            stats_host = dev.pinned_scratch("run statistics", 16, torch.float64)
         max_value, argmax = np.empty(iterations, np.float32), np.empty(iterations, np.int64)
         energies, executed = np.empty((iterations, 3), np.float64), np.empty(iterations, np.bool_)
         result = _lib.StateRunResult(max_value.ctypes.data, argmax.ctypes.data, energies.ctypes.data, executed.ctypes.data)
@@ -1833,8 +1781,7 @@ class SlavchevaEngine:
             dev._ptr(target, n, "live_out"), float(lower_threshold),
             ctypes.c_void_p(stats.data_ptr()) if statistics else none,
             ctypes.c_void_p(stats_scratch.data_ptr()) if statistics else none, ctypes.c_void_p(words.data_ptr()),
-            ctypes.c_void_p(words_host.data_ptr()), ctypes.c_void_p(stats_host.data_ptr()) if statistics else none,
-            ctypes.byref(result), stream), "lsf_state_run_finish")
+            ctypes.c_void_p(words_host.data_ptr()), ctypes.byref(result), stream), "lsf_state_run_finish")
         if result.reach_exceeded:
             raise _SparseStateExceeded()  # the pass has left the caller's array alone (its guard); optimize() repeats
         n_exec = int(executed.sum())
@@ -1846,7 +1793,6 @@ class SlavchevaEngine:
         f = _Counted(sum(b.count for b in bands))
         f.bands, f.records = bands, records
         self._fast = f
-        self._chain_used = False
         self.iteration_count = n_exec
         wd, ws, wl = self.weights
         self.log = dict(max_warps=max_value[:n_exec].tolist(), max_warp_indices=argmax[:n_exec].tolist(),
@@ -1856,7 +1802,7 @@ class SlavchevaEngine:
         # gradient_field() recomputes the last iteration's gradient on demand from its INPUT state, at the listed voxels
         self._gradient_state = ("recompute_listed", states[(n_exec - 1) % 2], canonical, grid, bands)
         return _RunOutcome(grid, canonical, states[n_exec % 2], target, bands,
-                           stats_host.numpy().copy() if statistics else None)
+                           words_host[n_words:].numpy().view(np.float64).copy() if statistics else None)
 
     def _call_hook(self, i, max_warp, lives, warps, states, canonical, grid, sob=None):
         """iteration i has run: hand its warp and gradient to the hook in the API layout (owned slices of a slab)"""

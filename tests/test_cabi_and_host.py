@@ -44,18 +44,36 @@ def test_library_exports_every_declared_symbol(pkg):
     assert pkg._lib.lib.lsf_target_arch() == b"gfx950"
 
 
-def test_chain_addon_exports_every_declared_symbol(pkg):
-    """the optional chain add-on (include/lsf_hip_chain.h -> liblsf_chain.so) is NOT part of the product library"""
-    from levelsetfusion_python_amd import _build
-    text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lsf_hip_chain.h")).read(), flags=re.S)
-    names = sorted(set(re.findall(r"\b(lsf_[a-z0-9_]+)\s*\(", text)))
-    assert names == sorted(pkg._lib.CHAIN_PROTOTYPES) and len(names) == 4
-    addon = ctypes.CDLL(_build.build_chain(verbose=False))
+def test_the_product_library_carries_what_the_product_runs(pkg):
+    """the chain kernel (K iterations per launch, measured 4 % slower: DESIGN.md section 7, round 3) is a measurement tool
+    under tools/chain/ with a library of its own -- neither the product library nor the package know it"""
     product = ctypes.CDLL(pkg._lib.LIB_PATH)
-    for name in names:
-        assert hasattr(addon, name), "liblsf_chain.so does not export %s" % name
+    for name in ("lsf_slavcheva_state_chain", "lsf_state_chain_plan", "lsf_state_chain_shape"):
         assert not hasattr(product, name), "the product library still carries %s" % name
     assert b"chain" not in open(pkg._lib.LIB_PATH, "rb").read()
+    assert not os.path.exists(os.path.join(ROOT, "include", "lsf_hip_chain.h"))
+    assert not hasattr(pkg._lib, "chain_lib") and not hasattr(pkg.device if hasattr(pkg, "device") else pkg._lib, "StateChain")
+
+
+def test_few_environment_knobs_in_the_package(pkg):
+    """measurement switches do not become product code paths: what the package reads from the environment is this list
+    (every entry either has a test of both settings or names a file to load)"""
+    allowed = {"LSF_HIP_LIBRARY",        # another build of the same library (A/B tools: tools/ab_state_kernel.py)
+               "LSF_SLAB_TRANSPORT",     # rccl | torch: tests/slab_loopback_worker.py runs both
+               "LSF_SLAB_FACES",         # compact | full: tests/slab_loopback_worker.py runs both
+               "LSF_SPARSE_REACH",       # 0 = fully initialised states: tests/test_gpu_sparse_state.py, test_gpu_run_path.py
+               "LSF_SPARSE_MIN_VOXELS"}  # tests force sparse states at small sizes
+    found = set()
+    package = os.path.join(ROOT, "levelsetfusion-python_amd")
+    for folder, _, files in os.walk(package):
+        for name in files:
+            if name.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(folder, name)).read()
+                found |= set(re.findall(r"environ(?:\.get)?\(\s*\"(LSF_[A-Z0-9_]+)\"", text))
+                found |= set(re.findall(r"environ\[\s*\"(LSF_[A-Z0-9_]+)\"", text))
+                found |= set(re.findall(r"getenv\(\s*\"(LSF_[A-Z0-9_]+)\"", text))
+    assert found <= allowed, sorted(found - allowed)
+    assert len(found) <= 10
 
 
 def test_abi_hash_binds_library_binding_and_header(pkg, tmp_path):
@@ -137,21 +155,6 @@ def test_argument_errors_are_reported_not_launched(pkg):
                                            None, None, 0, 0.0, None) == -1                        # statistics, no canonical
     assert L.lib.lsf_state_finalize_listed(1, 1, 1, 1, ctypes.byref(L.Grid(3, 4, 8, 8, 1, 4, 0, 0)), lists, counts, 1,
                                            0, -1, 0.0, None, None, None, None, 0, 0.0, None) == -1  # not a whole array
-    # the chain kernel: an INTERIOR list of a WHOLE array, distinct states, a scratch block
-    sp = L.SlavchevaParams()
-    C = L.chain_lib()  # the optional add-on library
-    assert C.lsf_slavcheva_state_chain(1, 1, 1, ctypes.byref(ok), ctypes.byref(sp), 1, 1, 5, 3, 1, 1, None) == -1
-    assert C.lsf_slavcheva_state_chain(1, 2, 1, ctypes.byref(ok), ctypes.byref(sp), 1, None, 5, 3, 1, 1, None) == -1
-    assert C.lsf_slavcheva_state_chain(1, 2, 1, ctypes.byref(L.Grid(3, 4, 8, 8, 1, 4, 0, 0)), ctypes.byref(sp), 1, 1,
-                                           5, 3, 1, 1, None) == -1                                # not a whole array
-    assert C.lsf_slavcheva_state_chain(1, 2, 1, ctypes.byref(ok), ctypes.byref(sp), 1, 1, 5, 3, 1, None, None) == -1
-    assert C.lsf_state_chain_plan(ctypes.byref(ok), None, 5, 1, 1, None) == -1
-    assert C.lsf_state_chain_scratch_elements(0, 1) == 0
-    # 20 000 entries = 313 wave-units: a unit per wave of a 1024-thread workgroup at least, so 19 -> 16 workgroups =
-    # chunks (a multiple of the 8 XCDs), one stage however many are asked for
-    shape = (ctypes.c_int32 * 4)()
-    assert C.lsf_state_chain_shape(20000, 4, shape) == 0 and list(shape) == [16, 1, 16, 313]
-    assert C.lsf_state_chain_scratch_elements(20000, 4) == 16 + 16 + 2 * 16
     with pytest.raises(pkg._lib.LsfHipError):
         pkg._lib.check(-2, "x")
 
@@ -387,6 +390,6 @@ def test_bench_scaling_modes_parse():
         sys.argv = ["bench.py", "--gpus", "8", "--scaling", "strong", "--workload", "hier2d"]
         a = bench.parse()
         assert (a.scaling, a.gpus, a.size) == ("strong", 8, 512)
-        assert [s[0] for s in bench.SECONDARY] == ["killing", "hier-tik", "hier-full", "multiframe", "sobolev", "hier2d"]
+        assert [s[0] for s in bench.SECONDARY] == ["killing", "killing-pairs", "hier-tik", "hier-full", "multiframe", "sobolev", "hier2d"]
     finally:
         sys.argv = old

@@ -47,10 +47,20 @@ def test_default_workload_line():
     assert r["traffic"] is None and r["traffic_source"]["loaded_build_id"]
     # the other configurations of BASELINE.json ride on the same line (here at 1/4 of their edge lengths)
     sec = {row["workload"]: row for row in d["secondary"]}
-    assert sorted(sec) == ["hier-full", "hier-tik", "hier2d", "killing", "multiframe", "sobolev"]
+    assert sorted(sec) == ["hier-full", "hier-tik", "hier2d", "killing", "killing-pairs", "multiframe", "sobolev"]
+    pairs = sec.pop("killing-pairs")  # two independent pairs in flight: milliseconds per pair, same results as one by one
+    assert "error" not in pairs, pairs
+    assert pairs["pairs_in_flight"] == 2 and pairs["results_equal"] and pairs["ms_per_pair"] > 0
+    assert pairs["ms_per_pair_one_in_flight"] > 0
     for name, row in sec.items():
         assert "error" not in row, row
         assert row["ms_per_step"] > 0 and row["visited_voxel_updates_per_s"] > 0 and row["frac"] > 0 and row["config"]
+    # the hierarchical rows name their dominant kernels and time them alone (HIP events): one finest-level iteration
+    for name in ("hier-tik", "hier-full", "multiframe"):
+        row = sec[name]
+        assert row["kernel"] and "hier_iteration_kernel" in row["kernel"] and row["kernel_ms"] > 0
+        assert row["finest_level_frac"] > 0 and all(v > 0 for v in row["kernels_ms"].values())
+    assert "convolve_xyz_kernel" in sec["hier-full"]["kernel"] and "convolve_xyz_kernel" not in sec["hier-tik"]["kernel"]
     assert sec["killing"]["size"] == 128 and sec["killing"]["kernel_ms"] > 0
     assert sec["hier2d"]["size"] == 128 and sec["hier2d"]["us_per_iteration"] > 0 and "LAUNCH-BOUND" in sec["hier2d"]["note"]
     assert abs(sec["hier2d"]["us_per_iteration"] - sec["hier2d"]["ms_per_step"] * 1e3 / 300) < 1e-6

@@ -112,9 +112,9 @@ def test_deferred_maximum_changes_nothing(monkeypatch):
     canonical, live = sphere_frame(n, 0), sphere_frame(n, 1)
     kw = dict(maximum_iteration_count=5, kernel=lsf.generate_1d_sobolev_kernel(7, 0.1), check_interval=3, **CONFIG5)
     runs = []
-    for defer in ("1", "0"):
-        monkeypatch.setenv("LSF_HIER_DEFER_MAX", defer)
+    for defer in (True, False):
         opt = lsf.HierarchicalOptimizer3d(**kw)
+        opt._engine.defer_maximum = defer
         warp = opt.optimize(canonical, live)
         res = opt._engine.level_results
         runs.append((warp, opt.get_per_level_maximum_updates(), [list(r.argmax) for r in res]))

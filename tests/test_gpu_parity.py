@@ -697,8 +697,8 @@ def test_state_prepare_reports_list_positions_of_chunk_boundaries(lsf):
 
 @pytest.mark.gpu
 def test_state_prepare_second_state_behind_the_sizes_or_in_the_pass(lsf, monkeypatch):
-    """the second ping-pong state is written either by the counting pass itself (above StatePrepare.SPLIT_MAX_VOXELS, or
-    LSF_PREPARE_SPLIT=0) or by lsf_state_pack behind the copy of the list sizes: same states, same lists either way"""
+    """the second ping-pong state is written either by the counting pass itself (above StatePrepare.SPLIT_MAX_VOXELS) or by
+    lsf_state_pack behind the copy of the list sizes: same states, same lists either way"""
     from levelsetfusion_python_amd import device as dev
     gen = torch.Generator("cuda").manual_seed(23)
     shape = (20, 24, 40)
@@ -707,8 +707,8 @@ def test_state_prepare_second_state_behind_the_sizes_or_in_the_pass(lsf, monkeyp
     far = torch.rand(shape, device="cuda", generator=gen) < 0.6
     live[far], canon[far] = -1.0, 1.0
     results = []
-    for mode in ("1", "0"):
-        monkeypatch.setenv("LSF_PREPARE_SPLIT", mode)
+    for limit in (dev.StatePrepare.SPLIT_MAX_VOXELS, 0):
+        monkeypatch.setattr(dev.StatePrepare, "SPLIT_MAX_VOXELS", limit)
         prepared = dev.StatePrepare(live, canon)
         lists, unlisted = prepared.collect()
         torch.cuda.synchronize()
@@ -721,7 +721,6 @@ def test_state_prepare_second_state_behind_the_sizes_or_in_the_pass(lsf, monkeyp
         for a, b in zip(lists, results[0][1]):
             assert a.count == b.count and torch.equal(a.indices[:a.count], b.indices[:b.count])
     monkeypatch.setattr(dev.StatePrepare, "SPLIT_MAX_VOXELS", 1)
-    monkeypatch.setenv("LSF_PREPARE_SPLIT", "1")
     big = dev.StatePrepare(live, canon)
     big.collect()
     torch.cuda.synchronize()

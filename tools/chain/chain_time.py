@@ -5,11 +5,13 @@ usage: chain_time.py [size] [iterations] [stages]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
 import levelsetfusion_python_amd as lsf
 from levelsetfusion_python_amd import device as dev
+import chain as chain_tool
 from levelsetfusion_python_amd.synthetic import sphere_pair
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -42,7 +44,7 @@ def timed(run):
 
 def run_chain(st, rec, chain):
     if chain is None:
-        return dev.StateChain(st, c, grid, eng.params, rec, bands[0], stages)
+        return chain_tool.StateChain(st, c, grid, eng.params, rec, bands[0], stages)
     assert chain.launch(0, iters)
     return chain
 
@@ -61,7 +63,7 @@ same = all(torch.equal(a, b) for a, b in zip(st_a, st_b))
 da, db = dev.decode_records(dev.records_to_host(rec_a)), dev.decode_records(dev.records_to_host(rec_b))
 same_rec = (da["max_value"] == db["max_value"]).all() and (da["argmax"] == db["argmax"]).all()
 count = bands[0].count
-probe = dev.StateChain(st_a, c, grid, eng.params, rec_a, bands[0], stages)
+probe = chain_tool.StateChain(st_a, c, grid, eng.params, rec_a, bands[0], stages)
 print("%d^3 threads=%s stages=%d(%d) wg=%d chunks=%d: chain %.2f us/iteration (%.3f of the HBM roofline at 52 B), per-iteration "
       "launches %.2f us (%.3f); states equal %s, records equal %s" % (
           n, os.environ.get("LSF_CHAIN_THREADS", "default"), stages, probe.stages_used, probe.workgroups, probe.chunks, t_chain,

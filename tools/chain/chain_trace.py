@@ -1,18 +1,21 @@
-"""100 MHz timeline of the chain kernel's work items (needs the -DLSF_CHAIN_TRACE build:
-tools/build_variant.sh chaintrace - -DLSF_CHAIN_TRACE).  Per workgroup and item: when it began to wait for its window,
+"""100 MHz timeline of the chain kernel's work items (built here with -DLSF_CHAIN_TRACE).  Per workgroup and item: when it began to wait for its window,
 when the poll matched, when the acquire had completed, when the walk began, when every wave had drained, when the item
 was published.  usage: chain_trace.py [size] [iterations] [stages]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("LSF_HIP_LIBRARY", os.path.join(ROOT, "levelsetfusion-python_amd/lib/variants/chaintrace.so"))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import ctypes
 import numpy as np
 import torch
 import levelsetfusion_python_amd as lsf
 from levelsetfusion_python_amd import _lib, device as dev
+import chain as chain_tool
+
+# the trace build of the tool's own library (-DLSF_CHAIN_TRACE)
+os.environ["LSF_CHAIN_LIBRARY"] = chain_tool.build(("-DLSF_CHAIN_TRACE",), os.path.join(os.path.dirname(chain_tool.LIB_PATH), "liblsf_chain_trace.so"))
 from levelsetfusion_python_amd.synthetic import sphere_pair
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
@@ -27,9 +30,9 @@ bands = dev.band_lists(l, c, grid)
 assert len(bands) == 1
 rec = dev.new_records(iters, "cuda")
 st = dev.state_pack(l, None, grid, copies=2)
-chain = dev.StateChain(st, c, grid, eng.params, rec, bands[0], stages)
+chain = chain_tool.StateChain(st, c, grid, eng.params, rec, bands[0], stages)
 print("workgroups %d stages %d chunks %d units %d" % (chain.workgroups, chain.stages_used, chain.chunks, chain.units))
-fn = _lib.lib.lsf_debug_set_chain_trace
+fn = chain_tool.chain_lib().lsf_debug_set_chain_trace
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p]
 trace = torch.zeros(chain.workgroups * ITEMS * WORDS, dtype=torch.int64, device="cuda")

@@ -32,7 +32,7 @@
 // (control word 1) which the finalize pass honours (it leaves the caller's fields alone) and the host sees in the records'
 // maxima: the caller then repeats the call with per-iteration launches.
 #include "lsf_slavcheva_state_taps.h"
-#include "../../include/lsf_hip_chain.h"
+#include "lsf_hip_chain.h"
 
 using namespace lsf;
 using namespace lsf::slav;

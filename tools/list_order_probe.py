@@ -1,7 +1,8 @@
 """the INTERIOR list kernel on the same band voxels in different LIST ORDERS: ascending (what lsf_state_prepare builds) and
 patches of PZ slices x PY rows (patches in z-major order, ascending inside); per order the kernel's time for several
-LSF_LIST_GROUP values is measured in separate processes (the knob is read once).  States must come out equal.
-usage: list_order_probe.py [size] [PZ] [PY]   (run with LSF_LIST_GROUP set to vary the CU assignment)"""
+group sizes is measured with variant builds (tools/build_variant.sh g16 - -DLSF_LIST_GROUP=16, then LSF_HIP_LIBRARY=...
+variants/g16.so: the group size is a compile-time constant since round 5).  States must come out equal.
+usage: list_order_probe.py [size] [PZ] [PY]"""
 import os
 import sys
 
@@ -52,5 +53,5 @@ for name, b in (("ascending", band), ("patches %d x %d" % (PZ, PY), patched)):
         torch.cuda.synchronize()
         t = e0.elapsed_time(e1) * 1e3 / 50
         best = t if best is None else min(best, t)
-    print("group %s, %-14s: %.2f us per launch" % (os.environ.get("LSF_LIST_GROUP", "4"), name, best))
+    print("library %s, %-14s: %.2f us per launch" % (os.path.basename(os.environ.get("LSF_HIP_LIBRARY", "default")), name, best))
 print("states equal:", all(torch.equal(a, b) for a, b in zip(*outs)))
