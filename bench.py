@@ -772,6 +772,12 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
         out["halo_band_voxels_per_face"] = min(halo_info["band_voxels_per_face"])
         out["halo_bytes_per_exchange"] = max(halo_info["bytes_sent_per_exchange_per_rank"])
     roofline["traffic_source"] = traffic_source
+    # rocprofv3's own per-dispatch average of the same kernel (profiles/<tag>_bench_kernel_stats.csv, committed with the
+    # traffic figure and valid for the same build only): per-dispatch timing reads ~6 % above back-to-back HIP events
+    avg_us = committed_traffic("list_kernel_avg_us" if eng.use_band_list else "dense_kernel_avg_us")
+    if avg_us:
+        roofline["rocprofv3"] = dict(kernel_us=avg_us, frac=roofline["algorithmic_bytes_per_launch"] / (avg_us * 1e-6) / 1e9
+                                     / HBM_PEAK_GBS, source=traffic_source.get("tag"))
     # the rate over the voxels the launches actually visit (band lists): comparable across inputs and rounds, where
     # `value` (field voxels, as the reference counts its work) grows with the share of the volume outside the band
     out["visited_voxel_updates_per_s"] = roofline["units_per_launch"] * world * iters * args.steps / elapsed
