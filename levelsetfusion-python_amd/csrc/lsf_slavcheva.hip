@@ -467,6 +467,104 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
     }
 }
 
+// The same pass with 16-byte loads: a thread takes FOUR consecutive voxels (rows of a multiple of four voxels, 16-byte
+// aligned fields: the launcher checks), a block four chunks with the eight loads of a thread issued together -- a quarter
+// of the load instructions and four times the bytes in flight per block (the dword version streams 128 MB at 3 TB/s at
+// 256^3: 16 384 blocks of 8 KB each).  Outputs are those of state_prepare_kernel, bit for bit: the ballot words are per 64
+// CONSECUTIVE voxels, i.e. per 16 lanes here -- a lane contributes a nibble at bit 4 * (lane % 16) and the sixteen lanes of
+// a DPP row OR theirs together (a butterfly of four lane exchanges on either half).
+constexpr int kPrepareChunksPerBlock = 4;
+__device__ inline unsigned long long row16_or(unsigned nibble, int lane) {
+    const int pos = lane & 15;
+    unsigned lo = pos < 8 ? nibble << (4 * pos) : 0u, hi = pos < 8 ? 0u : nibble << (4 * (pos - 8));
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        lo |= (unsigned)__shfl_xor((int)lo, d, kWave);
+        hi |= (unsigned)__shfl_xor((int)hi, d, kWave);
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(kBlock) void state_prepare4_kernel(const vf4* __restrict__ live4,
+                                                                const vf4* __restrict__ canonical4,
+                                                                vf4* __restrict__ a, vf4* __restrict__ b, unsigned n,
+                                                                unsigned chunks, Grid g, int dims,
+                                                                int* __restrict__ sums_interior,
+                                                                int* __restrict__ sums_boundary,
+                                                                unsigned long long* __restrict__ masks,
+                                                                int* __restrict__ opposite, int* __restrict__ nonempty) {
+    __shared__ int part[kPrepareChunksPerBlock][4][16];  // [chunk][INTERIOR, BOUNDARY, opposite count, first opposite][word]
+    const int t = threadIdx.x, wave = t / kWave, lane = t % kWave;
+    const unsigned chunk0 = blockIdx.x * kPrepareChunksPerBlock;
+    vf4 l[kPrepareChunksPerBlock], c[kPrepareChunksPerBlock];
+#pragma unroll
+    for (int k = 0; k < kPrepareChunksPerBlock; ++k) {
+        const unsigned v = (chunk0 + k) * kBandChunk + 4u * t;  // n is a multiple of four: a group is inside or outside
+        const vf4 one = {1.0f, 1.0f, 1.0f, 1.0f};
+        l[k] = v < n ? live4[v / 4] : one;
+        c[k] = v < n ? canonical4[v / 4] : one;
+    }
+#pragma unroll
+    for (int k = 0; k < kPrepareChunksPerBlock; ++k) {
+        const unsigned chunk = chunk0 + k, v = chunk * kBandChunk + 4u * t;
+        unsigned ni = 0u, nb = 0u, no = 0u;
+        if (v < n) {
+            const unsigned zy = fast_div(v, g.div_nx);
+            const int x0 = (int)(v - zy * (unsigned)g.nx);  // the four voxels share a row (nx % 4 == 0)
+            const int z = (int)fast_div(zy, g.div_ny);
+            const int y = (int)zy - z * g.ny;
+            const bool row_inside = y > 0 && y < g.ny - 1 && (dims == 2 || (z > 0 && z < g.nz - 1));
+            const float lv[4] = {l[k].x, l[k].y, l[k].z, l[k].w}, cv[4] = {c[k].x, c[k].y, c[k].z, c[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in_band = !(fabsf(lv[j]) == 1.0f && fabsf(cv[j]) == 1.0f);
+                const bool interior = row_inside && x0 + j > 0 && x0 + j < g.nx - 1;
+                ni |= (in_band && interior ? 1u : 0u) << j;
+                nb |= (in_band && !interior ? 1u : 0u) << j;
+                no |= (!in_band && lv[j] != cv[j] ? 1u : 0u) << j;
+                vf4 o;
+                o.x = lv[j]; o.y = 0.0f; o.z = 0.0f; o.w = 0.0f;
+                if (a) a[v + j] = o;
+                if (b) b[v + j] = o;
+            }
+        }
+        const unsigned long long mi = row16_or(ni, lane), mb = row16_or(nb, lane), mo = row16_or(no, lane);
+        if ((lane & 15) == 0 && chunk < chunks) {
+            const int word = wave * 4 + lane / 16;  // 64 consecutive voxels: chunk * 1024 + word * 64 ...
+            part[k][0][word] = __popcll(mi);
+            part[k][1][word] = __popcll(mb);
+            part[k][2][word] = __popcll(mo);
+            part[k][3][word] = mo ? (int)(chunk * kBandChunk + word * kWave) + __ffsll((long long)mo) - 1 : 0x7fffffff;
+            masks[((size_t)chunk * 16 + word) * 2 + 0] = mi;
+            masks[((size_t)chunk * 16 + word) * 2 + 1] = mb;
+        }
+    }
+    __syncthreads();
+    if (t < 4 * kPrepareChunksPerBlock) {
+        const int k = t / 4, what = t % 4;
+        const unsigned chunk = chunk0 + k;
+        if (chunk < chunks) {
+            if (what < 2) {
+                int sum = 0;
+                for (int w = 0; w < 16; ++w) sum += part[k][what][w];
+                (what == 0 ? sums_interior : sums_boundary)[chunk] = sum;
+            } else if (what == 2) {
+                int sum = 0, first = 0x7fffffff;
+                for (int w = 0; w < 16; ++w) {
+                    sum += part[k][2][w];
+                    first = min(first, part[k][3][w]);
+                }
+                opposite[2 * chunk] = sum;
+                opposite[2 * chunk + 1] = first;
+            } else {
+                int any = 0;
+                for (int w = 0; w < 16; ++w) any |= part[k][0][w] | part[k][1][w];
+                nonempty[chunk] = any != 0;
+            }
+        }
+    }
+}
+
 // The ping-pong states only where an iteration can READ them (lsf_state_pack_needed): chunk c (1024 consecutive voxels) is
 // needed when some chunk that holds band voxels has a voxel within `reach` voxels of it along every axis -- the 3^D
 // stencils reach 1, the re-warp gather of an update shorter than `reach` voxels floor(|w|) + 1 <= reach.  In linear
@@ -475,16 +573,18 @@ __global__ __launch_bounds__(kBlock) void state_prepare_kernel(const float* __re
 // from the chunks' non-empty flags (written by lsf_state_prepare), then the needed chunks written as (live, 0) to both
 // states; needed[c] keeps the verdict for whoever has to complete a state later (invert != 0: write exactly the chunks
 // NOT needed, from the kept verdicts).
-// step 1: the verdicts, one THREAD per chunk (a few dozen flag loads each: microseconds for the whole volume)
+// step 1: the verdicts.  One WAVE per chunk, the (dz, dy) offsets dealt to its lanes (25 of them at reach 2: one round; a
+// thread per chunk walked them one after the other, 12 us at 256^3 for a few dozen dependent flag loads each)
 __global__ __launch_bounds__(kBlock) void chunk_needed_kernel(unsigned chunks, long long row, long long slice, int dims,
                                                               int reach, const int* __restrict__ nonempty,
                                                               int* __restrict__ needed) {
-    const unsigned c = blockIdx.x * kBlock + threadIdx.x;
+    const unsigned c = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
     if (c >= chunks) return;
+    const int lane = threadIdx.x % kWave;
     const long long c0 = (long long)c * kBandChunk;
     const int span = 2 * reach + 1, zs = dims == 3 ? span : 1;
     bool hit = false;
-    for (int k = 0; k < zs * span && !hit; ++k) {
+    for (int k = lane; k < zs * span; k += kWave) {
         const int dy = k % span - reach, dz = dims == 3 ? k / span - reach : 0;
         const long long lo = c0 + dz * slice + dy * row - reach, hi = c0 + (long long)kBandChunk - 1 + dz * slice + dy * row + reach;
         // floor division of possibly negative voxel indices; chunks lo / 1024 .. hi / 1024 (at most three)
@@ -494,7 +594,8 @@ __global__ __launch_bounds__(kBlock) void chunk_needed_kernel(unsigned chunks, l
         last = last >= (long long)chunks ? (long long)chunks - 1 : last;
         for (long long cand = first; cand <= last; ++cand) hit |= nonempty[cand] != 0;
     }
-    needed[c] = hit ? 1 : 0;
+    const bool any = __any(hit);
+    if (lane == 0) needed[c] = any ? 1 : 0;
 }
 
 // step 2: (live, 0) into both states for the chunks whose verdict equals `want`: one chunk per block (four per block
@@ -731,10 +832,18 @@ extern "C" int lsf_state_prepare(const float* live, const float* canonical, floa
     hipStream_t s = as_stream(stream);
     int* sums_interior = scratch;
     int* sums_boundary = scratch + (chunks + 1);
-    hipLaunchKernelGGL(state_prepare_kernel, dim3(chunks), dim3(kBlock), 0, s, live, canonical,
-                       reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b), n, make_grid(grid), grid->dims,
-                       sums_interior, sums_boundary, prepare_masks(scratch, chunks), prepare_opposite(scratch, chunks),
-                       prepare_nonempty(scratch, chunks));
+    const bool wide = grid->nx % 4 == 0 && ((uintptr_t)live | (uintptr_t)canonical) % 16 == 0;
+    if (wide)  // 16-byte loads, four chunks per block
+        hipLaunchKernelGGL(state_prepare4_kernel, dim3((chunks + kPrepareChunksPerBlock - 1) / kPrepareChunksPerBlock),
+                           dim3(kBlock), 0, s, reinterpret_cast<const vf4*>(live), reinterpret_cast<const vf4*>(canonical),
+                           reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b), n, chunks, make_grid(grid),
+                           grid->dims, sums_interior, sums_boundary, prepare_masks(scratch, chunks),
+                           prepare_opposite(scratch, chunks), prepare_nonempty(scratch, chunks));
+    else
+        hipLaunchKernelGGL(state_prepare_kernel, dim3(chunks), dim3(kBlock), 0, s, live, canonical,
+                           reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b), n, make_grid(grid), grid->dims,
+                           sums_interior, sums_boundary, prepare_masks(scratch, chunks), prepare_opposite(scratch, chunks),
+                           prepare_nonempty(scratch, chunks));
     hipLaunchKernelGGL(band_scan_kernel, dim3(3), dim3(1024), 0, s, scratch, chunks, chunks + 1, 2u, (long long*)counts_out,
                        (const int*)prepare_opposite(scratch, chunks));
     return launch_status();
@@ -748,7 +857,7 @@ extern "C" int lsf_state_pack_needed(const float* live, float* state_a, float* s
     unsigned first, n, chunks;
     band_range(grid, first, n, chunks);
     if (!invert)
-        hipLaunchKernelGGL(chunk_needed_kernel, dim3((chunks + kBlock - 1) / kBlock), dim3(kBlock), 0, as_stream(stream),
+        hipLaunchKernelGGL(chunk_needed_kernel, dim3((chunks + kBlock / kWave - 1) / (kBlock / kWave)), dim3(kBlock), 0, as_stream(stream),
                            chunks, (long long)grid->nx, (long long)grid->nx * grid->ny, grid->dims, reach,
                            prepare_nonempty(scratch, chunks), prepare_needed(scratch, chunks));
     hipLaunchKernelGGL(state_pack_needed_kernel, dim3((chunks + kPackChunks - 1) / kPackChunks), dim3(kBlock), 0,

@@ -14,7 +14,7 @@ for r in csv.DictReader(open(f)):
     name = re.sub(r"\(anonymous namespace\)::|void |lsf::", "", r["Kernel_Name"]).split("(")[0][:58]
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 rows.sort()
-starts = [i for i, r in enumerate(rows) if "state_prepare_kernel" in r[2] or "prepare_count" in r[2] or "band_count" in r[2]]
+starts = [i for i, r in enumerate(rows) if "state_prepare" in r[2] or "prepare_count" in r[2] or "band_count" in r[2]]
 starts = [i for k, i in enumerate(starts) if k == 0 or i - starts[k - 1] > 10]
 a, b = starts[-back - 1], starts[-back]
 while a > 0 and rows[a][0] - rows[a - 1][1] < 60000 and "slavcheva_state_kernel" not in rows[a - 1][2] and a > starts[-back - 2] + 1 and "finalize" not in rows[a - 1][2] and "records_used" not in rows[a - 1][2]:
