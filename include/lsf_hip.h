@@ -384,6 +384,32 @@ int lsf_slavcheva_state_iteration(const float *state_in, const float *canonical,
                                   lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,
                                   int32_t band_subset, void *stream);
 
+/* ---- the fused iteration over BOXES (3-D, INTERIOR band voxels) -----------------------------
+ * The same pass of slavcheva_optimizer2d.py:238-330 as lsf_slavcheva_state_iteration over an INTERIOR band list, same
+ * results, with the work cut differently: a box is 4 x 4 x 4 voxels whose lowest corner (x0, y0, z0) has coordinates that
+ * are multiples of 4 -- origin = (z0 * ny + y0) * nx + x0 --, bit (lz * 4 + ly) * 4 + lx of `mask` says whether voxel
+ * (x0 + lx, y0 + ly, z0 + lz) is an INTERIOR band voxel (LSF_BAND_INTERIOR: its whole 3^3 neighbourhood inside the array).
+ * Boxes in ascending order of origin, every INTERIOR band voxel in exactly one box; voxels on the faces of the array keep
+ * their BOUNDARY list and lsf_slavcheva_state_iteration.  A wave stages a box and its one-voxel shell through LDS instead
+ * of loading 18 neighbours per voxel.  Requires dims = 3, extents that are multiples of 4, nz * ny * nx < 2^28
+ * (LSF_ERR_BAD_DIMS otherwise).  lsf_band_boxes_count / _fill build the boxes from the ballots lsf_state_prepare kept in its
+ * scratch: _count writes the number of boxes to *count_out (device) and keeps per-group counts in box_scratch
+ * (lsf_band_boxes_scratch_elements(grid) int32), the caller reads the count, allocates, and _fill writes the boxes. */
+typedef struct lsf_band_box {
+    int32_t origin;
+    int32_t reserved;
+    uint64_t mask;
+} lsf_band_box;
+int64_t lsf_band_boxes_scratch_elements(const lsf_grid *grid);
+int lsf_band_boxes_count(const lsf_grid *grid, const int32_t *prepare_scratch, int32_t *box_scratch, int64_t *count_out,
+                         void *stream);
+int lsf_band_boxes_fill(const lsf_grid *grid, const int32_t *prepare_scratch, const int32_t *box_scratch,
+                        lsf_band_box *boxes, void *stream);
+int lsf_slavcheva_state_iteration_boxes(const float *state_in, const float *canonical, float *state_out,
+                                        const lsf_grid *grid, const lsf_slavcheva_params *params, const lsf_gate *gate,
+                                        lsf_iteration_record *record, const lsf_band_box *boxes, int64_t box_count,
+                                        void *stream);
+
 /* ---- a whole fixed-count call of the fused path, enqueued by the library in two host calls ---------------------------
  * replaces the LOOP of slavcheva_optimizer2d.py:354-388 (min_iterations == max_iterations: its stop test :360-362 cannot
  * fire) around the calls above, for whole volumes on band lists: lsf_state_run_begin launches lsf_state_prepare and the

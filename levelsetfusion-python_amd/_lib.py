@@ -22,7 +22,7 @@ ABI_VERSION = 3
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "5c706a274c6e4af5"
+HEADER_ABI_HASH = "5dc8f8ae1c85f62d"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -83,6 +83,11 @@ class SlabFaces(ctypes.Structure):
     _fields_ = [("send_list", ctypes.c_void_p * 2), ("recv_list", ctypes.c_void_p * 2),
                 ("send_msg", ctypes.c_void_p * 2), ("recv_msg", ctypes.c_void_p * 2),
                 ("send_count", ctypes.c_int64 * 2), ("recv_count", ctypes.c_int64 * 2)]
+
+
+class BandBox(ctypes.Structure):
+    """lsf_band_box: a 4 x 4 x 4 box of the volume and which of its voxels are INTERIOR band voxels"""
+    _fields_ = [("origin", ctypes.c_int32), ("reserved", ctypes.c_int32), ("mask", ctypes.c_uint64)]
 
 
 class StateRun(ctypes.Structure):
@@ -172,6 +177,11 @@ PROTOTYPES = {
                                                  _i64, _i64, _f32, _vp, _vp, _vp, _vp, _i32, _f32, _vp]),
     "lsf_slavcheva_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp,
                                                      _vp, _i64, _i32, _vp]),
+    "lsf_band_boxes_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
+    "lsf_band_boxes_count": (ctypes.c_int, [_P(Grid), _vp, _vp, _vp, _vp]),
+    "lsf_band_boxes_fill": (ctypes.c_int, [_P(Grid), _vp, _vp, _vp, _vp]),
+    "lsf_slavcheva_state_iteration_boxes": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp, _vp,
+                                                           _i64, _vp]),
     "lsf_state_run_begin": (ctypes.c_int, [_P(StateRun), _vp]),
     "lsf_state_run_finish": (ctypes.c_int, [_P(StateRun), _P(SlavchevaParams), _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp,
                                             _vp, _vp, _P(StateRunResult), _vp]),

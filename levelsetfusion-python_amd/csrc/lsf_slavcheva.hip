@@ -821,6 +821,104 @@ extern "C" int lsf_band_list_fill_prepared(const lsf_grid* grid, int32_t subset,
     return launch_status();
 }
 
+// ---- boxes for lsf_slavcheva_state_iteration_boxes (lsf_slavcheva_box.hip), from the ballots lsf_state_prepare kept ------
+// Box B = (bz * ny/4 + by) * nx/4 + bx covers voxels (4bx .. 4bx+3, 4by .. 4by+3, 4bz .. 4bz+3); its mask takes four bits
+// from each of its sixteen x-rows out of the INTERIOR ballot word of the 64 consecutive voxels the row starts in (rows of a
+// multiple of four voxels never straddle a word).  One thread per box; sixteen boxes share a word.
+namespace {
+constexpr int kBoxGroup = kBlock;  // boxes per block = per count of the scan
+
+__device__ inline unsigned long long box_mask_of(const unsigned long long* __restrict__ masks, unsigned box, int nbx,
+                                                 int nby, int nx, int ny) {
+    const int bx = (int)(box % (unsigned)nbx), by = (int)((box / (unsigned)nbx) % (unsigned)nby);
+    const int bz = (int)(box / ((unsigned)nbx * (unsigned)nby));
+    unsigned long long m = 0ull;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned v = (unsigned)(((4 * bz + k) * ny + 4 * by + j) * nx + 4 * bx);
+            const unsigned long long word = masks[2 * (size_t)(v >> 6)];  // [2 W + 0]: the INTERIOR ballot of voxels 64 W ...
+            m |= ((word >> (v & 63u)) & 0xFull) << (4 * (k * 4 + j));
+        }
+    return m;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(kBlock) void band_boxes_kernel(const unsigned long long* __restrict__ masks, unsigned n_boxes,
+                                                            int nbx, int nby, int nx, int ny, int* __restrict__ group_sums,
+                                                            lsf_band_box* __restrict__ boxes) {
+    __shared__ int wave_count[kBlock / kWave];
+    const unsigned box = blockIdx.x * kBoxGroup + threadIdx.x;
+    const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
+    const unsigned long long m = box < n_boxes ? box_mask_of(masks, box, nbx, nby, nx, ny) : 0ull;
+    const unsigned long long any = __ballot(m != 0ull);
+    if (lane == 0) wave_count[wave] = __popcll(any);
+    __syncthreads();
+    if (!FILL) {
+        if (threadIdx.x == 0) {
+            int sum = 0;
+            for (int k = 0; k < kBlock / kWave; ++k) sum += wave_count[k];
+            group_sums[blockIdx.x] = sum;
+        }
+        return;
+    }
+    if (m == 0ull) return;
+    int at = group_sums[blockIdx.x];  // exclusive prefix after the scan
+    for (int k = 0; k < wave; ++k) at += wave_count[k];
+    at += __popcll(any & ((1ull << lane) - 1ull));
+    const int bx = (int)(box % (unsigned)nbx), by = (int)((box / (unsigned)nbx) % (unsigned)nby);
+    const int bz = (int)(box / ((unsigned)nbx * (unsigned)nby));
+    lsf_band_box b;
+    b.origin = ((4 * bz) * ny + 4 * by) * nx + 4 * bx;
+    b.reserved = 0;
+    b.mask = m;
+    boxes[at] = b;
+}
+
+inline bool boxes_ok(const lsf_grid* g) {
+    return g->dims == 3 && g->nx % 4 == 0 && g->ny % 4 == 0 && g->nz % 4 == 0 && g->z_begin == 0 && g->z_end == g->nz &&
+           (long long)g->nx * g->ny * g->nz <= 0x0fffffffll;
+}
+}  // namespace
+
+extern "C" int64_t lsf_band_boxes_scratch_elements(const lsf_grid* grid) {
+    if (check_grid(grid) || !boxes_ok(grid)) return 0;
+    const long long n_boxes = (long long)grid->nx * grid->ny * grid->nz / 64;
+    return (n_boxes + kBoxGroup - 1) / kBoxGroup + 1;
+}
+
+extern "C" int lsf_band_boxes_count(const lsf_grid* grid, const int32_t* prepare_scratch, int32_t* box_scratch,
+                                    int64_t* count_out, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!boxes_ok(grid)) return LSF_ERR_BAD_DIMS;
+    if (!prepare_scratch || !box_scratch || !count_out) return LSF_ERR_BAD_ARGUMENT;
+    unsigned first, n, chunks;
+    band_range(grid, first, n, chunks);
+    const unsigned n_boxes = n / 64, groups = (n_boxes + kBoxGroup - 1) / kBoxGroup;
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(band_boxes_kernel<false>, dim3(groups), dim3(kBlock), 0, s,
+                       prepare_masks(const_cast<int32_t*>(prepare_scratch), chunks), n_boxes, grid->nx / 4, grid->ny / 4,
+                       grid->nx, grid->ny, box_scratch, (lsf_band_box*)nullptr);
+    hipLaunchKernelGGL(band_scan_kernel, dim3(1), dim3(1024), 0, s, box_scratch, groups, 0u, 1u, (long long*)count_out,
+                       (const int*)nullptr);
+    return launch_status();
+}
+
+extern "C" int lsf_band_boxes_fill(const lsf_grid* grid, const int32_t* prepare_scratch, const int32_t* box_scratch,
+                                   lsf_band_box* boxes, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!boxes_ok(grid)) return LSF_ERR_BAD_DIMS;
+    if (!prepare_scratch || !box_scratch || !boxes) return LSF_ERR_BAD_ARGUMENT;
+    unsigned first, n, chunks;
+    band_range(grid, first, n, chunks);
+    const unsigned n_boxes = n / 64, groups = (n_boxes + kBoxGroup - 1) / kBoxGroup;
+    hipLaunchKernelGGL(band_boxes_kernel<true>, dim3(groups), dim3(kBlock), 0, as_stream(stream),
+                       prepare_masks(const_cast<int32_t*>(prepare_scratch), chunks), n_boxes, grid->nx / 4, grid->ny / 4,
+                       grid->nx, grid->ny, const_cast<int32_t*>(box_scratch), boxes);
+    return launch_status();
+}
+
 extern "C" int lsf_state_prepare(const float* live, const float* canonical, float* state_a, float* state_b,
                                  const lsf_grid* grid, int32_t* scratch, int64_t* counts_out, void* stream) {
     if (int e = check_grid(grid, true)) return e;
