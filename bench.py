@@ -682,6 +682,8 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
     grid = eng._grid(live0)
     rec = dev.new_records(2, device)
 
+    boxes = None  # (tensor, count) when the timed steps walked the INTERIOR band voxels box by box (engine._box_walk_used)
+
     def launches(bands):
         states = dev.state_pack(live0, None, grid, copies=2)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -689,8 +691,12 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
         e0.record()
         for i in range(iters):
             for band in bands:  # interior + (usually empty, then absent) boundary band voxels
-                dev.slavcheva_state_iteration(states[i % 2], canonical, states[(i + 1) % 2], grid, eng.params, None,
-                                              rec, 0, band)
+                if boxes is not None and band is not None and band.subset == _lib.BAND_INTERIOR:
+                    dev.slavcheva_state_iteration_boxes(states[i % 2], canonical, states[(i + 1) % 2], grid, eng.params,
+                                                        None, rec, 0, boxes[0], boxes[1])
+                else:
+                    dev.slavcheva_state_iteration(states[i % 2], canonical, states[(i + 1) % 2], grid, eng.params, None,
+                                                  rec, 0, band)
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / iters
@@ -743,8 +749,18 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
                     bands.append(dev.BandList(own, own.numel(), b.subset))
         else:
             bands = dev.band_lists(live0, canonical, grid)
-        # what the timed steps launched: one launch per iteration and list
-        roofline = roofline_of(bands, sum(b.count for b in bands), name % "LIST", committed_traffic("hbm_bytes_per_launch"))
+        # what the timed steps launched: one launch per iteration and list -- over the INTERIOR voxels' BOXES when the
+        # engine walked those (its choice by band size: a 512^3 sphere pair)
+        walk = "LIST"
+        if world == 1 and getattr(eng, "_box_walk_used", False):
+            boxes = dev.band_boxes(dev.StatePrepare(live0, canonical, grid))
+            walk = "BOXES of 4x4x4 through LDS"
+            name = "slavcheva_state_box_kernel<KILLING,LEVELSET,BASIC,DIRECT> (%s)"
+        roofline = roofline_of(bands, sum(b.count for b in bands), name % walk, committed_traffic("hbm_bytes_per_launch"))
+        name = "slavcheva_state_kernel<3,KILLING,LEVELSET,BASIC,DIRECT,%s>"
+        if boxes is not None:
+            roofline["boxes_per_launch"] = boxes[1]
+            boxes = None  # (the dense walk below is the list kernel's)
         roofline["dense_equivalent_gbs"] = B_ALG["killing"] * voxels_per_rank / (roofline["kernel_ms"] * 1e-3) / 1e9
     else:
         roofline = roofline_of([None], voxels_per_rank, name % "DENSE", committed_traffic("dense_hbm_bytes_per_launch"))

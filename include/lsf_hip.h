@@ -418,7 +418,8 @@ int lsf_slavcheva_state_iteration_boxes(const float *state_in, const float *cano
  * lsf_state_prepare are in totals_host; the caller sizes the two lists from them (totals_host[0] INTERIOR, [1] BOUNDARY
  * entries) and calls lsf_state_run_finish, which launches the list fills, `iterations` x lsf_slavcheva_state_iteration
  * per non-empty list (ungated; iteration i reads state[i % 2], writes the other, reduces into records[i], which the
- * caller has zeroed) and lsf_state_finalize_listed of the final state into live_out (which must hold the input live field:
+ * caller has zeroed; with `boxes` -- room for totals_host[4] of them, box_scratch given to lsf_state_run_begin -- the
+ * INTERIOR voxels are walked box by box instead, lsf_slavcheva_state_iteration_boxes: same results) and lsf_state_finalize_listed of the final state into live_out (which must hold the input live field:
  * the pass writes listed voxels only; statistics16 / finalize_scratch as there, may be NULL; with sparse states the pass
  * guards itself with the records), copies the records' used words and the statistics to the host in ONE transfer and
  * RETURNS when the stream has drained, the records decoded into `result` (lsf_records_decode).  The same launches in the
@@ -431,11 +432,13 @@ typedef struct lsf_state_run {
     const float *canonical;
     float *state[2];          /* the two ping-pong states, nz * ny * nx float4 each, contents undefined on entry */
     int32_t *prepare_scratch; /* lsf_state_prepare_scratch_elements(grid) int32 */
-    int64_t *totals_device;   /* 4 int64 */
-    int64_t *totals_host;     /* 4 int64, page-locked */
+    int64_t *totals_device;   /* 5 int64 */
+    int64_t *totals_host;     /* 5 int64, page-locked: lsf_state_prepare's four totals, then the number of boxes (or 0) */
     lsf_grid grid;            /* a whole volume: z_begin = 0, z_end = nz, no offsets */
     int32_t sparse_reach;     /* 0: both states are written in full */
     int32_t second_state_late;
+    int32_t *box_scratch;     /* NULL, or lsf_band_boxes_scratch_elements(grid) int32: lsf_state_run_begin then also counts the
+                                 boxes of lsf_slavcheva_state_iteration_boxes (totals_host[4]) */
 } lsf_state_run;
 typedef struct lsf_state_run_result {
     float *max_value;    /* host arrays of `iterations` entries (energies3: 3 per iteration), as lsf_records_decode */
@@ -450,7 +453,8 @@ typedef struct lsf_state_run_result {
 } lsf_state_run_result;
 int lsf_state_run_begin(const lsf_state_run *run, void *stream);
 int lsf_state_run_finish(const lsf_state_run *run, const lsf_slavcheva_params *params, int32_t *list_interior,
-                         int32_t *list_boundary, lsf_iteration_record *records, int32_t iterations, float *live_out,
+                         int32_t *list_boundary, lsf_band_box *boxes, lsf_iteration_record *records, int32_t iterations,
+                         float *live_out,
                          float lower_threshold, double *statistics16, double *finalize_scratch, int64_t *words_device,
                          int64_t *words_host, lsf_state_run_result *result, void *stream);
 

@@ -22,7 +22,7 @@ ABI_VERSION = 3
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "5dc8f8ae1c85f62d"
+HEADER_ABI_HASH = "ef19ddc4ab43e074"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -95,7 +95,7 @@ class StateRun(ctypes.Structure):
     _fields_ = [("live", ctypes.c_void_p), ("canonical", ctypes.c_void_p), ("state", ctypes.c_void_p * 2),
                 ("prepare_scratch", ctypes.c_void_p), ("totals_device", ctypes.c_void_p),
                 ("totals_host", ctypes.c_void_p), ("grid", Grid), ("sparse_reach", ctypes.c_int32),
-                ("second_state_late", ctypes.c_int32)]
+                ("second_state_late", ctypes.c_int32), ("box_scratch", ctypes.c_void_p)]
 
 
 class StateRunResult(ctypes.Structure):
@@ -183,7 +183,7 @@ PROTOTYPES = {
     "lsf_slavcheva_state_iteration_boxes": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp, _vp,
                                                            _i64, _vp]),
     "lsf_state_run_begin": (ctypes.c_int, [_P(StateRun), _vp]),
-    "lsf_state_run_finish": (ctypes.c_int, [_P(StateRun), _P(SlavchevaParams), _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp,
+    "lsf_state_run_finish": (ctypes.c_int, [_P(StateRun), _P(SlavchevaParams), _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp,
                                             _vp, _vp, _P(StateRunResult), _vp]),
     "lsf_band_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
     "lsf_band_count": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),

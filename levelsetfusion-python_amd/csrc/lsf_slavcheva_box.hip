@@ -18,9 +18,13 @@ namespace {
 
 constexpr int kBoxEdge = 4, kShellEdge = kBoxEdge + 2, kShell = kShellEdge * kShellEdge * kShellEdge;  // 216
 constexpr int kShellLoads = (kShell + kWave - 1) / kWave;                                                // 4
-// Waves per workgroup = per CU: 12, three per SIMD with up to 170 registers each -- at 16 (128 registers) the kernel spills
-// into scratch inside the loop, and a scratch reload is a vector-memory operation the LDS-DMA loads then queue behind
-// (124.8 against 119.8 us per 512^3 launch, 30.8 us both at 256^3; variant builds: tools/build_variant.sh NAME - -DLSF_BOX_WAVES=16)
+// Waves per workgroup = per CU: 12, three per SIMD with up to 170 registers each (the kernel takes 145).  At 16 waves (128
+// registers) it spills inside the loop -- a scratch reload is a vector-memory operation the LDS-DMA loads then queue behind:
+// 124.8 against 119.8 us per 512^3 launch, 30.8 us both at 256^3.  Built to fit 128 registers without spilling -- the taps
+// fetched in four groups that follow the arithmetic, the re-warp cell read from the image by seven computed offsets instead
+// of selected among the taps' live components, the energy sums kept in LDS between rounds: 120 -> 128 registers, bit-identical
+// -- it measured 31.5 us against 30.5 for the list walk at 256^3 and 125.7 against 144.4 at 512^3: no better than this form,
+// with twice the code.  (variant builds: tools/build_variant.sh NAME - -DLSF_BOX_WAVES=16)
 #ifndef LSF_BOX_WAVES
 #define LSF_BOX_WAVES 12
 #endif

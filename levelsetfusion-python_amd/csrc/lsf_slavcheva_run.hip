@@ -56,7 +56,13 @@ extern "C" int lsf_state_run_begin(const lsf_state_run* run, void* stream) {
     if (int e = lsf_state_prepare(run->live, run->canonical, sparse ? nullptr : run->state[0], b_in_pass, g,
                                   run->prepare_scratch, run->totals_device, stream))
         return e;
-    if (hipMemcpyAsync(run->totals_host, run->totals_device, 4 * sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess)
+    // (optional) the boxes of the box walk are counted behind the pass, so that their number comes back with the list sizes
+    if (run->box_scratch) {
+        if (int e = lsf_band_boxes_count(g, run->prepare_scratch, run->box_scratch, run->totals_device + 4, stream)) return e;
+    } else if (hipMemsetAsync(run->totals_device + 4, 0, sizeof(int64_t), s) != hipSuccess) {
+        return (int)hipGetLastError();
+    }
+    if (hipMemcpyAsync(run->totals_host, run->totals_device, 5 * sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess)
         return (int)hipGetLastError();
     hipEvent_t sizes = thread_event();
     if (!sizes) return (int)hipGetLastError();
@@ -72,7 +78,8 @@ extern "C" int lsf_state_run_begin(const lsf_state_run* run, void* stream) {
 }
 
 extern "C" int lsf_state_run_finish(const lsf_state_run* run, const lsf_slavcheva_params* params, int32_t* list_interior,
-                                    int32_t* list_boundary, lsf_iteration_record* records, int32_t iterations,
+                                    int32_t* list_boundary, lsf_band_box* boxes, lsf_iteration_record* records,
+                                    int32_t iterations,
                                     float* live_out, float lower_threshold, double* statistics16,
                                     double* finalize_scratch, int64_t* words_device, int64_t* words_host,
                                     lsf_state_run_result* result, void* stream) {
@@ -104,12 +111,23 @@ extern "C" int lsf_state_run_finish(const lsf_state_run* run, const lsf_slavchev
         lists[n_lists] = n_boundary ? list_boundary : reinterpret_cast<const int32_t*>(run->prepare_scratch);
         counts[n_lists] = n_boundary; subsets[n_lists++] = LSF_BAND_BOUNDARY;
     }
+    // the INTERIOR voxels box by box when the caller asks for it (same results; DESIGN.md section 5: the walk that pays
+    // when the band's states do not fit the Infinity Cache)
+    const int64_t n_boxes = boxes && run->box_scratch ? run->totals_host[4] : 0;
+    if (n_boxes > 0)
+        if (int e = lsf_band_boxes_fill(g, run->prepare_scratch, run->box_scratch, boxes, stream)) return e;
     // the iterations: ungated (a fixed count), iteration i reads state[i % 2] and writes the other
     for (int32_t i = 0; i < iterations; ++i)
-        for (int k = 0; k < n_lists; ++k)
-            if (int e = lsf_slavcheva_state_iteration(run->state[i % 2], run->canonical, run->state[(i + 1) % 2], g, params,
-                                                      nullptr, records + i, lists[k], counts[k], subsets[k], stream))
-                return e;
+        for (int k = 0; k < n_lists; ++k) {
+            int e;
+            if (n_boxes > 0 && subsets[k] == LSF_BAND_INTERIOR)
+                e = lsf_slavcheva_state_iteration_boxes(run->state[i % 2], run->canonical, run->state[(i + 1) % 2], g, params,
+                                                        nullptr, records + i, boxes, n_boxes, stream);
+            else
+                e = lsf_slavcheva_state_iteration(run->state[i % 2], run->canonical, run->state[(i + 1) % 2], g, params,
+                                                  nullptr, records + i, lists[k], counts[k], subsets[k], stream);
+            if (e) return e;
+        }
     // the end of the call behind the last iteration: the listed voxels' live values into the caller's array (which holds
     // the input everywhere else) and the convergence statistics; with sparsely initialised states the pass looks at the
     // records first and leaves everything alone when an update outran what was initialised

@@ -676,6 +676,43 @@ def state_finalize_listed(state, canonical, grid, bands, unlisted, live_out=None
     return stats
 
 
+BOX_EDGE = 4  # lsf_band_box: 4 x 4 x 4 voxels
+
+
+def boxes_ok(grid):
+    """can lsf_slavcheva_state_iteration_boxes walk this grid?  3-D, extents that are multiples of 4, < 2^28 voxels"""
+    return (grid.dims == 3 and grid.nx % BOX_EDGE == 0 and grid.ny % BOX_EDGE == 0 and grid.nz % BOX_EDGE == 0
+            and n_voxels(grid) <= 0x0fffffff)
+
+
+def band_boxes(prepared):
+    """the INTERIOR band voxels of a StatePrepare as boxes (lsf_band_boxes_count / _fill, from the ballots the counting pass
+    kept): (int64 tensor [n, 2] = lsf_band_box records, n).  One host read of the count."""
+    grid = full_range(prepared.grid)
+    scratch = torch.empty(int(lib.lsf_band_boxes_scratch_elements(ctypes.byref(grid))), dtype=torch.int32,
+                          device=prepared._scratch.device)
+    count = torch.zeros(1, dtype=torch.int64, device=scratch.device)
+    p_prepare = ctypes.c_void_p(prepared._scratch.data_ptr())
+    check(lib.lsf_band_boxes_count(ctypes.byref(grid), p_prepare, ctypes.c_void_p(scratch.data_ptr()),
+                                   ctypes.c_void_p(count.data_ptr()), stream_ptr()), "lsf_band_boxes_count")
+    n = int(count.item())
+    boxes = torch.empty((max(n, 1), 2), dtype=torch.int64, device=scratch.device)
+    if n:
+        check(lib.lsf_band_boxes_fill(ctypes.byref(grid), p_prepare, ctypes.c_void_p(scratch.data_ptr()),
+                                      ctypes.c_void_p(boxes.data_ptr()), stream_ptr()), "lsf_band_boxes_fill")
+    return boxes, n
+
+
+def slavcheva_state_iteration_boxes(state_in, canonical, state_out, grid, params, gate, records, index, boxes, n_boxes):
+    """the fused iteration over the INTERIOR band voxels, box by box (lsf_slavcheva_state_iteration_boxes)"""
+    n = n_voxels(grid)
+    check(lib.lsf_slavcheva_state_iteration_boxes(_ptr(state_in, 4 * n, "state_in"), _ptr(canonical, n, "canonical"),
+                                                  _ptr(state_out, 4 * n, "state_out"), ctypes.byref(grid),
+                                                  ctypes.byref(params), _gate_ref(gate), _record_ptr(records, index),
+                                                  ctypes.c_void_p(boxes.data_ptr()), int(n_boxes), stream_ptr()),
+          "lsf_slavcheva_state_iteration_boxes")
+
+
 def full_range(grid):
     """the same grid with the launch range widened to every allocated slice"""
     g = Grid.from_buffer_copy(grid)

@@ -893,6 +893,14 @@ class _SparseStateExceeded(Exception):
 # The ping-pong states are initialised only where an iteration can read them while every update stays below this many
 # voxels (0 = everywhere, as before round 4), for volumes of at least SPARSE_MIN_VOXELS (below, a call is launch-bound and
 # the initialisation passes cost nothing next to it)
+# The library-enqueued call walks the INTERIOR band voxels box by box (lsf_slavcheva_state_iteration_boxes: neighbourhoods
+# staged through LDS) instead of entry by entry when the listed voxels of the two ping-pong states -- 32 bytes each -- cannot
+# stay in the 256 MB Infinity Cache between iterations: the list walk's 18 loads per voxel then miss to HBM and its L1s
+# stand at their in-flight limit (profiles/r05_pmc_l2_tcp.txt), the box walk's four coalesced loads per 64 voxels do not:
+# 120-125 against 138-144 us per 512^3 launch.  Below that the two are level (256^3: 30.8 us both) and the list walk needs
+# no boxes built.
+BOX_WALK_MIN_BAND_BYTES = 200 * 1000 * 1000
+BOX_WALK_MIN_VOXELS = 1 << 25  # (volumes below this never reach the band size above: the boxes are not even counted)
 SPARSE_REACH = int(os.environ.get("LSF_SPARSE_REACH", "2"))
 SPARSE_MIN_VOXELS = int(os.environ.get("LSF_SPARSE_MIN_VOXELS", str(1 << 21)))
 
@@ -931,6 +939,7 @@ class SlavchevaEngine:
         # whole-volume fixed-count calls are enqueued by the library in one piece (_optimize_run); False: the general path,
         # one foreign call per launch (tests hold the two against each other)
         self.library_run = True
+        self.box_walk = None  # None: by band size (BOX_WALK_MIN_BAND_BYTES); True / False: always / never (tests)
         self.iteration_count = 0
         self.log = None
         self._gradient_state = None
@@ -1747,8 +1756,8 @@ class SlavchevaEngine:
         states = [torch.empty(tuple(live.shape) + (4,), dtype=torch.float32, device=device) for _ in range(2)]
         scratch = torch.empty(int(_lib.lib.lsf_state_prepare_scratch_elements(ctypes.byref(whole))), dtype=torch.int32,
                               device=device)
-        totals = torch.empty(4, dtype=torch.int64, device=device)
-        totals_host = dev.pinned_scratch("run totals", 4, torch.int64)
+        totals = torch.empty(5, dtype=torch.int64, device=device)
+        totals_host = dev.pinned_scratch("run totals", 5, torch.int64)
         run = _lib.StateRun()
         run.live, run.canonical = dev._ptr(live, n, "live"), dev._ptr(canonical, n, "canonical")
         run.state[0], run.state[1] = states[0].data_ptr(), states[1].data_ptr()
@@ -1756,11 +1765,22 @@ class SlavchevaEngine:
         run.grid = whole
         run.sparse_reach = SPARSE_REACH if sparse else 0
         run.second_state_late = int(not sparse and n <= dev.StatePrepare.SPLIT_MAX_VOXELS)
+        count_boxes = dev.boxes_ok(whole) and (self.box_walk is True or
+                                               (self.box_walk is None and n >= BOX_WALK_MIN_VOXELS))
+        box_scratch = None
+        if count_boxes:
+            box_scratch = torch.empty(int(_lib.lib.lsf_band_boxes_scratch_elements(ctypes.byref(whole))),
+                                      dtype=torch.int32, device=device)
+            run.box_scratch = box_scratch.data_ptr()
         stream = dev.stream_ptr()
         _lib.check(_lib.lib.lsf_state_run_begin(ctypes.byref(run), stream), "lsf_state_run_begin")
         # (the card is writing the states now; the lists are sized from the totals the call waited for)
-        n_interior, n_boundary, opposite, first_opposite = totals_host.tolist()
+        n_interior, n_boundary, opposite, first_opposite, n_boxes = totals_host.tolist()
         lists = torch.empty(max(n_interior + n_boundary, 1), dtype=torch.int32, device=device)
+        boxes = None
+        if n_boxes and (self.box_walk is True or 32 * n_interior > BOX_WALK_MIN_BAND_BYTES):
+            boxes = torch.empty((n_boxes, 2), dtype=torch.int64, device=device)
+        self._box_walk_used = boxes is not None
         records = dev.new_records(iterations, device)
         n_words = iterations * _lib.RECORD_SLOTS * dev.USED_SLOT_WORDS
         words = torch.empty(n_words + 16, dtype=torch.int64, device=device)  # the records' used words, then the statistics
@@ -1777,7 +1797,8 @@ class SlavchevaEngine:
         p_lists = lists.data_ptr()
         _lib.check(_lib.lib.lsf_state_run_finish(
             ctypes.byref(run), ctypes.byref(self.params), ctypes.c_void_p(p_lists),
-            ctypes.c_void_p(p_lists + 4 * n_interior), ctypes.c_void_p(records.data_ptr()), iterations,
+            ctypes.c_void_p(p_lists + 4 * n_interior), ctypes.c_void_p(boxes.data_ptr() if boxes is not None else 0),
+            ctypes.c_void_p(records.data_ptr()), iterations,
             dev._ptr(target, n, "live_out"), float(lower_threshold),
             ctypes.c_void_p(stats.data_ptr()) if statistics else none,
             ctypes.c_void_p(stats_scratch.data_ptr()) if statistics else none, ctypes.c_void_p(words.data_ptr()),
@@ -1791,7 +1812,7 @@ class SlavchevaEngine:
         if n_boundary or not bands:
             bands.append(dev.BandList(lists[n_interior:] if n_boundary else lists[:1], n_boundary, _lib.BAND_BOUNDARY))
         f = _Counted(sum(b.count for b in bands))
-        f.bands, f.records = bands, records
+        f.bands, f.records, f.boxes = bands, records, boxes
         self._fast = f
         self.iteration_count = n_exec
         wd, ws, wl = self.weights

@@ -29,8 +29,9 @@ def write_stats():
     table = list(csv.DictReader(open(stats)))
     for row in table:
         name = short(row["Name"])
-        if name.startswith("slavcheva_state_kernel"):
-            walk = "dense" if name.rstrip(">").endswith(" 0") else "list"
+        if name.startswith(("slavcheva_state_kernel", "slavcheva_state_box_kernel")):
+            # the band walk of the step: the list kernel, or the box kernel where the engine picks it (512^3)
+            walk = "dense" if name.startswith("slavcheva_state_kernel") and name.rstrip(">").endswith(" 0") else "list"
             if walk not in KERNEL_AVERAGES or int(row["Calls"]) > KERNEL_AVERAGES[walk][1]:
                 KERNEL_AVERAGES[walk] = (float(row["AverageNs"]) / 1e3, int(row["Calls"]))
     with open(os.path.join(out_dir, tag + "_bench_kernel_stats.csv"), "w") as f:
@@ -72,9 +73,10 @@ for run, subs in (("calibration", ("cal_fetch", "cal_write")), ("bench", ("pmc_f
             if run == "calibration" and kernel.startswith(("hier_update_kernel", "state_unpack_kernel",
                                                            "state_pack_kernel")):
                 cal[(kernel.split("<")[0], counter)] = mean
-            elif run == "bench" and "slavcheva_state_kernel" in kernel:
-                # last template argument: 0 dense walk, 1 list, 2 interior list (the bench's band list)
-                walk = "dense" if kernel.rstrip(">").endswith(" 0") else "list"
+            elif run == "bench" and ("slavcheva_state_kernel" in kernel or "slavcheva_state_box_kernel" in kernel):
+                # last template argument: 0 dense walk, 1 list, 2 interior list (the bench's band list); the box kernel
+                # stands for the band walk where the engine picks it
+                walk = "dense" if "slavcheva_state_kernel" in kernel and kernel.rstrip(">").endswith(" 0") else "list"
                 fused[walk][counter] = (mean, len(vals))
             else:
                 continue
