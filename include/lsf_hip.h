@@ -401,9 +401,11 @@ typedef struct lsf_band_box {
     uint64_t mask;
 } lsf_band_box;
 int64_t lsf_band_boxes_scratch_elements(const lsf_grid *grid);
-int lsf_band_boxes_count(const lsf_grid *grid, const int32_t *prepare_scratch, int32_t *box_scratch, int64_t *count_out,
-                         void *stream);
-int lsf_band_boxes_fill(const lsf_grid *grid, const int32_t *prepare_scratch, const int32_t *box_scratch,
+/* subset: LSF_BAND_INTERIOR (the boxes of lsf_slavcheva_state_iteration_boxes) or LSF_BAND_ALL (every band voxel, those on
+ * the faces included: lsf_sobolev_state_update_boxes); the same value in both calls */
+int lsf_band_boxes_count(const lsf_grid *grid, int32_t subset, const int32_t *prepare_scratch, int32_t *box_scratch,
+                         int64_t *count_out, void *stream);
+int lsf_band_boxes_fill(const lsf_grid *grid, int32_t subset, const int32_t *prepare_scratch, const int32_t *box_scratch,
                         lsf_band_box *boxes, void *stream);
 int lsf_slavcheva_state_iteration_boxes(const float *state_in, const float *canonical, float *state_out,
                                         const lsf_grid *grid, const lsf_slavcheva_params *params, const lsf_gate *gate,
@@ -464,7 +466,8 @@ int lsf_state_run_finish(const lsf_state_run *run, const lsf_slavcheva_params *p
  * fields -- same results -- with one vector-memory instruction per neighbour / tap instead of one per component:
  *   state  float4 [z][y][x] = (live, u, v, w)        as lsf_slavcheva_state_iteration (two ping-pong copies, both
  *                                                    (live, 0) at unlisted voxels: lsf_state_prepare / lsf_state_pack)
- *   g4     float4 [z][y][x] = (g_x, g_y, g_z, m)     raw gradient (m = 0), filter intermediates (m = mask bits), final gradient; the caller
+ *   g4     float4 [z][y][x] = (g_x, g_y, g_z, m)     raw gradient (m = 0), filter intermediates (m = mask bits 1 | 2 | 4 of the
+ *                                                    three components, 8: a listed voxel), final gradient (m = 0); the caller
  *                                                    zero-initialises them once (unlisted voxels are never written)
  * One iteration = lsf_sobolev_state_gradient, lsf_convolve_axis_listed4 for every axis but the last (3-D: x, y; 2-D: y),
  * lsf_sobolev_state_update for the last (3-D: z, 2-D: x) -- each once per band list (ascending voxel indices of any
@@ -501,6 +504,19 @@ int lsf_sobolev_state_update(const float *in4, const float *zero_mask_source4, c
                              const double *taps_host, int32_t n_taps, const lsf_gate *gate,
                              lsf_iteration_record *record, const int32_t *band_list, int64_t band_count,
                              int32_t first_list, void *stream);
+/* 3-D whole volumes: everything behind the FIRST pass in ONE launch, box by box -- the y pass, the z pass, the update and the
+ * re-warp of slavcheva_optimizer2d.py:208-236 / math_utils/convolution.py:94-132 / field_warping.py:112-151, i.e. what
+ * lsf_convolve_axis_listed4(in4, tmp, NULL, axis 1) followed by lsf_sobolev_state_update(tmp, NULL, ..., axis 2, ...,
+ * first_list = 1) over one list of the whole band leave in state_out, g_out4 and the record, bit for bit, without `tmp`:
+ * a wave stages the x-filtered gradient of a box's filter footprint (4 x (4 + 2c) x (4 + 2c) float4, c = n_taps / 2) and
+ * the state's shell of the box through LDS.  in4: the output of
+ * lsf_sobolev_state_gradient_x (bit 8 of its fourth component marks a listed voxel); g_out4 must not be in4 (other boxes
+ * still read it) and may be NULL; boxes: lsf_band_boxes_count / _fill with LSF_BAND_ALL.  Requires dims = 3, extents that
+ * are multiples of 4, the whole array as launch range, nz * ny * nx < 2^27 (LSF_ERR_BAD_DIMS otherwise). */
+int lsf_sobolev_state_update_boxes(const float *in4, const float *state_in, float *state_out, float *g_out4,
+                                   const lsf_grid *grid, const lsf_slavcheva_params *params, const double *taps_host,
+                                   int32_t n_taps, const lsf_gate *gate, lsf_iteration_record *record,
+                                   const lsf_band_box *boxes, int64_t box_count, void *stream);
 
 /* ---- z-slab runtime of the fused path for multi-GPU runs (new design) -----------------------------
  * One process per GPU; rank r owns z-slices [z_begin, z_end) of its local array and keeps `halo` slices of its

@@ -22,7 +22,7 @@ ABI_VERSION = 3
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "ef19ddc4ab43e074"
+HEADER_ABI_HASH = "3cc8065dbb02fcd2"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -178,8 +178,8 @@ PROTOTYPES = {
     "lsf_slavcheva_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp,
                                                      _vp, _i64, _i32, _vp]),
     "lsf_band_boxes_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
-    "lsf_band_boxes_count": (ctypes.c_int, [_P(Grid), _vp, _vp, _vp, _vp]),
-    "lsf_band_boxes_fill": (ctypes.c_int, [_P(Grid), _vp, _vp, _vp, _vp]),
+    "lsf_band_boxes_count": (ctypes.c_int, [_P(Grid), ctypes.c_int32, _vp, _vp, _vp, _vp]),
+    "lsf_band_boxes_fill": (ctypes.c_int, [_P(Grid), ctypes.c_int32, _vp, _vp, _vp, _vp]),
     "lsf_slavcheva_state_iteration_boxes": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp, _vp,
                                                            _i64, _vp]),
     "lsf_state_run_begin": (ctypes.c_int, [_P(StateRun), _vp]),
@@ -209,6 +209,8 @@ PROTOTYPES = {
                                                  _i64, _vp]),
     "lsf_sobolev_state_update": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _i32,
                                                 _P(ctypes.c_double), _i32, _P(Gate), _vp, _vp, _i64, _i32, _vp]),
+    "lsf_sobolev_state_update_boxes": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),
+                                                      _P(ctypes.c_double), _i32, _P(Gate), _vp, _vp, _i64, _vp]),
     "lsf_slavcheva_update_rewarp": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams),
                                                    _P(Gate), _vp, _vp, _i64, _vp]),
     "lsf_warp_statistics": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _f32, _vp, _vp]),

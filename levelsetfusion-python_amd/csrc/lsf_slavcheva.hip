@@ -829,7 +829,7 @@ namespace {
 constexpr int kBoxGroup = kBlock;  // boxes per block = per count of the scan
 
 __device__ inline unsigned long long box_mask_of(const unsigned long long* __restrict__ masks, unsigned box, int nbx,
-                                                 int nby, int nx, int ny) {
+                                                 int nby, int nx, int ny, bool all) {
     const int bx = (int)(box % (unsigned)nbx), by = (int)((box / (unsigned)nbx) % (unsigned)nby);
     const int bz = (int)(box / ((unsigned)nbx * (unsigned)nby));
     unsigned long long m = 0ull;
@@ -838,7 +838,8 @@ __device__ inline unsigned long long box_mask_of(const unsigned long long* __res
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const unsigned v = (unsigned)(((4 * bz + k) * ny + 4 * by + j) * nx + 4 * bx);
-            const unsigned long long word = masks[2 * (size_t)(v >> 6)];  // [2 W + 0]: the INTERIOR ballot of voxels 64 W ...
+            // [2 W + 0]: the INTERIOR ballot of voxels 64 W ..., [2 W + 1]: the BOUNDARY ballot (all: their union)
+            const unsigned long long word = masks[2 * (size_t)(v >> 6)] | (all ? masks[2 * (size_t)(v >> 6) + 1] : 0ull);
             m |= ((word >> (v & 63u)) & 0xFull) << (4 * (k * 4 + j));
         }
     return m;
@@ -846,12 +847,12 @@ __device__ inline unsigned long long box_mask_of(const unsigned long long* __res
 
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void band_boxes_kernel(const unsigned long long* __restrict__ masks, unsigned n_boxes,
-                                                            int nbx, int nby, int nx, int ny, int* __restrict__ group_sums,
-                                                            lsf_band_box* __restrict__ boxes) {
+                                                            int nbx, int nby, int nx, int ny, bool all,
+                                                            int* __restrict__ group_sums, lsf_band_box* __restrict__ boxes) {
     __shared__ int wave_count[kBlock / kWave];
     const unsigned box = blockIdx.x * kBoxGroup + threadIdx.x;
     const int lane = threadIdx.x % kWave, wave = threadIdx.x / kWave;
-    const unsigned long long m = box < n_boxes ? box_mask_of(masks, box, nbx, nby, nx, ny) : 0ull;
+    const unsigned long long m = box < n_boxes ? box_mask_of(masks, box, nbx, nby, nx, ny, all) : 0ull;
     const unsigned long long any = __ballot(m != 0ull);
     if (lane == 0) wave_count[wave] = __popcll(any);
     __syncthreads();
@@ -888,34 +889,36 @@ extern "C" int64_t lsf_band_boxes_scratch_elements(const lsf_grid* grid) {
     return (n_boxes + kBoxGroup - 1) / kBoxGroup + 1;
 }
 
-extern "C" int lsf_band_boxes_count(const lsf_grid* grid, const int32_t* prepare_scratch, int32_t* box_scratch,
-                                    int64_t* count_out, void* stream) {
+extern "C" int lsf_band_boxes_count(const lsf_grid* grid, int32_t subset, const int32_t* prepare_scratch,
+                                    int32_t* box_scratch, int64_t* count_out, void* stream) {
     if (int e = check_grid(grid)) return e;
     if (!boxes_ok(grid)) return LSF_ERR_BAD_DIMS;
-    if (!prepare_scratch || !box_scratch || !count_out) return LSF_ERR_BAD_ARGUMENT;
+    if (!prepare_scratch || !box_scratch || !count_out || (subset != LSF_BAND_INTERIOR && subset != LSF_BAND_ALL))
+        return LSF_ERR_BAD_ARGUMENT;
     unsigned first, n, chunks;
     band_range(grid, first, n, chunks);
     const unsigned n_boxes = n / 64, groups = (n_boxes + kBoxGroup - 1) / kBoxGroup;
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(band_boxes_kernel<false>, dim3(groups), dim3(kBlock), 0, s,
                        prepare_masks(const_cast<int32_t*>(prepare_scratch), chunks), n_boxes, grid->nx / 4, grid->ny / 4,
-                       grid->nx, grid->ny, box_scratch, (lsf_band_box*)nullptr);
+                       grid->nx, grid->ny, subset == LSF_BAND_ALL, box_scratch, (lsf_band_box*)nullptr);
     hipLaunchKernelGGL(band_scan_kernel, dim3(1), dim3(1024), 0, s, box_scratch, groups, 0u, 1u, (long long*)count_out,
                        (const int*)nullptr);
     return launch_status();
 }
 
-extern "C" int lsf_band_boxes_fill(const lsf_grid* grid, const int32_t* prepare_scratch, const int32_t* box_scratch,
-                                   lsf_band_box* boxes, void* stream) {
+extern "C" int lsf_band_boxes_fill(const lsf_grid* grid, int32_t subset, const int32_t* prepare_scratch,
+                                   const int32_t* box_scratch, lsf_band_box* boxes, void* stream) {
     if (int e = check_grid(grid)) return e;
     if (!boxes_ok(grid)) return LSF_ERR_BAD_DIMS;
-    if (!prepare_scratch || !box_scratch || !boxes) return LSF_ERR_BAD_ARGUMENT;
+    if (!prepare_scratch || !box_scratch || !boxes || (subset != LSF_BAND_INTERIOR && subset != LSF_BAND_ALL))
+        return LSF_ERR_BAD_ARGUMENT;
     unsigned first, n, chunks;
     band_range(grid, first, n, chunks);
     const unsigned n_boxes = n / 64, groups = (n_boxes + kBoxGroup - 1) / kBoxGroup;
     hipLaunchKernelGGL(band_boxes_kernel<true>, dim3(groups), dim3(kBlock), 0, as_stream(stream),
                        prepare_masks(const_cast<int32_t*>(prepare_scratch), chunks), n_boxes, grid->nx / 4, grid->ny / 4,
-                       grid->nx, grid->ny, const_cast<int32_t*>(box_scratch), boxes);
+                       grid->nx, grid->ny, subset == LSF_BAND_ALL, const_cast<int32_t*>(box_scratch), boxes);
     return launch_status();
 }
 

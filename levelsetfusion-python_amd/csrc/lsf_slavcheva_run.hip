@@ -58,7 +58,7 @@ extern "C" int lsf_state_run_begin(const lsf_state_run* run, void* stream) {
         return e;
     // (optional) the boxes of the box walk are counted behind the pass, so that their number comes back with the list sizes
     if (run->box_scratch) {
-        if (int e = lsf_band_boxes_count(g, run->prepare_scratch, run->box_scratch, run->totals_device + 4, stream)) return e;
+        if (int e = lsf_band_boxes_count(g, LSF_BAND_INTERIOR, run->prepare_scratch, run->box_scratch, run->totals_device + 4, stream)) return e;
     } else if (hipMemsetAsync(run->totals_device + 4, 0, sizeof(int64_t), s) != hipSuccess) {
         return (int)hipGetLastError();
     }
@@ -115,7 +115,7 @@ extern "C" int lsf_state_run_finish(const lsf_state_run* run, const lsf_slavchev
     // when the band's states do not fit the Infinity Cache)
     const int64_t n_boxes = boxes && run->box_scratch ? run->totals_host[4] : 0;
     if (n_boxes > 0)
-        if (int e = lsf_band_boxes_fill(g, run->prepare_scratch, run->box_scratch, boxes, stream)) return e;
+        if (int e = lsf_band_boxes_fill(g, LSF_BAND_INTERIOR, run->prepare_scratch, run->box_scratch, boxes, stream)) return e;
     // the iterations: ungated (a fixed count), iteration i reads state[i % 2] and writes the other
     for (int32_t i = 0; i < iterations; ++i)
         for (int k = 0; k < n_lists; ++k) {

@@ -162,8 +162,9 @@ __global__ __launch_bounds__(kBlock) void sobolev_state_gradient_x_kernel(const 
                     acc[2] = mac<FMA>(acc[2], k, (double)v.z);
                 }
             }
+            // (8: a listed voxel -- what lsf_sobolev_state_update_boxes tells from the zeros nobody ever wrote)
             const unsigned bits = (fabsf(raw.x) < 1e-6f ? 1u : 0u) | (fabsf(raw.y) < 1e-6f ? 2u : 0u) |
-                                  (fabsf(raw.z) < 1e-6f ? 4u : 0u);
+                                  (fabsf(raw.z) < 1e-6f ? 4u : 0u) | 8u;
             vf4 o;
             o.x = (bits & 1u) ? 0.0f : (float)acc[0];
             o.y = (bits & 2u) ? 0.0f : (float)acc[1];
@@ -209,7 +210,7 @@ __device__ inline vf4 filtered_at(const vf4* __restrict__ in, const vf4* __restr
         acc[2] = mac<FMA>(acc[2], taps.k[j], (double)v[j].z);
     }
     unsigned bits;
-    if (mask_src) bits = (fabsf(m.x) < 1e-6f ? 1u : 0u) | (fabsf(m.y) < 1e-6f ? 2u : 0u) | (fabsf(m.z) < 1e-6f ? 4u : 0u);
+    if (mask_src) bits = (fabsf(m.x) < 1e-6f ? 1u : 0u) | (fabsf(m.y) < 1e-6f ? 2u : 0u) | (fabsf(m.z) < 1e-6f ? 4u : 0u) | 8u;
     else bits = __float_as_uint(v[c].w);  // the centre tap of the previous pass's output
     vf4 o;
     o.x = (bits & 1u) ? 0.0f : (float)acc[0];

@@ -685,20 +685,20 @@ def boxes_ok(grid):
             and n_voxels(grid) <= 0x0fffffff)
 
 
-def band_boxes(prepared):
-    """the INTERIOR band voxels of a StatePrepare as boxes (lsf_band_boxes_count / _fill, from the ballots the counting pass
-    kept): (int64 tensor [n, 2] = lsf_band_box records, n).  One host read of the count."""
+def band_boxes(prepared, subset=_lib.BAND_INTERIOR):
+    """the INTERIOR (or, subset = BAND_ALL, all) band voxels of a StatePrepare as boxes (lsf_band_boxes_count / _fill, from
+    the ballots the counting pass kept): (int64 tensor [n, 2] = lsf_band_box records, n).  One host read of the count."""
     grid = full_range(prepared.grid)
     scratch = torch.empty(int(lib.lsf_band_boxes_scratch_elements(ctypes.byref(grid))), dtype=torch.int32,
                           device=prepared._scratch.device)
     count = torch.zeros(1, dtype=torch.int64, device=scratch.device)
     p_prepare = ctypes.c_void_p(prepared._scratch.data_ptr())
-    check(lib.lsf_band_boxes_count(ctypes.byref(grid), p_prepare, ctypes.c_void_p(scratch.data_ptr()),
+    check(lib.lsf_band_boxes_count(ctypes.byref(grid), subset, p_prepare, ctypes.c_void_p(scratch.data_ptr()),
                                    ctypes.c_void_p(count.data_ptr()), stream_ptr()), "lsf_band_boxes_count")
     n = int(count.item())
     boxes = torch.empty((max(n, 1), 2), dtype=torch.int64, device=scratch.device)
     if n:
-        check(lib.lsf_band_boxes_fill(ctypes.byref(grid), p_prepare, ctypes.c_void_p(scratch.data_ptr()),
+        check(lib.lsf_band_boxes_fill(ctypes.byref(grid), subset, p_prepare, ctypes.c_void_p(scratch.data_ptr()),
                                       ctypes.c_void_p(boxes.data_ptr()), stream_ptr()), "lsf_band_boxes_fill")
     return boxes, n
 

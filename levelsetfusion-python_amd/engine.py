@@ -771,12 +771,14 @@ class _SobolevStatePlan:
     """launch arguments of the SobolevFusion iteration on the float4 layouts (lsf_sobolev_state.hip), materialised once per
     optimize() call: iteration i reads states[i % 2] and writes the other; g4 = [raw gradient, filter buffer A, filter
     buffer B] (float4, zero-initialised: unlisted voxels are never written).  3-D: gradient -> raw, x pass raw -> A,
-    y pass A -> B, z pass + update + re-warp B -> final gradient in A; 2-D: y pass raw -> A, x pass + update A -> B."""
+    y pass A -> B, z pass + update + re-warp B -> final gradient in A; 2-D: y pass raw -> A, x pass + update A -> B.
+    3-D whole volumes with `boxes` (the band's LSF_BAND_ALL boxes): gradient + x pass -> A, then y pass, z pass, update and
+    re-warp in ONE launch box by box (lsf_sobolev_state_update_boxes), final gradient in B."""
 
     STRIPS = 8  # row bands of the strip-major list the z pass walks (8 / 16 / 32 measured: profiles/r04_probe_sobolev_sweep.txt)
 
     def __init__(self, launcher, states, canonical, grid, params, bands, g4, taps, min_iterations, iterations_hint=0,
-                 gradient_every_iteration=True):
+                 gradient_every_iteration=True, boxes=None):
         f = self.f = launcher
         n = dev.n_voxels(grid)
         self.p_state = [f.pointer(t, 4 * n, "state") for t in states]
@@ -808,6 +810,12 @@ class _SobolevStatePlan:
             self.bands_first = [dev.BandList(merged, merged.numel(), _lib.BAND_ALL)]
         # index of the buffer that holds the final gradient
         self.final = (0 if self.fused_x else 1) if grid.dims == 3 else 2
+        self.boxes = boxes if self.fused_x else None  # (tensor [n, 2] int64, n)
+        if self.boxes is not None:
+            self.final = 1
+            self.p_boxes = ctypes.c_void_p(self.boxes[0].data_ptr())
+            self.bands_last = self.bands
+            return
         # The LAST pass runs along z: its seven taps lie in seven slices.  In list order an XCD sweeps a z-range with a
         # window of ~2 slices of the band in flight, its 4 MB L2 cannot keep seven slices of five streams, and every tap
         # comes through the fabric (237 MB per launch at 256^3 against 130 MB of compulsory traffic: the kernel ran at the
@@ -855,6 +863,12 @@ class _SobolevStatePlan:
                 check(lib.lsf_sobolev_state_gradient_x(s_in, self.p_canon, a, f.grid_ref, self.params_ref, self.p_taps,
                                                        self.n_taps, gate, rec, band.pointer, band.count, self.stream),
                       "lsf_sobolev_state_gradient_x")
+            if self.boxes is not None:
+                keep = self.last_iteration is None or i == self.last_iteration
+                check(lib.lsf_sobolev_state_update_boxes(a, s_in, s_out, b if keep else none, f.grid_ref, self.params_ref,
+                                                         self.p_taps, self.n_taps, gate, rec, self.p_boxes,
+                                                         self.boxes[1], self.stream), "lsf_sobolev_state_update_boxes")
+                return
             src, dst, axes = a, b, self.axes[1:-1]
         else:
             raw, a, b = self.p_g
@@ -940,6 +954,7 @@ class SlavchevaEngine:
         # one foreign call per launch (tests hold the two against each other)
         self.library_run = True
         self.box_walk = None  # None: by band size (BOX_WALK_MIN_BAND_BYTES); True / False: always / never (tests)
+        self.sobolev_boxes = True  # SobolevFusion on whole 3-D volumes: y pass, z pass and update box by box (False: lists)
         self.iteration_count = 0
         self.log = None
         self._gradient_state = None
@@ -1642,8 +1657,15 @@ class SlavchevaEngine:
                       for _ in range(2 if _SobolevStatePlan.fuses_x(grid) else 3)]
                 n_max = max(self.max_iterations, self.min_iterations)
                 every = self.iteration_hook is not None or self.min_iterations < n_max
+                # whole 3-D volumes of whole boxes: everything behind the x pass box by box in one launch
+                boxes = None
+                if (fused_prepare and not slab and self.sobolev_boxes and _SobolevStatePlan.fuses_x(grid)
+                        and dev.boxes_ok(grid) and dev.n_voxels(grid) < (1 << 27)
+                        and len(self.sobolev_kernel) in dev.LISTED_TAP_COUNTS):
+                    boxes = dev.band_boxes(prepared, _lib.BAND_ALL)
+                self._sobolev_boxes_used = boxes is not None
                 sob = _SobolevStatePlan(f, states, canonical, grid, self.params, bands, g4, self.sobolev_kernel,
-                                        self.min_iterations, n_max, gradient_every_iteration=every)
+                                        self.min_iterations, n_max, gradient_every_iteration=every, boxes=boxes)
                 self._sobolev_band = _Counted(sum(b.count for b in bands))  # what bench.py prices this path over
             if slab:
                 self._plan_slab(f, live, grid, bands, 0 if self.min_iterations == 0

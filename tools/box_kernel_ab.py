@@ -30,11 +30,11 @@ band = [b for b in bands if b.subset == _lib.BAND_INTERIOR][0]
 L = _lib.lib
 box_scratch = torch.empty(int(L.lsf_band_boxes_scratch_elements(ctypes.byref(grid))), dtype=torch.int32, device="cuda")
 count = torch.zeros(1, dtype=torch.int64, device="cuda")
-_lib.check(L.lsf_band_boxes_count(ctypes.byref(grid), prep._scratch.data_ptr(), box_scratch.data_ptr(), count.data_ptr(),
+_lib.check(L.lsf_band_boxes_count(ctypes.byref(grid), _lib.BAND_INTERIOR, prep._scratch.data_ptr(), box_scratch.data_ptr(), count.data_ptr(),
                                   dev.stream_ptr()), "lsf_band_boxes_count")
 n_boxes = int(count.item())
 boxes = torch.empty((n_boxes, 2), dtype=torch.int64, device="cuda")
-_lib.check(L.lsf_band_boxes_fill(ctypes.byref(grid), prep._scratch.data_ptr(), box_scratch.data_ptr(), boxes.data_ptr(),
+_lib.check(L.lsf_band_boxes_fill(ctypes.byref(grid), _lib.BAND_INTERIOR, prep._scratch.data_ptr(), box_scratch.data_ptr(), boxes.data_ptr(),
                                  dev.stream_ptr()), "lsf_band_boxes_fill")
 torch.cuda.synchronize()
 # the boxes hold exactly the list's voxels
