@@ -269,7 +269,9 @@ def extra_workload(args, device, world, rank, dist):
         b_alg = 76
         name = "3D %d^3 SobolevFusion-style SlavchevaOptimizer3d (Tikhonov + 7-tap Sobolev), %d iterations" % (n, iters)
         note = "rate over the voxels the launches VISIT (the band list; the gradient is zero elsewhere and the " \
-               "zero-preserving filter keeps it there) x B_alg (76 B), all five kernels of the iteration together"
+               "zero-preserving filter keeps it there) x B_alg (76 B), both kernels of the iteration together " \
+               "(sobolev_state_gradient_x_kernel: gradient + x pass over the band list; sobolev_state_box_kernel: y pass, z " \
+               "pass, update and re-warp box by box through LDS)"
     else:
         full = args.workload in ("hier-full", "multiframe")
         # tikhonov_strength 0.05: the reference's recurrence diverges for strength >= 1/12 in 3-D

@@ -483,11 +483,15 @@ int lsf_sobolev_state_gradient(const float *state, const float *canonical, float
 /* 3-D: lsf_sobolev_state_gradient and the x pass (the FIRST pass of a volume, math_utils/convolution.py:94-105) in ONE
  * launch: out4 = what lsf_convolve_axis_listed4(raw, out4, raw, axis 0) would hold, bit for bit, mask bits included; the
  * raw gradient is never stored.  band_list must then hold EVERY band voxel whose gradient can be non-zero (one
- * ascending list of the whole band, e.g. LSF_BAND_ALL): a tap at a voxel that is not in THIS list counts as zero. */
+ * ascending list of the whole band, e.g. LSF_BAND_ALL): a tap at a voxel that is not in THIS list counts as zero.
+ * out_bricks != 0 (extents that are multiples of 4: LSF_ERR_BAD_DIMS otherwise): out4 is laid out in BRICKS of 4 x 4 x 4
+ * voxels, 1 KB each -- voxel (x, y, z) at float4 index (((z/4 * ny/4 + y/4) * nx/4 + x/4) * 64 + (z%4 * 4 + y%4) * 4 + x%4)
+ * --, the layout lsf_sobolev_state_update_boxes stages its footprints from (a box's footprint is then 23 contiguous pieces
+ * instead of 100 rows of 64 bytes a row's pitch apart). */
 int lsf_sobolev_state_gradient_x(const float *state, const float *canonical, float *out4, const lsf_grid *grid,
                                  const lsf_slavcheva_params *params, const double *taps_host, int32_t n_taps,
                                  const lsf_gate *gate, lsf_iteration_record *record, const int32_t *band_list,
-                                 int64_t band_count, void *stream);
+                                 int64_t band_count, int32_t out_bricks, void *stream);
 int lsf_convolve_axis_listed4(const float *in4, float *out4, const float *zero_mask_source4, const lsf_grid *grid,
                               int32_t axis, const double *taps_host, int32_t n_taps, const lsf_gate *gate,
                               const int32_t *band_list, int64_t band_count, void *stream);
@@ -510,7 +514,8 @@ int lsf_sobolev_state_update(const float *in4, const float *zero_mask_source4, c
  * first_list = 1) over one list of the whole band leave in state_out, g_out4 and the record, bit for bit, without `tmp`:
  * a wave stages the x-filtered gradient of a box's filter footprint (4 x (4 + 2c) x (4 + 2c) float4, c = n_taps / 2) and
  * the state's shell of the box through LDS.  in4: the output of
- * lsf_sobolev_state_gradient_x (bit 8 of its fourth component marks a listed voxel); g_out4 must not be in4 (other boxes
+ * lsf_sobolev_state_gradient_x with out_bricks = 1 (bit 8 of its fourth component marks a listed voxel; every other brick
+ * zero); g_out4 ([z][y][x] like the states) must not be in4 (other boxes
  * still read it) and may be NULL; boxes: lsf_band_boxes_count / _fill with LSF_BAND_ALL.  Requires dims = 3, extents that
  * are multiples of 4, the whole array as launch range, nz * ny * nx < 2^27 (LSF_ERR_BAD_DIMS otherwise). */
 int lsf_sobolev_state_update_boxes(const float *in4, const float *state_in, float *state_out, float *g_out4,

@@ -4,7 +4,10 @@
 // the y-filtered gradient and read it back seven times.  Here a wave owns a box of 4 x 4 x 4 band voxels (lsf_band_box of
 // the LSF_BAND_ALL subset) and copies by LDS-DMA, straight into its own LDS image,
 //   * the x-filtered gradient of the box's filter footprint: 4 (x) by 4 + 2c (y) by 4 + 2c (z) float4 (c = taps / 2;
-//     400 of them for seven taps: seven wave-loads),
+//     400 of them for seven taps: seven wave-loads) -- out of a gradient buffer laid out in BRICKS of 4 x 4 x 4 voxels
+//     (lsf_sobolev_state_gradient_x writes it so): the footprint is the box's own brick and slabs of its 8 y / z
+//     neighbours, 23 contiguous pieces of 192 B to 1 KB instead of 100 rows of 64 B a row's pitch (4 KB at 256^3) apart.
+//     The kernel is bound by the NUMBER of cache-line requests a box makes, not by their bytes,
 //   * the state's 6 x 6 x 6 shell of the box (four wave-loads) for the re-warp's cell,
 // runs the y pass for the 4 x 4 x (4 + 2c) voxels the z pass will read (their results stay in LDS), the z pass for its own
 // 64, and the update + re-warp of sobolev_state_update_kernel.  Every tap is an LDS read at a compile-time offset from a
@@ -29,6 +32,9 @@ constexpr int kShellLoads = (kShell + kWave - 1) / kWave;                       
 // shell is staged as the 216 LIVE values only (four bytes per slot): 9.2 KB per wave with seven taps, sixteen waves per CU
 // (8 waves of 15.3 KB images -- float4 shell, separate y buffer -- took 49 us per 256^3 launch against 45.6 for the two list
 // kernels this replaces).
+#ifndef LSF_SOB_PROBE
+#define LSF_SOB_PROBE 0  // measurements only: 1: no y pass, 2: the z pass reads its centre tap seven times, 4: no footprint staged, 8: a made-up gradient, 16: nothing stored, 32: no shell staged
+#endif
 #ifndef LSF_SOBOLEV_BOX_WAVES
 #define LSF_SOBOLEV_BOX_WAVES 16
 #endif
@@ -103,10 +109,13 @@ __global__ __launch_bounds__(Footprint<NT>::threads) void sobolev_state_box_kern
     const int last_voxel = g.nz * sz - 1;
     if (wave == 0) {
 #pragma unroll
-        for (int j = 0; j < F::loads; ++j) {  // footprint slot k = (dz * E + dy) * 4 + dx, relative to its lowest corner
+        for (int j = 0; j < F::loads; ++j) {
+            // footprint slot k = (dz * E + dy) * 4 + dx holds voxel (x0 + dx, y0 - c + dy, z0 - c + dz); the gradient lies in
+            // bricks of 4 x 4 x 4 (lsf_sobolev_state_gradient_x, out_bricks): offset relative to the box's own brick
             int k = (int)lane + kWave * j;
             k = k < F::slots ? k : F::slots - 1;
-            s_goff[lane][j] = (k / (4 * E)) * sz + ((k / 4) % E) * sy + k % 4;
+            const int ry = (k / 4) % E - c, rz = k / (4 * E) - c;  // relative to the box's corner: -c .. 3 + c
+            s_goff[lane][j] = (((rz >> 2) * (g.ny >> 2) + (ry >> 2)) * (g.nx >> 2)) * 64 + (((rz & 3) << 4) | ((ry & 3) << 2) | (k % 4));
         }
 #pragma unroll
         for (int j = 0; j < kShellLoads; ++j) {
@@ -131,15 +140,25 @@ __global__ __launch_bounds__(Footprint<NT>::threads) void sobolev_state_box_kern
     const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         g_out ? g_out : state_out, 0, g_out ? (int)((unsigned)(last_voxel + 1) * 16u) : 0, 0x00020000);
 
-    unsigned u = w.unit(wave);
+    // a box's header is fetched one round ahead, by scalar loads (the unit number is wave-uniform and is made to look so):
+    // nothing in a round waits for memory but the staged data
+    auto header = [&](unsigned unit) { return boxes[unit < box_count ? unit : box_count - 1u]; };
+    unsigned u = (unsigned)__builtin_amdgcn_readfirstlane((int)w.unit(wave));
+    lsf_band_box b = {0, 0, 0ull};
+    if (box_count) b = header(u);
     while (u < w.x_end && u < box_count) {
-        const lsf_band_box b = boxes[u];  // wave-uniform: scalar loads
+        // the next box of this wave: an LDS atomic and its header's scalar loads, issued BEFORE the staging loads (the
+        // compiler makes every LDS operation behind an LDS-DMA load wait for the whole vector-memory counter)
+        unsigned next = 0u;
+        if (lane == 0) next = atomicAdd(&s_next_unit, 1u);
+        next = w.unit((unsigned)__builtin_amdgcn_readfirstlane((int)next));
+        const lsf_band_box b_next = header(next);
         int x0, y0, z0;
         decode_voxel(g, (unsigned)b.origin, x0, y0, z0);
         {
-            const int corner = b.origin - c * sy - c * sz;
+            const int corner = (((z0 >> 2) * (g.ny >> 2) + (y0 >> 2)) * (g.nx >> 2) + (x0 >> 2)) * 64;  // the box's brick
 #pragma unroll
-            for (int j = 0; j < F::loads; ++j) {
+            for (int j = 0; j < (LSF_SOB_PROBE & 4 ? 0 : F::loads); ++j) {
                 int v = corner + s_goff[lane][j];
                 v = v < 0 ? 0 : (v > last_voxel ? last_voxel : v);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gx + v),
@@ -147,17 +166,13 @@ __global__ __launch_bounds__(Footprint<NT>::threads) void sobolev_state_box_kern
             }
             const int shell_corner = b.origin - 1 - sy - sz;
 #pragma unroll
-            for (int j = 0; j < kShellLoads; ++j) {
+            for (int j = 0; j < (LSF_SOB_PROBE & 32 ? 0 : kShellLoads); ++j) {
                 int v = shell_corner + s_goff[lane][F::loads + j];
                 v = v < 0 ? 0 : (v > last_voxel ? last_voxel : v);
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(state_in + v),
                                                  (__attribute__((address_space(3))) void*)(shell + j * kWave), 4, 0, 0);
             }
         }
-        // the next box of this wave (an LDS atomic and a scalar multiply while the loads fly)
-        unsigned next = 0u;
-        if (lane == 0) next = atomicAdd(&s_next_unit, 1u);
-        next = w.unit((unsigned)__builtin_amdgcn_readfirstlane((int)next));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // a footprint that sticks out of the array along y or z: those taps count as zero (np.convolve(mode='same')); the
         // clamped addresses brought other voxels' data (wave-uniform test; boxes at the faces only)
@@ -175,7 +190,7 @@ __global__ __launch_bounds__(Footprint<NT>::threads) void sobolev_state_box_kern
         }
         // ---- y pass of the 4 x 4 x E voxels the z pass reads (filtered_at: float64 sums in tap order, one rounding) ----------
 #pragma unroll
-        for (int r = 0; r < F::y_rounds; ++r) {
+        for (int r = 0; r < (LSF_SOB_PROBE & 1 ? 0 : F::y_rounds); ++r) {
             const vf4* ctr = image + y_base + r * (4 * E * 4);
             vf4 v[NT];
 #pragma unroll
@@ -199,12 +214,12 @@ __global__ __launch_bounds__(Footprint<NT>::threads) void sobolev_state_box_kern
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // other lanes' y results (one wave: LDS executes in order)
         // ---- z pass of the lane's own voxel ------------------------------------------------------------------------------
-        float gv[3];
-        {
+        float gv[3] = {0.0f, 0.0f, 0.0f};
+        if (!(LSF_SOB_PROBE & 8)) {
             const vf4* ctr = image + (lz + c) * F::plane + (lane & 15);
             vf4 v[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) v[j] = ctr[F::plane * (c - j)];
+            for (int j = 0; j < NT; ++j) v[j] = ctr[F::plane * (LSF_SOB_PROBE & 2 ? 0 : c - j)];
             double acc[3] = {0.0, 0.0, 0.0};
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
@@ -217,6 +232,7 @@ __global__ __launch_bounds__(Footprint<NT>::threads) void sobolev_state_box_kern
             gv[1] = (bits & 2u) ? 0.0f : (float)acc[1];
             gv[2] = (bits & 4u) ? 0.0f : (float)acc[2];
         }
+        if (LSF_SOB_PROBE & 8) gv[0] = gv[1] = gv[2] = 1e-3f * (float)(lane & 7);
         // ---- update + re-warp (sobolev_state_update_kernel) ---------------------------------------------------------------
         const bool listed = ((b.mask >> lane) & 1ull) != 0ull;
         const int i = b.origin + voxel_off;
@@ -246,12 +262,13 @@ __global__ __launch_bounds__(Footprint<NT>::threads) void sobolev_state_box_kern
         go.x = gv[0]; go.y = gv[1]; go.z = gv[2]; go.w = 0.0f;
         // a lane that has nothing to store names an offset behind the buffer and the hardware drops it (range-checked raw
         // buffer stores; a null g_out is a buffer of zero bytes): no branch around the stores
-        const int offset = listed ? i * 16 : (int)0xfffffff0u;
+        const int offset = listed && !(LSF_SOB_PROBE & 16) ? i * 16 : (int)0xfffffff0u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, o), state_rsrc, offset, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, go), g_rsrc, offset, 0, 0);
         const unsigned long long q = listed ? pack_max(len_w, linear_index(g, x, y, z)) : 0ull;
         best = q > best ? q : best;
         u = next;
+        b = b_next;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // the unlisted voxels: zero update, smallest index

@@ -96,8 +96,8 @@ template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, bool FMA>
 __global__ __launch_bounds__(kBlock) void sobolev_state_gradient_x_kernel(const vf4* __restrict__ state,
                                                                           const float* __restrict__ canonical,
                                                                           vf4* __restrict__ out, Grid g, Params p,
-                                                                          TapsN<kMaxTaps> taps, int n_taps, lsf_gate gate,
-                                                                          lsf_iteration_record* record,
+                                                                          TapsN<kMaxTaps> taps, int n_taps, int bricks,
+                                                                          lsf_gate gate, lsf_iteration_record* record,
                                                                           const int* __restrict__ band_list,
                                                                           unsigned band_count) {
     if (gate_closed(gate)) return;
@@ -170,7 +170,12 @@ __global__ __launch_bounds__(kBlock) void sobolev_state_gradient_x_kernel(const 
             o.y = (bits & 2u) ? 0.0f : (float)acc[1];
             o.z = (bits & 4u) ? 0.0f : (float)acc[2];
             o.w = __uint_as_float(bits);
-            out[i] = o;
+            // bricks: the output in boxes of 4 x 4 x 4 voxels, 1 KB each, box (bz, by, bx) at ((bz * ny/4 + by) * nx/4 + bx)
+            // * 64, voxel (lz, ly, lx) of it at (lz * 4 + ly) * 4 + lx -- what lsf_sobolev_state_update_boxes stages from
+            const long long at = bricks ? ((((long long)(z >> 2) * (g.ny >> 2) + (y >> 2)) * (g.nx >> 2) + (x >> 2)) << 6) +
+                                              (((z & 3) << 4) | ((y & 3) << 2) | (x & 3))
+                                        : (long long)i;
+            out[at] = o;
         }
         __syncthreads();  // the next tile overwrites the LDS arrays
     }
@@ -341,6 +346,7 @@ struct GradArgs {
     TapsN<kMaxTaps> taps;
     int n_taps;  // 0: gradient only
     bool fma;
+    int bricks;  // the fused gradient + x pass writes its output in boxes of 4 x 4 x 4 voxels
 };
 
 template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY>
@@ -353,12 +359,12 @@ void grad_one(const GradArgs& a) {
     if constexpr (D == 3) {
         if (a.fma)
             hipLaunchKernelGGL((sobolev_state_gradient_x_kernel<3, SMOOTH, LEVELSET, DATA, ENERGY, true>), dim3(a.blocks),
-                               dim3(kBlock), 0, a.s, a.state, a.canonical, a.g_raw, a.g, a.p, a.taps, a.n_taps, a.gate,
-                               a.record, a.list, a.count);
+                               dim3(kBlock), 0, a.s, a.state, a.canonical, a.g_raw, a.g, a.p, a.taps, a.n_taps, a.bricks,
+                               a.gate, a.record, a.list, a.count);
         else
             hipLaunchKernelGGL((sobolev_state_gradient_x_kernel<3, SMOOTH, LEVELSET, DATA, ENERGY, false>), dim3(a.blocks),
-                               dim3(kBlock), 0, a.s, a.state, a.canonical, a.g_raw, a.g, a.p, a.taps, a.n_taps, a.gate,
-                               a.record, a.list, a.count);
+                               dim3(kBlock), 0, a.s, a.state, a.canonical, a.g_raw, a.g, a.p, a.taps, a.n_taps, a.bricks,
+                               a.gate, a.record, a.list, a.count);
     }
 }
 
@@ -521,7 +527,7 @@ extern "C" int lsf_sobolev_state_gradient(const float* state, const float* canon
     if (g.z_end == g.z_begin || band_count == 0) return 0;
     GradArgs a{band_list_blocks((unsigned)band_count), as_stream(stream), reinterpret_cast<const vf4*>(state), canonical,
                reinterpret_cast<vf4*>(g_raw4), g, params_of(params), gate_or_open(gate), record, band_list,
-               (unsigned)band_count, TapsN<kMaxTaps>(), 0, false};
+               (unsigned)band_count, TapsN<kMaxTaps>(), 0, false, 0};
     if (grid->dims == 2) grad_terms<2>(params, a);
     else grad_terms<3>(params, a);
     return launch_status();
@@ -530,17 +536,18 @@ extern "C" int lsf_sobolev_state_gradient(const float* state, const float* canon
 extern "C" int lsf_sobolev_state_gradient_x(const float* state, const float* canonical, float* out4, const lsf_grid* grid,
                                             const lsf_slavcheva_params* params, const double* taps_host, int32_t n_taps,
                                             const lsf_gate* gate, lsf_iteration_record* record, const int32_t* band_list,
-                                            int64_t band_count, void* stream) {
+                                            int64_t band_count, int32_t out_bricks, void* stream) {
     if (int e = check_grid(grid)) return e;
     if (!state || !canonical || !out4 || !params || !record || !band_list || !taps_host || band_count < 0 ||
         band_count > 0x7fffffffll || grid->dims != 3)
         return LSF_ERR_BAD_ARGUMENT;
+    if (out_bricks && (grid->nx % 4 || grid->ny % 4 || grid->nz % 4)) return LSF_ERR_BAD_DIMS;
     if (!taps_ok(n_taps)) return LSF_ERR_KERNEL_TOO_LONG;
     const Grid g = state_grid(grid);
     if (g.z_end == g.z_begin || band_count == 0) return 0;
     GradArgs a{band_list_blocks((unsigned)band_count), as_stream(stream), reinterpret_cast<const vf4*>(state), canonical,
                reinterpret_cast<vf4*>(out4), g, params_of(params), gate_or_open(gate), record, band_list,
-               (unsigned)band_count, TapsN<kMaxTaps>(), n_taps, taps_are_float32(taps_host, n_taps)};
+               (unsigned)band_count, TapsN<kMaxTaps>(), n_taps, taps_are_float32(taps_host, n_taps), out_bricks != 0};
     for (int j = 0; j < kMaxTaps; ++j) a.taps.k[j] = j < n_taps ? taps_host[j] : 0.0;
     grad_terms<3>(params, a);
     return launch_status();

@@ -80,16 +80,22 @@ def test_boxes_equal_y_pass_then_update(lsf, kind, n, rate, n_taps, float32_valu
     rec = [ctypes.c_void_p(records.data_ptr() + i * _lib.RECORD_BYTES) for i in range(3)]
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())
     stream = dev.stream_ptr()
-    gx, gy, g_ref, g_box = (torch.zeros((n, n, n, 4), dtype=torch.float32, device="cuda") for _ in range(4))
+    gx, gxb, gy, g_ref, g_box = (torch.zeros((n, n, n, 4), dtype=torch.float32, device="cuda") for _ in range(5))
     out_ref, out_box = state.clone(), state.clone()
     G = ctypes.byref(grid)
     _lib.check(_lib.lib.lsf_sobolev_state_gradient_x(ptr(state), ptr(canonical), ptr(gx), G, params, p_taps, n_taps, None,
-                                                     rec[0], ptr(whole), whole.numel(), stream), "gradient + x")
+                                                     rec[0], ptr(whole), whole.numel(), 0, stream), "gradient + x")
+    _lib.check(_lib.lib.lsf_sobolev_state_gradient_x(ptr(state), ptr(canonical), ptr(gxb), G, params, p_taps, n_taps, None,
+                                                     rec[0], ptr(whole), whole.numel(), 1, stream), "gradient + x, bricks")
+    # the same values brick by brick: [bz][by][bx][lz][ly][lx]
+    m = n // 4
+    bricked = gx.view(m, 4, m, 4, m, 4, 4).permute(0, 2, 4, 1, 3, 5, 6).contiguous().view(n, n, n, 4)
+    assert torch.equal(gxb.view(torch.int32), bricked.view(torch.int32)), "brick layout"
     _lib.check(_lib.lib.lsf_convolve_axis_listed4(ptr(gx), ptr(gy), None, G, 1, p_taps, n_taps, None, ptr(whole),
                                                   whole.numel(), stream), "y pass")
     _lib.check(_lib.lib.lsf_sobolev_state_update(ptr(gy), None, ptr(state), ptr(out_ref), ptr(g_ref), G, params, 2, p_taps,
                                                  n_taps, None, rec[1], ptr(whole), whole.numel(), 1, stream), "z pass + update")
-    _lib.check(_lib.lib.lsf_sobolev_state_update_boxes(ptr(gx), ptr(state), ptr(out_box), ptr(g_box), G, params, p_taps,
+    _lib.check(_lib.lib.lsf_sobolev_state_update_boxes(ptr(gxb), ptr(state), ptr(out_box), ptr(g_box), G, params, p_taps,
                                                        n_taps, None, rec[2], ptr(boxes), n_boxes, stream), "boxes")
     torch.cuda.synchronize()
     assert float(g_ref[..., :3].abs().max()) > 1e-4
@@ -101,7 +107,7 @@ def test_boxes_equal_y_pass_then_update(lsf, kind, n, rate, n_taps, float32_valu
         assert dec["max_value"][2] > 1.0, "this case is meant to take the gather beyond the voxel's own neighbourhood"
     # a NULL gradient output: the same state, nothing else written
     out_box2 = state.clone()
-    _lib.check(_lib.lib.lsf_sobolev_state_update_boxes(ptr(gx), ptr(state), ptr(out_box2), None, G, params, p_taps, n_taps,
+    _lib.check(_lib.lib.lsf_sobolev_state_update_boxes(ptr(gxb), ptr(state), ptr(out_box2), None, G, params, p_taps, n_taps,
                                                        None, rec[2], ptr(boxes), n_boxes, stream), "boxes, no gradient")
     torch.cuda.synchronize()
     assert torch.equal(out_box2.view(torch.int32), out_ref.view(torch.int32))

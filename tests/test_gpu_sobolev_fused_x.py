@@ -80,7 +80,7 @@ def test_fused_gradient_x_equals_gradient_then_x_pass(lsf, kind, n, n_taps, floa
         _lib.check(_lib.lib.lsf_convolve_axis_listed4(ptr(raw), ptr(ref), ptr(raw), ctypes.byref(grid), 0, p_taps, n_taps,
                                                       None, b.pointer, b.count, stream), "x pass")
     _lib.check(_lib.lib.lsf_sobolev_state_gradient_x(ptr(state), ptr(canonical), ptr(fused), ctypes.byref(grid), params,
-                                                     p_taps, n_taps, None, rec[1], ptr(whole), whole.numel(), stream),
+                                                     p_taps, n_taps, None, rec[1], ptr(whole), whole.numel(), 0, stream),
                "fused")
     torch.cuda.synchronize()
     assert float(raw[..., :3].abs().max()) > 1e-3 and float(ref[..., :3].abs().max()) > 1e-3
@@ -103,9 +103,11 @@ def test_fused_entry_rejects_what_it_cannot_do(lsf):
     p_taps = taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
     one = ctypes.c_void_p(1)
     call = _lib.lib.lsf_sobolev_state_gradient_x
-    assert call(one, one, one, ctypes.byref(grid2), params, p_taps, 7, None, one, one, 1, None) == -1  # 2-D filters y first
-    assert call(one, one, one, ctypes.byref(grid3), params, p_taps, 11, None, one, one, 1, None) != 0  # 3 / 5 / 7 / 9 taps
-    assert call(one, one, None, ctypes.byref(grid3), params, p_taps, 7, None, one, one, 1, None) == -1
+    assert call(one, one, one, ctypes.byref(grid2), params, p_taps, 7, None, one, one, 1, 0, None) == -1  # 2-D filters y first
+    assert call(one, one, one, ctypes.byref(grid3), params, p_taps, 11, None, one, one, 1, 0, None) != 0  # 3 / 5 / 7 / 9 taps
+    assert call(one, one, None, ctypes.byref(grid3), params, p_taps, 7, None, one, one, 1, 0, None) == -1
+    odd = dev.make_grid((16, 18, 16))  # bricks of 4 x 4 x 4 need extents that are multiples of 4
+    assert call(one, one, one, ctypes.byref(odd), params, p_taps, 7, None, one, one, 1, 1, None) == -2
 
 
 @pytest.mark.parametrize("shape,limit,strips", [((12, 40, 16), 12 * 40 * 16, 8), ((64, 64, 64), 64 ** 3, 8),

@@ -46,7 +46,8 @@ write, _ = means("pmc_write")
 ALG = {"sobolev_state_gradient_kernel": (20 + 12, "R state 16 + canonical 4, W raw gradient 12 (16 on the float4 layout)"),
        "sobolev_state_gradient_x_kernel": (20 + 12, "gradient AND x pass in one launch (round 4): R state 16 + canonical 4, W the x-filtered gradient 12 (16 on the float4 layout); the raw gradient stays in LDS"),
        "convolve_list4_kernel": (12 + 12, "R gradient 12 (+ mask 12 from L2), W 12 (16 + 16 on the float4 layout)"),
-       "sobolev_state_update_kernel": (12 + 4 + 12 + 4, "R gradient 12 + live 4 (gathered), W warp 12 + live 4 (+ final gradient)")}
+       "sobolev_state_update_kernel": (12 + 4 + 12 + 4, "R gradient 12 + live 4 (gathered), W warp 12 + live 4 (+ final gradient)"),
+       "sobolev_state_box_kernel": (12 + 4 + 12 + 4 + 12 + 12, "y pass, z pass, update and re-warp in one launch, box by box (round 5): R the x-filtered gradient 12 (16) + live 4, W warp 12 + live 4; the y-filtered gradient (W 12 + R 12 of the budget) stays in LDS")}
 out = os.path.join(ROOT, "profiles", tag + "_sobolev_pmc_hbm_traffic.csv")
 with open(out, "w") as f:
     f.write("kernel,dispatches,mean_us,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_side_MB_calibrated,algorithmic_MB,what\n")
