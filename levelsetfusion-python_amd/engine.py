@@ -911,12 +911,14 @@ class _SparseStateExceeded(Exception):
 # voxels (0 = everywhere, as before round 4), for volumes of at least SPARSE_MIN_VOXELS (below, a call is launch-bound and
 # the initialisation passes cost nothing next to it)
 # The library-enqueued call walks the INTERIOR band voxels box by box (lsf_slavcheva_state_iteration_boxes: neighbourhoods
-# staged through LDS) instead of entry by entry when the listed voxels of the two ping-pong states -- 32 bytes each -- cannot
-# stay in the 256 MB Infinity Cache between iterations: the list walk's 18 loads per voxel then miss to HBM and its L1s
-# stand at their in-flight limit (profiles/r05_pmc_l2_tcp.txt), the box walk's four coalesced loads per 64 voxels do not:
-# 120-125 against 138-144 us per 512^3 launch.  Below that the two are level (256^3: 30.8 us both) and the list walk needs
-# no boxes built.
-BOX_WALK_MIN_BAND_BYTES = 200 * 1000 * 1000
+# staged through LDS) instead of entry by entry when the listed voxels of the two ping-pong states -- 32 bytes each -- and
+# what else an iteration touches crowd the 256 MB Infinity Cache: the list walk's 18 loads per voxel then miss to HBM and
+# its L1s stand at their in-flight limit (profiles/r05_pmc_l2_tcp.txt), the box walk's four coalesced loads per 64 voxels
+# do not: 120-125 against 138-144 us per 512^3 launch.  Measured on one box, list / box walk in us per launch
+# (tools/box_kernel_ab.py, profiles/r05_box_walk_by_size.txt): sphere pairs 320^3 (84 MB of listed states) 43.6 / 43.6,
+# 384^3 (122 MB) 65.2 / 62.2, 448^3 (169 MB) 103.1 / 88.8, 512^3 (224 MB) 138-144 / 119-125; the 512^3 depth pair (119 MB)
+# 76.0 / 66.9.  Below ~100 MB the two are level (256^3: 30.8 us both) and the list walk needs no boxes built.
+BOX_WALK_MIN_BAND_BYTES = 100 * 1000 * 1000
 BOX_WALK_MIN_VOXELS = 1 << 25  # (volumes below this never reach the band size above: the boxes are not even counted)
 SPARSE_REACH = int(os.environ.get("LSF_SPARSE_REACH", "2"))
 SPARSE_MIN_VOXELS = int(os.environ.get("LSF_SPARSE_MIN_VOXELS", str(1 << 21)))
