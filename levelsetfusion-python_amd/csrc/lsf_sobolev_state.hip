@@ -91,6 +91,9 @@ __global__ __launch_bounds__(kBlock) void sobolev_state_gradient_kernel(const vf
 // and a launch (21.4 + 15.9 us of kernels at 256^3, profiles/r04_sobolev_pmc_hbm_traffic.csv), and per call one
 // zero-filled gradient buffer.
 constexpr int kMaxTaps = 9;
+// workgroups per XCD of the fused gradient + x launch: two to three tiles each at 256^3 (a tile is a chain of dependent
+// round trips with two barriers; 7 / 4 / 3 / 2 / 1 tiles per workgroup: 79 / 73.7 / 71.0 / 70.4-71.5 / 74.5 us per iteration)
+constexpr unsigned kGradientXBlocksPerXcd = 512u;
 
 template <int D, int SMOOTH, bool LEVELSET, int DATA, int ENERGY, bool FMA>
 __global__ __launch_bounds__(kBlock) void sobolev_state_gradient_x_kernel(const vf4* __restrict__ state,
@@ -545,7 +548,7 @@ extern "C" int lsf_sobolev_state_gradient_x(const float* state, const float* can
     if (!taps_ok(n_taps)) return LSF_ERR_KERNEL_TOO_LONG;
     const Grid g = state_grid(grid);
     if (g.z_end == g.z_begin || band_count == 0) return 0;
-    GradArgs a{band_list_blocks((unsigned)band_count), as_stream(stream), reinterpret_cast<const vf4*>(state), canonical,
+    GradArgs a{band_list_blocks((unsigned)band_count, kGradientXBlocksPerXcd), as_stream(stream), reinterpret_cast<const vf4*>(state), canonical,
                reinterpret_cast<vf4*>(out4), g, params_of(params), gate_or_open(gate), record, band_list,
                (unsigned)band_count, TapsN<kMaxTaps>(), n_taps, taps_are_float32(taps_host, n_taps), out_bricks != 0};
     for (int j = 0; j < kMaxTaps; ++j) a.taps.k[j] = j < n_taps ? taps_host[j] : 0.0;

@@ -17,7 +17,7 @@ rows.sort()
 starts = [i for i, r in enumerate(rows) if "state_prepare" in r[2] or "prepare_count" in r[2] or "band_count" in r[2]]
 starts = [i for k, i in enumerate(starts) if k == 0 or i - starts[k - 1] > 10]
 a, b = starts[-back - 1], starts[-back]
-while a > 0 and rows[a][0] - rows[a - 1][1] < 60000 and "slavcheva_state_kernel" not in rows[a - 1][2] and a > starts[-back - 2] + 1 and "finalize" not in rows[a - 1][2] and "records_used" not in rows[a - 1][2]:
+while a > 0 and rows[a][0] - rows[a - 1][1] < 60000 and "slavcheva_state" not in rows[a - 1][2] and a > starts[-back - 2] + 1 and "finalize" not in rows[a - 1][2] and "records_used" not in rows[a - 1][2]:
     a -= 1  # launches in front of the counting pass that belong to the step (copies, fills)
 step = rows[a:b]
 t0 = step[0][0]
@@ -28,7 +28,7 @@ busy = 0
 for s, e, name in step:
     gap, dur = s - prev_end, e - s
     busy += dur
-    if "slavcheva_state_kernel" in name:
+    if "slavcheva_state_kernel" in name or "slavcheva_state_box_kernel" in name:
         if it_n == 0:
             it_first = (s - t0, gap)
         it_n += 1
