@@ -40,6 +40,13 @@ constexpr int kShellLoads = (kShell + kWave - 1) / kWave;                       
 #endif
 constexpr int kSobWaves = LSF_SOBOLEV_BOX_WAVES;
 
+#ifdef LSF_SOB_TRACE  // measurement builds only (tools/sobolev_trace.py): shader-clock totals per wave of the box walk
+__device__ unsigned long long* g_sob_trace = nullptr;  // [block][wave 16][8]: rounds, cycles in stage issue / wait / y / z+update / stores, total, entry stamp
+#define LSF_SOB_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define LSF_SOB_T(var) do {} while (0)
+#endif
+
 template <int NT>
 struct Footprint {
     static constexpr int c = NT / 2;
@@ -132,6 +139,10 @@ __global__ __launch_bounds__(Footprint<NT>::threads) void sobolev_state_box_kern
     const int y_base = ((lz * E) + ly + c) * 4 + lx;
 
     unsigned long long best = 0ull;
+#ifdef LSF_SOB_TRACE
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, __builtin_amdgcn_s_memrealtime()};
+    const unsigned long long t_entry = __builtin_readcyclecounter();
+#endif
     const WaveWalk w = wave_list_walk(box_count * kWave, g.list_group);
     if (threadIdx.x == 0) s_next_unit = waves;
     __syncthreads();
@@ -153,6 +164,7 @@ __global__ __launch_bounds__(Footprint<NT>::threads) void sobolev_state_box_kern
         if (lane == 0) next = atomicAdd(&s_next_unit, 1u);
         next = w.unit((unsigned)__builtin_amdgcn_readfirstlane((int)next));
         const lsf_band_box b_next = header(next);
+        LSF_SOB_T(t0);
         int x0, y0, z0;
         decode_voxel(g, (unsigned)b.origin, x0, y0, z0);
         {
@@ -173,7 +185,9 @@ __global__ __launch_bounds__(Footprint<NT>::threads) void sobolev_state_box_kern
                                                  (__attribute__((address_space(3))) void*)(shell + j * kWave), 4, 0, 0);
             }
         }
+        LSF_SOB_T(t1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LSF_SOB_T(t2);
         // a footprint that sticks out of the array along y or z: those taps count as zero (np.convolve(mode='same')); the
         // clamped addresses brought other voxels' data (wave-uniform test; boxes at the faces only)
         if (y0 < c || y0 + kBoxEdge + c > g.ny || z0 < c || z0 + kBoxEdge + c > g.nz) {
@@ -213,6 +227,7 @@ __global__ __launch_bounds__(Footprint<NT>::threads) void sobolev_state_box_kern
             image[(lz + 4 * r) * F::plane + (lane & 15)] = o;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // other lanes' y results (one wave: LDS executes in order)
+        LSF_SOB_T(t3);
         // ---- z pass of the lane's own voxel ------------------------------------------------------------------------------
         float gv[3] = {0.0f, 0.0f, 0.0f};
         if (!(LSF_SOB_PROBE & 8)) {
@@ -262,6 +277,7 @@ __global__ __launch_bounds__(Footprint<NT>::threads) void sobolev_state_box_kern
         go.x = gv[0]; go.y = gv[1]; go.z = gv[2]; go.w = 0.0f;
         // a lane that has nothing to store names an offset behind the buffer and the hardware drops it (range-checked raw
         // buffer stores; a null g_out is a buffer of zero bytes): no branch around the stores
+        LSF_SOB_T(t4);
         const int offset = listed && !(LSF_SOB_PROBE & 16) ? i * 16 : (int)0xfffffff0u;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, o), state_rsrc, offset, 0, 0);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(vu4, go), g_rsrc, offset, 0, 0);
@@ -269,8 +285,21 @@ __global__ __launch_bounds__(Footprint<NT>::threads) void sobolev_state_box_kern
         best = q > best ? q : best;
         u = next;
         b = b_next;
+#ifdef LSF_SOB_TRACE
+        {
+            const unsigned long long t5 = __builtin_readcyclecounter();
+            tr[0] += 1; tr[1] += t1 - t0; tr[2] += t2 - t1; tr[3] += t3 - t2; tr[4] += t4 - t3; tr[5] += t5 - t4;
+        }
+#endif
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LSF_SOB_TRACE
+    if (g_sob_trace && lane == 0) {
+        tr[6] = __builtin_readcyclecounter() - t_entry;
+        unsigned long long* row = g_sob_trace + ((unsigned long long)blockIdx.x * 16 + wave) * 8;
+        for (int k = 0; k < 8; ++k) row[k] = tr[k];
+    }
+#endif
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // the unlisted voxels: zero update, smallest index
         const unsigned long long q = pack_max(0.0f, linear_index(g, 0, 0, g.z_begin));
         best = q > best ? q : best;
@@ -335,6 +364,12 @@ inline unsigned sob_box_compute_units() {
 }
 
 }  // namespace
+
+#ifdef LSF_SOB_TRACE
+extern "C" int lsf_debug_set_sobolev_trace(void* rows) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sob_trace), &rows, sizeof(rows));
+}
+#endif
 
 extern "C" int lsf_sobolev_state_update_boxes(const float* in4, const float* state_in, float* state_out, float* g_out4,
                                               const lsf_grid* grid, const lsf_slavcheva_params* params,
