@@ -694,7 +694,7 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
         for i in range(iters):
             for band in bands:  # interior + (usually empty, then absent) boundary band voxels
                 if boxes is not None and band is not None and band.subset == _lib.BAND_INTERIOR:
-                    dev.slavcheva_state_iteration_boxes(states[i % 2], canonical, states[(i + 1) % 2], grid, eng.params,
+                    dev.slavcheva_state_iteration_boxes(states[i % 2], boxes[2], states[(i + 1) % 2], grid, eng.params,
                                                         None, rec, 0, boxes[0], boxes[1])
                 else:
                     dev.slavcheva_state_iteration(states[i % 2], canonical, states[(i + 1) % 2], grid, eng.params, None,
@@ -756,6 +756,7 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
         walk = "LIST"
         if world == 1 and getattr(eng, "_box_walk_used", False):
             boxes = dev.band_boxes(dev.StatePrepare(live0, canonical, grid))
+            boxes = boxes + (dev.band_boxes_canonical(canonical, grid, *boxes),)
             walk = "BOXES of 4x4x4 through LDS"
             name = "slavcheva_state_box_kernel<KILLING,LEVELSET,BASIC,DIRECT> (%s)"
         roofline = roofline_of(bands, sum(b.count for b in bands), name % walk, committed_traffic("hbm_bytes_per_launch"))

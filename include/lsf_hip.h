@@ -407,7 +407,11 @@ int lsf_band_boxes_count(const lsf_grid *grid, int32_t subset, const int32_t *pr
                          int64_t *count_out, void *stream);
 int lsf_band_boxes_fill(const lsf_grid *grid, int32_t subset, const int32_t *prepare_scratch, const int32_t *box_scratch,
                         lsf_band_box *boxes, void *stream);
-int lsf_slavcheva_state_iteration_boxes(const float *state_in, const float *canonical, float *state_out,
+/* the canonical values of the boxes' voxels, box by box: canonical_boxed[64 b + (lz * 4 + ly) * 4 + lx] -- what the box walk
+ * reads instead of the [z][y][x] array (256 contiguous bytes per box instead of sixteen rows of 16 bytes); once per call */
+int lsf_band_boxes_canonical(const float *canonical, const lsf_grid *grid, const lsf_band_box *boxes, int64_t box_count,
+                             float *canonical_boxed, void *stream);
+int lsf_slavcheva_state_iteration_boxes(const float *state_in, const float *canonical_boxed, float *state_out,
                                         const lsf_grid *grid, const lsf_slavcheva_params *params, const lsf_gate *gate,
                                         lsf_iteration_record *record, const lsf_band_box *boxes, int64_t box_count,
                                         void *stream);
@@ -420,8 +424,9 @@ int lsf_slavcheva_state_iteration_boxes(const float *state_in, const float *cano
  * lsf_state_prepare are in totals_host; the caller sizes the two lists from them (totals_host[0] INTERIOR, [1] BOUNDARY
  * entries) and calls lsf_state_run_finish, which launches the list fills, `iterations` x lsf_slavcheva_state_iteration
  * per non-empty list (ungated; iteration i reads state[i % 2], writes the other, reduces into records[i], which the
- * caller has zeroed; with `boxes` -- room for totals_host[4] of them, box_scratch given to lsf_state_run_begin -- the
- * INTERIOR voxels are walked box by box instead, lsf_slavcheva_state_iteration_boxes: same results) and lsf_state_finalize_listed of the final state into live_out (which must hold the input live field:
+ * caller has zeroed; with `boxes` -- room for totals_host[4] of them, box_scratch given to lsf_state_run_begin, and
+ * `box_canonical`, room for 64 floats per box -- the INTERIOR voxels are walked box by box instead,
+ * lsf_band_boxes_canonical + lsf_slavcheva_state_iteration_boxes: same results) and lsf_state_finalize_listed of the final state into live_out (which must hold the input live field:
  * the pass writes listed voxels only; statistics16 / finalize_scratch as there, may be NULL; with sparse states the pass
  * guards itself with the records), copies the records' used words and the statistics to the host in ONE transfer and
  * RETURNS when the stream has drained, the records decoded into `result` (lsf_records_decode).  The same launches in the
@@ -455,8 +460,8 @@ typedef struct lsf_state_run_result {
 } lsf_state_run_result;
 int lsf_state_run_begin(const lsf_state_run *run, void *stream);
 int lsf_state_run_finish(const lsf_state_run *run, const lsf_slavcheva_params *params, int32_t *list_interior,
-                         int32_t *list_boundary, lsf_band_box *boxes, lsf_iteration_record *records, int32_t iterations,
-                         float *live_out,
+                         int32_t *list_boundary, lsf_band_box *boxes, float *box_canonical, lsf_iteration_record *records,
+                         int32_t iterations, float *live_out,
                          float lower_threshold, double *statistics16, double *finalize_scratch, int64_t *words_device,
                          int64_t *words_host, lsf_state_run_result *result, void *stream);
 

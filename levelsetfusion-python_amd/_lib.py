@@ -22,7 +22,7 @@ ABI_VERSION = 3
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "c275b40adbcdd8ef"
+HEADER_ABI_HASH = "cc10a5efbfe45d84"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -180,10 +180,11 @@ PROTOTYPES = {
     "lsf_band_boxes_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
     "lsf_band_boxes_count": (ctypes.c_int, [_P(Grid), ctypes.c_int32, _vp, _vp, _vp, _vp]),
     "lsf_band_boxes_fill": (ctypes.c_int, [_P(Grid), ctypes.c_int32, _vp, _vp, _vp, _vp]),
+    "lsf_band_boxes_canonical": (ctypes.c_int, [_vp, _P(Grid), _vp, ctypes.c_int64, _vp, _vp]),
     "lsf_slavcheva_state_iteration_boxes": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp, _vp,
                                                            _i64, _vp]),
     "lsf_state_run_begin": (ctypes.c_int, [_P(StateRun), _vp]),
-    "lsf_state_run_finish": (ctypes.c_int, [_P(StateRun), _P(SlavchevaParams), _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp,
+    "lsf_state_run_finish": (ctypes.c_int, [_P(StateRun), _P(SlavchevaParams), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp,
                                             _vp, _vp, _P(StateRunResult), _vp]),
     "lsf_band_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
     "lsf_band_count": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),

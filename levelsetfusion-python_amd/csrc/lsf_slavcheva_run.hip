@@ -78,8 +78,8 @@ extern "C" int lsf_state_run_begin(const lsf_state_run* run, void* stream) {
 }
 
 extern "C" int lsf_state_run_finish(const lsf_state_run* run, const lsf_slavcheva_params* params, int32_t* list_interior,
-                                    int32_t* list_boundary, lsf_band_box* boxes, lsf_iteration_record* records,
-                                    int32_t iterations,
+                                    int32_t* list_boundary, lsf_band_box* boxes, float* box_canonical,
+                                    lsf_iteration_record* records, int32_t iterations,
                                     float* live_out, float lower_threshold, double* statistics16,
                                     double* finalize_scratch, int64_t* words_device, int64_t* words_host,
                                     lsf_state_run_result* result, void* stream) {
@@ -114,14 +114,17 @@ extern "C" int lsf_state_run_finish(const lsf_state_run* run, const lsf_slavchev
     // the INTERIOR voxels box by box when the caller asks for it (same results; DESIGN.md section 5: the walk that pays
     // when the band's states do not fit the Infinity Cache)
     const int64_t n_boxes = boxes && run->box_scratch ? run->totals_host[4] : 0;
-    if (n_boxes > 0)
+    if (n_boxes > 0) {
+        if (!box_canonical) return LSF_ERR_BAD_ARGUMENT;
         if (int e = lsf_band_boxes_fill(g, LSF_BAND_INTERIOR, run->prepare_scratch, run->box_scratch, boxes, stream)) return e;
+        if (int e = lsf_band_boxes_canonical(run->canonical, g, boxes, n_boxes, box_canonical, stream)) return e;
+    }
     // the iterations: ungated (a fixed count), iteration i reads state[i % 2] and writes the other
     for (int32_t i = 0; i < iterations; ++i)
         for (int k = 0; k < n_lists; ++k) {
             int e;
             if (n_boxes > 0 && subsets[k] == LSF_BAND_INTERIOR)
-                e = lsf_slavcheva_state_iteration_boxes(run->state[i % 2], run->canonical, run->state[(i + 1) % 2], g, params,
+                e = lsf_slavcheva_state_iteration_boxes(run->state[i % 2], box_canonical, run->state[(i + 1) % 2], g, params,
                                                         nullptr, records + i, boxes, n_boxes, stream);
             else
                 e = lsf_slavcheva_state_iteration(run->state[i % 2], run->canonical, run->state[(i + 1) % 2], g, params,

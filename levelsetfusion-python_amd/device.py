@@ -703,10 +703,21 @@ def band_boxes(prepared, subset=_lib.BAND_INTERIOR):
     return boxes, n
 
 
-def slavcheva_state_iteration_boxes(state_in, canonical, state_out, grid, params, gate, records, index, boxes, n_boxes):
-    """the fused iteration over the INTERIOR band voxels, box by box (lsf_slavcheva_state_iteration_boxes)"""
+def band_boxes_canonical(canonical, grid, boxes, n_boxes):
+    """the canonical values of the boxes' voxels, 64 per box in box order (lsf_band_boxes_canonical): what the box walk reads"""
+    out = torch.empty(max(n_boxes, 1) * BOX_EDGE ** 3, dtype=torch.float32, device=canonical.device)
+    check(lib.lsf_band_boxes_canonical(_ptr(canonical, n_voxels(grid), "canonical"), ctypes.byref(grid),
+                                       ctypes.c_void_p(boxes.data_ptr()), int(n_boxes), ctypes.c_void_p(out.data_ptr()),
+                                       stream_ptr()), "lsf_band_boxes_canonical")
+    return out
+
+
+def slavcheva_state_iteration_boxes(state_in, canonical_boxed, state_out, grid, params, gate, records, index, boxes, n_boxes):
+    """the fused iteration over the INTERIOR band voxels, box by box (lsf_slavcheva_state_iteration_boxes); canonical_boxed:
+    band_boxes_canonical of the same boxes"""
     n = n_voxels(grid)
-    check(lib.lsf_slavcheva_state_iteration_boxes(_ptr(state_in, 4 * n, "state_in"), _ptr(canonical, n, "canonical"),
+    check(lib.lsf_slavcheva_state_iteration_boxes(_ptr(state_in, 4 * n, "state_in"),
+                                                  _ptr(canonical_boxed, n_boxes * BOX_EDGE ** 3, "canonical_boxed"),
                                                   _ptr(state_out, 4 * n, "state_out"), ctypes.byref(grid),
                                                   ctypes.byref(params), _gate_ref(gate), _record_ptr(records, index),
                                                   ctypes.c_void_p(boxes.data_ptr()), int(n_boxes), stream_ptr()),

@@ -1804,9 +1804,10 @@ class SlavchevaEngine:
         # (the card is writing the states now; the lists are sized from the totals the call waited for)
         n_interior, n_boundary, opposite, first_opposite, n_boxes = totals_host.tolist()
         lists = torch.empty(max(n_interior + n_boundary, 1), dtype=torch.int32, device=device)
-        boxes = None
+        boxes = box_canonical = None
         if n_boxes and (self.box_walk is True or 32 * n_interior > BOX_WALK_MIN_BAND_BYTES):
             boxes = torch.empty((n_boxes, 2), dtype=torch.int64, device=device)
+            box_canonical = torch.empty(n_boxes * dev.BOX_EDGE ** 3, dtype=torch.float32, device=device)
         self._box_walk_used = boxes is not None
         records = dev.new_records(iterations, device)
         n_words = iterations * _lib.RECORD_SLOTS * dev.USED_SLOT_WORDS
@@ -1825,6 +1826,7 @@ class SlavchevaEngine:
         _lib.check(_lib.lib.lsf_state_run_finish(
             ctypes.byref(run), ctypes.byref(self.params), ctypes.c_void_p(p_lists),
             ctypes.c_void_p(p_lists + 4 * n_interior), ctypes.c_void_p(boxes.data_ptr() if boxes is not None else 0),
+            ctypes.c_void_p(box_canonical.data_ptr() if boxes is not None else 0),
             ctypes.c_void_p(records.data_ptr()), iterations,
             dev._ptr(target, n, "live_out"), float(lower_threshold),
             ctypes.c_void_p(stats.data_ptr()) if statistics else none,
@@ -1839,7 +1841,7 @@ class SlavchevaEngine:
         if n_boundary or not bands:
             bands.append(dev.BandList(lists[n_interior:] if n_boundary else lists[:1], n_boundary, _lib.BAND_BOUNDARY))
         f = _Counted(sum(b.count for b in bands))
-        f.bands, f.records, f.boxes = bands, records, boxes
+        f.bands, f.records, f.boxes = bands, records, (boxes, box_canonical)
         self._fast = f
         self.iteration_count = n_exec
         wd, ws, wl = self.weights

@@ -38,6 +38,7 @@ def _walks(lsf, canonical, live, iterations, params, sparse_reach=0):
     prepared = dev.StatePrepare(live, canonical, grid, sparse_reach=sparse_reach)
     bands, _ = prepared.collect()
     boxes, n_boxes = dev.band_boxes(prepared)
+    canonical_boxed = dev.band_boxes_canonical(canonical, grid, boxes, n_boxes)
     interior = [b for b in bands if b.subset == _lib.BAND_INTERIOR and b.count]
     others = [b for b in bands if b.subset != _lib.BAND_INTERIOR]
     out = []
@@ -46,7 +47,7 @@ def _walks(lsf, canonical, live, iterations, params, sparse_reach=0):
         records = dev.new_records(iterations, live.device)
         for i in range(iterations):
             if boxed and n_boxes:
-                dev.slavcheva_state_iteration_boxes(states[i % 2], canonical, states[(i + 1) % 2], grid, params, None,
+                dev.slavcheva_state_iteration_boxes(states[i % 2], canonical_boxed, states[(i + 1) % 2], grid, params, None,
                                                     records, i, boxes, n_boxes)
             else:
                 for b in interior:
@@ -80,6 +81,12 @@ def test_boxes_hold_the_interior_list(lsf):
     prepared = dev.StatePrepare(live, canonical, grid)
     bands, _ = prepared.collect()
     boxes, count = dev.band_boxes(prepared)
+    # ... and their canonical values, gathered box by box: [box][lz][ly][lx]
+    boxed = dev.band_boxes_canonical(canonical, grid, boxes, count).view(-1, 4, 4, 4)
+    for b in (0, count // 2, count - 1):
+        o = int(boxes[b, 0]) & 0xffffffff
+        x0, y0, z0 = o % n, (o // n) % n, o // (n * n)
+        assert torch.equal(boxed[b], canonical[z0:z0 + 4, y0:y0 + 4, x0:x0 + 4])
     interior = [b for b in bands if b.subset == _lib.BAND_INTERIOR][0]
     origin, mask = boxes[:count, 0] & 0xffffffff, boxes[:count, 1]
     assert bool((origin[1:] > origin[:-1]).all()), "ascending origins"

@@ -44,6 +44,7 @@ print("%d^3 %s: %d INTERIOR band voxels in %d boxes (fill %.1f %%); voxels in th
       (n, data, band.count, n_boxes, 100.0 * band.count / (64.0 * n_boxes), int(bits.sum().item())))
 assert int(bits.sum().item()) == band.count
 st0 = dev.state_pack(l, None, grid, copies=2)
+c_boxed = dev.band_boxes_canonical(c, grid, boxes, n_boxes)
 
 
 def run_list(st, rec):
@@ -53,7 +54,7 @@ def run_list(st, rec):
 
 def run_boxes(st, rec):
     for i in range(iters):
-        _lib.check(L.lsf_slavcheva_state_iteration_boxes(st[i % 2].data_ptr(), c.data_ptr(), st[(i + 1) % 2].data_ptr(),
+        _lib.check(L.lsf_slavcheva_state_iteration_boxes(st[i % 2].data_ptr(), c_boxed.data_ptr(), st[(i + 1) % 2].data_ptr(),
                                                          ctypes.byref(grid), ctypes.byref(eng.params), None,
                                                          rec.data_ptr() + i * _lib.RECORD_BYTES, boxes.data_ptr(), n_boxes,
                                                          dev.stream_ptr()), "lsf_slavcheva_state_iteration_boxes")
