@@ -30,12 +30,58 @@ class ComputeMethod(Enum):
 
 
 class OptimizationLog:
-    def __init__(self):
-        self.data_energies = []
-        self.smoothing_energies = []
-        self.level_set_energies = []
-        self.max_warps = []
-        self.convergence_report = ConvergenceReport()
+    """slavcheva_optimizer2d.py's log of a call: four lists with one entry per iteration, the locations of the longest
+    updates and the convergence report.  With a `source` (the engine's log of the call) the lists are taken from it when
+    they are first read -- what the call leaves on the host is looked at by whoever wants it, not converted behind the
+    call's last synchronisation"""
+    _LISTS = {"data_energies": "data_energies", "smoothing_energies": "smoothing_energies",
+              "level_set_energies": "level_set_energies", "max_warps": "max_warps"}
+
+    def __init__(self, source=None):
+        self._source = source
+        self._convergence_report = ConvergenceReport()
+        self._max_warp_locations = []
+        if source is None:
+            self.data_energies = []
+            self.smoothing_energies = []
+            self.level_set_energies = []
+            self.max_warps = []
+
+    def __getattr__(self, name):  # only reached for attributes that have not been set
+        key = OptimizationLog._LISTS.get(name)
+        source = self.__dict__.get("_source")
+        if key is None or source is None:
+            raise AttributeError(name)
+        value = source[key]
+        setattr(self, name, value)
+        return value
+
+    @property
+    def convergence_report(self):
+        """slavcheva_optimizer2d.py:393-404; built from the finalize pass's sixteen sums when somebody looks"""
+        if callable(self._convergence_report):
+            self._convergence_report = self._convergence_report()
+        return self._convergence_report
+
+    @convergence_report.setter
+    def convergence_report(self, value):
+        self._convergence_report = value
+
+    @property
+    def max_warp_locations(self):
+        """(x, y[, z]) of every iteration's longest update; given as flat voxel indices + the field's shape, they are
+        unravelled when somebody looks (a 50-iteration call's list costs 10 us of host time behind the call's last
+        synchronisation, where the card waits for the next call)"""
+        pending = self._max_warp_locations
+        if isinstance(pending, tuple):
+            indices, shape = pending
+            coords = np.unravel_index(np.asarray(indices, dtype=np.int64), shape)
+            self._max_warp_locations = pending = list(zip(*(c.tolist() for c in coords[::-1])))
+        return pending
+
+    @max_warp_locations.setter
+    def max_warp_locations(self, value):
+        self._max_warp_locations = value
 
 
 class _SlavchevaOptimizerBase:
@@ -148,21 +194,13 @@ class _SlavchevaOptimizerBase:
         finalize_args = (live_field if on_device else None, self.maximum_warp_length_lower_threshold, want_report)
         outcome = self._engine.optimize(live, canonical, finalize=finalize_args)
         eng_log = self._engine.log
-        self.log = OptimizationLog()
-        self.log.max_warps = eng_log["max_warps"]
-        self.log.data_energies = eng_log["data_energies"]
-        self.log.smoothing_energies = eng_log["smoothing_energies"]
-        self.log.level_set_energies = eng_log["level_set_energies"]
+        self.log = OptimizationLog(eng_log)
         if self._engine.comm is None or not self._engine.comm.active:
-            coords = np.unravel_index(np.asarray(eng_log["max_warp_indices"], dtype=np.int64), tuple(live.shape))
-            self.log.max_warp_locations = list(zip(*(c.tolist() for c in coords[::-1])))
+            self.log.max_warp_locations = (eng_log["max_warp_indices"], tuple(live.shape))  # unravelled when read
         else:
             self.log.max_warp_locations = eng_log["max_warp_indices"]
-        if self.log.max_warps:
-            self.total_data_energy = self.log.data_energies[-1]
-            self.total_smoothing_energy = self.log.smoothing_energies[-1]
-            self.total_level_set_energy = self.log.level_set_energies[-1]
         n = self._engine.iteration_count
+        self._totals_from_log = n > 0  # total_data_energy / _smoothing_ / _level_set_: the last iteration's, when read
         if self.verbose:
             for i in range(n):
                 print("[Iteration %d done], data energy: %f; smoothing energy: %f; level set energy: %f; max warp: %f"
@@ -171,10 +209,14 @@ class _SlavchevaOptimizerBase:
         final_live, warp, raw = outcome.finalize(*finalize_args)
         if want_report:
             shape = tuple(live.shape)
-            ws = warp_delta_statistics_from_raw(raw[:8], shape, self.maximum_warp_length_lower_threshold,
-                                                self.maximum_warp_length_upper_threshold)
-            ds = tsdf_difference_statistics_from_raw(raw[8:], shape)
-            self.log.convergence_report = ConvergenceReport(n, n >= self.max_iterations, ws, ds)
+            lower, upper, limit = self.maximum_warp_length_lower_threshold, self.maximum_warp_length_upper_threshold, \
+                self.max_iterations
+
+            def report():
+                ws = warp_delta_statistics_from_raw(raw[:8], shape, lower, upper)
+                ds = tsdf_difference_statistics_from_raw(raw[8:], shape)
+                return ConvergenceReport(n, n >= limit, ws, ds)
+            self.log.convergence_report = report  # evaluated on first access
         if on_device:
             self.warp_field = warp  # a tensor, or a callable that builds it on first access (the warp_field property)
         else:
@@ -184,6 +226,23 @@ class _SlavchevaOptimizerBase:
 
     def get_convergence_report(self):
         return self.log.convergence_report
+
+    # the energies of the last executed iteration (slavcheva_optimizer2d.py:231-236,:330): read from the call's log
+    def _total(self, name, stored):
+        if getattr(self, "_totals_from_log", False):
+            return getattr(self.log, name)[-1]
+        return self.__dict__.get(stored, 0.)
+
+    total_data_energy = property(lambda self: self._total("data_energies", "_total_data"),
+                                 lambda self, v: self._set_total("_total_data", v))
+    total_smoothing_energy = property(lambda self: self._total("smoothing_energies", "_total_smoothing"),
+                                      lambda self, v: self._set_total("_total_smoothing", v))
+    total_level_set_energy = property(lambda self: self._total("level_set_energies", "_total_level_set"),
+                                      lambda self, v: self._set_total("_total_level_set", v))
+
+    def _set_total(self, stored, value):
+        self.__dict__[stored] = value
+        self._totals_from_log = False
 
 
 class SlavchevaOptimizer2d(_SlavchevaOptimizerBase):
