@@ -20,6 +20,24 @@ class Lib:
             return inner
         return fn
 engine._lib.lib = Lib(_lib.lib)
+stamps = {}
+def stamp_init(cls, name):
+    orig = cls.__init__
+    def init(self, *a, **k):
+        stamps.setdefault(name + " in", time.perf_counter())
+        orig(self, *a, **k)
+        stamps[name + " out"] = time.perf_counter()
+    cls.__init__ = init
+from levelsetfusion_python_amd import device as dev
+stamp_init(dev.BandList, "BandList")
+stamp_init(engine._Counted, "_Counted")
+stamp_init(engine._RunOutcome, "_RunOutcome")
+stamp_init(engine._RunLog, "_RunLog")
+orig_opt = engine.SlavchevaEngine.optimize
+def eng_opt(self, *a, **k):
+    r = orig_opt(self, *a, **k); stamps["engine.optimize out"] = time.perf_counter(); return r
+engine.SlavchevaEngine.optimize = eng_opt
+detail = {}
 live = torch.empty_like(live0)
 gc.collect(); gc.freeze(); gc.disable()
 acc = [0.0] * 5
@@ -33,5 +51,13 @@ for k in range(N + 10):
     if k >= 10:
         b0, b1 = marks["lsf_state_run_begin"]; f0, f1 = marks["lsf_state_run_finish"]
         acc[0] += t1 - t0; acc[1] += b0 - t1; acc[2] += f0 - b1; acc[3] += t2 - f1; acc[4] += t2 - t0
+        prev = f1
+        for key in ("BandList in", "BandList out", "_Counted out", "_RunLog out", "_RunOutcome in", "_RunOutcome out", "engine.optimize out"):
+            if key in stamps:
+                detail[key] = detail.get(key, 0.0) + stamps[key] - prev
+                prev = stamps[key]
+        detail["optimize() out"] = detail.get("optimize() out", 0.0) + t2 - prev
+    stamps.clear()
 print("per step, us: copy_ call %.1f | optimize() entry -> run_begin %.1f | between begin and finish (host) %.1f | after run_finish returned -> optimize() returned %.1f | whole step %.1f"
       % tuple(1e6 * a / N for a in acc))
+print("after run_finish returned, us between: " + " | ".join("%s %.1f" % (k, 1e6 * v / N) for k, v in detail.items()))
