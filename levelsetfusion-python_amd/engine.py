@@ -1872,6 +1872,17 @@ class SlavchevaEngine:
         result = _lib.StateRunResult(max_value.ctypes.data, argmax.ctypes.data, energies.ctypes.data, executed.ctypes.data)
         none = ctypes.c_void_p(0)
         p_lists = lists.data_ptr()
+        # everything about the call's aftermath that does not depend on its results is made BEFORE the blocking call below --
+        # behind it the card idles until the next call's first launch (tools/host_tail.py)
+        bands = []
+        if n_interior:
+            bands.append(dev.BandList(lists[:n_interior], n_interior, _lib.BAND_INTERIOR))
+        if n_boundary or not bands:
+            bands.append(dev.BandList(lists[n_interior:] if n_boundary else lists[:1], n_boundary, _lib.BAND_BOUNDARY))
+        f = _Counted(sum(b.count for b in bands))
+        f.bands, f.records, f.boxes = bands, records, (boxes, box_canonical)
+        outcome = _RunOutcome(grid, canonical, None, target, bands, None)
+        weights = tuple(self.weights)
         _lib.check(_lib.lib.lsf_state_run_finish(
             ctypes.byref(run), ctypes.byref(self.params), ctypes.c_void_p(p_lists),
             ctypes.c_void_p(p_lists + 4 * n_interior), ctypes.c_void_p(boxes.data_ptr() if boxes is not None else 0),
@@ -1883,22 +1894,16 @@ class SlavchevaEngine:
             ctypes.c_void_p(words_host.data_ptr()), ctypes.byref(result), stream), "lsf_state_run_finish")
         if result.reach_exceeded:
             raise _SparseStateExceeded()  # the pass has left the caller's array alone (its guard); optimize() repeats
-        n_exec = int(executed.sum())
-        bands = []
-        if n_interior:
-            bands.append(dev.BandList(lists[:n_interior], n_interior, _lib.BAND_INTERIOR))
-        if n_boundary or not bands:
-            bands.append(dev.BandList(lists[n_interior:] if n_boundary else lists[:1], n_boundary, _lib.BAND_BOUNDARY))
-        f = _Counted(sum(b.count for b in bands))
-        f.bands, f.records, f.boxes = bands, records, (boxes, box_canonical)
+        n_exec = iterations if executed.all() else int(executed.sum())
         self._fast = f
         self.iteration_count = n_exec
-        wd, ws, wl = self.weights
-        self.log = _RunLog(max_value[:n_exec], argmax[:n_exec], energies[:n_exec], (wd, ws, wl))
+        self.log = _RunLog(max_value[:n_exec], argmax[:n_exec], energies[:n_exec], weights)
         # gradient_field() recomputes the last iteration's gradient on demand from its INPUT state, at the listed voxels
         self._gradient_state = ("recompute_listed", states[(n_exec - 1) % 2], canonical, grid, bands)
-        return _RunOutcome(grid, canonical, states[n_exec % 2], target, bands,
-                           words_host[n_words:].numpy().view(np.float64).copy() if statistics else None)
+        outcome.state = states[n_exec % 2]
+        if statistics:
+            outcome._raw = words_host[n_words:].numpy().view(np.float64).copy()
+        return outcome
 
     def _call_hook(self, i, max_warp, lives, warps, states, canonical, grid, sob=None):
         """iteration i has run: hand its warp and gradient to the hook in the API layout (owned slices of a slab)"""
