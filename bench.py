@@ -264,7 +264,7 @@ def extra_workload(args, device, world, rank, dist):
         def step():
             live.copy_(live0)
             opt.optimize(live, canonical)
-            band = opt._engine._sobolev_band
+            band = opt.engine._sobolev_band
             return iters * n ** 3, iters * (band.count if band is not None else n ** 3)
         b_alg = 76
         name = "3D %d^3 SobolevFusion-style SlavchevaOptimizer3d (Tikhonov + 7-tap Sobolev), %d iterations" % (n, iters)
@@ -662,7 +662,7 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
             mine.append(int(band.narrow(L.axis, L.begin, h).sum().item()))
         if L.rank < world - 1:
             mine.append(int(band.narrow(L.axis, L.end - h, h).sum().item()))
-        fast = getattr(opt._engine, "_fast", None)
+        fast = getattr(opt.engine, "_fast", None)
         compact = fast is not None and getattr(fast, "native", None) is not None and getattr(fast, "faces_ref", None) is not None
         face_voxels = h * live0.numel() // live0.shape[L.axis]
         face_bytes = [16 * v for v in mine] if compact else [16 * face_voxels] * len(mine)
@@ -680,11 +680,11 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
 
     # ---- roofline of the dominant kernel: the fused warp-update kernel alone, HIP events on its stream, over exactly
     # the launch sequence of one step (band lists of the initial pair, `iters` ping-pong launches on the float4 state)
-    eng = opt._engine
+    eng = opt.engine
     grid = eng._grid(live0)
     rec = dev.new_records(2, device)
 
-    boxes = None  # (tensor, count) when the timed steps walked the INTERIOR band voxels box by box (engine._box_walk_used)
+    boxes = None  # (tensor, count) when the timed steps walked the INTERIOR band voxels box by box (engine.last_call.box_walk)
 
     def launches(bands):
         states = dev.state_pack(live0, None, grid, copies=2)
@@ -754,7 +754,7 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
         # what the timed steps launched: one launch per iteration and list -- over the INTERIOR voxels' BOXES when the
         # engine walked those (its choice by band size: a 512^3 sphere pair)
         walk = "LIST"
-        if world == 1 and getattr(eng, "_box_walk_used", False):
+        if world == 1 and eng.last_call.box_walk:
             boxes = dev.band_boxes(dev.StatePrepare(live0, canonical, grid))
             boxes = boxes + (dev.band_boxes_canonical(canonical, grid, *boxes),)
             walk = "BOXES of 4x4x4 through LDS"

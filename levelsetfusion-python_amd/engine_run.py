@@ -1,0 +1,114 @@
+"""Whole optimize() calls enqueued by the LIBRARY (csrc/lsf_slavcheva_run.hip): the loop of
+slavcheva_optimizer2d.py:354-388 without a Python iteration -- two foreign calls that run without the interpreter lock."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, device as dev
+from .engine_common import _Counted
+from .engine_outcome import _RunLog, _RunOutcome
+
+
+class _SparseStateExceeded(Exception):
+    """a call whose ping-pong states were initialised near the band only (dev.StatePrepare(sparse_reach=...)) met a warp
+    update that can read beyond that; nothing of the caller's has been modified (SlavchevaEngine.optimize repeats the
+    call on fully initialised states and keeps doing so for this optimizer)"""
+
+
+class RunMixin:
+    """SlavchevaEngine's library-enqueued calls on whole volumes"""
+
+    def _optimize_run(self, live, canonical, grid, finalize):
+        """_optimize for the case the library enqueues in one piece (lsf_state_run_begin / _finish): prepare pass, (sparse)
+        states, band lists, all iterations, the listed finalize pass and the read-backs -- the same launches in the same
+        order as the general path below makes one by one, hence the same results, in two foreign calls that run without the
+        interpreter lock."""
+        live_out, lower_threshold, statistics = finalize
+        iterations = self.min_iterations
+        device = live.device
+        n = dev.n_voxels(grid)
+        whole = dev.full_range(grid)
+        sparse = (self.sparse_reach > 0 and n >= self.sparse_min_voxels and not self.sparse_disabled)
+        self.last_call.sparse_states = sparse
+        self.last_call.library_run = True
+        usable = (live_out is not None and live_out.is_cuda and live_out.dtype == torch.float32
+                  and live_out.is_contiguous() and tuple(live_out.shape) == tuple(live.shape))
+        target = live_out if usable else torch.empty_like(live)
+        if target is not live:
+            target.copy_(live)  # the finalize pass writes listed voxels only
+        states = [torch.empty(tuple(live.shape) + (4,), dtype=torch.float32, device=device) for _ in range(2)]
+        scratch = torch.empty(int(_lib.lib.lsf_state_prepare_scratch_elements(ctypes.byref(whole))), dtype=torch.int32,
+                              device=device)
+        totals = torch.empty(5, dtype=torch.int64, device=device)
+        totals_host = dev.pinned_scratch("run totals", 5, torch.int64)
+        run = _lib.StateRun()
+        run.live, run.canonical = dev._ptr(live, n, "live"), dev._ptr(canonical, n, "canonical")
+        run.state[0], run.state[1] = states[0].data_ptr(), states[1].data_ptr()
+        run.prepare_scratch, run.totals_device, run.totals_host = scratch.data_ptr(), totals.data_ptr(), totals_host.data_ptr()
+        run.grid = whole
+        run.sparse_reach = self.sparse_reach if sparse else 0
+        run.second_state_late = int(not sparse and n <= dev.StatePrepare.SPLIT_MAX_VOXELS)
+        count_boxes = dev.boxes_ok(whole) and (self.box_walk is True or
+                                               (self.box_walk is None and n >= self.box_walk_min_voxels))
+        box_scratch = None
+        if count_boxes:
+            box_scratch = torch.empty(int(_lib.lib.lsf_band_boxes_scratch_elements(ctypes.byref(whole))),
+                                      dtype=torch.int32, device=device)
+            run.box_scratch = box_scratch.data_ptr()
+        stream = dev.stream_ptr()
+        _lib.check(_lib.lib.lsf_state_run_begin(ctypes.byref(run), stream), "lsf_state_run_begin")
+        # (the card is writing the states now; the lists are sized from the totals the call waited for)
+        n_interior, n_boundary, opposite, first_opposite, n_boxes = totals_host.tolist()
+        lists = torch.empty(max(n_interior + n_boundary, 1), dtype=torch.int32, device=device)
+        boxes = box_canonical = None
+        if n_boxes and (self.box_walk is True or 32 * n_interior > self.box_walk_min_band_bytes):
+            boxes = torch.empty((n_boxes, 2), dtype=torch.int64, device=device)
+            box_canonical = torch.empty(n_boxes * dev.BOX_EDGE ** 3, dtype=torch.float32, device=device)
+        self.last_call.box_walk = boxes is not None
+        records = dev.new_records(iterations, device)
+        n_words = iterations * _lib.RECORD_SLOTS * dev.USED_SLOT_WORDS
+        words = torch.empty(n_words + 16, dtype=torch.int64, device=device)  # the records' used words, then the statistics
+        words_host = dev.pinned_scratch("run records", words.numel(), torch.int64)
+        stats = stats_scratch = None
+        if statistics:
+            stats = torch.empty(16, dtype=torch.float64, device=device)
+            stats_scratch = torch.empty(2 * int(_lib.lib.lsf_state_finalize_scratch_elements(ctypes.byref(whole))),
+                                        dtype=torch.float64, device=device)
+        max_value, argmax = np.empty(iterations, np.float32), np.empty(iterations, np.int64)
+        energies, executed = np.empty((iterations, 3), np.float64), np.empty(iterations, np.bool_)
+        result = _lib.StateRunResult(max_value.ctypes.data, argmax.ctypes.data, energies.ctypes.data, executed.ctypes.data)
+        none = ctypes.c_void_p(0)
+        p_lists = lists.data_ptr()
+        # everything about the call's aftermath that does not depend on its results is made BEFORE the blocking call below --
+        # behind it the card idles until the next call's first launch (tools/host_tail.py)
+        bands = []
+        if n_interior:
+            bands.append(dev.BandList(lists[:n_interior], n_interior, _lib.BAND_INTERIOR))
+        if n_boundary or not bands:
+            bands.append(dev.BandList(lists[n_interior:] if n_boundary else lists[:1], n_boundary, _lib.BAND_BOUNDARY))
+        f = _Counted(sum(b.count for b in bands))
+        f.bands, f.records, f.boxes = bands, records, (boxes, box_canonical)
+        outcome = _RunOutcome(grid, canonical, None, target, bands, None)
+        weights = tuple(self.weights)
+        _lib.check(_lib.lib.lsf_state_run_finish(
+            ctypes.byref(run), ctypes.byref(self.params), ctypes.c_void_p(p_lists),
+            ctypes.c_void_p(p_lists + 4 * n_interior), ctypes.c_void_p(boxes.data_ptr() if boxes is not None else 0),
+            ctypes.c_void_p(box_canonical.data_ptr() if boxes is not None else 0),
+            ctypes.c_void_p(records.data_ptr()), iterations,
+            dev._ptr(target, n, "live_out"), float(lower_threshold),
+            ctypes.c_void_p(stats.data_ptr()) if statistics else none,
+            ctypes.c_void_p(stats_scratch.data_ptr()) if statistics else none, ctypes.c_void_p(words.data_ptr()),
+            ctypes.c_void_p(words_host.data_ptr()), ctypes.byref(result), stream), "lsf_state_run_finish")
+        if result.reach_exceeded:
+            raise _SparseStateExceeded()  # the pass has left the caller's array alone (its guard); optimize() repeats
+        n_exec = iterations if executed.all() else int(executed.sum())
+        self._fast = f
+        self.iteration_count = n_exec
+        self.log = _RunLog(max_value[:n_exec], argmax[:n_exec], energies[:n_exec], weights)
+        # gradient_field() recomputes the last iteration's gradient on demand from its INPUT state, at the listed voxels
+        self._gradient_state = ("recompute_listed", states[(n_exec - 1) % 2], canonical, grid, bands)
+        outcome.state = states[n_exec % 2]
+        if statistics:
+            outcome._raw = words_host[n_words:].numpy().view(np.float64).copy()
+        return outcome

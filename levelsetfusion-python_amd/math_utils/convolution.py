@@ -4,7 +4,7 @@
 import numpy as np
 
 from .. import device as dev
-from ..engine import _conv_axis_order, as_device_field
+from ..engine_common import _conv_axis_order, as_device_field
 
 # the (size 7, strength 0.1) filter as float64 -- numerical data of math_utils/convolution.py:20-26
 sobolev_kernel_1d = np.array([2.995900285895913839e-04, 4.410949535667896271e-03, 6.571318954229354858e-02,

@@ -69,7 +69,8 @@ class _HierarchicalOptimizerBase:
     def __init__(self, tikhonov_term_enabled=True, gradient_kernel_enabled=True, maximum_chunk_size=8, rate=0.1,
                  maximum_iteration_count=100, maximum_warp_update_threshold=0.001, data_term_amplifier=1.0,
                  tikhonov_strength=0.2, kernel=None, verbosity_parameters=None, visualization_parameters=None,
-                 logging_parameters=None, check_interval=32, comm=None, linear_resampling=False, use_graphs=True):
+                 logging_parameters=None, check_interval=32, comm=None, linear_resampling=False, use_graphs=True,
+                 engine_options=None):
         self.verbosity_parameters = verbosity_parameters or self.VerbosityParameters()
         self.visualization_parameters = visualization_parameters  # accepted, unused: no video writers here
         self.logging_parameters = logging_parameters or self.LoggingParameters()
@@ -82,9 +83,15 @@ class _HierarchicalOptimizerBase:
             check_interval=check_interval,
             collect_reports=self.logging_parameters.collect_per_level_convergence_reports, comm=comm,
             collect_iteration_data=self.logging_parameters.collect_per_level_iteration_data,
-            linear_resampling=linear_resampling, use_graphs=use_graphs)
+            linear_resampling=linear_resampling, options=dict(dict(use_graphs=use_graphs), **(engine_options or {})))
         self.hierarchy_level = 0
         self._reports = []
+
+    @property
+    def engine(self):
+        """the HierarchicalEngine behind this optimizer: its knobs (engine_options.HIERARCHICAL_DEFAULTS, also settable
+        through the constructor's `engine_options=dict(...)`) and `last_call`, the report of what the last call took"""
+        return self._engine
 
     @property
     def iteration_hook(self):

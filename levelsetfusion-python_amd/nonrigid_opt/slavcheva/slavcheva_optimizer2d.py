@@ -95,7 +95,7 @@ class _SlavchevaOptimizerBase:
                  level_set_term_weight=0.2, maximum_warp_length_lower_threshold=0.1,
                  maximum_warp_length_upper_threshold=10000, max_iterations=100, min_iterations=1,
                  sobolev_kernel=None, visualization_settings=None, enable_convergence_status_logging=True,
-                 verbose=False, check_interval=32, comm=None):
+                 verbose=False, check_interval=32, comm=None, engine_options=None):
         self.visualization_settings = visualization_settings  # accepted, unused
         self.field_size = field_size
         self.out_path = out_path
@@ -138,7 +138,7 @@ class _SlavchevaOptimizerBase:
             upper_threshold=maximum_warp_length_upper_threshold, max_iterations=max_iterations,
             min_iterations=min_iterations,
             sobolev_kernel=None if sobolev_kernel is None else np.asarray(sobolev_kernel, dtype=np.float64),
-            check_interval=check_interval, comm=comm)
+            check_interval=check_interval, comm=comm, options=engine_options)
 
     def _run_checks(self, live_field, canonical_field):
         # slavcheva_optimizer2d.py:157-161,339: equal shapes, square/cubic, side == field_size
@@ -147,6 +147,12 @@ class _SlavchevaOptimizerBase:
                 or any(s != self.field_size for s in shape):
             raise ValueError("warp field, warped live field, and canonical field all need to be arrays of the same "
                              "size (field_size = %d on every side)." % self.field_size)
+
+    @property
+    def engine(self):
+        """the SlavchevaEngine behind this optimizer: its knobs (engine_options.SLAVCHEVA_DEFAULTS, also settable through
+        the constructor's `engine_options=dict(...)`) and `last_call`, the report of what the last call took"""
+        return self._engine
 
     @property
     def iteration_hook(self):

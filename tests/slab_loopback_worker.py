@@ -36,27 +36,26 @@ def main(out_path, port):
                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING, maximum_warp_length_lower_threshold=0.0,
                   max_iterations=12, min_iterations=12, check_interval=5)
     results = {}
-    from levelsetfusion_python_amd import engine
-    full_states_below = engine.SPARSE_MIN_VOXELS
     # ..._sparse: the ping-pong states initialised near the band only (by default from 2^21 voxels on; here at 48^2 x 52)
     for tag, transport, faces in (("rccl", "rccl", "compact"), ("rccl_full", "rccl", "full"), ("torch", "torch", "full"),
                                   ("rccl_sparse", "rccl", "compact"), ("rccl_full_sparse", "rccl", "full")):
         os.environ["LSF_SLAB_TRANSPORT"] = transport
         os.environ["LSF_SLAB_FACES"] = faces
-        engine.SPARSE_MIN_VOXELS = 0 if tag.endswith("_sparse") else full_states_below
+        options = dict(sparse_min_voxels=0) if tag.endswith("_sparse") else {}
         comm = SelfComm(layout)
         used = "rccl" if comm.native() is not None else "torch"
         if tag == "rccl":
             # a call of exactly one exchange group plans its faces (and starts the count collective) but never exchanges:
             # the next call on the same communicator must not trip over the collective left in flight
-            short = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, **dict(kwargs, max_iterations=halo, min_iterations=halo))
+            short = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, engine_options=options,
+                                             **dict(kwargs, max_iterations=halo, min_iterations=halo))
             short.optimize(live0.clone(), canonical)
             assert len(short.log.max_warps) == halo
-        opt = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, **kwargs)
+        opt = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, engine_options=options, **kwargs)
         live = live0.clone()
         opt.optimize(live, canonical)
         if tag == "rccl":
-            used += ":compact" if opt._engine._fast.faces_ref is not None else ":full"
+            used += ":compact" if opt.engine._fast.faces_ref is not None else ":full"
         own = layout.owned_local()
         results[tag] = dict(used=used, live=live[own].cpu().numpy(), warp=opt.warp_field[own].cpu().numpy(),
                             max_warps=np.float32(opt.log.max_warps), data=np.float64(opt.log.data_energies))

@@ -216,7 +216,7 @@ def test_no_cpu_fallback(pkg):
 
 
 def test_pyramid_rules(pkg):
-    from levelsetfusion_python_amd.engine import _conv_axis_order, pyramid_level_count
+    from levelsetfusion_python_amd.engine_common import _conv_axis_order, pyramid_level_count
     assert pyramid_level_count((128, 128), 8) == 4 and pyramid_level_count((16, 16), 4) == 3
     assert pyramid_level_count((64, 64, 64), 8) == 4
     for shape, chunk in (((12, 16), 4), ((16, 16), 3), ((8, 8), 8), ((16, 4), 4)):

@@ -65,22 +65,42 @@ def assert_same_run(opt, live, o, live_ref):
         assert np.allclose(mine, theirs, rtol=1e-9, atol=1e-12)
 
 
+_ORACLE_RUNS = {}
+
+
+def oracle_run(kind, n, iterations):
+    """the oracle's run of a case, made once per module (128^3 x 50 iterations takes 25 s)"""
+    key = (kind, n, iterations)
+    if key not in _ORACLE_RUNS:
+        if kind == "sphere":
+            canonical, live0 = O.sphere_pair(n, d=3)
+        else:
+            from levelsetfusion_python_amd.synthetic import depth_pair
+            canonical, live0 = (t.cpu().numpy() for t in depth_pair(n))
+        _ORACLE_RUNS[key] = (canonical, live0) + run_oracle(canonical, live0, iterations)
+    return _ORACLE_RUNS[key]
+
+
+# box_walk None: the engine's own choice at these sizes, the LIST walk (slavcheva_state_kernel<..., LIST>); True: the
+# 512^3 dominant kernel, slavcheva_state_box_kernel (4 x 4 x 4 boxes staged through LDS), held DIRECTLY against the oracle
+@pytest.mark.parametrize("box_walk", [None, True])
 @pytest.mark.parametrize("n", [64, 128])
-def test_sphere_pair_50_iterations_equal_the_oracle(lsf, n):
+def test_sphere_pair_50_iterations_equal_the_oracle(lsf, n, box_walk):
     """the bench's generator and configuration at sizes the oracle finishes in seconds (64^3: 3 s, 128^3: 25 s)"""
-    canonical, live0 = O.sphere_pair(n, d=3)
-    opt, live = run_pair(lsf, canonical, live0, 50)
-    o, live_ref = run_oracle(canonical, live0, 50)
+    canonical, live0, o, live_ref = oracle_run("sphere", n, 50)
+    opt, live = run_pair(lsf, canonical, live0, 50, engine_options=dict(box_walk=box_walk))
+    assert opt.engine.last_call.box_walk == bool(box_walk) and opt.engine.last_call.library_run
     assert_same_run(opt, live, o, live_ref)
     assert max(opt.log.max_warps) < 1.0 and min(opt.log.max_warps) > 0.0  # the run moves, and stays in the taps' reach
 
 
-def test_depth_pair_20_iterations_equal_the_oracle(lsf):
-    """SURVEY 8(d)'s other generator: two synthetic depth frames -> TSDF volumes (on the GPU) -> 20 iterations"""
-    from levelsetfusion_python_amd.synthetic import depth_pair
-    canonical, live0 = (t.cpu().numpy() for t in depth_pair(64))
-    opt, live = run_pair(lsf, canonical, live0, 20)
-    o, live_ref = run_oracle(canonical, live0, 20)
+@pytest.mark.parametrize("box_walk", [None, True])
+def test_depth_pair_20_iterations_equal_the_oracle(lsf, box_walk):
+    """SURVEY 8(d)'s other generator: two synthetic depth frames -> TSDF volumes (on the GPU) -> 20 iterations.  Its first
+    update is several voxels long: the box walk's re-warp cell leaves the staged shell there (its global-gather branch)"""
+    canonical, live0, o, live_ref = oracle_run("depth", 64, 20)
+    opt, live = run_pair(lsf, canonical, live0, 20, engine_options=dict(box_walk=box_walk))
+    assert opt.engine.last_call.box_walk == bool(box_walk)
     assert_same_run(opt, live, o, live_ref)
     assert float(np.abs(live - live0).max()) > 0.0
 
@@ -97,8 +117,8 @@ def test_full_size_list_walk_equals_dense_walk(lsf, n, iterations):
     for use_list in (True, False):
         opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT,
                                        smoothing_term_method=lsf.SmoothingTermMethod.KILLING, max_iterations=iterations,
-                                       min_iterations=iterations, check_interval=iterations, **BENCH)
-        opt._engine.use_band_list = use_list
+                                       min_iterations=iterations, check_interval=iterations,
+                                       engine_options=dict(use_band_list=use_list), **BENCH)
         live = live0.clone()
         opt.optimize(live, canonical)
         runs.append((opt, live))

@@ -28,7 +28,7 @@ def lsf():
 def _engine(lsf, n, **kw):
     args = dict(KILLING, smoothing_term_method=lsf.SmoothingTermMethod.KILLING)
     args.update(kw)
-    return lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, **args)._engine
+    return lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, **args).engine
 
 
 def _walks(lsf, canonical, live, iterations, params, sparse_reach=0):
@@ -151,11 +151,11 @@ def test_the_library_enqueued_call_on_boxes(lsf):
     results = []
     for boxed in (True, False):
         opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, max_iterations=10,
-                                       min_iterations=10, smoothing_term_method=lsf.SmoothingTermMethod.KILLING, **KILLING)
-        opt._engine.box_walk = boxed
+                                       min_iterations=10, smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
+                                       engine_options=dict(box_walk=boxed), **KILLING)
         live = live0.clone()
         opt.optimize(live, canonical)
-        assert opt._engine._box_walk_used == boxed
+        assert opt.engine.last_call.box_walk == boxed
         results.append((opt, live))
     (oa, la), (ob, lb) = results
     assert torch.equal(la, lb)
@@ -193,11 +193,11 @@ def test_full_size_box_walk_equals_list_walk_512(lsf):
     results = []
     for boxed in (None, False):
         opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, max_iterations=8,
-                                       min_iterations=8, smoothing_term_method=lsf.SmoothingTermMethod.KILLING, **KILLING)
-        opt._engine.box_walk = boxed
+                                       min_iterations=8, smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
+                                       engine_options=dict(box_walk=boxed), **KILLING)
         live = live0.clone()
         opt.optimize(live, canonical)
-        assert opt._engine._box_walk_used == (boxed is None), "512^3: the box walk is the engine's own choice"
+        assert opt.engine.last_call.box_walk == (boxed is None), "512^3: the box walk is the engine's own choice"
         results.append((opt.log, opt.get_convergence_report(), live))
         del opt
         torch.cuda.empty_cache()

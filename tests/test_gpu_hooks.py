@@ -87,7 +87,7 @@ def test_hierarchical_settings_write_through(lsf):
     first = opt.optimize(canonical, live)  # captures the graphs of the small levels with rate 0.1
     opt.rate = 0.25
     opt.maximum_iteration_count = 6
-    assert opt.rate == 0.25 and opt._engine.rate == 0.25
+    assert opt.rate == 0.25 and opt.engine.rate == 0.25
     changed = opt.optimize(canonical, live)
     fresh = lsf.HierarchicalOptimizer2d(rate=0.25, **dict(kw, maximum_iteration_count=6)).optimize(canonical, live)
     assert exact(changed, fresh) and not exact(changed, first)

@@ -113,10 +113,9 @@ def test_deferred_maximum_changes_nothing(monkeypatch):
     kw = dict(maximum_iteration_count=5, kernel=lsf.generate_1d_sobolev_kernel(7, 0.1), check_interval=3, **CONFIG5)
     runs = []
     for defer in (True, False):
-        opt = lsf.HierarchicalOptimizer3d(**kw)
-        opt._engine.defer_maximum = defer
+        opt = lsf.HierarchicalOptimizer3d(engine_options=dict(defer_maximum=defer), **kw)
         warp = opt.optimize(canonical, live)
-        res = opt._engine.level_results
+        res = opt.engine.level_results
         runs.append((warp, opt.get_per_level_maximum_updates(), [list(r.argmax) for r in res]))
     assert torch.equal(runs[0][0], runs[1][0])
     assert runs[0][1] == runs[1][1] and all(len(m) == 5 and min(m) > 0.0 for m in runs[0][1])

@@ -472,7 +472,7 @@ def test_slavcheva_band_list_is_invisible(lsf):
     canon[:, :, 130:] = -1.0
     eng = lsf.SlavchevaOptimizer3d(field_size=32, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
                                    smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
-                                   gradient_descent_rate=0.5)._engine
+                                   gradient_descent_rate=0.5).engine
     grid = dev.make_grid(shape)
     outs = []
     for mode in ("dense", "one list", "interior + boundary"):
@@ -513,7 +513,7 @@ def test_slavcheva_band_list_all_zero_update_reports_first_voxel(lsf):
     from levelsetfusion_python_amd import _lib, device as dev
     shape = (4, 8, 70)
     ones = torch.ones(shape, device="cuda")
-    eng = lsf.SlavchevaOptimizer3d(field_size=8)._engine
+    eng = lsf.SlavchevaOptimizer3d(field_size=8).engine
     grid = dev.make_grid(shape, 1, 3, 5)
     band = dev.band_list(ones, ones, grid)
     assert band.count == 0
@@ -539,7 +539,7 @@ def test_hierarchical_energy_printouts(lsf, capsys):
         warp = opt.optimize(canon, live)
         o = O.HierarchicalOracle(**kw)
         assert maxdiff(warp, o.optimize(canon, live)) == EXACT
-        results = opt._engine.level_results
+        results = opt.engine.level_results
         assert len(results) == len(o.per_level_data_energy_sums)
         for r, want_data, want_tik in zip(results, o.per_level_data_energy_sums, o.per_level_tikhonov_energy_sums):
             assert np.allclose(r.data_energies, want_data, rtol=1e-9, atol=0.0)
@@ -866,7 +866,7 @@ def test_full_size_fixed_point_and_slab_invariance_256(lsf):
     assert torch.equal(live, ct) and float(opt.warp_field.abs().max()) == 0.0
     # (ii) one fused iteration, full volume vs two slabs
     eng = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
-                                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING)._engine
+                                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING).engine
     warp_prev = (0.3 * torch.randn((3, n, n, n), device="cuda", generator=torch.Generator("cuda").manual_seed(3)))
     rec = dev.new_records(3, "cuda")
     s_in = dev.state_pack(lt, warp_prev, dev.make_grid(lt.shape), copies=1)[0]
@@ -921,7 +921,6 @@ def test_full_size_config3_hierarchical_3d_128_with_sobolev_kernel(lsf):
     assert float(np.abs(want).max()) > 1e-3
     # the same with the three filter passes of every level in one launch (lsf_convolve_xyz; by default only levels of
     # 2^23 voxels and more take it)
-    fused = lsf.HierarchicalOptimizer3d(**kw)
-    fused._engine.fused_filter_min_voxels = 0
+    fused = lsf.HierarchicalOptimizer3d(engine_options=dict(fused_filter_min_voxels=0), **kw)
     warp_fused = fused.optimize(torch.from_numpy(canon).cuda(), torch.from_numpy(live).cuda())
     assert torch.equal(warp_fused, warp)

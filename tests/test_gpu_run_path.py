@@ -1,5 +1,5 @@
 """A whole fixed-count call enqueued by the LIBRARY (lsf_state_run_begin / lsf_state_run_finish, engine._optimize_run;
-round 5) against the same call made launch by launch from Python (engine.library_run = False) and against the oracle:
+round 5) against the same call made launch by launch from Python (engine_options=dict(library_run=False)) and against the oracle:
 live field, every record, the convergence report, the warp field and the gradient field -- bit for bit, on fully and on
 sparsely initialised states, in 2-D and 3-D, with voxels on the array's faces and with an empty band.  And what the
 call leaves behind (warp_field / gradient_field, both built on demand) does not depend on the caller's tensor staying
@@ -25,40 +25,24 @@ def lsf():
     return pkg
 
 
-class _Sparse:
-    def __init__(self, reach, min_voxels=0):
-        self.new = (reach, min_voxels)
-
-    def __enter__(self):
-        from levelsetfusion_python_amd import engine
-        self.engine = engine
-        self.old = (engine.SPARSE_REACH, engine.SPARSE_MIN_VOXELS)
-        engine.SPARSE_REACH, engine.SPARSE_MIN_VOXELS = self.new
-
-    def __exit__(self, *a):
-        self.engine.SPARSE_REACH, self.engine.SPARSE_MIN_VOXELS = self.old
-
-
-def _optimizer(lsf, shape, iterations, library_run, smoothing="killing"):
+def _optimizer(lsf, shape, iterations, library_run, smoothing="killing", reach=0, **extra):
     cls = lsf.SlavchevaOptimizer3d if len(shape) == 3 else lsf.SlavchevaOptimizer2d
     kw = dict(KILLING)
     kw["smoothing_term_method"] = lsf.SmoothingTermMethod.KILLING if smoothing == "killing" else \
         lsf.SmoothingTermMethod.TIKHONOV
     opt = cls(field_size=shape[-1], compute_method=lsf.ComputeMethod.DIRECT, max_iterations=iterations,
-              min_iterations=iterations, **kw)
-    opt._engine.library_run = library_run
+              min_iterations=iterations,
+              engine_options=dict(library_run=library_run, sparse_reach=reach, sparse_min_voxels=0), **dict(kw, **extra))
     return opt
 
 
 def _call(lsf, canonical, live0, iterations, library_run, reach=0, **kw):
-    with _Sparse(reach):
-        opt = _optimizer(lsf, tuple(live0.shape), iterations, library_run, **kw)
-        live = live0.clone()
-        out = opt.optimize(live, canonical)
-        assert out is live
-        took_run = type(opt._engine._fast).__name__ == "_Counted"
-        assert took_run == library_run, "the call took the other path"
-        return opt, live
+    opt = _optimizer(lsf, tuple(live0.shape), iterations, library_run, reach=reach, **kw)
+    live = live0.clone()
+    out = opt.optimize(live, canonical)
+    assert out is live
+    assert opt.engine.last_call.library_run == library_run, "the call took the other path"
+    return opt, live
 
 
 def _same(a, b):
@@ -84,7 +68,7 @@ def test_library_run_equals_launch_by_launch_3d(lsf, n, reach):
     canonical, live0 = sphere_pair(n, 3, "cuda")
     a = _call(lsf, canonical, live0, 12, True, reach)
     b = _call(lsf, canonical, live0, 12, False, reach)
-    assert a[0]._engine._sparse_used == bool(reach)
+    assert a[0].engine.last_call.sparse_states == bool(reach)
     _same(a, b)
 
 
@@ -108,7 +92,7 @@ def test_library_run_2d_with_voxels_on_the_faces(lsf, ref_slavcheva, smoothing):
     live0 = torch.from_numpy(ref_slavcheva["ortho64.live"]).cuda()
     a = _call(lsf, canonical, live0, 5, True, smoothing=smoothing)
     b = _call(lsf, canonical, live0, 5, False, smoothing=smoothing)
-    assert len(a[0]._engine._fast.bands) == 2 and all(band.count for band in a[0]._engine._fast.bands)
+    assert len(a[0].engine._fast.bands) == 2 and all(band.count for band in a[0].engine._fast.bands)
     _same(a, b)
 
 
@@ -134,17 +118,16 @@ def test_large_updates_on_sparse_states_fall_back_and_stay_right(lsf, ref_slavch
     from levelsetfusion_python_amd import _lib, engine
 
     def run(library_run, reach):
-        with _Sparse(reach):
-            eng = engine.SlavchevaEngine(True, True, False, _lib.DATA_BASIC, _lib.SMOOTHING_KILLING, 0.1, 1.0, 0.2, 0.1, 0.2,
-                                         0.0, 10000.0, 3, 3, None)
-            eng.library_run = library_run
-            live = live0.clone()
-            outcome = eng.optimize(live, canonical, finalize=(live, 0.0, True))
-            final, warp, raw = outcome.finalize(live, 0.0, True)
-            return eng, live, (warp() if callable(warp) else warp), raw
+        eng = engine.SlavchevaEngine(True, True, False, _lib.DATA_BASIC, _lib.SMOOTHING_KILLING, 0.1, 1.0, 0.2, 0.1, 0.2,
+                                     0.0, 10000.0, 3, 3, None,
+                                     options=dict(library_run=library_run, sparse_reach=reach, sparse_min_voxels=0))
+        live = live0.clone()
+        outcome = eng.optimize(live, canonical, finalize=(live, 0.0, True))
+        final, warp, raw = outcome.finalize(live, 0.0, True)
+        return eng, live, (warp() if callable(warp) else warp), raw
     ea, la, wa, ra = run(True, 2)
     eb, lb, wb, rb = run(False, 0)
-    assert getattr(ea, "_sparse_disabled", False), "the sparse attempt must have been abandoned"
+    assert ea.sparse_disabled, "the sparse attempt must have been abandoned"
     assert max(ea.log["max_warps"]) >= 2.0
     assert torch.equal(la, lb) and torch.equal(wa, wb) and np.array_equal(ra, rb)
     assert ea.log["max_warps"] == eb.log["max_warps"] and ea.log["max_warp_indices"] == eb.log["max_warp_indices"]
@@ -158,7 +141,7 @@ def test_what_the_call_leaves_behind_does_not_depend_on_the_caller_s_tensor(lsf)
     canonical, live0 = sphere_pair(64, 3, "cuda")
     a = _call(lsf, canonical, live0, 8, True, 2)
     b = _call(lsf, canonical, live0, 8, False, 0)
-    assert a[0]._engine._sparse_used
+    assert a[0].engine.last_call.sparse_states
     a[1].fill_(float("nan"))  # the caller reuses its buffer before looking at anything
     assert torch.equal(torch.as_tensor(a[0].warp_field), torch.as_tensor(b[0].warp_field))
     assert np.array_equal(a[0].gradient_field, b[0].gradient_field)

@@ -66,10 +66,9 @@ def _worker(rank, world, port, kind, n, nz, halo, kwargs, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import levelsetfusion_python_amd as lsf
-    from levelsetfusion_python_amd import engine
     from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
-    if "LSF_SPARSE_MIN_VOXELS" in env:  # (the package is imported already: the enum members among the arguments brought it in)
-        engine.SPARSE_MIN_VOXELS = int(env["LSF_SPARSE_MIN_VOXELS"])
+    if "LSF_SPARSE_MIN_VOXELS" in env:
+        kwargs["engine_options"] = dict(sparse_min_voxels=int(env["LSF_SPARSE_MIN_VOXELS"]))
     layout = SlabLayout(nz, rank, world, halo)
     comm = SlabComm(layout)
     sl = layout.local_slice()
@@ -77,7 +76,7 @@ def _worker(rank, world, port, kind, n, nz, halo, kwargs, out_dir):
     opt = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, **kwargs)
     opt.optimize(live, canonical)
     if env.get("LSF_SPARSE_MIN_VOXELS") == "0" and max(opt.log.max_warps) < 1.0:
-        assert opt._engine._sparse_used, "this case is meant to run on states initialised near the band only"
+        assert opt.engine.last_call.sparse_states, "this case is meant to run on states initialised near the band only"
     own = layout.owned_local()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), live=live[own].cpu().numpy(),
              warp=opt.warp_field[own].cpu().numpy(), max_warps=np.float32(opt.log.max_warps),
@@ -89,7 +88,7 @@ CASES = {
     # name: (world, volume, halo, fixed iteration count or None for a threshold-terminated run, sobolev)
     "three_slabs_groups": (3, "sphere", 2, 6, False),
     "three_slabs_empty_end_ranks": (3, "island", 2, 6, False),
-    # the ping-pong states initialised near the band only (engine.SPARSE_REACH; volumes of 2^21 voxels and more by
+    # the ping-pong states initialised near the band only (engine option sparse_reach; volumes of 2^21 voxels and more by
     # default, every volume here): whole faces travel on this transport, i.e. also voxels a rank never initialised
     "three_slabs_groups_sparse_states": (3, "sphere", 2, 6, "sparse"),
     "two_slabs_large_updates_sparse_states": (2, "ortho", 2, 5, "sparse"),
@@ -192,7 +191,7 @@ def _hier_worker(rank, world, port, n, nz, halo, kwargs, out_dir):
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), warp=warp.cpu().numpy(),
              counts=np.int64(opt.get_per_level_iteration_counts()),
              last_max=np.float32([m[-1] for m in opt.get_per_level_maximum_updates()]),
-             replicated=np.int64(opt._engine.replicated_levels),
+             replicated=np.int64(opt.engine.replicated_levels),
              diff_max=np.float64([r.tsdf_difference_statistics.difference_max for r in reports]),
              diff_mean=np.float64([r.tsdf_difference_statistics.difference_mean for r in reports]))
     dist.destroy_process_group()

@@ -111,9 +111,9 @@ def _hier_worker(rank, world, port, n, nz, halo, kwargs, out_dir):
     opt = lsf.HierarchicalOptimizer3d(
         comm=SlabComm(layout),
         logging_parameters=lsf.HierarchicalOptimizer3d.LoggingParameters(collect_per_level_convergence_reports=True),
+        # every level filters with lsf_convolve_xyz on its owned z-range (default: levels of >= 2^23 voxels)
+        engine_options=dict(fused_filter_min_voxels=0) if fused_filter else None,
         **kwargs)
-    if fused_filter:  # every level filters with lsf_convolve_xyz on its owned z-range (default: levels of >= 2^23 voxels)
-        opt._engine.fused_filter_min_voxels = 0
     warp = opt.optimize(canonical, live)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), warp=warp.cpu().numpy(),
              counts=np.int64(opt.get_per_level_iteration_counts()),

@@ -41,10 +41,9 @@ def _worker(rank, world, port, kind, n, halo, kwargs, out_dir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import levelsetfusion_python_amd as lsf
-    from levelsetfusion_python_amd import engine
     from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
-    if "LSF_SPARSE_MIN_VOXELS" in env:  # (the package is imported already: the enum members among the arguments brought it in)
-        engine.SPARSE_MIN_VOXELS = int(env["LSF_SPARSE_MIN_VOXELS"])
+    if "LSF_SPARSE_MIN_VOXELS" in env:
+        kwargs["engine_options"] = dict(sparse_min_voxels=int(env["LSF_SPARSE_MIN_VOXELS"]))
     layout = SlabLayout(n, rank, world, halo, axis=1)
     comm = SlabComm(layout)
     canonical, live = (layout.cut(v) for v in _volume(kind, n))
@@ -52,7 +51,7 @@ def _worker(rank, world, port, kind, n, halo, kwargs, out_dir):
     opt = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, **kwargs)
     opt.optimize(live, canonical)
     if env.get("LSF_SPARSE_MIN_VOXELS") == "0" and max(opt.log.max_warps) < 1.0:
-        assert opt._engine._sparse_used, "this case is meant to run on states initialised near the band only"
+        assert opt.engine.last_call.sparse_states, "this case is meant to run on states initialised near the band only"
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), live=layout.owned_of(live).cpu().numpy(),
              warp=layout.owned_of(opt.warp_field).cpu().numpy(), max_warps=np.float32(opt.log.max_warps),
              locations=np.int64(opt.log.max_warp_locations), data=np.float64(opt.log.data_energies),

@@ -75,7 +75,7 @@ def test_boxes_equal_y_pass_then_update(lsf, kind, n, rate, n_taps, float32_valu
     opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, sobolev_smoothing_enabled=True,
                                    sobolev_kernel=lsf.generate_1d_sobolev_kernel(7, 0.1), level_set_term_enabled=True,
                                    smoothing_term_method=lsf.SmoothingTermMethod.KILLING, gradient_descent_rate=rate)
-    params = ctypes.byref(opt._engine.params)
+    params = ctypes.byref(opt.engine.params)
     records = dev.new_records(3, live.device)
     rec = [ctypes.c_void_p(records.data_ptr() + i * _lib.RECORD_BYTES) for i in range(3)]
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -117,7 +117,7 @@ def test_box_entry_rejects_what_it_cannot_do(lsf):
     from levelsetfusion_python_amd import _lib, device as dev
     opt = lsf.SlavchevaOptimizer3d(field_size=16, sobolev_smoothing_enabled=True,
                                    sobolev_kernel=lsf.generate_1d_sobolev_kernel(7, 0.1))
-    params = ctypes.byref(opt._engine.params)
+    params = ctypes.byref(opt.engine.params)
     taps = np.ones(11, dtype=np.float64)
     p_taps = taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
     one, two, three = ctypes.c_void_p(16), ctypes.c_void_p(32), ctypes.c_void_p(48)
@@ -143,11 +143,11 @@ def _run(lsf, canonical, live0, iterations, boxes, kind="sphere"):
     opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, sobolev_smoothing_enabled=True,
                                    sobolev_kernel=lsf.generate_1d_sobolev_kernel(7, 0.1), level_set_term_enabled=True,
                                    smoothing_term_method=lsf.SmoothingTermMethod.KILLING, max_iterations=iterations,
-                                   min_iterations=iterations, maximum_warp_length_lower_threshold=0.0)
-    opt._engine.sobolev_boxes = boxes
+                                   min_iterations=iterations, maximum_warp_length_lower_threshold=0.0,
+                                   engine_options=dict(sobolev_boxes=boxes))
     live = live0.clone()
     opt.optimize(live, canonical)
-    assert opt._engine._sobolev_boxes_used == boxes
+    assert opt.engine.last_call.sobolev_boxes == boxes
     return opt, live
 
 

@@ -67,7 +67,7 @@ def test_fused_gradient_x_equals_gradient_then_x_pass(lsf, kind, n, n_taps, floa
     opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, sobolev_smoothing_enabled=True,
                                    sobolev_kernel=lsf.generate_1d_sobolev_kernel(7, 0.1), level_set_term_enabled=True,
                                    smoothing_term_method=lsf.SmoothingTermMethod.KILLING)
-    params = ctypes.byref(opt._engine.params)
+    params = ctypes.byref(opt.engine.params)
     records = dev.new_records(2, live.device)
     rec = [ctypes.c_void_p(records.data_ptr() + i * _lib.RECORD_BYTES) for i in range(2)]
     ptr = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -98,7 +98,7 @@ def test_fused_entry_rejects_what_it_cannot_do(lsf):
     grid3, grid2 = dev.make_grid((n, n, n)), dev.make_grid((n, n))
     opt = lsf.SlavchevaOptimizer3d(field_size=n, sobolev_smoothing_enabled=True,
                                    sobolev_kernel=lsf.generate_1d_sobolev_kernel(7, 0.1))
-    params = ctypes.byref(opt._engine.params)
+    params = ctypes.byref(opt.engine.params)
     taps = np.ones(11, dtype=np.float64)
     p_taps = taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
     one = ctypes.c_void_p(1)
@@ -116,13 +116,13 @@ def test_fused_entry_rejects_what_it_cannot_do(lsf):
 def test_strip_major_list(lsf, shape, limit, strips):
     """lsf_band_list_strip_major (the walk order of the SobolevFusion z pass): the same voxels, strip by strip (strips of
     ceil(ny / strips) rows), ascending inside a strip -- equal to a sort by (strip, index)"""
-    from levelsetfusion_python_amd import _lib, device as dev, engine
+    from levelsetfusion_python_amd import _lib, device as dev, engine_sobolev
     grid = dev.make_grid(shape)
     g = torch.Generator().manual_seed(3)
     for take in (min(3000, limit), 1, limit if limit <= 40000 else 20000):
         idx = torch.sort(torch.randperm(limit, generator=g)[:take]).values.to(torch.int32).cuda()
         band = dev.BandList(idx, idx.numel(), _lib.BAND_ALL)
-        out = engine._SobolevStatePlan._strip_major(band, grid, strips=strips)
+        out = engine_sobolev._SobolevStatePlan._strip_major(band, grid, strips=strips)
         torch.cuda.synchronize()
         assert out.indices.dtype == torch.int32 and out.count == band.count and out.subset == band.subset
         got = out.indices[:out.count].long()

@@ -24,28 +24,17 @@ def lsf():
     return pkg
 
 
-class _Sparse:
-    """engine.SPARSE_REACH / SPARSE_MIN_VOXELS for the duration of a block"""
-
-    def __init__(self, reach, min_voxels=0):
-        self.new = (reach, min_voxels)
-
-    def __enter__(self):
-        from levelsetfusion_python_amd import engine
-        self.engine = engine
-        self.old = (engine.SPARSE_REACH, engine.SPARSE_MIN_VOXELS)
-        engine.SPARSE_REACH, engine.SPARSE_MIN_VOXELS = self.new
-
-    def __exit__(self, *a):
-        self.engine.SPARSE_REACH, self.engine.SPARSE_MIN_VOXELS = self.old
+def _sparse(reach):
+    """engine options: states initialised within `reach` voxels of the band (0: everywhere), at every volume size"""
+    return dict(sparse_reach=reach, sparse_min_voxels=0)
 
 
 def _run3d(lsf, canonical, live0, reach, **kw):
-    with _Sparse(reach):
-        opt = lsf.SlavchevaOptimizer3d(field_size=canonical.shape[-1], compute_method=lsf.ComputeMethod.DIRECT, **kw)
-        live = live0.clone()
-        opt.optimize(live, canonical)
-        g = opt.gradient_field
+    opt = lsf.SlavchevaOptimizer3d(field_size=canonical.shape[-1], compute_method=lsf.ComputeMethod.DIRECT,
+                                   engine_options=_sparse(reach), **kw)
+    live = live0.clone()
+    opt.optimize(live, canonical)
+    g = opt.gradient_field
     return opt, live, g
 
 
@@ -71,7 +60,7 @@ def test_sparse_states_change_nothing(lsf, n, iterations):
     full = _run3d(lsf, canonical, live0, 0, **kw)
     for reach in (1, 2):
         sparse = _run3d(lsf, canonical, live0, reach, **kw)
-        assert not getattr(sparse[0]._engine, "_sparse_disabled", False)
+        assert not sparse[0].engine.sparse_disabled
         _same(sparse, full)
     # what the step saves: the share of the volume the prepare step wrote (reach 2)
     from levelsetfusion_python_amd import device as dev
@@ -122,12 +111,11 @@ def test_updates_beyond_the_reach_fall_back_and_stay_right(lsf):
         full = _run3d(lsf, canonical, live0, 0, **kw)
         assert max(full[0].log.max_warps) > 2.0
         sparse = _run3d(lsf, canonical, live0, 2, **kw)
-        assert sparse[0]._engine._sparse_disabled
+        assert sparse[0].engine.sparse_disabled
         _same(sparse, full)
         # the same optimizer again: straight to full states, same answer
-        with _Sparse(2):
-            live = live0.clone()
-            sparse[0].optimize(live, canonical)
+        live = live0.clone()
+        sparse[0].optimize(live, canonical)
         assert torch.equal(live, full[1])
 
 
@@ -139,11 +127,10 @@ def test_reference_sized_updates_in_2d(lsf, ref_slavcheva, tmp_path):
     kw = dict(compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
               smoothing_term_method=lsf.SmoothingTermMethod.KILLING, maximum_warp_length_lower_threshold=0.0,
               max_iterations=3, min_iterations=3)
-    with _Sparse(2):
-        opt = lsf.SlavchevaOptimizer2d(out_path=str(tmp_path), field_size=64, **kw)
-        live = live0.copy()
-        opt.optimize(live, canon)
-    assert opt._engine._sparse_disabled
+    opt = lsf.SlavchevaOptimizer2d(out_path=str(tmp_path), field_size=64, engine_options=_sparse(2), **kw)
+    live = live0.copy()
+    opt.optimize(live, canon)
+    assert opt.engine.sparse_disabled
     ref = O.SlavchevaOracle(compute_method=O.DIRECT, level_set_term_enabled=True, smoothing_term_method=O.KILLING,
                             maximum_warp_length_lower_threshold=0.0, max_iterations=3, min_iterations=3)
     live_ref = live0.copy()

@@ -21,7 +21,7 @@ def child(sizes, iters):
     for n in sizes:
         eng = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT,
                                        level_set_term_enabled=True,
-                                       smoothing_term_method=lsf.SmoothingTermMethod.KILLING)._engine
+                                       smoothing_term_method=lsf.SmoothingTermMethod.KILLING).engine
         if os.environ.get("ENERGY", "1") == "0":
             eng.params.energy_mode = _lib.ENERGY_NONE
         grid = dev.make_grid((n, n, n))

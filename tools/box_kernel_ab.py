@@ -15,7 +15,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 data = sys.argv[3] if len(sys.argv) > 3 else "sphere"
 eng = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
-                               smoothing_term_method=lsf.SmoothingTermMethod.KILLING)._engine
+                               smoothing_term_method=lsf.SmoothingTermMethod.KILLING).engine
 if os.environ.get("ENERGY", "1") == "0":  # measurements: the kernels without the energy sums
     eng.params.energy_mode = _lib.ENERGY_NONE
 if data == "depth":

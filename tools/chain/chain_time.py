@@ -18,7 +18,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 stages = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 eng = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
-                               smoothing_term_method=lsf.SmoothingTermMethod.KILLING)._engine
+                               smoothing_term_method=lsf.SmoothingTermMethod.KILLING).engine
 grid = dev.make_grid((n, n, n))
 c, l = sphere_pair(n, 3, "cuda")
 bands = dev.band_lists(l, c, grid)

@@ -28,7 +28,7 @@ def child(sizes, out):
         l = l0.clone()
         opt.optimize(l, c)
         np.savez(out % n, live=l.cpu().numpy(), warp=opt.warp_field.cpu().numpy(), max_warps=np.float32(opt.log.max_warps))
-        eng = opt._engine
+        eng = opt.engine
         grid = dev.make_grid((n, n, n))
         bands = dev.band_lists(l0, c, grid)
         rec = dev.new_records(1, "cuda")

@@ -15,7 +15,7 @@ iters = 50
 for kind in ("depth", "sphere"):
     for n in [int(s) for s in (sys.argv[1] if len(sys.argv) > 1 else "256,512").split(",")]:
         eng = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
-                                       smoothing_term_method=lsf.SmoothingTermMethod.KILLING)._engine
+                                       smoothing_term_method=lsf.SmoothingTermMethod.KILLING).engine
         grid = dev.make_grid((n, n, n))
         c, l = depth_pair(n, "cuda") if kind == "depth" else sphere_pair(n, 3, "cuda")
         rec = dev.new_records(iters, "cuda")

@@ -65,8 +65,8 @@ for p in (1, 2, 3):
     optimizers = [make_optimizer() for _ in range(p)]
     for opt in optimizers:
         call(opt, torch.empty_like(live0))
-        if hasattr(opt._engine, "allow_graph_capture"):
-            opt._engine.allow_graph_capture = False
+        if hasattr(opt.engine, "allow_graph_capture"):
+            opt.engine.allow_graph_capture = False
     torch.cuda.synchronize()
     threads = [threading.Thread(target=worker, args=(streams[k], optimizers[k], steps, barrier, out, k)) for k in range(p)]
     for t in threads:

@@ -10,7 +10,7 @@ from levelsetfusion_python_amd.synthetic import sphere_pair
 
 n = int(os.environ.get("N", "256"))
 eng = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
-                               smoothing_term_method=lsf.SmoothingTermMethod.KILLING)._engine
+                               smoothing_term_method=lsf.SmoothingTermMethod.KILLING).engine
 if os.environ.get("ENERGY", "1") == "0":
     eng.params.energy_mode = _lib.ENERGY_NONE
 grid = dev.make_grid((n, n, n))

@@ -20,7 +20,7 @@ for run in (True, False):
                                    smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
                                    maximum_warp_length_lower_threshold=0.0, max_iterations=50, min_iterations=50,
                                    check_interval=50)
-    opt._engine.library_run = run
+    opt.engine.library_run = run
     opts[run] = opt
 live = torch.empty_like(live0)
 finals = {}

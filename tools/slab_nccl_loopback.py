@@ -103,7 +103,7 @@ for fixed in ((True,) if os.environ.get("FIXED_ONLY") == "1" else (True, False))
                                             _plan.get("_plan_compact_faces", 0.0) * 1e6))
         _host[0], _host[1] = 0.0, 0
         _plan.clear()
-        _f = getattr(opt._engine, "_fast", None)
+        _f = getattr(opt.engine, "_fast", None)
         if rep == 0 and _f is not None and getattr(_f, "faces", None) is not None:
             print("    compact faces: send %s / recv %s band voxels = %s / %s bytes per exchange (whole faces: 2 x %d bytes)"
                   % (list(_f.faces.send_count), list(_f.faces.recv_count), [16 * int(c) for c in _f.faces.send_count],

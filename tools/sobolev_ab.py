@@ -22,7 +22,7 @@ for boxes in sides:
                                    sobolev_kernel=lsf.generate_1d_sobolev_kernel(7, 0.1),
                                    maximum_warp_length_lower_threshold=0.0, max_iterations=50, min_iterations=50,
                                    check_interval=50)
-    opt._engine.sobolev_boxes = boxes
+    opt.engine.sobolev_boxes = boxes
     opts[boxes] = opt
 live = torch.empty_like(live0)
 finals = {}
@@ -43,9 +43,9 @@ for rnd in range(3):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps * 1e3
         finals[boxes] = live.clone()
-        band = opt._engine._sobolev_band.count
+        band = opt.engine._sobolev_band.count
         print("%d^3 round %d  %-28s %.4f ms per optimize() = %.1f us per iteration, %.3f of the HBM roofline at 76 B per "
               "band voxel (%d); boxes used: %s" % (n, rnd, "boxes behind the x pass" if boxes else "lists", dt, dt * 20.0,
-                                                  76.0 * band * 50 / (dt * 1e-3) / 8e12, band, opt._engine._sobolev_boxes_used))
+                                                  76.0 * band * 50 / (dt * 1e-3) / 8e12, band, opt.engine.last_call.sobolev_boxes))
 if len(sides) == 2:
     print("final live fields equal:", torch.equal(finals[True], finals[False]))
