@@ -407,6 +407,7 @@ def main():
 SECONDARY = (  # (workload, size, steps, warmup, iterations, extra arguments): short runs of BASELINE's other configurations
     ("killing", 512, 20, 4, 50, {}),
     ("killing-pairs", 256, 60, 4, 50, {}),
+    ("killing-default", 256, 20, 4, 100, {}),
     ("hier-tik", 256, 3, 1, 50, {}),
     ("hier-full", 256, 3, 1, 50, {}),
     ("multiframe", 512, 1, 1, 50, {}),
@@ -439,6 +440,11 @@ def secondary_measurements(args, device):
                 row["wall_s"] = time.perf_counter() - t0
                 rows.append(row)
                 continue
+            if workload == "killing-default":
+                row.update(default_loop_call(a, device))
+                row["wall_s"] = time.perf_counter() - t0
+                rows.append(row)
+                continue
             if workload == "killing":
                 d = killing_workload(a, device, 1, 0, device.index or 0, None, dense_walk=False)
             else:
@@ -462,6 +468,39 @@ def secondary_measurements(args, device):
         gc.collect()
         torch.cuda.empty_cache()
     return rows
+
+
+def default_loop_call(args, device):
+    """BASELINE config 4's terms under the reference's DEFAULT loop condition (slavcheva_optimizer2d.py:74-102,360-362:
+    min_iterations 1, max_iterations 100, lower threshold 0.1 -- what every reference caller constructs): the call ends
+    when the longest update falls to 0.1 voxels.  The library enqueues check_interval (32) gated launches at a time and
+    reads the records in between (lsf_state_run_finish with an lsf_run_loop): milliseconds per CALL and the iterations the
+    call executed, next to the same call enqueued launch by launch from Python."""
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd.hostloop import parked_collector
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    n = args.size
+    canonical, live0 = sphere_pair(n, 3, device)
+    out = {}
+    for key, library_run in (("ms_per_call", True), ("ms_per_call_launch_by_launch", False)):
+        opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                                       smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
+                                       engine_options=dict(library_run=library_run))
+        live = torch.empty_like(live0)
+        with parked_collector():
+            for k in range(args.warmup + args.steps):
+                if k == args.warmup:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                live.copy_(live0)
+                opt.optimize(live, canonical)
+            torch.cuda.synchronize()
+            out[key] = (time.perf_counter() - t0) / args.steps * 1e3
+        out.setdefault("iterations_executed", len(opt.log.max_warps))
+        assert out["iterations_executed"] == len(opt.log.max_warps)
+    return dict(config="3D %d^3 KillingFusion under the reference's default loop condition (min_iterations 1, max_iterations "
+                       "100, lower threshold 0.1), sphere-pair TSDF" % n, ms_per_step=out["ms_per_call"],
+                value=n ** 3 * out["iterations_executed"] / (out["ms_per_call"] * 1e-3), **out)
 
 
 def pairs_in_flight(args, device, lanes=2):
@@ -785,6 +824,18 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
                                if comm.native() is not None else "torch.distributed " + args.backend))
                            if world > 1 else "single GPU"),
                roofline=roofline)
+    if world > 1:
+        # the transport as RCCL itself reports it (ncclCommUserRank / ncclCommCount of the library's communicator) and how
+        # the timed calls were enqueued
+        info = comm.native_info()
+        fast = getattr(eng, "_fast", None)
+        out["rccl"] = dict(transport="native RCCL (lsf_slab_run_begin / _finish: the whole call enqueued by the library)"
+                           if eng.last_call.library_run else
+                           ("native RCCL (lsf_slab_state_iteration, one call per iteration)" if info is not None
+                            else "torch.distributed " + args.backend),
+                           nranks=info[1] if info is not None else None, rank=info[0] if info is not None else None,
+                           library_run=bool(eng.last_call.library_run),
+                           compact_faces=getattr(fast, "compact_faces", None))
     if halo_info is not None:
         out["halo_exchange"] = halo_info
         # every interior face of the run carries at least this many band voxels / the busiest rank sends this much

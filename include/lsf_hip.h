@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LSF_ABI_VERSION 3
+#define LSF_ABI_VERSION 4
 #define LSF_MAX_KERNEL_TAPS 31
 
 #define LSF_ERR_BAD_ARGUMENT (-1)
@@ -433,7 +433,21 @@ int lsf_slavcheva_state_iteration_boxes(const float *state_in, const float *cano
  * same order as the calls made one by one: identical results.  Both functions block the calling thread only (no
  * device-wide synchronisation); totals_host and words_host must be page-locked host memory; words_host and words_device
  * hold iterations x LSF_RECORD_SLOTS x 4 + 16 int64: the used words of every record slot, then the 16 statistics (as
- * doubles; zeros without statistics16). */
+ * doubles; zeros without statistics16).
+ * Threshold-terminated calls (round 6; `loop` not NULL and min_iterations < max_iterations: every reference caller's
+ * default, slavcheva_optimizer2d.py:360-362 -- min 1, max 100, lower threshold 0.1): `iterations` = max_iterations is the
+ * number of records; iteration i >= min_iterations is launched behind the device-side gate on record i - 1 (lsf_gate,
+ * LSF_GATE_SLAVCHEVA with the two thresholds), `check_interval` iterations at a time; after each batch the function reads
+ * the batch's records (one small transfer, one wait) and stops enqueueing when the reference's loop would have ended --
+ * so the executed count, every record and the final fields are the reference's, and at most check_interval - 1 gated
+ * no-op launches are wasted.  The finalize pass then reads state[executed % 2]. */
+typedef struct lsf_run_loop {
+    int32_t min_iterations;  /* >= 1 (with 0 the reference never enters its loop: the caller handles that) */
+    int32_t max_iterations;  /* the loop runs while it < min or (it < max and lower < max_warp < upper) */
+    float lower_threshold, upper_threshold;
+    int32_t check_interval;  /* >= 1 */
+    int32_t reserved;
+} lsf_run_loop;
 typedef struct lsf_state_run {
     const float *live;        /* the input live field; read again by the sparse initialisation */
     const float *canonical;
@@ -456,12 +470,14 @@ typedef struct lsf_state_run_result {
     int32_t n_lists;        /* out: launches per iteration */
     int32_t reach_exceeded; /* out: sparse states and an update of sparse_reach voxels or more -- live_out was left alone
                                (the finalize pass's guard) and the call has to be repeated on full states */
-    int32_t reserved;
+    int32_t compact_faces;  /* out (lsf_slab_run_finish): 1 = only the band voxels of the faces travelled, 0 = whole slices
+                               (no message buffer given, or a neighbour's face counts disagreed), -1 = nothing was exchanged */
 } lsf_state_run_result;
 int lsf_state_run_begin(const lsf_state_run *run, void *stream);
 int lsf_state_run_finish(const lsf_state_run *run, const lsf_slavcheva_params *params, int32_t *list_interior,
                          int32_t *list_boundary, lsf_band_box *boxes, float *box_canonical, lsf_iteration_record *records,
-                         int32_t iterations, float *live_out,
+                         int32_t iterations, const lsf_run_loop *loop /* NULL: `iterations` ungated launches */,
+                         float *live_out,
                          float lower_threshold, double *statistics16, double *finalize_scratch, int64_t *words_device,
                          int64_t *words_host, lsf_state_run_result *result, void *stream);
 
@@ -581,6 +597,8 @@ int lsf_slab_unique_id(const char *rccl_library_path, uint8_t *id_out128);
 int lsf_slab_comm_create(const char *rccl_library_path, const uint8_t *id128, int32_t rank, int32_t world,
                          lsf_slab_comm **out);
 int lsf_slab_comm_destroy(lsf_slab_comm *comm);
+/* what RCCL itself says about the communicator: ncclCommUserRank and ncclCommCount (bench.py puts them on its N > 1 line) */
+int lsf_slab_comm_info(lsf_slab_comm *comm, int32_t *rank_out, int32_t *nranks_out);
 /* The cross-check of a call's compact faces ("the caller verifies that the counts agree"), without a host round trip in
  * front of the launches: _begin hands this rank's four counts (send lower, send upper, recv lower, recv upper) to an
  * ncclAllGather on the communicator's stream and returns at once; _end waits for it and copies every rank's four counts,
@@ -594,6 +612,44 @@ int lsf_slab_state_iteration(lsf_slab_comm *comm, const float *state_in, const f
                              const lsf_slavcheva_params *params, const lsf_gate *gate, lsf_iteration_record *record,
                              int32_t exchange /* LSF_SLAB_* */,
                              const lsf_slab_faces *faces /* NULL: whole slices travel */, void *stream);
+
+/* ---- a whole fixed-count call of a z-SLAB rank, enqueued by the library in two host calls (round 6) ---------------------
+ * lsf_state_run_begin / _finish for one rank of a z-slab run: the loop of slavcheva_optimizer2d.py:354-388 over this
+ * rank's slab, with the schedule the calls above implement one iteration at a time -- exchange groups of `halo`
+ * iterations (iteration j of a group runs over the owned range widened by halo - 1 - j slices on every interior side;
+ * the group's last iteration computes the boundary slices first, sends the faces on the communicator's stream while the
+ * interior runs, and leaves the wait to the next iteration, LSF_SLAB_EXCHANGE_DEFERRED / LSF_SLAB_RESUME), compact faces
+ * cross-checked with the neighbours (lsf_slab_face_counts_*; whole slices when a neighbour disagrees), the listed
+ * finalize pass, and ONE gather of every rank's record words (ncclAllGather) so that all ranks decode the same records.
+ * Caller shape: one rank of run_hierarchical_optimizer3d_multipair.py:403-432's loop, the volume cut along z.
+ *   base: as lsf_state_run for the LOCAL array (owned slices + halos, grid.z_begin = 0, z_end = nz; z_global_offset as the
+ *         slab's); slices must be a multiple of 1024 voxels (the cut positions are per-chunk prefix counts of the
+ *         counting pass); box_scratch must be NULL; totals_device / totals_host hold 5 + 2 * LSF_SLAB_MAX_CUTS int64.
+ *   lsf_slab_run_begin: launches the counting pass and the states' initialisation and RETURNS when the list sizes and the
+ *         positions of the schedule's z cuts are on the host; it fills the out members: the caller allocates
+ *         index_scratch (out_index_entries int32) and face_messages (4 * out_face_entries + 16 floats; NULL = whole faces).
+ *   lsf_slab_run_finish: list fills, `iterations` iterations, lsf_state_finalize_listed into live_out (which holds the
+ *         input live field), the record gather; RETURNS when both streams have drained, the records of ALL ranks decoded
+ *         into `result` (energies summed over the ranks' owned slices, maxima over everything computed).  The caller
+ *         checks the maxima: an update of one voxel or more inside an exchange group has read invalid halo slices
+ *          -- every rank sees the same numbers and repeats the call on a wider slab.
+ *         words_device: (1 + world) * iterations * LSF_RECORD_SLOTS * 4 int64; words_host (page-locked): world * ... . */
+#define LSF_SLAB_MAX_CUTS 72
+typedef struct lsf_slab_run {
+    lsf_state_run base;
+    lsf_slab_layout layout;
+    int32_t exchange_interval;    /* iterations per exchange: layout.halo (exchange groups) or 1 */
+    int32_t n_cuts;               /* out: the slices at which the band lists are cut, ascending ... */
+    int32_t cut_slices[LSF_SLAB_MAX_CUTS];
+    int64_t cut_entries[2][LSF_SLAB_MAX_CUTS]; /* out: ... and the number of INTERIOR / BOUNDARY entries in front of each */
+    int64_t out_index_entries;    /* out: int32 elements of index_scratch lsf_slab_run_finish needs */
+    int64_t out_face_entries;     /* out: band voxels of the four faces (send lower, send upper, recv lower, recv upper) */
+} lsf_slab_run;
+int lsf_slab_run_begin(lsf_slab_run *run, void *stream);
+int lsf_slab_run_finish(const lsf_slab_run *run, lsf_slab_comm *comm, const lsf_slavcheva_params *params,
+                        int32_t *list_interior, int32_t *list_boundary, int32_t *index_scratch, float *face_messages,
+                        lsf_iteration_record *records, int32_t iterations, float *live_out, int64_t *words_device,
+                        int64_t *words_host, lsf_state_run_result *result, void *stream);
 
 /* the LAST pass of the zero-preserving filter at the voxels of a band list (axis = 2 in 3-D, 0 in 2-D:
  * math_utils/convolution.py:94-111,114-132; 3 / 5 / 7 / 9 taps) fused with lsf_slavcheva_update_rewarp

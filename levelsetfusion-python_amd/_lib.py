@@ -16,13 +16,13 @@ from ._build import LIB_PATH
 c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
 MAX_KERNEL_TAPS = 31
-ABI_VERSION = 3
+ABI_VERSION = 4
 # _build.abi_hash() of the include/lsf_hip.h THIS binding was written against (structures and prototypes below mirror
 # it).  The library carries the hash of the header it was compiled from (lsf_abi_hash()); a mismatch is refused at load
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "cc10a5efbfe45d84"
+HEADER_ABI_HASH = "15c3a6d973baffed"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -101,7 +101,24 @@ class StateRun(ctypes.Structure):
 class StateRunResult(ctypes.Structure):
     _fields_ = [("max_value", ctypes.c_void_p), ("argmax", ctypes.c_void_p), ("energies3", ctypes.c_void_p),
                 ("executed", ctypes.c_void_p), ("final_state", ctypes.c_int32), ("n_lists", ctypes.c_int32),
-                ("reach_exceeded", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("reach_exceeded", ctypes.c_int32), ("compact_faces", ctypes.c_int32)]
+
+
+class RunLoop(ctypes.Structure):
+    """lsf_run_loop: the loop condition of slavcheva_optimizer2d.py:360-362 for lsf_state_run_finish"""
+    _fields_ = [("min_iterations", ctypes.c_int32), ("max_iterations", ctypes.c_int32), ("lower_threshold", ctypes.c_float),
+                ("upper_threshold", ctypes.c_float), ("check_interval", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+SLAB_MAX_CUTS = 72
+
+
+class SlabRun(ctypes.Structure):
+    """lsf_slab_run: a whole fixed-count call of a z-slab rank enqueued by the library (lsf_slab_run_begin / _finish)"""
+    _fields_ = [("base", StateRun), ("layout", SlabLayoutC), ("exchange_interval", ctypes.c_int32),
+                ("n_cuts", ctypes.c_int32), ("cut_slices", ctypes.c_int32 * SLAB_MAX_CUTS),
+                ("cut_entries", (ctypes.c_int64 * SLAB_MAX_CUTS) * 2), ("out_index_entries", ctypes.c_int64),
+                ("out_face_entries", ctypes.c_int64)]
 
 
 class HierParams(ctypes.Structure):
@@ -184,8 +201,11 @@ PROTOTYPES = {
     "lsf_slavcheva_state_iteration_boxes": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp, _vp,
                                                            _i64, _vp]),
     "lsf_state_run_begin": (ctypes.c_int, [_P(StateRun), _vp]),
-    "lsf_state_run_finish": (ctypes.c_int, [_P(StateRun), _P(SlavchevaParams), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _f32, _vp, _vp,
-                                            _vp, _vp, _P(StateRunResult), _vp]),
+    "lsf_state_run_finish": (ctypes.c_int, [_P(StateRun), _P(SlavchevaParams), _vp, _vp, _vp, _vp, _vp, _i32, _P(RunLoop), _vp,
+                                            _f32, _vp, _vp, _vp, _vp, _P(StateRunResult), _vp]),
+    "lsf_slab_run_begin": (ctypes.c_int, [_P(SlabRun), _vp]),
+    "lsf_slab_run_finish": (ctypes.c_int, [_P(SlabRun), _vp, _P(SlavchevaParams), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
+                                           _P(StateRunResult), _vp]),
     "lsf_band_scratch_elements": (ctypes.c_int64, [_P(Grid)]),
     "lsf_band_count": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),
     "lsf_band_list_fill": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp, _vp, _vp]),
@@ -194,6 +214,7 @@ PROTOTYPES = {
     "lsf_slab_unique_id": (ctypes.c_int, [ctypes.c_char_p, _vp]),
     "lsf_slab_comm_create": (ctypes.c_int, [ctypes.c_char_p, _vp, _i32, _i32, _P(_vp)]),
     "lsf_slab_comm_destroy": (ctypes.c_int, [_vp]),
+    "lsf_slab_comm_info": (ctypes.c_int, [_vp, _P(_i32), _P(_i32)]),
     "lsf_slab_face_counts_begin": (ctypes.c_int, [_vp, _P(_i64)]),
     "lsf_slab_face_counts_end": (ctypes.c_int, [_vp, _P(_i64)]),
     "lsf_slab_state_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(SlabLayoutC), _P(SlabPart), _i32, _P(SlabPart),

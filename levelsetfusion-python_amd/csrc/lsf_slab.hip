@@ -31,6 +31,8 @@ struct RcclApi {
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -64,6 +66,7 @@ int load_rccl(const char* path) {
                     bind(api.CommDestroy, "ncclCommDestroy") && bind(api.GroupStart, "ncclGroupStart") &&
                     bind(api.GroupEnd, "ncclGroupEnd") && bind(api.Send, "ncclSend") &&
                     bind(api.Recv, "ncclRecv") && bind(api.AllGather, "ncclAllGather") &&
+                    bind(api.CommCount, "ncclCommCount") && bind(api.CommUserRank, "ncclCommUserRank") &&
                     bind(api.GetErrorString, "ncclGetErrorString");
     if (!ok) return LSF_ERR_RCCL_UNAVAILABLE;
     g_rccl = api;  // the handle is stored last of all members' owner: readers test it first
@@ -173,6 +176,16 @@ extern "C" int lsf_slab_comm_destroy(lsf_slab_comm* c) {
     (void)hipStreamDestroy(c->comm_stream);
     if (g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     delete c;
+    return 0;
+}
+
+extern "C" int lsf_slab_comm_info(lsf_slab_comm* c, int32_t* rank_out, int32_t* nranks_out) {
+    if (!c || !rank_out || !nranks_out) return LSF_ERR_BAD_ARGUMENT;
+    int rank = -1, count = -1;  // RCCL's own answer (ncclCommUserRank / ncclCommCount), not what the creator passed in
+    LSF_RCCL_CHECK(g_rccl.CommUserRank(c->comm, &rank));
+    LSF_RCCL_CHECK(g_rccl.CommCount(c->comm, &count));
+    *rank_out = rank;
+    *nranks_out = count;
     return 0;
 }
 
@@ -405,5 +418,404 @@ extern "C" int lsf_slab_state_iteration(lsf_slab_comm* comm, const float* state_
         return 0;
     }
     LSF_HIP_CHECK(hipStreamWaitEvent(main, comm->halos_done[k], 0));
+    return 0;
+}
+
+// ======================================================================================================================
+// A whole fixed-count call of a z-slab rank, enqueued by the library (include/lsf_hip.h: lsf_slab_run_begin / _finish;
+// round 6).  The schedule is the one SlabMixin._plan_slab (engine_slab.py) builds for lsf_slab_state_iteration, here
+// derived from the layout and the cut positions in C: the 50 Python -> C calls of a call, the 13 part descriptors, the
+// face plan's tensor bookkeeping and two torch.distributed collectives become two foreign calls.
+// ======================================================================================================================
+namespace {
+
+struct SlabCuts {
+    int chunk[LSF_SLAB_MAX_CUTS];  // first 1024-voxel chunk of the cut slice (== chunks for a cut at the end of the array)
+    int n, chunks;
+};
+
+// cut_entries[which][k] = list entries of subset `which` in front of cut slice k: the counting pass's exclusive per-chunk
+// prefix counts (two arrays, chunks + 1 apart, at the start of its scratch), or the subset's total for a cut at the end
+__global__ void slab_cuts_kernel(const int* __restrict__ prepare_scratch, const long long* __restrict__ totals, SlabCuts c,
+                                 long long* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= 2 * c.n) return;
+    const int which = k / c.n, j = k % c.n;
+    out[which * LSF_SLAB_MAX_CUTS + j] =
+        c.chunk[j] >= c.chunks ? totals[which] : (long long)prepare_scratch[(size_t)which * (c.chunks + 1) + c.chunk[j]];
+}
+
+__global__ __launch_bounds__(256) void slab_record_words_kernel(const long long* __restrict__ records,
+                                                                long long* __restrict__ out, int n_slots) {
+    const int k = blockIdx.x * 256 + threadIdx.x;  // (slot, word)
+    if (k < n_slots * 4) out[k] = records[(long long)(k >> 2) * (sizeof(lsf_record_slot) / 8) + (k & 3)];
+}
+
+inline bool slab_run_ok(const lsf_slab_run* r) {
+    const lsf_state_run& b = r->base;
+    const lsf_slab_layout& L = r->layout;
+    const lsf_grid& g = b.grid;
+    return b.live && b.canonical && b.state[0] && b.state[1] && b.state[0] != b.state[1] && b.prepare_scratch &&
+           b.totals_device && b.totals_host && !b.box_scratch && b.sparse_reach >= 0 && b.sparse_reach <= 8 &&
+           g.dims == 3 && g.z_begin == 0 && g.z_end == g.nz && g.y_global_offset == 0 &&
+           (g.ny_global == 0 || g.ny_global == g.ny) && L.nz == g.nz && L.ny == g.ny && L.nx == g.nx && L.halo >= 1 &&
+           L.z_begin >= (L.lo_rank >= 0 ? L.halo : 0) && L.z_end + (L.hi_rank >= 0 ? L.halo : 0) <= L.nz &&
+           L.z_end - L.z_begin >= 2 * L.halo && ((long long)g.ny * g.nx) % 1024 == 0 &&
+           (r->exchange_interval == 1 || r->exchange_interval == L.halo);
+}
+
+// the slices at which the schedule cuts the lists (SlabMixin._slab_cut_slices): every boundary of a widened, boundary,
+// interior or resume range, ascending, inside the array
+inline int slab_cut_slices(const lsf_slab_layout& L, int32_t* out) {
+    bool mark[4096] = {};
+    if (L.nz + 1 > 4096) return -1;
+    auto add = [&](int z) { if (z >= 0 && z <= L.nz) mark[z] = true; };
+    for (int e = 0; e <= L.halo; ++e) { add(L.z_begin - e); add(L.z_end + e); }
+    add(L.z_begin + L.halo); add(L.z_end - L.halo); add(L.z_begin + 1); add(L.z_end - 1);
+    int n = 0;
+    for (int z = 0; z <= L.nz; ++z)
+        if (mark[z]) {
+            if (n == LSF_SLAB_MAX_CUTS) return -1;
+            out[n++] = z;
+        }
+    return n;
+}
+
+struct CutTable {
+    const lsf_slab_run* run;
+    int64_t at(int which, int z) const {  // entries of list `which` in front of slice z (z must be a cut slice)
+        for (int k = 0; k < run->n_cuts; ++k)
+            if (run->cut_slices[k] == z) return run->cut_entries[which][k];
+        return -1;
+    }
+};
+
+// entries of both lists inside [z0, z1)
+inline int64_t entries_in(const CutTable& t, int z0, int z1) {
+    return (t.at(0, z1) - t.at(0, z0)) + (t.at(1, z1) - t.at(1, z0));
+}
+
+struct Range { int z0, z1; };
+
+// the launch of a phase over up to two z-ranges (ascending, disjoint): per band list ONE run of entries -- the list is
+// sorted by voxel index, so a z-range is a contiguous run of it, and two ranges are concatenated into the scratch once
+struct PartBuilder {
+    const lsf_slab_run* run;
+    CutTable cuts;
+    const int32_t* list[2];
+    int64_t total[2];
+    int32_t* scratch;
+    int64_t scratch_used, scratch_size;
+    hipStream_t stream;
+    int error = 0;
+
+    // returns the number of parts (0 or 1) written to *out
+    int build(const Range* ranges, int n_ranges, lsf_slab_part* out) {
+        Range r[2];
+        int n = 0;
+        for (int k = 0; k < n_ranges; ++k)
+            if (ranges[k].z1 > ranges[k].z0) r[n++] = ranges[k];
+        if (!n) return 0;
+        const lsf_slab_layout& L = run->layout;
+        lsf_slab_part p;
+        memset(&p, 0, sizeof(p));
+        p.grid = run->base.grid;
+        p.grid.z_begin = r[0].z0;
+        p.grid.z_end = r[n - 1].z1;
+        p.grid.energy_z_begin = L.z_begin;
+        p.grid.energy_z_end = L.z_end;
+        p.n_lists = 0;
+        for (int which = 0; which < 2; ++which) {
+            if (!total[which]) continue;
+            int64_t first[2], count[2], sum = 0;
+            int pieces = 0;
+            for (int k = 0; k < n; ++k) {
+                const int64_t a = cuts.at(which, r[k].z0), b = cuts.at(which, r[k].z1);
+                if (a < 0 || b < a) { error = LSF_ERR_BAD_ARGUMENT; return 0; }
+                if (b > a) { first[pieces] = a; count[pieces++] = b - a; sum += b - a; }
+            }
+            if (!pieces) continue;
+            const int32_t* at = list[which] + first[0];
+            if (pieces == 2) {
+                if (scratch_used + sum > scratch_size) { error = LSF_ERR_BAD_ARGUMENT; return 0; }
+                int32_t* dst = scratch + scratch_used;
+                scratch_used += sum;
+                if (hipMemcpyAsync(dst, list[which] + first[0], (size_t)count[0] * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+                    hipMemcpyAsync(dst + count[0], list[which] + first[1], (size_t)count[1] * 4, hipMemcpyDeviceToDevice, stream) != hipSuccess) {
+                    error = (int)hipGetLastError();
+                    return 0;
+                }
+                at = dst;
+            }
+            p.band_list[p.n_lists] = at;
+            p.band_count[p.n_lists] = sum;
+            p.band_subset[p.n_lists++] = which == 0 ? LSF_BAND_INTERIOR : LSF_BAND_BOUNDARY;
+        }
+        if (!p.n_lists) {  // at least one (empty) list, so that the launch still reports the arg-max of an all-zero update
+            const int which = total[0] ? 0 : 1;
+            p.band_list[0] = list[which] ? list[which] : reinterpret_cast<const int32_t*>(run->base.prepare_scratch);
+            p.band_count[0] = 0;
+            p.band_subset[0] = which == 0 ? LSF_BAND_INTERIOR : LSF_BAND_BOUNDARY;
+            p.n_lists = 1;
+        }
+        *out = p;
+        return 1;
+    }
+};
+
+// how many int32 of index scratch a call needs: the two-range parts' concatenations (boundary part of an exchange, outer
+// part of a resume) and the merged face lists
+inline void slab_scratch_sizes(const lsf_slab_run* run, int64_t* index_entries, int64_t* face_entries) {
+    const lsf_slab_layout& L = run->layout;
+    const CutTable t{run};
+    const bool lo = L.lo_rank >= 0, hi = L.hi_rank >= 0;
+    const int h = L.halo, e_last = run->exchange_interval - 1;
+    int64_t faces = 0, concat = 0;
+    if (lo) faces += entries_in(t, L.z_begin, L.z_begin + h) + entries_in(t, L.z_begin - h, L.z_begin);
+    if (hi) faces += entries_in(t, L.z_end - h, L.z_end) + entries_in(t, L.z_end, L.z_end + h);
+    if (lo && hi) {
+        concat += entries_in(t, L.z_begin, L.z_begin + h) + entries_in(t, L.z_end - h, L.z_end);  // boundary part
+        if (e_last > 0)
+            concat += entries_in(t, L.z_begin - e_last, L.z_begin + 1) + entries_in(t, L.z_end - 1, L.z_end + e_last);
+    }
+    *face_entries = faces;
+    *index_entries = concat + faces + 16;
+}
+
+}  // namespace
+
+extern "C" int lsf_slab_run_begin(lsf_slab_run* run, void* stream) {
+    if (!run || !slab_run_ok(run)) return LSF_ERR_BAD_ARGUMENT;
+    const lsf_state_run& b = run->base;
+    const lsf_grid* g = &b.grid;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool sparse = b.sparse_reach > 0;
+    run->n_cuts = slab_cut_slices(run->layout, run->cut_slices);
+    if (run->n_cuts < 2) return LSF_ERR_BAD_ARGUMENT;
+    float* b_in_pass = (sparse || b.second_state_late) ? nullptr : b.state[1];
+    if (int e = lsf_state_prepare(b.live, b.canonical, sparse ? nullptr : b.state[0], b_in_pass, g, b.prepare_scratch,
+                                  b.totals_device, stream))
+        return e;
+    SlabCuts c;
+    const long long per_slice = ((long long)g->ny * g->nx) / 1024;
+    c.n = run->n_cuts;
+    c.chunks = (int)(per_slice * g->nz);
+    for (int k = 0; k < c.n; ++k) c.chunk[k] = (int)(per_slice * run->cut_slices[k]);
+    hipLaunchKernelGGL(slab_cuts_kernel, dim3(1), dim3(2 * LSF_SLAB_MAX_CUTS), 0, s, b.prepare_scratch,
+                       reinterpret_cast<const long long*>(b.totals_device), c,
+                       reinterpret_cast<long long*>(b.totals_device) + 5);
+    LSF_HIP_CHECK(hipGetLastError());
+    LSF_HIP_CHECK(hipMemsetAsync(b.totals_device + 4, 0, sizeof(int64_t), s));
+    LSF_HIP_CHECK(hipMemcpyAsync(b.totals_host, b.totals_device, (5 + 2 * LSF_SLAB_MAX_CUTS) * sizeof(int64_t),
+                                 hipMemcpyDeviceToHost, s));
+    hipEvent_t sizes = nullptr;
+    LSF_HIP_CHECK(hipEventCreateWithFlags(&sizes, hipEventDisableTiming));
+    int status = 0;
+    if (hipEventRecord(sizes, s) != hipSuccess) status = (int)hipGetLastError();
+    // the states are written BEHIND the copy of the sizes: the card fills them while the host wakes up on the sizes
+    if (!status && sparse)
+        status = lsf_state_pack_needed(b.live, b.state[0], b.state[1], g, b.prepare_scratch, b.sparse_reach, 0, stream);
+    else if (!status && b.second_state_late)
+        status = lsf_state_pack(b.live, nullptr, b.state[1], nullptr, g, stream);
+    if (!status && hipEventSynchronize(sizes) != hipSuccess) status = (int)hipGetLastError();
+    (void)hipEventDestroy(sizes);
+    if (status) return status;
+    for (int which = 0; which < 2; ++which)
+        for (int k = 0; k < run->n_cuts; ++k) run->cut_entries[which][k] = b.totals_host[5 + which * LSF_SLAB_MAX_CUTS + k];
+    slab_scratch_sizes(run, &run->out_index_entries, &run->out_face_entries);
+    return 0;
+}
+
+extern "C" int lsf_slab_run_finish(const lsf_slab_run* run, lsf_slab_comm* comm, const lsf_slavcheva_params* params,
+                                   int32_t* list_interior, int32_t* list_boundary, int32_t* index_scratch,
+                                   float* face_messages, lsf_iteration_record* records, int32_t iterations,
+                                   float* live_out, int64_t* words_device, int64_t* words_host,
+                                   lsf_state_run_result* result, void* stream) {
+    if (!run || !slab_run_ok(run) || !comm || !params || !records || iterations < 1 || !live_out || !words_device ||
+        !words_host || !result || !result->max_value || !result->argmax || !result->energies3 || !result->executed ||
+        !index_scratch)
+        return LSF_ERR_BAD_ARGUMENT;
+    const lsf_state_run& b = run->base;
+    const lsf_slab_layout& L = run->layout;
+    const lsf_grid* g = &b.grid;
+    if (L.lo_rank >= comm->world || L.hi_rank >= comm->world) return LSF_ERR_BAD_ARGUMENT;
+    const int64_t n_interior = b.totals_host[0], n_boundary = b.totals_host[1];
+    if (n_interior < 0 || n_boundary < 0 || n_interior > 0x7fffffffll || n_boundary > 0x7fffffffll ||
+        (n_interior && !list_interior) || (n_boundary && !list_boundary))
+        return LSF_ERR_BAD_ARGUMENT;
+    hipStream_t main = reinterpret_cast<hipStream_t>(stream);
+    if (n_interior)
+        if (int e = lsf_band_list_fill_prepared(g, LSF_BAND_INTERIOR, b.prepare_scratch, list_interior, stream)) return e;
+    if (n_boundary)
+        if (int e = lsf_band_list_fill_prepared(g, LSF_BAND_BOUNDARY, b.prepare_scratch, list_boundary, stream)) return e;
+
+    const bool lo = L.lo_rank >= 0, hi = L.hi_rank >= 0;
+    const int h = L.halo, k_group = run->exchange_interval, e_last = k_group - 1;
+    PartBuilder pb{run, CutTable{run}, {list_interior, list_boundary}, {n_interior, n_boundary}, index_scratch, 0,
+                   run->out_index_entries, main};
+
+    // ---- the schedule's parts (SlabMixin._plan_slab) ----------------------------------------------------------------
+    lsf_slab_part widened[32];  // [e]: the owned range widened by e slices on every interior side
+    int n_widened[32];
+    if (k_group > 32) return LSF_ERR_BAD_ARGUMENT;
+    for (int e = 0; e < k_group; ++e) {
+        const Range r{L.z_begin - (lo ? e : 0), L.z_end + (hi ? e : 0)};
+        n_widened[e] = pb.build(&r, 1, &widened[e]);
+    }
+    const int z_lo = L.z_begin + (lo ? h : 0), z_hi = L.z_end - (hi ? h : 0);
+    const bool exchanges = iterations > k_group;  // is there an iteration j == k - 1 with another one behind it?
+    lsf_slab_part x_boundary, x_interior, r_first, r_second;
+    int n_xb = 0, n_xi = 0, n_r1 = 0, n_r2 = 0;
+    if (exchanges) {
+        const Range bnd[2] = {{L.z_begin, lo ? z_lo : L.z_begin}, {hi ? z_hi : L.z_end, L.z_end}};
+        const Range inner{z_lo, z_hi};
+        n_xb = pb.build(bnd, 2, &x_boundary);
+        n_xi = pb.build(&inner, 1, &x_interior);
+        if (k_group > 1) {
+            const int in_lo = L.z_begin + (lo ? 1 : 0), in_hi = L.z_end - (hi ? 1 : 0);
+            const Range first{in_lo, in_hi};
+            const Range outer[2] = {{lo ? L.z_begin - e_last : in_lo, in_lo}, {in_hi, hi ? L.z_end + e_last : in_hi}};
+            n_r1 = pb.build(&first, 1, &r_first);
+            n_r2 = pb.build(outer, 2, &r_second);
+        }
+    }
+    if (pb.error) return pb.error;
+
+    // ---- compact faces: the band voxels of the boundary / halo slices, ascending (both lists merged) ------------------
+    lsf_slab_faces faces;
+    memset(&faces, 0, sizeof(faces));
+    bool compact = exchanges && face_messages != nullptr;
+    if (compact) {
+        const CutTable& t = pb.cuts;
+        const Range face_ranges[4] = {{L.z_begin, L.z_begin + h}, {L.z_end - h, L.z_end},      // send lower, upper
+                                      {L.z_begin - h, L.z_begin}, {L.z_end, L.z_end + h}};     // recv lower, upper
+        const bool present[4] = {lo, hi, lo, hi};
+        const int32_t* face_list[4] = {nullptr, nullptr, nullptr, nullptr};
+        int64_t face_count[4] = {0, 0, 0, 0};
+        const int32_t* ma[4]; const int32_t* mb[4]; int32_t* mo[4];
+        int64_t mna[4], mnb[4];
+        int merges = 0;
+        for (int f = 0; f < 4; ++f) {
+            if (!present[f]) continue;
+            const int64_t a0 = t.at(0, face_ranges[f].z0), a1 = t.at(0, face_ranges[f].z1);
+            const int64_t b0 = t.at(1, face_ranges[f].z0), b1 = t.at(1, face_ranges[f].z1);
+            if (a0 < 0 || a1 < a0 || b0 < 0 || b1 < b0) return LSF_ERR_BAD_ARGUMENT;
+            face_count[f] = (a1 - a0) + (b1 - b0);
+            if (a1 > a0 && b1 > b0) {
+                if (pb.scratch_used + face_count[f] > pb.scratch_size) return LSF_ERR_BAD_ARGUMENT;
+                ma[merges] = list_interior + a0; mna[merges] = a1 - a0;
+                mb[merges] = list_boundary + b0; mnb[merges] = b1 - b0;
+                mo[merges] = index_scratch + pb.scratch_used;
+                face_list[f] = mo[merges++];
+                pb.scratch_used += face_count[f];
+            } else if (a1 > a0) {
+                face_list[f] = list_interior + a0;
+            } else if (b1 > b0) {
+                face_list[f] = list_boundary + b0;
+            }
+        }
+        if (merges)
+            if (int e = lsf_merge_sorted_runs(ma, mna, mb, mnb, mo, merges, stream)) return e;
+        float* msg = face_messages;
+        const int32_t* none = reinterpret_cast<const int32_t*>(b.prepare_scratch);  // a valid address for an empty face
+        for (int f = 0; f < 4; ++f) {
+            const int side = f & 1;
+            (f < 2 ? faces.send_list : faces.recv_list)[side] = face_list[f] ? face_list[f] : none;
+            (f < 2 ? faces.send_count : faces.recv_count)[side] = face_count[f];
+            (f < 2 ? faces.send_msg : faces.recv_msg)[side] = msg;
+            msg += 4 * (face_count[f] > 0 ? face_count[f] : 1);
+        }
+        const int64_t mine[4] = {faces.send_count[0], faces.send_count[1], faces.recv_count[0], faces.recv_count[1]};
+        if (int e = lsf_slab_face_counts_begin(comm, mine)) return e;
+    }
+
+    // ---- the iterations ---------------------------------------------------------------------------------------------
+    bool faces_checked = !compact;
+    for (int32_t i = 0; i < iterations; ++i) {
+        const float* s_in = b.state[i % 2];
+        float* s_out = b.state[(i + 1) % 2];
+        const int j = i % k_group;
+        const bool exchange = j == k_group - 1 && i + 1 < iterations;
+        const bool resume = k_group > 1 && j == 0 && i > 0;
+        int e = 0;
+        if (exchange) {
+            if (!faces_checked) {
+                // the neighbours' counts (the collective started in front of the first iteration has long finished): a rank's
+                // lower boundary lands in its lower neighbour's UPPER halo, its upper boundary in the upper one's LOWER halo
+                int64_t table[4 * 64];
+                if (comm->world > 64) return LSF_ERR_BAD_ARGUMENT;
+                if (int ee = lsf_slab_face_counts_end(comm, table)) return ee;
+                bool ok = true;
+                if (comm->world == 1) ok = table[0] == table[3] && table[1] == table[2];  // the loop-back: its own neighbour
+                for (int r = 0; r + 1 < comm->world; ++r)
+                    ok = ok && table[4 * r + 1] == table[4 * (r + 1) + 2] && table[4 * (r + 1) + 0] == table[4 * r + 3];
+                if (!ok) compact = false;  // every rank sees every row: all of them fall back to whole slices together
+                faces_checked = true;
+            }
+            e = lsf_slab_state_iteration(comm, s_in, b.canonical, s_out, &L, &x_boundary, n_xb, &x_interior, n_xi, params,
+                                         nullptr, records + i, k_group > 1 ? LSF_SLAB_EXCHANGE_DEFERRED : LSF_SLAB_EXCHANGE,
+                                         compact ? &faces : nullptr, stream);
+        } else if (resume) {
+            e = lsf_slab_state_iteration(comm, s_in, b.canonical, s_out, &L, &r_first, n_r1, &r_second, n_r2, params, nullptr,
+                                         records + i, LSF_SLAB_RESUME, nullptr, stream);
+        } else {
+            const int w = j == k_group - 1 ? 0 : k_group - 1 - j;
+            e = lsf_slab_state_iteration(comm, s_in, b.canonical, s_out, &L, nullptr, 0, &widened[w], n_widened[w], params,
+                                         nullptr, records + i, LSF_SLAB_LAUNCH, nullptr, stream);
+        }
+        if (e) return e;
+    }
+    if (compact && !faces_checked) {  // (cannot happen: compact implies an exchange) -- never leave the collective open
+        int64_t table[4 * 64];
+        (void)lsf_slab_face_counts_end(comm, table);
+    }
+
+    // ---- the end of the call: final live values of the listed voxels into the caller's array, the records of all ranks --
+    const bool sparse = b.sparse_reach > 0;
+    const int32_t* listed[2] = {nullptr, nullptr};
+    int64_t listed_counts[2] = {0, 0};
+    int n_listed = 0;
+    if (n_interior) { listed[n_listed] = list_interior; listed_counts[n_listed++] = n_interior; }
+    if (n_boundary) { listed[n_listed] = list_boundary; listed_counts[n_listed++] = n_boundary; }
+    if (int e = lsf_state_finalize_listed(b.state[iterations % 2], b.canonical, live_out, nullptr, g, listed, listed_counts,
+                                          n_listed, 0, -1, 0.0f, nullptr, nullptr, nullptr, sparse ? records : nullptr,
+                                          sparse ? iterations : 0, (float)b.sparse_reach, stream))
+        return e;
+    const int n_slots = iterations * LSF_RECORD_SLOTS;
+    const size_t words = (size_t)n_slots * 4;
+    hipLaunchKernelGGL(slab_record_words_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, main,
+                       reinterpret_cast<const long long*>(records), reinterpret_cast<long long*>(words_device), n_slots);
+    LSF_HIP_CHECK(hipGetLastError());
+    // every rank's words side by side on every rank: one collective on the communicator's stream (all of a
+    // communicator's operations are issued there, in the same order on every rank)
+    const unsigned k = comm->parity++ & 1u;
+    LSF_HIP_CHECK(hipEventRecord(comm->boundary_done[k], main));
+    LSF_HIP_CHECK(hipStreamWaitEvent(comm->comm_stream, comm->boundary_done[k], 0));
+    LSF_RCCL_CHECK(g_rccl.AllGather(words_device, words_device + words, words, ncclInt64, comm->comm, comm->comm_stream));
+    LSF_HIP_CHECK(hipMemcpyAsync(words_host, words_device + words, words * (size_t)comm->world * sizeof(int64_t),
+                                 hipMemcpyDeviceToHost, comm->comm_stream));
+    LSF_HIP_CHECK(hipStreamSynchronize(comm->comm_stream));
+    LSF_HIP_CHECK(hipStreamSynchronize(main));
+    comm->pending = -1;
+    // rank-major [world][iterations][slots][4] -> per iteration the ranks' slots side by side (in place would overlap: go
+    // through the decoder one iteration at a time)
+    {
+        int64_t row[64 * LSF_RECORD_SLOTS * 4];
+        if (comm->world > 64) return LSF_ERR_BAD_ARGUMENT;
+        for (int32_t i = 0; i < iterations; ++i) {
+            for (int r = 0; r < comm->world; ++r)
+                memcpy(row + (size_t)r * LSF_RECORD_SLOTS * 4,
+                       words_host + ((size_t)r * iterations + i) * LSF_RECORD_SLOTS * 4, LSF_RECORD_SLOTS * 4 * sizeof(int64_t));
+            if (int e = lsf_records_decode(row, 1, LSF_RECORD_SLOTS * comm->world, 4, result->max_value + i,
+                                           result->argmax + i, result->energies3 + 3 * (size_t)i, result->executed + i))
+                return e;
+        }
+    }
+    result->final_state = iterations % 2;
+    result->n_lists = n_listed;
+    result->reach_exceeded = 0;
+    result->compact_faces = exchanges ? (compact ? 1 : 0) : -1;
+    for (int32_t i = 0; i < iterations && sparse; ++i)
+        if (result->executed[i] && !(result->max_value[i] < (float)b.sparse_reach)) result->reach_exceeded = 1;
     return 0;
 }

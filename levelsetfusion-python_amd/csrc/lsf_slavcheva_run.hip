@@ -1,4 +1,5 @@
-// A whole fixed-count KillingFusion-style optimize() call of a whole volume, enqueued by the LIBRARY in two host calls
+// A whole KillingFusion-style optimize() call of a whole volume -- a fixed iteration count or the reference's default
+// threshold-terminated loop --, enqueued by the LIBRARY in two host calls
 // (include/lsf_hip.h: lsf_state_run_begin / lsf_state_run_finish).  Reference loop: nonrigid_opt/slavcheva/
 // slavcheva_optimizer2d.py:354-388 -- one Python iteration of which is ONE kernel launch here; caller shape
 // run_hierarchical_optimizer3d_multipair.py:403-432 (a loop of such calls over independent pairs).
@@ -21,10 +22,10 @@ namespace {
 // the convergence statistics, gathered for ONE copy to the host
 __global__ __launch_bounds__(kBlock) void records_used_words_kernel(const long long* __restrict__ records,
                                                                     const long long* __restrict__ statistics16,
-                                                                    long long* __restrict__ out, int n_slots) {
-    const int k = blockIdx.x * kBlock + threadIdx.x;  // (slot, word), then the statistics
+                                                                    long long* __restrict__ out, int n_slots, int tail) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;  // (slot, word), then (tail != 0) the statistics
     if (k < n_slots * 4) out[k] = records[(long long)(k >> 2) * (sizeof(lsf_record_slot) / 8) + (k & 3)];
-    else if (k < n_slots * 4 + 16) out[k] = statistics16 ? statistics16[k - n_slots * 4] : 0ll;
+    else if (tail && k < n_slots * 4 + 16) out[k] = statistics16 ? statistics16[k - n_slots * 4] : 0ll;
 }
 
 // one timing-less event per host thread and device, created on first use (an event per call costs a create / destroy pair)
@@ -79,13 +80,16 @@ extern "C" int lsf_state_run_begin(const lsf_state_run* run, void* stream) {
 
 extern "C" int lsf_state_run_finish(const lsf_state_run* run, const lsf_slavcheva_params* params, int32_t* list_interior,
                                     int32_t* list_boundary, lsf_band_box* boxes, float* box_canonical,
-                                    lsf_iteration_record* records, int32_t iterations,
+                                    lsf_iteration_record* records, int32_t iterations, const lsf_run_loop* loop,
                                     float* live_out, float lower_threshold, double* statistics16,
                                     double* finalize_scratch, int64_t* words_device, int64_t* words_host,
                                     lsf_state_run_result* result, void* stream) {
     if (!run_ok(run) || !params || !records || iterations < 1 || !live_out || !words_device || !words_host || !result ||
         (statistics16 && !finalize_scratch) || !result->max_value || !result->argmax ||
         !result->energies3 || !result->executed)
+        return LSF_ERR_BAD_ARGUMENT;
+    if (loop && (loop->min_iterations < 1 || loop->check_interval < 1 ||
+                 (loop->max_iterations > loop->min_iterations ? loop->max_iterations : loop->min_iterations) != iterations))
         return LSF_ERR_BAD_ARGUMENT;
     const lsf_grid* g = &run->grid;
     if (int e = check_grid(g)) return e;
@@ -119,37 +123,68 @@ extern "C" int lsf_state_run_finish(const lsf_state_run* run, const lsf_slavchev
         if (int e = lsf_band_boxes_fill(g, LSF_BAND_INTERIOR, run->prepare_scratch, run->box_scratch, boxes, stream)) return e;
         if (int e = lsf_band_boxes_canonical(run->canonical, g, boxes, n_boxes, box_canonical, stream)) return e;
     }
-    // the iterations: ungated (a fixed count), iteration i reads state[i % 2] and writes the other
-    for (int32_t i = 0; i < iterations; ++i)
-        for (int k = 0; k < n_lists; ++k) {
-            int e;
-            if (n_boxes > 0 && subsets[k] == LSF_BAND_INTERIOR)
-                e = lsf_slavcheva_state_iteration_boxes(run->state[i % 2], box_canonical, run->state[(i + 1) % 2], g, params,
-                                                        nullptr, records + i, boxes, n_boxes, stream);
-            else
-                e = lsf_slavcheva_state_iteration(run->state[i % 2], run->canonical, run->state[(i + 1) % 2], g, params,
-                                                  nullptr, records + i, lists[k], counts[k], subsets[k], stream);
-            if (e) return e;
+    const bool sparse = run->sparse_reach > 0;
+    const int n_slots = iterations * LSF_RECORD_SLOTS;
+    // The iterations: iteration i reads state[i % 2] and writes the other.  A fixed count: all of them ungated, at once.
+    // With a stop test that can fire (slavcheva_optimizer2d.py:360-362) iteration i >= min_iterations sits behind the
+    // device-side gate on record i - 1, and the host looks at the records every check_interval iterations.
+    const bool fixed = !loop || loop->min_iterations >= iterations;
+    int32_t it = 0, n_exec = fixed ? iterations : 0;
+    while (it < iterations) {
+        const int32_t batch = fixed ? iterations : (loop->check_interval < iterations - it ? loop->check_interval : iterations - it);
+        for (int32_t i = it; i < it + batch; ++i) {
+            lsf_gate gate_i{records + (i > 0 ? i - 1 : 0), LSF_GATE_SLAVCHEVA, loop ? loop->lower_threshold : 0.0f,
+                            loop ? loop->upper_threshold : 0.0f};
+            const lsf_gate* gate = (fixed || i < loop->min_iterations) ? nullptr : &gate_i;
+            for (int k = 0; k < n_lists; ++k) {
+                int e;
+                if (n_boxes > 0 && subsets[k] == LSF_BAND_INTERIOR)
+                    e = lsf_slavcheva_state_iteration_boxes(run->state[i % 2], box_canonical, run->state[(i + 1) % 2], g, params,
+                                                            gate, records + i, boxes, n_boxes, stream);
+                else
+                    e = lsf_slavcheva_state_iteration(run->state[i % 2], run->canonical, run->state[(i + 1) % 2], g, params,
+                                                      gate, records + i, lists[k], counts[k], subsets[k], stream);
+                if (e) return e;
+            }
         }
+        it += batch;
+        if (fixed) break;
+        // the batch's records (their used words) to the host, one wait; then the reference's loop condition
+        const int first_slot = (it - batch) * LSF_RECORD_SLOTS, batch_slots = batch * LSF_RECORD_SLOTS;
+        hipLaunchKernelGGL(records_used_words_kernel, dim3((batch_slots * 4 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                           reinterpret_cast<const long long*>(records + (it - batch)), nullptr,
+                           reinterpret_cast<long long*>(words_device) + (size_t)first_slot * 4, batch_slots, 0);
+        if (int e = launch_status()) return e;
+        if (hipMemcpyAsync(words_host + (size_t)first_slot * 4, words_device + (size_t)first_slot * 4,
+                           (size_t)batch_slots * 4 * sizeof(int64_t), hipMemcpyDeviceToHost, s) != hipSuccess)
+            return (int)hipGetLastError();
+        if (hipStreamSynchronize(s) != hipSuccess) return (int)hipGetLastError();
+        if (int e = lsf_records_decode(words_host, it, LSF_RECORD_SLOTS, 4, result->max_value, result->argmax,
+                                       result->energies3, result->executed))
+            return e;
+        n_exec = 0;
+        while (n_exec < it && result->executed[n_exec]) ++n_exec;
+        if (n_exec < it) break;  // the gate closed inside the batch
+        const float m = result->max_value[n_exec - 1];
+        if (n_exec >= loop->min_iterations && !(loop->lower_threshold < m && m < loop->upper_threshold)) break;
+    }
     // the end of the call behind the last iteration: the listed voxels' live values into the caller's array (which holds
     // the input everywhere else) and the convergence statistics; with sparsely initialised states the pass looks at the
     // records first and leaves everything alone when an update outran what was initialised
-    const float* final_state = run->state[iterations % 2];
+    const float* final_state = run->state[n_exec % 2];
     int64_t listed_counts[2] = {0, 0};
     const int32_t* listed[2] = {nullptr, nullptr};
     int n_listed = 0;
     for (int k = 0; k < n_lists; ++k)
         if (counts[k]) { listed[n_listed] = lists[k]; listed_counts[n_listed++] = counts[k]; }
-    const bool sparse = run->sparse_reach > 0;
     if (int e = lsf_state_finalize_listed(final_state, run->canonical, live_out, nullptr, g, listed, listed_counts, n_listed,
                                           run->totals_host[2], run->totals_host[3], lower_threshold, statistics16,
                                           finalize_scratch, nullptr, sparse ? records : nullptr, sparse ? iterations : 0,
                                           (float)run->sparse_reach, stream))
         return e;
-    const int n_slots = iterations * LSF_RECORD_SLOTS;
     hipLaunchKernelGGL(records_used_words_kernel, dim3((n_slots * 4 + 16 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
                        reinterpret_cast<const long long*>(records), reinterpret_cast<const long long*>(statistics16),
-                       reinterpret_cast<long long*>(words_device), n_slots);
+                       reinterpret_cast<long long*>(words_device), n_slots, 1);
     if (int e = launch_status()) return e;
     if (hipMemcpyAsync(words_host, words_device, ((size_t)n_slots * 4 + 16) * sizeof(int64_t), hipMemcpyDeviceToHost, s) !=
         hipSuccess)
@@ -158,9 +193,10 @@ extern "C" int lsf_state_run_finish(const lsf_state_run* run, const lsf_slavchev
     if (int e = lsf_records_decode(words_host, iterations, LSF_RECORD_SLOTS, 4, result->max_value, result->argmax,
                                    result->energies3, result->executed))
         return e;
-    result->final_state = iterations % 2;
+    result->final_state = n_exec % 2;
     result->n_lists = n_lists;
     result->reach_exceeded = 0;
+    result->compact_faces = -1;
     for (int32_t i = 0; i < iterations && sparse; ++i)
         if (result->executed[i] && !(result->max_value[i] < (float)run->sparse_reach)) result->reach_exceeded = 1;
     return 0;

@@ -21,11 +21,17 @@ class RunMixin:
 
     def _optimize_run(self, live, canonical, grid, finalize):
         """_optimize for the case the library enqueues in one piece (lsf_state_run_begin / _finish): prepare pass, (sparse)
-        states, band lists, all iterations, the listed finalize pass and the read-backs -- the same launches in the same
-        order as the general path below makes one by one, hence the same results, in two foreign calls that run without the
-        interpreter lock."""
+        states, band lists, all iterations -- a fixed count, or the reference's threshold-terminated loop in batches of
+        check_interval gated launches --, the listed finalize pass and the read-backs: the same launches in the same order
+        as the general path makes one by one, hence the same results, in two foreign calls that run without the interpreter
+        lock."""
         live_out, lower_threshold, statistics = finalize
-        iterations = self.min_iterations
+        # the number of records; with min < max the stop test can fire (the reference's default: slavcheva_optimizer2d.py:
+        # 360-362) and the library enqueues check_interval gated iterations at a time, reading the records in between
+        iterations = max(self.min_iterations, self.max_iterations)
+        loop = None
+        if self.min_iterations < iterations:
+            loop = _lib.RunLoop(self.min_iterations, self.max_iterations, self.lo, self.hi, self.check_interval, 0)
         device = live.device
         n = dev.n_voxels(grid)
         whole = dev.full_range(grid)
@@ -95,7 +101,7 @@ class RunMixin:
             ctypes.byref(run), ctypes.byref(self.params), ctypes.c_void_p(p_lists),
             ctypes.c_void_p(p_lists + 4 * n_interior), ctypes.c_void_p(boxes.data_ptr() if boxes is not None else 0),
             ctypes.c_void_p(box_canonical.data_ptr() if boxes is not None else 0),
-            ctypes.c_void_p(records.data_ptr()), iterations,
+            ctypes.c_void_p(records.data_ptr()), iterations, ctypes.byref(loop) if loop is not None else None,
             dev._ptr(target, n, "live_out"), float(lower_threshold),
             ctypes.c_void_p(stats.data_ptr()) if statistics else none,
             ctypes.c_void_p(stats_scratch.data_ptr()) if statistics else none, ctypes.c_void_p(words.data_ptr()),

@@ -6,11 +6,12 @@ run_hierarchical_optimizer3d_multipair.py:403-432."""
 import ctypes
 import os
 
+import numpy as np
 import torch
 
 from . import _lib, device as dev
-from .engine_common import _Lazy
-from .engine_outcome import SlavchevaOutcome
+from .engine_common import _Counted, _Lazy
+from .engine_outcome import SlavchevaOutcome, _RunLog, _RunOutcome
 
 
 class _HaloTooNarrow(Exception):
@@ -427,6 +428,111 @@ class SlabMixin:
         if f.native is None and not hasattr(self, "_comm_stream"):
             self._comm_stream = torch.cuda.Stream(device=live.device)
             self._events = [(torch.cuda.Event(), torch.cuda.Event()) for _ in range(2)]
+
+    # ---- the whole call of a z-slab rank enqueued by the library (csrc/lsf_slab.hip: lsf_slab_run_begin / _finish) ---------
+    def _slab_run_ok(self, grid):
+        """can this slab call be handed to the library in one piece?  z-slabs on the native RCCL transport whose slices are a
+        multiple of 1024 voxels (the cut positions of the schedule are per-chunk prefix counts of the counting pass)"""
+        L = self.comm.layout
+        return (L.axis == 0 and (grid.ny * grid.nx) % dev.StatePrepare.CHUNK == 0 and L.halo <= 32
+                and L.z_end - L.z_begin >= 2 * L.halo and grid.nz <= 4095 and self.comm.native() is not None)
+
+    def _optimize_slab_run(self, live, canonical, grid, finalize):
+        """_optimize for a fixed-count call of a z-slab rank, enqueued by the library in two foreign calls: the counting pass
+        with the schedule's cut positions, (sparse) states, list fills, the exchange groups of _plan_slab (boundary first,
+        compact faces cross-checked with the neighbours, deferred waits), the listed finalize pass and ONE gather of every
+        rank's records.  The same launches as _enqueue_slab_state_iteration makes one by one from Python
+        (tests/slab_loopback_worker.py holds the two against each other bit for bit), without ~50 Python -> C calls, the
+        part descriptors and two torch.distributed collectives per call."""
+        live_out, lower_threshold, statistics = finalize
+        L = self.comm.layout
+        iterations = self.min_iterations
+        device = live.device
+        n = dev.n_voxels(grid)
+        whole = dev.full_range(grid)  # the local array: owned slices + halos (z_global_offset stays)
+        every = getattr(self, "_exchange_every_iteration", False)
+        # sparse states in exchange groups only, with a halo of at least the reach (see _optimize)
+        sparse = (not every and L.halo >= max(self.sparse_reach, 2) and self.sparse_reach > 0
+                  and n >= self.sparse_min_voxels and not self.sparse_disabled)
+        self.last_call.sparse_states = sparse
+        self.last_call.library_run = True
+        usable = (live_out is not None and live_out.is_cuda and live_out.dtype == torch.float32
+                  and live_out.is_contiguous() and tuple(live_out.shape) == tuple(live.shape))
+        target = live_out if usable else torch.empty_like(live)
+        if target is not live:
+            target.copy_(live)  # the finalize pass writes listed voxels only
+        elif usable:
+            # the pass writes the caller's tensor before every rank's records have said whether the call stands: what it
+            # overwrites is kept (optimize() puts it back before a wider re-run)
+            self._slab_restore = (live_out, live_out.clone())
+        states = [torch.empty(tuple(live.shape) + (4,), dtype=torch.float32, device=device) for _ in range(2)]
+        scratch = torch.empty(int(_lib.lib.lsf_state_prepare_scratch_elements(ctypes.byref(whole))), dtype=torch.int32,
+                              device=device)
+        n_totals = 5 + 2 * _lib.SLAB_MAX_CUTS
+        totals = torch.empty(n_totals, dtype=torch.int64, device=device)
+        totals_host = dev.pinned_scratch("slab run totals", n_totals, torch.int64)
+        _, world, lo_rank, hi_rank = self.comm.native_identity()
+        run = _lib.SlabRun()
+        base = run.base
+        base.live, base.canonical = dev._ptr(live, n, "live"), dev._ptr(canonical, n, "canonical")
+        base.state[0], base.state[1] = states[0].data_ptr(), states[1].data_ptr()
+        base.prepare_scratch, base.totals_device, base.totals_host = scratch.data_ptr(), totals.data_ptr(), \
+            totals_host.data_ptr()
+        base.grid = whole
+        base.sparse_reach = self.sparse_reach if sparse else 0
+        base.second_state_late = int(not sparse and n <= dev.StatePrepare.SPLIT_MAX_VOXELS)
+        run.layout = _lib.SlabLayoutC(grid.nz, grid.ny, grid.nx, L.z_begin, L.z_end, L.halo, lo_rank, hi_rank)
+        run.exchange_interval = 1 if every else L.halo
+        stream = dev.stream_ptr()
+        native = self.comm.native()
+        _lib.check(_lib.lib.lsf_slab_run_begin(ctypes.byref(run), stream), "lsf_slab_run_begin")
+        n_interior, n_boundary = totals_host[:2].tolist()
+        lists = torch.empty(max(n_interior + n_boundary, 1), dtype=torch.int32, device=device)
+        index_scratch = torch.empty(max(int(run.out_index_entries), 1), dtype=torch.int32, device=device)
+        messages = None
+        if os.environ.get("LSF_SLAB_FACES", "compact") != "full":
+            messages = torch.empty(4 * int(run.out_face_entries) + 16, dtype=torch.float32, device=device)
+        records = dev.new_records(iterations, device)
+        n_words = iterations * _lib.RECORD_SLOTS * dev.USED_SLOT_WORDS
+        words = torch.empty((1 + world) * n_words, dtype=torch.int64, device=device)
+        words_host = dev.pinned_scratch("slab run records", world * n_words, torch.int64)
+        max_value, argmax = np.empty(iterations, np.float32), np.empty(iterations, np.int64)
+        energies, executed = np.empty((iterations, 3), np.float64), np.empty(iterations, np.bool_)
+        result = _lib.StateRunResult(max_value.ctypes.data, argmax.ctypes.data, energies.ctypes.data, executed.ctypes.data)
+        p_lists = lists.data_ptr()
+        bands = []
+        if n_interior:
+            bands.append(dev.BandList(lists[:n_interior], n_interior, _lib.BAND_INTERIOR))
+        if n_boundary or not bands:
+            bands.append(dev.BandList(lists[n_interior:] if n_boundary else lists[:1], n_boundary, _lib.BAND_BOUNDARY))
+        f = _Counted(sum(b.count for b in bands))
+        f.bands, f.records, f.exchange_interval, f.keep = bands, records, int(run.exchange_interval), (index_scratch, messages)
+        outcome = _RunOutcome(grid, canonical, None, target, bands, None)
+        weights = tuple(self.weights)
+        _lib.check(_lib.lib.lsf_slab_run_finish(
+            ctypes.byref(run), native, ctypes.byref(self.params), ctypes.c_void_p(p_lists),
+            ctypes.c_void_p(p_lists + 4 * n_interior), ctypes.c_void_p(index_scratch.data_ptr()),
+            ctypes.c_void_p(messages.data_ptr() if messages is not None else 0), ctypes.c_void_p(records.data_ptr()),
+            iterations, dev._ptr(target, n, "live_out"), ctypes.c_void_p(words.data_ptr()),
+            ctypes.c_void_p(words_host.data_ptr()), ctypes.byref(result), stream), "lsf_slab_run_finish")
+        f.compact_faces = int(result.compact_faces)
+        if result.compact_faces == 0 and messages is not None:
+            import warnings
+            warnings.warn("slab halos are not consistent with the neighbours' slabs (band voxel counts differ): whole "
+                          "slices are exchanged")
+        self._fast = f
+        n_exec = iterations if executed.all() else int(executed.sum())
+        # every EXECUTED iteration must have stayed inside what the halo schedule keeps valid: one slice inside an exchange
+        # group, the halo width with an exchange per iteration.  Every rank decoded the same gathered records, so the raise
+        # is collective; optimize() restores the caller's tensor and runs the call again on a wider slab
+        reach = 1 if run.exchange_interval > 1 else L.halo
+        if n_exec > 0 and not (max_value[:n_exec].max() < reach):
+            raise _HaloTooNarrow(float(max_value[:n_exec].max()), reach)
+        self.iteration_count = n_exec
+        self.log = _RunLog(max_value[:n_exec], argmax[:n_exec], energies[:n_exec], weights)
+        self._gradient_state = ("recompute_listed", states[(n_exec - 1) % 2], canonical, whole, bands)
+        outcome.state = states[n_exec % 2]
+        return outcome
 
     def _optimize_widened(self, live, canonical, max_update):
         import copy

@@ -154,13 +154,16 @@ class SlavchevaEngine(RunMixin, SlabMixin, PlanarSobolevMixin):
         dims = grid.dims
         n_rec = max(self.max_iterations, self.min_iterations, 1)
         slab = self._slab()
-        if (self.library_run and finalize is not None and not slab and not self.sobolev and self.use_band_list
-                and self.iteration_hook is None
-                and self.min_iterations > 0 and self.min_iterations >= self.max_iterations
-                and dev.buffer_addressing_ok(grid)):
-            # a whole volume, a fixed iteration count, no Sobolev filter, nobody watching the iterations: the whole call is
-            # enqueued by the library (two host calls; slavcheva_optimizer2d.py:354-388's loop without a Python iteration)
+        run_ok = (self.library_run and finalize is not None and not self.sobolev and self.use_band_list
+                  and self.iteration_hook is None and self.min_iterations > 0 and dev.buffer_addressing_ok(grid))
+        if run_ok and not slab:
+            # a whole volume, no Sobolev filter, nobody watching the iterations: the whole call is enqueued by the library
+            # (two host calls; slavcheva_optimizer2d.py:354-388's loop without a Python iteration) -- a fixed iteration count
+            # at once, the reference's default threshold-terminated loop in batches of check_interval gated launches
             return self._optimize_run(live, canonical, grid, finalize)
+        if run_ok and slab and not finalize[2] and self.min_iterations >= self.max_iterations and self._slab_run_ok(grid):
+            # a z-slab rank on the library's RCCL transport, a fixed iteration count: likewise (lsf_slab_run_begin / _finish)
+            return self._optimize_slab_run(live, canonical, grid, finalize)
         if slab:
             need = 1 if not self.sobolev else max(1, len(self.sobolev_kernel) // 2)
             if self.comm.layout.halo < need:

@@ -135,6 +135,16 @@ class SlabComm:
             self._native = None
         return self._native
 
+    def native_info(self):
+        """(rank, number of ranks) as RCCL reports them for the native communicator (ncclCommUserRank, ncclCommCount), or
+        None on the torch.distributed transport"""
+        handle = self.native()
+        if handle is None:
+            return None
+        rank, count = ctypes.c_int32(-1), ctypes.c_int32(-1)
+        _lib.check(_lib.lib.lsf_slab_comm_info(handle, ctypes.byref(rank), ctypes.byref(count)), "lsf_slab_comm_info")
+        return int(rank.value), int(count.value)
+
     def close(self):
         """release the native communicator (before torch.distributed.destroy_process_group)"""
         handle = getattr(self, "_native", None)

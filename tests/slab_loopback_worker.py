@@ -86,5 +86,89 @@ def main(out_path, port):
              moved=float(np.abs(a["live"] - live0[layout.owned_local()].cpu().numpy()).max()))
 
 
+def main_library_run(out_path, port):
+    """the call of a z-slab rank enqueued by the LIBRARY (lsf_slab_run_begin / _finish, engine option library_run) against the
+    same call made iteration by iteration from Python (lsf_slab_state_iteration), both on the native RCCL transport in the
+    one-GPU loop-back: exchange groups with and without a remainder, calls too short to exchange, an exchange per iteration,
+    end ranks (one neighbour), band voxels on the x faces (BOUNDARY lists, merged face lists), whole and compact faces,
+    sparse states; and once against the torch.distributed transport.  Everything must agree bit for bit (energies: 1e-10)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import levelsetfusion_python_amd as lsf
+    from levelsetfusion_python_amd.slab import SlabComm, SlabLayout
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+
+    def comm_class(identity):
+        class SelfComm(SlabComm):
+            def native_identity(self):
+                return identity
+        return SelfComm
+
+    n = 64  # slices of 4096 voxels: a multiple of the counting pass's 1024-voxel chunks
+    kwargs = dict(compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                  smoothing_term_method=lsf.SmoothingTermMethod.KILLING, maximum_warp_length_lower_threshold=0.0)
+    # name: (halo, iterations, rank of the layout among three slabs, (rank, world, lower, upper) in the communicator, roll x)
+    cases = {"groups": (2, 12, 1, (0, 1, 0, 0), False), "remainder": (4, 13, 1, (0, 1, 0, 0), False),
+             "too_short_to_exchange": (4, 3, 1, (0, 1, 0, 0), False), "one_exchange": (4, 5, 1, (0, 1, 0, 0), False),
+             "lower_end_rank": (2, 9, 0, (0, 1, -1, 0), False), "upper_end_rank": (2, 9, 2, (0, 1, 0, -1), False),
+             "band_on_x_faces": (2, 8, 1, (0, 1, 0, 0), True), "exchange_every_iteration": (1, 6, 1, (0, 1, 0, 0), False)}
+    problems, taken = [], []
+    for name, (halo, iterations, rank, identity, roll) in cases.items():
+        layout = SlabLayout(3 * n, rank, 3, halo)
+        sl = layout.local_slice()
+        canonical, live0 = sphere_pair(n, 3, "cuda", (sl.start, sl.stop), n // 2)
+        if roll:  # the band crosses x = 0 and x = n - 1: BOUNDARY list entries in every slice, faces merged from two lists
+            canonical, live0 = (torch.roll(t, n // 2, dims=2).contiguous() for t in (canonical, live0))
+        own = layout.owned_local()
+        runs = {}
+        variants = [("python", "rccl", "compact", dict(library_run=False)), ("library", "rccl", "compact", {}),
+                    ("library_whole_faces", "rccl", "full", {}), ("library_sparse", "rccl", "compact", dict(sparse_min_voxels=0))]
+        if name in ("groups", "band_on_x_faces"):
+            variants.append(("torch", "torch", "full", {}))
+        for tag, transport, faces, options in variants:
+            os.environ["LSF_SLAB_TRANSPORT"] = transport
+            os.environ["LSF_SLAB_FACES"] = faces
+            comm = comm_class(identity)(layout)
+            opt = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, engine_options=options, max_iterations=iterations,
+                                           min_iterations=iterations, **kwargs)
+            live = live0.clone()
+            opt.optimize(live, canonical)
+            if tag.startswith("library"):
+                taken.append(bool(opt.engine.last_call.library_run))
+                want = -1 if iterations <= halo else (0 if faces == "full" else 1)
+                if opt.engine._fast.compact_faces != want:
+                    problems.append("%s/%s: compact_faces %d" % (name, tag, opt.engine._fast.compact_faces))
+                if tag == "library_sparse" and halo >= 2 and not opt.engine.last_call.sparse_states:
+                    problems.append("%s/%s: did not run on sparse states" % (name, tag))
+            elif opt.engine.last_call.library_run:
+                problems.append("%s/%s: took the library run" % (name, tag))
+            runs[tag] = dict(live=live[own].cpu().numpy(), warp=opt.warp_field[own].cpu().numpy(),
+                             gradient=np.asarray(opt.gradient_field)[own.start:own.stop],
+                             max_warps=np.float32(opt.log.max_warps), where=np.int64(opt.log.max_warp_locations),
+                             data=np.float64(opt.log.data_energies), smoothing=np.float64(opt.log.smoothing_energies),
+                             level_set=np.float64(opt.log.level_set_energies))
+            comm.close()
+        base = runs["python"]
+        if not (len(base["max_warps"]) == iterations and float(base["max_warps"].max()) < 1.0
+                and float(base["max_warps"].min()) > 0.0):
+            problems.append("%s: maxima %r" % (name, base["max_warps"]))
+        if roll and not np.any(np.abs(base["warp"][:, :, 0]) > 0):
+            problems.append("%s: nothing moves on the x face" % name)
+        for tag, r in runs.items():
+            for key in ("live", "warp", "gradient", "max_warps", "where"):
+                if not np.array_equal(r[key], base[key]):
+                    problems.append("%s/%s: %s differs" % (name, tag, key))
+            for key in ("data", "smoothing", "level_set"):
+                if not np.allclose(r[key], base[key], rtol=1e-10, atol=0.0):
+                    problems.append("%s/%s: %s energies differ" % (name, tag, key))
+    dist.destroy_process_group()
+    np.savez(out_path, problems="; ".join(problems), taken=np.array(taken))
+
+
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]))
+    if len(sys.argv) > 3 and sys.argv[3] == "library_run":
+        main_library_run(sys.argv[1], int(sys.argv[2]))
+    else:
+        main(sys.argv[1], int(sys.argv[2]))

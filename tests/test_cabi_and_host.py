@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol(pkg):
         assert hasattr(lib, name), "liblsf_hip.so does not export %s" % name
         assert name in pkg._lib.PROTOTYPES, "no ctypes prototype for %s" % name
     assert sorted(pkg._lib.PROTOTYPES) == names
-    assert pkg._lib.lib.lsf_abi_version() == pkg._lib.ABI_VERSION == 3
+    assert pkg._lib.lib.lsf_abi_version() == pkg._lib.ABI_VERSION == 4
     assert pkg._lib.lib.lsf_target_arch() == b"gfx950"
 
 
@@ -114,7 +114,14 @@ def test_ctypes_structs_match_header_layout(pkg):
     assert ctypes.sizeof(L.HierParams) == 40 and L.HierParams.packed_nz.offset == 32
     assert ctypes.sizeof(L.SlavchevaParams) == 56 and L.SlavchevaParams.rate.offset == 8
     text = open(HEADER).read()
-    for macro, value in (("LSF_ABI_VERSION", 3), ("LSF_MAX_KERNEL_TAPS", L.MAX_KERNEL_TAPS),
+    # lsf_run_loop, lsf_slab_run (round 6): the out members' offsets are what the binding reads back
+    assert ctypes.sizeof(L.RunLoop) == 24 and L.RunLoop.check_interval.offset == 16
+    assert ctypes.sizeof(L.StateRunResult) == 48 and L.StateRunResult.compact_faces.offset == 44
+    assert L.SlabRun.layout.offset == ctypes.sizeof(L.StateRun) == 128 and L.SlabRun.cut_slices.offset == 168
+    assert L.SlabRun.cut_entries.offset == 456 and L.SlabRun.out_face_entries.offset == 456 + 2 * 8 * L.SLAB_MAX_CUTS + 8
+    assert ctypes.sizeof(L.SlabRun) == 1624
+    for macro, value in (("LSF_ABI_VERSION", 4), ("LSF_SLAB_MAX_CUTS", L.SLAB_MAX_CUTS),
+                         ("LSF_MAX_KERNEL_TAPS", L.MAX_KERNEL_TAPS),
                          ("LSF_SMOOTHING_KILLING", L.SMOOTHING_KILLING),
                          ("LSF_DATA_THRESHOLDED_FDM", L.DATA_THRESHOLDED_FDM),
                          ("LSF_ENERGY_VECTORIZED", L.ENERGY_VECTORIZED), ("LSF_GATE_SLAVCHEVA", L.GATE_SLAVCHEVA)):
@@ -390,6 +397,7 @@ def test_bench_scaling_modes_parse():
         sys.argv = ["bench.py", "--gpus", "8", "--scaling", "strong", "--workload", "hier2d"]
         a = bench.parse()
         assert (a.scaling, a.gpus, a.size) == ("strong", 8, 512)
-        assert [s[0] for s in bench.SECONDARY] == ["killing", "killing-pairs", "hier-tik", "hier-full", "multiframe", "sobolev", "hier2d"]
+        assert [s[0] for s in bench.SECONDARY] == ["killing", "killing-pairs", "killing-default", "hier-tik", "hier-full", "multiframe",
+                                                  "sobolev", "hier2d"]
     finally:
         sys.argv = old

@@ -47,7 +47,12 @@ def test_default_workload_line():
     assert r["traffic"] is None and r["traffic_source"]["loaded_build_id"]
     # the other configurations of BASELINE.json ride on the same line (here at 1/4 of their edge lengths)
     sec = {row["workload"]: row for row in d["secondary"]}
-    assert sorted(sec) == ["hier-full", "hier-tik", "hier2d", "killing", "killing-pairs", "multiframe", "sobolev"]
+    assert sorted(sec) == ["hier-full", "hier-tik", "hier2d", "killing", "killing-default", "killing-pairs", "multiframe",
+                           "sobolev"]
+    default = sec.pop("killing-default")  # the reference's default loop condition: ms per call, iterations executed
+    assert "error" not in default, default
+    assert 1 <= default["iterations_executed"] <= 100 and default["ms_per_call"] > 0
+    assert default["ms_per_call_launch_by_launch"] > 0 and "default loop condition" in default["config"]
     pairs = sec.pop("killing-pairs")  # two independent pairs in flight: milliseconds per pair, same results as one by one
     assert "error" not in pairs, pairs
     assert pairs["pairs_in_flight"] == 2 and pairs["results_equal"] and pairs["ms_per_pair"] > 0

@@ -27,13 +27,12 @@ def lsf():
 
 def _optimizer(lsf, shape, iterations, library_run, smoothing="killing", reach=0, **extra):
     cls = lsf.SlavchevaOptimizer3d if len(shape) == 3 else lsf.SlavchevaOptimizer2d
-    kw = dict(KILLING)
+    kw = dict(KILLING, max_iterations=iterations, min_iterations=iterations)
     kw["smoothing_term_method"] = lsf.SmoothingTermMethod.KILLING if smoothing == "killing" else \
         lsf.SmoothingTermMethod.TIKHONOV
-    opt = cls(field_size=shape[-1], compute_method=lsf.ComputeMethod.DIRECT, max_iterations=iterations,
-              min_iterations=iterations,
-              engine_options=dict(library_run=library_run, sparse_reach=reach, sparse_min_voxels=0), **dict(kw, **extra))
-    return opt
+    kw.update(extra)
+    return cls(field_size=shape[-1], compute_method=lsf.ComputeMethod.DIRECT,
+               engine_options=dict(library_run=library_run, sparse_reach=reach, sparse_min_voxels=0), **kw)
 
 
 def _call(lsf, canonical, live0, iterations, library_run, reach=0, **kw):
@@ -69,6 +68,53 @@ def test_library_run_equals_launch_by_launch_3d(lsf, n, reach):
     a = _call(lsf, canonical, live0, 12, True, reach)
     b = _call(lsf, canonical, live0, 12, False, reach)
     assert a[0].engine.last_call.sparse_states == bool(reach)
+    _same(a, b)
+
+
+# the reference's DEFAULT loop condition (slavcheva_optimizer2d.py:360-362, constructor defaults :74-102: min_iterations 1,
+# max_iterations 100, lower threshold 0.1): what every reference caller runs
+DEFAULT_LOOP = dict(min_iterations=1, max_iterations=100, maximum_warp_length_lower_threshold=0.1)
+
+
+@pytest.mark.parametrize("check_interval", [1, 7, 32])
+def test_threshold_terminated_library_run_equals_launch_by_launch(lsf, check_interval):
+    """the stop test fires inside a batch of gated launches, at a batch boundary, or after a single-iteration batch: the
+    executed count, every record and the final fields are those of the call enqueued launch by launch from Python"""
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live0 = sphere_pair(64, 3, "cuda")
+    extra = dict(DEFAULT_LOOP, check_interval=check_interval)
+    a = _call(lsf, canonical, live0, 100, True, 2, **extra)
+    b = _call(lsf, canonical, live0, 100, False, 2, **extra)
+    n = len(a[0].log.max_warps)
+    assert 1 < n < 100 and not (a[0].log.max_warps[-1] > 0.1) and min(a[0].log.max_warps[:-1]) > 0.1
+    _same(a, b)
+    assert a[0].get_convergence_report().iteration_count == n
+
+
+def test_default_loop_condition_equals_the_oracle(lsf):
+    """the default-constructed loop through the library-enqueued call against the oracle: the same iteration count, maxima
+    and fields (the sphere pair at 48^3; Killing + level set)"""
+    canonical, live0 = O.sphere_pair(48, d=3)
+    opt, live = _call(lsf, torch.from_numpy(canonical).cuda(), torch.from_numpy(live0).cuda(), 100, True, 2, **DEFAULT_LOOP)
+    ref = O.SlavchevaOracle(compute_method=O.DIRECT, smoothing_term_method=O.KILLING, **dict(KILLING, **DEFAULT_LOOP))
+    live_ref = live0.copy()
+    ref.optimize(live_ref, canonical)
+    assert len(opt.log.max_warps) == ref.iteration_count and 1 < ref.iteration_count < 100
+    assert np.array_equal(live.cpu().numpy(), live_ref)
+    assert np.array_equal(opt.warp_field.cpu().numpy(), ref.warp_field)
+    assert np.array_equal(np.float32(opt.log.max_warps), np.float32(ref.log["max_warps"]))
+    assert np.array_equal(opt.gradient_field, ref.gradient_field)
+
+
+def test_upper_threshold_ends_the_library_run(lsf, ref_slavcheva):
+    """the reference's orthographic pair moves 6-10 voxels per iteration: with an upper threshold of 5 the first iteration is
+    the last (slavcheva_optimizer2d.py:360-362), through the gate of the library-enqueued call too"""
+    canonical = torch.from_numpy(ref_slavcheva["ortho64.canonical"]).cuda()
+    live0 = torch.from_numpy(ref_slavcheva["ortho64.live"]).cuda()
+    extra = dict(min_iterations=1, max_iterations=20, maximum_warp_length_upper_threshold=5.0, check_interval=4)
+    a = _call(lsf, canonical, live0, 20, True, **extra)
+    b = _call(lsf, canonical, live0, 20, False, **extra)
+    assert len(a[0].log.max_warps) == 1 and a[0].log.max_warps[0] > 5.0
     _same(a, b)
 
 

@@ -228,3 +228,21 @@ def test_native_rccl_transport_equals_torch_transport(tmp_path):
     assert float(r["moved"]) > 1e-3  # the optimisation did something
     # the same call on states initialised near the band only (slab exchange groups, compact and whole faces): same bits
     assert str(r["sparse_differs"]) == "", str(r["sparse_differs"])
+
+
+def test_library_enqueued_slab_call_equals_the_call_made_from_python(tmp_path):
+    """lsf_slab_run_begin / _finish (the whole call of a z-slab rank in two foreign calls: cut positions from the counting
+    pass, the exchange-group schedule, compact faces, the gather of every rank's records -- round 6) against the same call
+    enqueued iteration by iteration from Python and against the torch.distributed transport, over real RCCL in the one-GPU
+    loop-back (slab_loopback_worker.py, mode library_run): eight schedules, bit-identical fields, records and gradients"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    out = os.path.join(str(tmp_path), "library_run.npz")
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "slab_loopback_worker.py")
+    proc = subprocess.run([sys.executable, worker, out, str(_free_port()), "library_run"], capture_output=True, text=True,
+                          timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-3000:]
+    r = np.load(out)
+    assert str(r["problems"]) == "", str(r["problems"])
+    assert r["taken"].size == 24 and bool(r["taken"].all()), "the library-enqueued slab call was not taken"

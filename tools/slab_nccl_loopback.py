@@ -80,58 +80,72 @@ if os.environ.get("LB_TIMELINE") == "1":  # start / end of the host-side phases 
                    (SlavchevaEngine, "_plan_compact_faces"), (_eng.SlavchevaOutcome, "enqueue_finalize"),
                    (_slab.SlabComm, "gather_records"), (_dev, "decode_records"), (_eng.SlavchevaOutcome, "finalize")):
         _mark(_o, _n)
-for fixed in ((True,) if os.environ.get("FIXED_ONLY") == "1" else (True, False)):
+def make(fixed, library_run):
     kw = dict(maximum_warp_length_lower_threshold=0.0, max_iterations=iters, min_iterations=iters if fixed else 1)
-    opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
-                                   smoothing_term_method=lsf.SmoothingTermMethod.KILLING, check_interval=50,
-                                   comm=comm, **kw)
-    for rep in range(3):
-        live = live0.clone()
-        torch.cuda.synchronize()
-        del _marks[:]
-        t0 = time.perf_counter()
-        opt.optimize(live, canonical)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        for _label, _a, _b in _marks:
-            print("      %-44s %8.1f -> %8.1f us" % (_label, (_a - t0) * 1e6, (_b - t0) * 1e6))
-        print("%s: %d iterations, %.1f us per iteration (whole optimize %.2f ms)"
-              % ("fixed count (no per-iteration all-reduce)" if fixed else "gated (MAX all-reduce per iteration)",
-                 len(opt.log.max_warps), dt / max(len(opt.log.max_warps), 1) * 1e6, dt * 1e3), flush=True)
-        print("    host time inside the enqueue call: %.1f us per iteration; launch plan %.0f us per call, of which the "
-              "compact-face plan %.0f us" % (_host[0] / max(_host[1], 1) * 1e6, _plan.get("_plan_slab", 0.0) * 1e6,
-                                            _plan.get("_plan_compact_faces", 0.0) * 1e6))
-        _host[0], _host[1] = 0.0, 0
-        _plan.clear()
-        _f = getattr(opt.engine, "_fast", None)
-        if rep == 0 and _f is not None and getattr(_f, "faces", None) is not None:
-            print("    compact faces: send %s / recv %s band voxels = %s / %s bytes per exchange (whole faces: 2 x %d bytes)"
-                  % (list(_f.faces.send_count), list(_f.faces.recv_count), [16 * int(c) for c in _f.faces.send_count],
-                     [16 * int(c) for c in _f.faces.recv_count], 16 * _h * n * n), flush=True)
-        elif rep == 0 and _f is not None:
-            print("    whole faces travel: 2 x %d bytes per exchange" % (16 * _h * n * n), flush=True)
-if os.environ.get("LB_SINGLE", "1") == "1":
-    # the same box's single-GPU call for the ratio: one n^3 sphere pair (as many band voxels as the slab owns), no comm
-    c1, l1 = sphere_pair(n, 3, "cuda")
-    single = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
-                                      smoothing_term_method=lsf.SmoothingTermMethod.KILLING, check_interval=50,
-                                      maximum_warp_length_lower_threshold=0.0, max_iterations=iters, min_iterations=iters)
-    for rep in range(4):
-        live = l1.clone()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        single.optimize(live, c1)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+    return lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                                    smoothing_term_method=lsf.SmoothingTermMethod.KILLING, check_interval=50,
+                                    comm=comm, engine_options=dict(library_run=library_run), **kw)
+
+
+def timed_call(opt, live_in, canon):
+    live = live_in.clone()
+    torch.cuda.synchronize()
+    del _marks[:]
+    t0 = time.perf_counter()
+    opt.optimize(live, canon)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, t0
+
+
+# ROUND 6: the whole slab call enqueued by the library (lsf_slab_run_begin / _finish, the default) against the call
+# enqueued iteration by iteration from Python (library_run=False: rounds 3-5) and the single-GPU call, ALTERNATING on one box
+c1, l1 = sphere_pair(n, 3, "cuda")
+single = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                                  smoothing_term_method=lsf.SmoothingTermMethod.KILLING, check_interval=50,
+                                  maximum_warp_length_lower_threshold=0.0, max_iterations=iters, min_iterations=iters)
+contenders = [("slab, library-enqueued call (lsf_slab_run_*)", make(True, True), live0, canonical),
+              ("slab, one call per iteration (lsf_slab_state_iteration)", make(True, False), live0, canonical),
+              ("single GPU (lsf_state_run_*)", single, l1, c1)]
+times = {name: [] for name, *_ in contenders}
+for rep in range(int(os.environ.get("REPS", "6"))):
+    for name, opt, live_in, canon in contenders:
+        dt, t0 = timed_call(opt, live_in, canon)
         if rep:
-            print("single GPU, the same box: %d iterations, %.1f us per iteration (whole optimize %.2f ms)"
-                  % (iters, dt / iters * 1e6, dt * 1e3), flush=True)
+            times[name].append(dt * 1e3)
+        if rep == 1:
+            for _label, _a, _b in _marks:
+                print("      %-44s %8.1f -> %8.1f us" % (_label, (_a - t0) * 1e6, (_b - t0) * 1e6))
+        if rep == 0 and opt is not single:
+            _f = opt.engine._fast
+            print("    %s: library_run %s, exchange interval %d, compact faces %s" % (
+                name, opt.engine.last_call.library_run, _f.exchange_interval,
+                getattr(_f, "compact_faces", getattr(_f, "faces_ref", None) is not None)), flush=True)
+            if getattr(_f, "faces", None) is not None:
+                print("    compact faces: send %s / recv %s band voxels = %s / %s bytes per exchange (whole faces: 2 x %d bytes)"
+                      % (list(_f.faces.send_count), list(_f.faces.recv_count), [16 * int(c) for c in _f.faces.send_count],
+                         [16 * int(c) for c in _f.faces.recv_count], 16 * _h * n * n), flush=True)
+for name, ts in times.items():
+    print("%-58s %d iterations: whole optimize() %s ms (median %.3f)" % (name, iters, " ".join("%.3f" % t for t in ts),
+                                                                         sorted(ts)[len(ts) // 2]), flush=True)
+med = {name: sorted(ts)[len(ts) // 2] for name, ts in times.items()}
+names = [name for name, *_ in contenders]
+print("single GPU / slab, library-enqueued: %.3f   single GPU / slab, call per iteration: %.3f"
+      % (med[names[2]] / med[names[0]], med[names[2]] / med[names[1]]), flush=True)
+print("host time inside the per-iteration enqueue calls: %.1f us per iteration; launch plan %.0f us per call, of which the "
+      "compact-face plan %.0f us" % (_host[0] / max(_host[1], 1) * 1e6, _plan.get("_plan_slab", 0.0) * 1e6,
+                                    _plan.get("_plan_compact_faces", 0.0) * 1e6))
+if os.environ.get("FIXED_ONLY") != "1":
+    gated = make(False, True)
+    for rep in range(3):
+        dt, _ = timed_call(gated, live0, canonical)
+        print("gated (MAX all-reduce per iteration, Python path): %d iterations, %.1f us per iteration (whole optimize %.2f ms)"
+              % (len(gated.log.max_warps), dt / max(len(gated.log.max_warps), 1) * 1e6, dt * 1e3), flush=True)
 if os.environ.get("LB_PROFILE") == "1":
     import cProfile, pstats
     live = live0.clone()
     pr = cProfile.Profile()
     pr.enable()
-    opt.optimize(live, canonical)
+    contenders[0][1].optimize(live, canonical)
     torch.cuda.synchronize()
     pr.disable()
     pstats.Stats(pr).sort_stats("tottime").print_stats(22)
