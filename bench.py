@@ -249,8 +249,10 @@ def extra_workload(args, device, world, rank, dist):
         b_alg = 48
         name = "2D %d^2 HierarchicalOptimizer2d, 3 levels (maximum_chunk_size 4), Tikhonov (tikhonov_strength 0.05), %d " \
                "fixed iterations per level" % (n, iters)
-        note = "LAUNCH-BOUND, not a roofline point: a %d^2 level is %d KiB per field and an iteration is one ~4-8 us " \
-               "kernel replayed from a HIP graph; read us_per_iteration.  frac = whole-step rate x B_alg (48 B) for " \
+        note = "LAUNCH-BOUND, not a roofline point: a %d^2 level is %d KiB per field -- 1024 voxels per CU; since round 6 a " \
+               "launch advances 32 x 32 (16 x 16 on small levels) tiles EIGHT iterations inside LDS (lsf_hier_level_run_2d: " \
+               "temporal blocking, the rings around a tile recomputed), 13 launches per 100 iterations instead of 100; " \
+               "read us_per_iteration (round 5: 7.5 from a HIP graph).  frac = whole-step rate x B_alg (48 B) for " \
                "completeness" % (n, n * n * 4 // 1024)
         extra["us_per_iteration_of"] = "3 levels x %d iterations" % iters
     elif args.workload == "sobolev":
@@ -479,27 +481,31 @@ def default_loop_call(args, device):
     import levelsetfusion_python_amd as lsf
     from levelsetfusion_python_amd.hostloop import parked_collector
     from levelsetfusion_python_amd.synthetic import sphere_pair
+    from levelsetfusion_python_amd.synthetic import depth_pair
     n = args.size
-    canonical, live0 = sphere_pair(n, 3, device)
     out = {}
-    for key, library_run in (("ms_per_call", True), ("ms_per_call_launch_by_launch", False)):
-        opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
-                                       smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
-                                       engine_options=dict(library_run=library_run))
-        live = torch.empty_like(live0)
-        with parked_collector():
-            for k in range(args.warmup + args.steps):
-                if k == args.warmup:
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                live.copy_(live0)
-                opt.optimize(live, canonical)
-            torch.cuda.synchronize()
-            out[key] = (time.perf_counter() - t0) / args.steps * 1e3
-        out.setdefault("iterations_executed", len(opt.log.max_warps))
-        assert out["iterations_executed"] == len(opt.log.max_warps)
+    # two inputs: the bench's sphere pair (at 256^3 its first update is already shorter than 0.1 voxels: the default loop ends
+    # after ONE iteration) and SURVEY 8(d)'s depth-frame pair (updates of several voxels: the loop runs on)
+    for tag, (canonical, live0) in (("", sphere_pair(n, 3, device)), ("_depth_pair", depth_pair(n, device))):
+        for key, library_run in (("ms_per_call", True), ("ms_per_call_launch_by_launch", False)):
+            opt = lsf.SlavchevaOptimizer3d(field_size=n, compute_method=lsf.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                                           smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
+                                           engine_options=dict(library_run=library_run))
+            live = torch.empty_like(live0)
+            with parked_collector():
+                for k in range(args.warmup + args.steps):
+                    if k == args.warmup:
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                    live.copy_(live0)
+                    opt.optimize(live, canonical)
+                torch.cuda.synchronize()
+                out[key + tag] = (time.perf_counter() - t0) / args.steps * 1e3
+            executed = out.setdefault("iterations_executed" + tag, len(opt.log.max_warps))
+            assert executed == len(opt.log.max_warps)
     return dict(config="3D %d^3 KillingFusion under the reference's default loop condition (min_iterations 1, max_iterations "
-                       "100, lower threshold 0.1), sphere-pair TSDF" % n, ms_per_step=out["ms_per_call"],
+                       "100, lower threshold 0.1): sphere-pair TSDF, and (_depth_pair) the TSDF pair of two synthetic depth "
+                       "frames" % n, ms_per_step=out["ms_per_call"],
                 value=n ** 3 * out["iterations_executed"] / (out["ms_per_call"] * 1e-3), **out)
 
 

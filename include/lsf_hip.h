@@ -240,6 +240,18 @@ int lsf_hier_iteration(const float *packed_live4, const float *canonical, float 
 
 /* warp -= rate*g ; the record's max_packed = max |g|   (hierarchical_optimizer2d.py:220-225).  warp_planar may be
  * NULL: only the maximum (the warp was moved by lsf_convolve_xyz already). */
+/* A whole 2-D level with a FIXED iteration count, K = iterations_per_launch (1..8) iterations per launch: temporal blocking
+ * through LDS (round 6; BASELINE config 2 is launch-bound -- a 512^2 level is 1024 voxels per CU).  Replaces `iterations`
+ * calls of lsf_hier_iteration (Tikhonov term, apply_update = 1, no energies; hierarchical_optimizer2d.py:184-225 with a
+ * threshold that cannot fire) with ceil(iterations / K) launches whose workgroups each advance a 32 x 32 tile K iterations
+ * inside LDS, recomputing the K - 1 - j rings of voxels around it that iteration j needs (identical arithmetic on identical
+ * inputs: identical results).  Launch b reads (warp_a, g_a) when b is even, (warp_b, g_b) when odd, and writes the other
+ * pair; after the call the warp and the last iteration's gradient are in the _a buffers when ceil(iterations / K) is even,
+ * in the _b buffers otherwise.  records[0..iterations): one record per iteration (the caller has zeroed them), maxima only.
+ * LSF_ERR_BAD_DIMS for anything but dims = 2, tikhonov_enabled, apply_update, compute_energy = 0. */
+int lsf_hier_level_run_2d(const float *packed_live4, const float *canonical, float *warp_a, float *warp_b, float *g_a,
+                          float *g_b, const lsf_grid *grid, const lsf_hier_params *params, lsf_iteration_record *records,
+                          int32_t iterations, int32_t iterations_per_launch, void *stream);
 int lsf_hier_update(const float *g_planar, float *warp_planar, const lsf_grid *grid, float rate,
                     const lsf_gate *gate, lsf_iteration_record *record, void *stream);
 

@@ -194,6 +194,175 @@ __global__ __launch_bounds__(kBlock) void hier_update_kernel(const float* __rest
     block_reduce_commit<0>(best, sums, record_max(record), dst);
 }
 
+// ---- 2-D levels, K iterations per launch: temporal blocking through LDS (round 6) ------------------------------------------
+// A 512^2 level is 1 MiB per field and 1024 voxels per CU: one iteration per launch is a ~4.5 us kernel plus a ~1.5 us launch
+// boundary whatever the level's size (BASELINE config 2 ran at 7.5 us per iteration from a HIP graph).  An iteration at voxel
+// p reads the previous gradient at p and its 4 neighbours, the warp and the canonical value at p, and the STATIC packed live
+// field at the data-dependent position p + warp(p) -- so K iterations of a tile T need nothing that K - 1 more rows and
+// columns of the dynamic fields around T do not determine.  A workgroup (a tile T of 32 x 32 voxels, or 16 x 16 on small
+// levels) loads the warp on T (+) (K - 1) and the previous
+// gradient on T (+) K into LDS, runs iteration j on T (+) (K - 1 - j) -- recomputing, bit for bit, what the neighbouring
+// workgroups compute for those voxels: the same arithmetic on the same inputs --, and stores its own tile's warp and last
+// gradient: no grid-wide barrier (4-5 us on this chip, more than a launch boundary), no hand-off.  Array edges clip the
+// regions; the Laplacian's edge rule (a missing neighbour is the centre) then applies exactly where the level ends.  Every
+// iteration's maximum is taken over the tile's OWN voxels.  Only for runs whose stop test cannot fire (threshold <= 0: the
+// warp after K iterations is wanted whatever the K maxima are) and without the energy printouts.
+constexpr int kBlkMaxK = 8, kBlkThreads = 1024;  // (tiles of 32 x 32 or 16 x 16 voxels, see lsf_hier_level_run_2d)
+
+template <int T>
+__global__ __launch_bounds__(kBlkThreads) void hier2d_blocked_kernel(const float4* __restrict__ packed,
+                                                                     const float* __restrict__ canonical,
+                                                                     const float* __restrict__ warp_in,
+                                                                     float* __restrict__ warp_out,
+                                                                     const float* __restrict__ g_in,
+                                                                     float* __restrict__ g_out, Grid g, float amp,
+                                                                     float strength, float rate,
+                                                                     lsf_iteration_record* records, int k) {
+    // (row pitch W + 1: a ring's left / right columns are cells a row apart -- at a pitch of 48 or 32 words they would
+    // fall into two LDS banks, or one)
+    constexpr int H = kBlkMaxK, N = T + 2 * H, W = N + 1;
+    constexpr int C = (N * N + kBlkThreads - 1) / kBlkThreads;  // cells per thread: 3 for 32 x 32 tiles, 1 for 16 x 16
+    __shared__ float s_w[2][N * W];          // the warp's two components
+    __shared__ float s_g[2][2][N * W];       // [buffer][component]: iteration j reads buffer j % 2, writes the other
+    __shared__ unsigned long long s_best[kBlkMaxK][kBlkThreads / kWave];
+    const int tiles_x = (g.nx + T - 1) / T;
+    const int tx0 = (int)(blockIdx.x % tiles_x) * T, ty0 = (int)(blockIdx.x / tiles_x) * T;
+    const int tx1 = min(tx0 + T, g.nx), ty1 = min(ty0 + T, g.ny);
+    const long long plane = g.plane;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    // A thread owns the SAME cells in every iteration, so everything about a cell that does not change -- its voxel, its
+    // canonical value, the Laplacian's clamped neighbour offsets, how many rings outside the tile it lies -- is worked out
+    // once per launch.  The cells are numbered RING BY RING: the tile's own T x T voxels first (row-major), then the ring of
+    // voxels one step outside it, the next ring, ...; cell number q belongs to thread q mod 1024.  Iteration j works on the
+    // cells at most k - 1 - j rings out, i.e. on a PREFIX of that numbering: whole waves work or skip (numbered row by row
+    // over the 48 x 48 image, with a wave's 64 cells spread over two rows, an iteration took 3.2 us instead of ~2).
+    int cell[C], ring[C], vox[C], nb[C];
+    float fx[C], fy[C], cn[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int q = (int)threadIdx.x + c * kBlkThreads;
+        int u, v, r = 0;  // tile coordinates (0 .. T - 1 inside the tile) and ring
+        if (q < T * T) {
+            u = q % T;
+            v = q / T;
+        } else {
+            const int h = q - T * T;  // rings 1 .. r hold 4 r (T + r) cells
+            r = 1;
+            while (r < H && h >= 4 * r * (T + r)) ++r;
+            const int p = h - 4 * (r - 1) * (T + r - 1), side = T + 2 * r;  // position on ring r: top, bottom, left, right
+            if (p < side) { u = p - r; v = -r; }
+            else if (p < 2 * side) { u = p - side - r; v = T - 1 + r; }
+            else if (p < 3 * side - 2) { u = -r; v = p - 2 * side + 1 - r; }
+            else { u = T - 1 + r; v = p - (3 * side - 2) + 1 - r; }
+        }
+        const int x = tx0 + u, y = ty0 + v;
+        const bool in_array = q < N * N && x >= 0 && x < g.nx && y >= 0 && y < g.ny;
+        cell[c] = (v + H) * W + (u + H);
+        // rings outside the tile AS CLIPPED BY THE ARRAY (0 = one of the tile's own voxels): a tile at the array's edge is
+        // smaller than T x T, and its missing rows / columns count as rings
+        const int dx = max(max(tx0 - x, x - (tx1 - 1)), 0), dy = max(max(ty0 - y, y - (ty1 - 1)), 0);
+        ring[c] = in_array ? max(dx, dy) : 0x7fff;
+        vox[c] = in_array ? y * g.nx + x : 0;
+        fx[c] = (float)x;
+        fy[c] = (float)y;
+        // the Laplacian's neighbours: a missing one is the centre (scipy's mode='nearest')
+        nb[c] = (y > 0 ? 1 : 0) | (y < g.ny - 1 ? 2 : 0) | (x > 0 ? 4 : 0) | (x < g.nx - 1 ? 8 : 0);
+        cn[c] = 0.0f;
+    }
+    // the previous gradient k rings out, the warp with it (needed k - 1 rings out only; one load pattern), the canonical
+    // values: all of a thread's loads in flight together
+    {
+        float v[C][4];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (ring[c] <= k) {
+                v[c][0] = g_in[vox[c]];
+                v[c][1] = g_in[plane + vox[c]];
+                v[c][2] = warp_in[vox[c]];
+                v[c][3] = warp_in[plane + vox[c]];
+                cn[c] = canonical[vox[c]];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (ring[c] <= k) {
+                s_g[0][0][cell[c]] = v[c][0];
+                s_g[0][1][cell[c]] = v[c][1];
+                s_w[0][cell[c]] = v[c][2];
+                s_w[1][cell[c]] = v[c][3];
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {  // (k is uniform over the grid)
+        const int cur = j & 1, nxt = cur ^ 1, reach = k - 1 - j;
+        float w0[C], w1[C];
+        Packed smp[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (ring[c] <= reach) {
+                w0[c] = s_w[0][cell[c]];
+                w1[c] = s_w[1][cell[c]];
+                smp[c] = gather_packed<2>(packed, g, fx[c] + w0[c], fy[c] + w1[c], 0.0f);
+            }
+        }
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (ring[c] <= reach) {
+                const int l = cell[c];
+                const float diff = smp[c].l - cn[c];
+                const float live_grad[2] = {smp[c].gx, smp[c].gy};
+                const int up = (nb[c] & 1) ? W : 0, down = (nb[c] & 2) ? W : 0, left = (nb[c] & 4) ? 1 : 0,
+                          right = (nb[c] & 8) ? 1 : 0;
+                float gv[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const float* a = s_g[cur][d];
+                    const float a0 = a[l];
+                    const float d2y = second_difference_f64(a[l - up], a0, a[l + down]);
+                    const float d2x = second_difference_f64(a[l - left], a0, a[l + right]);
+                    const float lap = d2y + d2x;
+                    const float gd = diff * live_grad[d];
+                    gv[d] = amp * gd - strength * lap;
+                }
+                s_g[nxt][0][l] = gv[0];
+                s_g[nxt][1][l] = gv[1];
+                s_w[0][l] = w0[c] - rate * gv[0];
+                s_w[1][l] = w1[c] - rate * gv[1];
+                if (ring[c] == 0) {
+                    const unsigned long long p = pack_max(vec_length<2>(gv), (unsigned)vox[c] + g.index_offset);
+                    best = p > best ? p : best;
+                }
+            }
+        }
+        // this iteration's maximum over the tile's own voxels, wave by wave (the workgroup's reduction follows the loop)
+        const unsigned long long m = wave_max_u64(best);
+        if (lane == 0) s_best[j][wave] = m;
+        __syncthreads();
+    }
+    // the tile's own voxels: the warp after k iterations and the gradient of the last one
+    {
+        const int fin = k & 1;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (ring[c] == 0) {
+                g_out[vox[c]] = s_g[fin][0][cell[c]];
+                g_out[plane + vox[c]] = s_g[fin][1][cell[c]];
+                warp_out[vox[c]] = s_w[0][cell[c]];
+                warp_out[plane + vox[c]] = s_w[1][cell[c]];
+            }
+        }
+    }
+    // the k maxima: the waves' partial maxima are in LDS (the loop's barriers have published them)
+    if (wave == 0) {
+        for (int j = 0; j < k; ++j) {
+            const unsigned long long mm = wave_max_u64(lane < kBlkThreads / kWave ? s_best[j][lane] : 0ull);
+            if (lane == 0 && mm != 0ull) atomicMax(record_max(records + j), mm);
+        }
+    }
+}
+
 template <int D, bool TIK, bool UPDATE>
 void launch_hier(bool energy, unsigned blocks, hipStream_t s, const float4* packed, const float* canonical,
                  float* warp, const float* g_prev, float* g_out, const Grid& g, const lsf_hier_params* p,
@@ -290,4 +459,41 @@ extern "C" int lsf_hier_update(const float* g_planar, float* warp_planar, const 
     else
         hipLaunchKernelGGL((hier_update_kernel<3, false>), blocks, dim3(kBlock), 0, s, g_planar, warp_planar, g, rate, gt, record);
     return launch_status();
+}
+
+extern "C" int lsf_hier_level_run_2d(const float* packed_live4, const float* canonical, float* warp_a, float* warp_b,
+                                     float* g_a, float* g_b, const lsf_grid* grid, const lsf_hier_params* params,
+                                     lsf_iteration_record* records, int32_t iterations, int32_t iterations_per_launch,
+                                     void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!packed_live4 || !canonical || !warp_a || !warp_b || warp_a == warp_b || !g_a || !g_b || g_a == g_b || !params ||
+        !records || iterations < 0 || iterations_per_launch < 1 || iterations_per_launch > kBlkMaxK)
+        return LSF_ERR_BAD_ARGUMENT;
+    // 2-D, Tikhonov term, the update applied in the launch, no energy sums, the level's own packed field
+    if (grid->dims != 2 || !params->tikhonov_enabled || !params->apply_update || params->compute_energy ||
+        params->previous_max || params->packed_nz != 0)
+        return LSF_ERR_BAD_DIMS;
+    const Grid g = make_grid(grid);
+    // 32 x 32 tiles keep the recomputed rings cheapest (1.5 x the level's voxels over a launch of eight); levels too small
+    // to give every CU such a tile take 16 x 16 tiles: more workgroups, each with a third of the cells
+    auto tiles_of = [&](int t) { return (unsigned)((grid->nx + t - 1) / t) * (unsigned)((grid->ny + t - 1) / t); };
+    const bool small = tiles_of(32) < 192u;
+    const unsigned tiles = tiles_of(small ? 16 : 32);
+    const float4* packed = reinterpret_cast<const float4*>(packed_live4);
+    hipStream_t s = as_stream(stream);
+    int launch = 0;
+    for (int32_t i = 0; i < iterations; i += iterations_per_launch, ++launch) {
+        const int k = iterations - i < iterations_per_launch ? iterations - i : iterations_per_launch;
+        const bool even = (launch & 1) == 0;  // launch b reads (warp_a, g_a) when b is even and writes the other pair
+        if (small)
+            hipLaunchKernelGGL(hier2d_blocked_kernel<16>, dim3(tiles), dim3(kBlkThreads), 0, s, packed, canonical,
+                               even ? warp_a : warp_b, even ? warp_b : warp_a, even ? g_a : g_b, even ? g_b : g_a, g,
+                               params->data_term_amplifier, params->tikhonov_strength, params->rate, records + i, k);
+        else
+            hipLaunchKernelGGL(hier2d_blocked_kernel<32>, dim3(tiles), dim3(kBlkThreads), 0, s, packed, canonical,
+                               even ? warp_a : warp_b, even ? warp_b : warp_a, even ? g_a : g_b, even ? g_b : g_a, g,
+                               params->data_term_amplifier, params->tikhonov_strength, params->rate, records + i, k);
+        if (int e = launch_status()) return e;
+    }
+    return 0;
 }

@@ -31,7 +31,7 @@ class HierarchicalEngine:
                  maximum_iteration_count, maximum_warp_update_threshold, data_term_amplifier, tikhonov_strength,
                  kernel, compute_energy=False, check_interval=32, collect_reports=False, comm=None,
                  collect_iteration_data=False, linear_resampling=False, options=None):
-        # use_graphs, graph_max_voxels, fused_filter, fused_filter_min_voxels, defer_maximum, persistent_levels
+        # use_graphs, graph_max_voxels, fused_filter, fused_filter_min_voxels, defer_maximum, blocked_levels
         engine_options.apply(self, engine_options.HIERARCHICAL_DEFAULTS, options)
         self.graph_max_voxels = int(self.graph_max_voxels)
         self.last_call = engine_options.new_call_report()
@@ -157,8 +157,10 @@ class HierarchicalEngine:
         if canonical.shape != live.shape:
             raise ValueError("canonical and live fields must have the same shape")
         dims = live.dim()
+        self.last_call = engine_options.new_call_report()
         canon_levels, packed_levels, comms = self.build_pyramids(canonical, live)
         self.level_results = []
+        self._pending_levels = []
         self.iteration_data = []
         # z-slab runs: levels whose gather operand had to be replicated on every rank because the cumulative warp
         # outgrew the halo (optimize_level); once a level needed it the finer ones start that way -- warps are not
@@ -182,6 +184,7 @@ class HierarchicalEngine:
                     lo = comm_l.layout.halo_lo
                     fine = fine[:, lo:lo + comms[level + 1].layout.nz_local].contiguous()
                 warp = fine
+        self._finish_pending_levels()
         return warp
 
     # ------------------------------------------------------------------------------------------------
@@ -357,6 +360,10 @@ class HierarchicalEngine:
         max_it = self.maximum_iteration_count
         n_vox = canonical.numel()
         hooked = self.iteration_hook is not None
+        if (self.blocked_levels and canonical.dim() == 2 and not slab and not hooked and not self.collect_iteration_data
+                and self.tikhonov_term_enabled and not self.gradient_kernel_enabled and not self.compute_energy
+                and max_it >= 1 and not float(self.maximum_warp_update_threshold) > 0.0):
+            return self._optimize_level_blocked(canonical, packed, warp)
         if (self.use_graphs and not slab and not self.collect_iteration_data and not hooked and max_it >= 4
                 and self.check_interval >= 2 and n_vox <= self.graph_max_voxels
                 and (self.allow_graph_capture or self._graph_key(canonical) in self._graphs)):
@@ -447,6 +454,63 @@ class HierarchicalEngine:
         return warp
 
     # ------------------------------------------------------------------------------------------------
+    BLOCKED_ITERATIONS_PER_LAUNCH = 8
+
+    def _optimize_level_blocked(self, canonical, packed, warp):
+        """2-D levels whose stop test cannot fire (threshold <= 0), Tikhonov term, no filter, no energy printouts: the whole
+        level in ONE foreign call, K = 8 iterations per launch advanced inside LDS tile by tile (lsf_hier_level_run_2d:
+        temporal blocking -- a 512^2 level is launch-bound, 7.5 us per iteration from a HIP graph against ~1 us of work).
+        Same arithmetic on the same inputs: warp, gradient and every iteration's maximum equal the per-iteration path's
+        (tests/test_gpu_blocked_levels.py)."""
+        max_it = self.maximum_iteration_count
+        grid = dev.make_grid(canonical.shape)
+        n = dev.n_voxels(grid)
+        K = self.BLOCKED_ITERATIONS_PER_LAUNCH
+        warps = [warp, torch.empty_like(warp)]
+        F = [torch.zeros_like(warp), torch.empty_like(warp)]
+        records = dev.new_records(max_it, canonical.device)
+        params = _lib.HierParams(float(self.data_term_amplifier), float(self.tikhonov_strength), float(self.rate), 1, 1, 0)
+        _lib.check(_lib.lib.lsf_hier_level_run_2d(
+            dev._ptr(packed, 4 * n, "packed live"), dev._ptr(canonical, n, "canonical"),
+            dev._ptr(warps[0], 2 * n, "warp"), dev._ptr(warps[1], 2 * n, "warp"), dev._ptr(F[0], 2 * n, "gradient"),
+            dev._ptr(F[1], 2 * n, "gradient"), ctypes.byref(grid), ctypes.byref(params),
+            ctypes.c_void_p(records.data_ptr()), max_it, K, dev.stream_ptr()), "lsf_hier_level_run_2d")
+        launches = (max_it + K - 1) // K
+        if launches % 2:
+            warp.copy_(warps[1])
+        lv = HierarchicalEngine._Level()
+        lv.canonical, lv.packed, lv.warp, lv.grid, lv.full_grid, lv.dims = canonical, packed, warp, grid, grid, 2
+        final = F[launches % 2]
+        lv.F = [final, final]  # _final_gradient reads F[n_exec % 2]
+        lv.report_g = None
+        self.last_call.blocked_levels += 1
+        # nothing on the host depends on this level's records (a fixed count): they are read with the other levels' at the
+        # end of optimize() -- ONE synchronisation per call instead of one per level, with the next level's launches
+        # already queued behind this one's
+        self._pending_levels.append((lv, records, max_it))
+        self.level_results.append(None)
+        return warp
+
+    def _finish_pending_levels(self):
+        """the records of the levels _optimize_level_blocked left unread: one transfer, then every level's results"""
+        pending, self._pending_levels = self._pending_levels, []
+        if not pending:
+            return
+        used = torch.cat([dev.slot_view(records)[:n, :, :dev.USED_SLOT_WORDS].reshape(-1) for _, records, n in pending])
+        host = dev.pinned_scratch("level records", used.numel(), torch.int64)[:used.numel()]
+        host.copy_(used, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        flat, at = host.numpy(), 0
+        slots = dev.slot_view(pending[0][1]).shape[1]
+        first = self.level_results.index(None)
+        results, self.level_results = self.level_results, self.level_results[:first]
+        for lv, records, n in pending:
+            words = n * slots * dev.USED_SLOT_WORDS
+            dec = dev.decode_records(flat[at:at + words].reshape(n, slots, dev.USED_SLOT_WORDS).copy())
+            at += words
+            self._finish_level(lv, int(dec["executed"].sum()), dec)
+        assert len(self.level_results) == len(results)
+
     def _optimize_level_graph(self, canonical, packed, warp):
         """launch-bound levels: K iterations (K even) are captured once per level shape as a HIP graph over persistent
         buffers and replayed; a replay costs one launch instead of K x (1..5).  Record slots 0..K-1 form a ring that the

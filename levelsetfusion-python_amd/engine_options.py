@@ -39,7 +39,8 @@ HIERARCHICAL_DEFAULTS = dict(
     fused_filter=True,             # (False: three convolve_axis passes -- measurements, tests)
     fused_filter_min_voxels=1 << 23,
     defer_maximum=True,            # (False: every iteration keeps its own maximum pass)
-    persistent_levels=True,        # 2-D levels: all iterations of a batch in ONE cooperative launch (lsf_hier_level_run)
+    blocked_levels=True,           # 2-D levels with a fixed iteration count: 8 iterations per launch inside LDS tiles
+                                   # (lsf_hier_level_run_2d); False: one launch per iteration (HIP graphs)
 )
 
 
@@ -61,4 +62,4 @@ def apply(engine, defaults, options):
 def new_call_report():
     """what the last optimize() call took: tests and measurements read it instead of private attributes"""
     return types.SimpleNamespace(sparse_states=False, box_walk=False, sobolev_boxes=False, library_run=False,
-                                 persistent_levels=0)
+                                 blocked_levels=0)

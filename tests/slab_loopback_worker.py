@@ -114,11 +114,18 @@ def main_library_run(out_path, port):
              "too_short_to_exchange": (4, 3, 1, (0, 1, 0, 0), False), "one_exchange": (4, 5, 1, (0, 1, 0, 0), False),
              "lower_end_rank": (2, 9, 0, (0, 1, -1, 0), False), "upper_end_rank": (2, 9, 2, (0, 1, 0, -1), False),
              "band_on_x_faces": (2, 8, 1, (0, 1, 0, 0), True), "exchange_every_iteration": (1, 6, 1, (0, 1, 0, 0), False)}
+    # (with the level-set term a band voxel ON an array face moves more than a voxel per iteration -- its out-of-bounds
+    # neighbour reads 1, level_set_term.py:28-64 -- and the call would be re-run on a wider slab, which a rank that is its own
+    # neighbour cannot do: that case runs the data and Killing terms only)
+    case_kwargs = {"band_on_x_faces": dict(level_set_term_enabled=False)}
     problems, taken = [], []
     for name, (halo, iterations, rank, identity, roll) in cases.items():
         layout = SlabLayout(3 * n, rank, 3, halo)
         sl = layout.local_slice()
-        canonical, live0 = sphere_pair(n, 3, "cuda", (sl.start, sl.stop), n // 2)
+        # spheres centred ON the slab faces, so that the faces carry band voxels -- except for the end ranks: a rank that is
+        # its own only neighbour receives its own boundary slices as its halo, which is consistent data only where nothing
+        # moves (spheres inside the slab: the compact faces are empty, whole faces carry the truncated values)
+        canonical, live0 = sphere_pair(n, 3, "cuda", (sl.start, sl.stop), n // 2 if rank == 1 else 0)
         if roll:  # the band crosses x = 0 and x = n - 1: BOUNDARY list entries in every slice, faces merged from two lists
             canonical, live0 = (torch.roll(t, n // 2, dims=2).contiguous() for t in (canonical, live0))
         own = layout.owned_local()
@@ -132,12 +139,18 @@ def main_library_run(out_path, port):
             os.environ["LSF_SLAB_FACES"] = faces
             comm = comm_class(identity)(layout)
             opt = lsf.SlavchevaOptimizer3d(field_size=n, comm=comm, engine_options=options, max_iterations=iterations,
-                                           min_iterations=iterations, **kwargs)
+                                           min_iterations=iterations, **dict(kwargs, **case_kwargs.get(name, {})))
             live = live0.clone()
-            opt.optimize(live, canonical)
+            try:
+                opt.optimize(live, canonical)
+            except Exception as exc:  # noqa: BLE001 -- say which case it was
+                raise RuntimeError("case %s / %s failed" % (name, tag)) from exc
             if tag.startswith("library"):
                 taken.append(bool(opt.engine.last_call.library_run))
-                want = -1 if iterations <= halo else (0 if faces == "full" else 1)
+                # (a rank that is its own ONLY neighbour pairs its lower boundary with its lower halo: the cross-check, made for
+                # a periodic stack -- lower boundary against upper halo --, refuses the counts and whole faces travel, from
+                # Python and from the library alike)
+                want = -1 if iterations <= halo else (0 if faces == "full" or rank != 1 else 1)
                 if opt.engine._fast.compact_faces != want:
                     problems.append("%s/%s: compact_faces %d" % (name, tag, opt.engine._fast.compact_faces))
                 if tag == "library_sparse" and halo >= 2 and not opt.engine.last_call.sparse_states:

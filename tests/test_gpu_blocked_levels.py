@@ -1,0 +1,103 @@
+"""2-D pyramid levels with a fixed iteration count advanced EIGHT iterations per launch inside LDS tiles
+(lsf_hier_level_run_2d, engine option blocked_levels; round 6: BASELINE config 2 is launch-bound) against the
+one-launch-per-iteration path and against the oracle: warp, every iteration's maximum and its location, the last gradient
+-- bit for bit (a tile recomputes the rings of voxels around it with the same arithmetic on the same inputs).
+Reference loop: nonrigid_opt/hierarchical/hierarchical_optimizer2d.py:184-225."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import lsf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lsf():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import levelsetfusion_python_amd as pkg
+    return pkg
+
+
+def _run(lsf, canonical, live, blocked, **kw):
+    opt = lsf.HierarchicalOptimizer2d(engine_options=dict(blocked_levels=blocked), **kw)
+    warp = opt.optimize(canonical, live)
+    assert opt.engine.last_call.blocked_levels == (len(opt.engine.level_results) if blocked else 0)
+    return opt, warp
+
+
+def _same(a, b):
+    (oa, wa), (ob, wb) = a, b
+    assert torch.equal(torch.as_tensor(wa), torch.as_tensor(wb)), "warp"
+    assert oa.get_per_level_iteration_counts() == ob.get_per_level_iteration_counts()
+    for ma, mb in zip(oa.get_per_level_maximum_updates(), ob.get_per_level_maximum_updates()):
+        assert np.array_equal(np.float32(ma), np.float32(mb))
+    for ra, rb in zip(oa.engine.level_results, ob.engine.level_results):
+        assert list(ra.argmax) == list(rb.argmax)
+    assert torch.equal(oa.engine.last_gradient, ob.engine.last_gradient), "the last iteration's gradient"
+
+
+# iteration counts: a multiple of 8, a remainder, fewer than one launch's worth, one
+@pytest.mark.parametrize("n,chunk,iterations", [(512, 4, 100), (256, 8, 16), (128, 4, 13), (64, 8, 3), (64, 4, 1)])
+def test_blocked_levels_equal_one_launch_per_iteration(lsf, n, chunk, iterations):
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live = sphere_pair(n, 2, "cuda")
+    kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=chunk, rate=0.1,
+              maximum_iteration_count=iterations, maximum_warp_update_threshold=0.0, tikhonov_strength=0.05)
+    a = _run(lsf, canonical, live, True, **kw)
+    b = _run(lsf, canonical, live, False, **kw)
+    _same(a, b)
+    assert float(torch.as_tensor(a[1]).abs().max()) > 1e-3
+
+
+def test_blocked_levels_on_fields_that_are_not_square(lsf):
+    """128 x 512: tiles clipped by the array on one axis only, a level of a single row of tiles"""
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live = (t[192:320].contiguous() for t in sphere_pair(512, 2, "cuda"))
+    kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=4, rate=0.1,
+              maximum_iteration_count=20, maximum_warp_update_threshold=0.0, tikhonov_strength=0.05)
+    _same(_run(lsf, canonical, live, True, **kw), _run(lsf, canonical, live, False, **kw))
+
+
+def test_blocked_levels_equal_the_oracle_in_the_divergent_regime(lsf):
+    """BASELINE config 2 as SURVEY 8(d) names it (chunk 4, tikhonov_strength 0.2: the recurrence amplifies the highest
+    frequency 1.6-fold per iteration) for 24 fixed iterations at 128^2: warp and maxima == oracle"""
+    canonical, live = O.sphere_pair(128, d=2)
+    kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=4, rate=0.1,
+              maximum_iteration_count=24, maximum_warp_update_threshold=0.0, tikhonov_strength=0.2)
+    opt, warp = _run(lsf, canonical, live, True, **kw)
+    o = O.HierarchicalOracle(**kw)
+    want = o.optimize(canonical, live)
+    assert np.array_equal(warp, want)
+    assert float(np.abs(want).max()) > 1e-3
+
+
+def test_threshold_terminated_and_filtered_runs_keep_the_per_iteration_path(lsf):
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live = sphere_pair(64, 2, "cuda")
+    base = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=8, rate=0.1,
+                maximum_iteration_count=10, tikhonov_strength=0.05)
+    opt = lsf.HierarchicalOptimizer2d(maximum_warp_update_threshold=0.001, **base)
+    opt.optimize(canonical, live)
+    assert opt.engine.last_call.blocked_levels == 0
+    opt = lsf.HierarchicalOptimizer2d(maximum_warp_update_threshold=0.0, **dict(base, gradient_kernel_enabled=True,
+                                                                               kernel=lsf.generate_1d_sobolev_kernel(3, 0.1)))
+    opt.optimize(canonical, live)
+    assert opt.engine.last_call.blocked_levels == 0
+
+
+def test_entry_point_refuses_what_it_does_not_implement(lsf):
+    import ctypes
+    from levelsetfusion_python_amd import _lib
+    g2, g3 = _lib.Grid(2, 1, 64, 64, 0, 1, 0, 0), _lib.Grid(3, 8, 64, 64, 0, 8, 0, 0)
+    ok = _lib.HierParams(1.0, 0.05, 0.1, 1, 1, 0)
+    call = _lib.lib.lsf_hier_level_run_2d
+    one, two, three, four, five = (ctypes.c_void_p(k * 4096) for k in (1, 2, 3, 4, 5))
+    assert call(one, one, two, three, four, five, ctypes.byref(g3), ctypes.byref(ok), one, 4, 8, None) == -2  # 3-D
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(_lib.HierParams(1.0, 0.05, 0.1, 0, 1, 0)),
+                one, 4, 8, None) == -2  # no Tikhonov term
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(_lib.HierParams(1.0, 0.05, 0.1, 1, 1, 1)),
+                one, 4, 8, None) == -2  # energies
+    assert call(one, one, two, two, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 8, None) == -1    # same buffer twice
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 9, None) == -1  # K > 8

@@ -81,7 +81,7 @@ def test_threshold_terminated_library_run_equals_launch_by_launch(lsf, check_int
     """the stop test fires inside a batch of gated launches, at a batch boundary, or after a single-iteration batch: the
     executed count, every record and the final fields are those of the call enqueued launch by launch from Python"""
     from levelsetfusion_python_amd.synthetic import sphere_pair
-    canonical, live0 = sphere_pair(64, 3, "cuda")
+    canonical, live0 = sphere_pair(48, 3, "cuda")  # eight iterations (from 56^3 on the first update is below 0.1 voxels)
     extra = dict(DEFAULT_LOOP, check_interval=check_interval)
     a = _call(lsf, canonical, live0, 100, True, 2, **extra)
     b = _call(lsf, canonical, live0, 100, False, 2, **extra)
