@@ -400,6 +400,101 @@ __global__ __launch_bounds__(1024) void band_scan_kernel(int* __restrict__ sums_
     if (t == 0) totals[blockIdx.x] = carry;
 }
 
+// The same scan with ONE BLOCK PER TILE of 4096 counts (round 6: lsf_state_prepare's two arrays of per-chunk counts are
+// 131 072 long at 512^3 -- 32 tiles that one block walked one after the other, two barriers and a dependent load each: 78 us
+// where the whole counting pass takes 240).  Two launches: (1) every tile's total, and per tile the (count, first) of the
+// unlisted voxels with live = -canonical; (2) every tile scans itself in place behind the sum of the totals in front of it.
+// tile_out: [0, tiles) totals of array 0, [tiles, 2 tiles) of array 1, [2 tiles, 3 tiles) opposite counts, then their firsts.
+constexpr unsigned kScanTile = 4096u;
+
+__global__ __launch_bounds__(1024) void band_tile_totals_kernel(const int* __restrict__ sums_base, unsigned n,
+                                                                unsigned stride, const int* __restrict__ opposite,
+                                                                int* __restrict__ tile_out, unsigned tiles) {
+    __shared__ int s_sum[1024 / kWave], s_first[1024 / kWave];
+    const unsigned tile = blockIdx.x, a = blockIdx.y, t = threadIdx.x;
+    const unsigned i = tile * kScanTile + 4u * t;
+    int sum = 0, first = 0x7fffffff;
+    if (a < 2u) {
+        const int* __restrict__ sums = sums_base + (size_t)a * stride;
+#pragma unroll
+        for (unsigned k = 0; k < 4u; ++k) sum += i + k < n ? sums[i + k] : 0;
+    } else {
+#pragma unroll
+        for (unsigned k = 0; k < 4u; ++k)
+            if (i + k < n) {
+                sum += opposite[2 * (i + k)];
+                first = min(first, opposite[2 * (i + k) + 1]);
+            }
+    }
+    for (int d = kWave / 2; d > 0; d >>= 1) {
+        sum += __shfl_down(sum, d, kWave);
+        first = min(first, __shfl_down(first, d, kWave));
+    }
+    if ((t & (kWave - 1)) == 0) {
+        s_sum[t / kWave] = sum;
+        s_first[t / kWave] = first;
+    }
+    __syncthreads();
+    if (t == 0) {
+        for (int k = 1; k < 1024 / kWave; ++k) {
+            sum += s_sum[k];
+            first = min(first, s_first[k]);
+        }
+        tile_out[(size_t)a * tiles + tile] = sum;
+        if (a == 2u) tile_out[(size_t)3 * tiles + tile] = first;
+    }
+}
+
+__global__ __launch_bounds__(1024) void band_scan_tiles_kernel(int* __restrict__ sums_base, unsigned n, unsigned stride,
+                                                               const int* __restrict__ tile_out, unsigned tiles,
+                                                               long long* __restrict__ totals) {
+    const unsigned tile = blockIdx.x, a = blockIdx.y, t = threadIdx.x, lane = t & (kWave - 1), wave = t / kWave;
+    if (a == 2u) {  // the unlisted voxels with live = -canonical: their number and the first of them (one thread: <= 256 tiles)
+        if (tile == 0u && t == 0u) {
+            long long sum = 0;
+            int first = 0x7fffffff;
+            for (unsigned k = 0; k < tiles; ++k) {
+                sum += tile_out[(size_t)2 * tiles + k];
+                first = min(first, tile_out[(size_t)3 * tiles + k]);
+            }
+            totals[2] = sum;
+            totals[3] = first == 0x7fffffff ? -1 : first;
+        }
+        return;
+    }
+    __shared__ int wave_total[1024 / kWave];
+    int* __restrict__ sums = sums_base + (size_t)a * stride;
+    int carry = 0;  // the totals of the tiles in front of this one (every thread adds them up for itself: L2 hits)
+    for (unsigned k = 0; k < tile; ++k) carry += tile_out[(size_t)a * tiles + k];
+    const unsigned i = tile * kScanTile + 4u * t;
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = i + k < n ? sums[i + k] : 0;
+    const int mine = v[0] + v[1] + v[2] + v[3];
+    int inclusive = mine;
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        const int up = __shfl_up(inclusive, d, kWave);
+        if ((int)lane >= d) inclusive += up;
+    }
+    if (lane == kWave - 1) wave_total[wave] = inclusive;
+    __syncthreads();
+    int before = 0, whole = 0;
+#pragma unroll
+    for (int w = 0; w < 1024 / kWave; ++w) {
+        const int x = wave_total[w];
+        before += w < (int)wave ? x : 0;
+        whole += x;
+    }
+    int run = carry + before + inclusive - mine;  // exclusive prefix of this thread's four
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (i + k < n) sums[i + k] = run;
+        run += v[k];
+    }
+    if (tile == tiles - 1u && t == 0u) totals[a] = (long long)carry + whole;
+}
+
 typedef float vf4 __attribute__((ext_vector_type(4)));
 
 // start of an optimize() call on the fused path in ONE pass over live and canonical: the ping-pong states = (live, 0)
@@ -798,12 +893,16 @@ static inline int* prepare_opposite(int32_t* scratch, unsigned chunks) {
 // ... then one int per chunk: does the chunk hold band voxels; then one per chunk: lsf_state_pack_needed's verdict
 static inline int* prepare_nonempty(int32_t* scratch, unsigned chunks) { return prepare_opposite(scratch, chunks) + 2 * (size_t)chunks; }
 static inline int* prepare_needed(int32_t* scratch, unsigned chunks) { return prepare_nonempty(scratch, chunks) + chunks; }
+// ... then the scan's per-tile totals (band_tile_totals_kernel): 4 ints per tile of 4096 chunks
+static inline unsigned prepare_scan_tiles(unsigned chunks) { return (chunks + kScanTile - 1u) / kScanTile; }
+static inline int* prepare_tile_totals(int32_t* scratch, unsigned chunks) { return prepare_needed(scratch, chunks) + chunks; }
 
 extern "C" int64_t lsf_state_prepare_scratch_elements(const lsf_grid* grid) {
     if (check_grid(grid, true)) return 0;
     unsigned first, n, chunks;
     band_range(grid, first, n, chunks);
-    return 2 * (int64_t)(chunks + 1) + 64 * (int64_t)chunks + 2 + 2 * (int64_t)chunks + 2 * (int64_t)chunks;
+    return 2 * (int64_t)(chunks + 1) + 64 * (int64_t)chunks + 2 + 2 * (int64_t)chunks + 2 * (int64_t)chunks +
+           4 * ((int64_t)prepare_scan_tiles(chunks) + 1);
 }
 
 extern "C" int lsf_band_list_fill_prepared(const lsf_grid* grid, int32_t subset, const int32_t* scratch, int32_t* list,
@@ -945,8 +1044,12 @@ extern "C" int lsf_state_prepare(const float* live, const float* canonical, floa
                            reinterpret_cast<vf4*>(state_a), reinterpret_cast<vf4*>(state_b), n, make_grid(grid), grid->dims,
                            sums_interior, sums_boundary, prepare_masks(scratch, chunks), prepare_opposite(scratch, chunks),
                            prepare_nonempty(scratch, chunks));
-    hipLaunchKernelGGL(band_scan_kernel, dim3(3), dim3(1024), 0, s, scratch, chunks, chunks + 1, 2u, (long long*)counts_out,
-                       (const int*)prepare_opposite(scratch, chunks));
+    // the scan of the two count arrays and the reduction of the unlisted voxels' counts: a block per tile of 4096 chunks
+    const unsigned tiles = prepare_scan_tiles(chunks) > 0u ? prepare_scan_tiles(chunks) : 1u;
+    hipLaunchKernelGGL(band_tile_totals_kernel, dim3(tiles, 3), dim3(1024), 0, s, scratch, chunks, chunks + 1,
+                       (const int*)prepare_opposite(scratch, chunks), prepare_tile_totals(scratch, chunks), tiles);
+    hipLaunchKernelGGL(band_scan_tiles_kernel, dim3(tiles, 3), dim3(1024), 0, s, scratch, chunks, chunks + 1,
+                       (const int*)prepare_tile_totals(scratch, chunks), tiles, (long long*)counts_out);
     return launch_status();
 }
 
