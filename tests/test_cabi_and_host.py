@@ -194,7 +194,9 @@ def test_slab_runtime_argument_errors(pkg):
     four = (ctypes.c_int64 * 4)(1, 2, 3, 4)
     assert L.lib.lsf_slab_face_counts_begin(None, four) == -1
     assert L.lib.lsf_slab_face_counts_end(None, four) == -1
-    assert L.lib.lsf_state_prepare_scratch_elements(ctypes.byref(grid)) == 2 * 2 + 64 * 1 + 2 + 2 + 2  # one 1024-voxel chunk
+    # one 1024-voxel chunk: two prefix arrays, ballots, the unlisted counts, two verdicts, the scan's per-tile totals (4 ints
+    # per tile of 4096 chunks, + 1 tile)
+    assert L.lib.lsf_state_prepare_scratch_elements(ctypes.byref(grid)) == 2 * 2 + 64 * 1 + 2 + 2 + 2 + 4 * 2
     # the sparse initialisation: whole arrays, a reach of 1..8 voxels, at least one state
     whole = L.Grid(3, 16, 8, 8, 0, 16, 0, 0)
     assert L.lib.lsf_state_pack_needed(1, 1, 1, ctypes.byref(grid), 1, 2, 0, None) == -1      # not a whole array
