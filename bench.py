@@ -708,7 +708,9 @@ def killing_workload(args, device, world, rank, local_rank, dist, dense_walk=Tru
         if L.rank < world - 1:
             mine.append(int(band.narrow(L.axis, L.end - h, h).sum().item()))
         fast = getattr(opt.engine, "_fast", None)
-        compact = fast is not None and getattr(fast, "native", None) is not None and getattr(fast, "faces_ref", None) is not None
+        # (the library-enqueued slab call reports what travelled: lsf_state_run_result::compact_faces)
+        compact = fast is not None and (getattr(fast, "compact_faces", None) == 1 or (
+            getattr(fast, "native", None) is not None and getattr(fast, "faces_ref", None) is not None))
         face_voxels = h * live0.numel() // live0.shape[L.axis]
         face_bytes = [16 * v for v in mine] if compact else [16 * face_voxels] * len(mine)
         interval = getattr(fast, "exchange_interval", 1) if fast is not None else 1

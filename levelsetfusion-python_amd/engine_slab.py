@@ -405,6 +405,11 @@ class SlabMixin:
         f.resume_parts = _Lazy(lambda: (parts([(in_lo, in_hi)]),
                                         parts(([(L.begin - e_last, in_lo)] if lo else []) +
                                               ([(in_hi, L.end + e_last)] if hi else []))))
+        # every part list is a filtered copy (boolean masks: device -> host reads of the counts): made NOW, while the card is
+        # still busy with the states' initialisation, instead of one by one between the iterations' launches, where each
+        # read would drain the launch stream
+        for lazy in f.widened_parts + [f.exchange_parts, f.resume_parts]:
+            lazy.get()
         self._pending_halos = None
         f.native = self.comm.native()
         f.faces_ref = None

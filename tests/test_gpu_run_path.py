@@ -106,6 +106,26 @@ def test_default_loop_condition_equals_the_oracle(lsf):
     assert np.array_equal(opt.gradient_field, ref.gradient_field)
 
 
+def test_threshold_terminated_sobolev_call_equals_the_oracle(lsf):
+    """SobolevFusion (VECTORIZED terms + the zero-preserving 7-tap filter, slavcheva_optimizer2d.py:163-236) under the default
+    loop condition: the call stops at the oracle's iteration (its launches sit behind the device-side gate, check_interval 4:
+    the stop falls inside a batch), with the oracle's fields -- on the float4 lists / boxes of a whole 3-D volume"""
+    canonical, live0 = O.sphere_pair(32, d=3)
+    kernel = lsf.generate_1d_sobolev_kernel(7, 0.1)
+    # (the longest update falls from 0.0406 to 0.0392 voxels between iterations 16 and 17)
+    loop = dict(min_iterations=1, max_iterations=40, maximum_warp_length_lower_threshold=0.04)
+    opt = lsf.SlavchevaOptimizer3d(field_size=32, compute_method=lsf.ComputeMethod.VECTORIZED, sobolev_smoothing_enabled=True,
+                                   sobolev_kernel=kernel, check_interval=4, **loop)
+    live = live0.copy()
+    opt.optimize(live, canonical)
+    ref = O.SlavchevaOracle(compute_method=O.VECTORIZED, sobolev_smoothing_enabled=True, sobolev_kernel=kernel, **loop)
+    live_ref = live0.copy()
+    ref.optimize(live_ref, canonical)
+    assert len(opt.log.max_warps) == ref.iteration_count == 17
+    assert np.allclose(np.float32(opt.log.max_warps), np.float32(ref.log["max_warps"]), rtol=1e-5, atol=0.0)
+    assert float(np.abs(live - live_ref).max()) <= 1e-6 and float(np.abs(opt.warp_field - ref.warp_field).max()) <= 1e-6
+
+
 def test_upper_threshold_ends_the_library_run(lsf, ref_slavcheva):
     """the reference's orthographic pair moves 6-10 voxels per iteration: with an upper threshold of 5 the first iteration is
     the last (slavcheva_optimizer2d.py:360-362), through the gate of the library-enqueued call too"""
