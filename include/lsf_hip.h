@@ -472,6 +472,9 @@ typedef struct lsf_state_run {
     int32_t second_state_late;
     int32_t *box_scratch;     /* NULL, or lsf_band_boxes_scratch_elements(grid) int32: lsf_state_run_begin then also counts the
                                  boxes of lsf_slavcheva_state_iteration_boxes (totals_host[4]) */
+    int32_t box_all;          /* 0: the boxes of the INTERIOR band voxels (lsf_state_run_finish); 1: of ALL band voxels
+                                 (LSF_BAND_ALL: lsf_sobolev_run_finish) */
+    int32_t reserved;
 } lsf_state_run;
 typedef struct lsf_state_run_result {
     float *max_value;    /* host arrays of `iterations` entries (energies3: 3 per iteration), as lsf_records_decode */
@@ -492,6 +495,22 @@ int lsf_state_run_finish(const lsf_state_run *run, const lsf_slavcheva_params *p
                          float *live_out,
                          float lower_threshold, double *statistics16, double *finalize_scratch, int64_t *words_device,
                          int64_t *words_host, lsf_state_run_result *result, void *stream);
+
+/* The SobolevFusion counterpart of lsf_state_run_finish (round 6): the loop of slavcheva_optimizer2d.py:354-388 WITH a Sobolev
+ * filter, for whole 3-D volumes of whole boxes (the conditions of lsf_sobolev_state_update_boxes), behind a
+ * lsf_state_run_begin with box_scratch and box_all = 1.  Launches the list fills, the ascending list of ALL band voxels
+ * (lsf_merge_sorted_runs into list_all -- room for totals_host[0] + totals_host[1] entries -- when both lists have entries),
+ * the boxes (room for totals_host[4]), then per iteration lsf_sobolev_state_gradient_x (bricks) into g4_a and
+ * lsf_sobolev_state_update_boxes (the final gradient into g4_b: in the last iteration of a fixed count, in every iteration
+ * of a threshold-terminated call), the listed finalize pass and the read-backs; `loop`, records, words, result as
+ * lsf_state_run_finish.  g4_a / g4_b: nz * ny * nx float4 each, ZERO-filled by the caller.  Same launches in the same order as
+ * the calls made one by one: identical results. */
+int lsf_sobolev_run_finish(const lsf_state_run *run, const lsf_slavcheva_params *params, const double *taps_host,
+                           int32_t n_taps, int32_t *list_interior, int32_t *list_boundary, int32_t *list_all,
+                           lsf_band_box *boxes, float *g4_a, float *g4_b, lsf_iteration_record *records, int32_t iterations,
+                           const lsf_run_loop *loop, float *live_out, float lower_threshold, double *statistics16,
+                           double *finalize_scratch, int64_t *words_device, int64_t *words_host,
+                           lsf_state_run_result *result, void *stream);
 
 /* ---- the SobolevFusion iteration on the float4 layouts (band lists) ------------------------------
  * replaces one pass of slavcheva_optimizer2d.py:163-236 / :238-330 WITH a Sobolev filter (math_utils/convolution.py:

@@ -22,7 +22,7 @@ ABI_VERSION = 4
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "440f08d6c0c07e3a"
+HEADER_ABI_HASH = "99460b4445395491"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -95,7 +95,8 @@ class StateRun(ctypes.Structure):
     _fields_ = [("live", ctypes.c_void_p), ("canonical", ctypes.c_void_p), ("state", ctypes.c_void_p * 2),
                 ("prepare_scratch", ctypes.c_void_p), ("totals_device", ctypes.c_void_p),
                 ("totals_host", ctypes.c_void_p), ("grid", Grid), ("sparse_reach", ctypes.c_int32),
-                ("second_state_late", ctypes.c_int32), ("box_scratch", ctypes.c_void_p)]
+                ("second_state_late", ctypes.c_int32), ("box_scratch", ctypes.c_void_p), ("box_all", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
 
 
 class StateRunResult(ctypes.Structure):
@@ -204,6 +205,9 @@ PROTOTYPES = {
     "lsf_state_run_begin": (ctypes.c_int, [_P(StateRun), _vp]),
     "lsf_state_run_finish": (ctypes.c_int, [_P(StateRun), _P(SlavchevaParams), _vp, _vp, _vp, _vp, _vp, _i32, _P(RunLoop), _vp,
                                             _f32, _vp, _vp, _vp, _vp, _P(StateRunResult), _vp]),
+    "lsf_sobolev_run_finish": (ctypes.c_int, [_P(StateRun), _P(SlavchevaParams), _P(ctypes.c_double), _i32, _vp, _vp, _vp, _vp,
+                                              _vp, _vp, _vp, _i32, _P(RunLoop), _vp, _f32, _vp, _vp, _vp, _vp,
+                                              _P(StateRunResult), _vp]),
     "lsf_slab_run_begin": (ctypes.c_int, [_P(SlabRun), _vp]),
     "lsf_slab_run_finish": (ctypes.c_int, [_P(SlabRun), _vp, _P(SlavchevaParams), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp,
                                            _P(StateRunResult), _vp]),

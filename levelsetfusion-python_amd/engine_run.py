@@ -16,15 +16,26 @@ class _SparseStateExceeded(Exception):
     call on fully initialised states and keeps doing so for this optimizer)"""
 
 
+class _RunGradient:
+    """the SobolevFusion call's final gradient (float4 [z,]y,x,4), handed out planar like _SobolevStatePlan's"""
+
+    def __init__(self, g4):
+        self._g4 = g4
+
+    def final_gradient_planar(self, dims):
+        return self._g4[..., :dims].movedim(-1, 0).contiguous()
+
+
 class RunMixin:
     """SlavchevaEngine's library-enqueued calls on whole volumes"""
 
-    def _optimize_run(self, live, canonical, grid, finalize):
+    def _optimize_run(self, live, canonical, grid, finalize, sobolev=False):
         """_optimize for the case the library enqueues in one piece (lsf_state_run_begin / _finish): prepare pass, (sparse)
         states, band lists, all iterations -- a fixed count, or the reference's threshold-terminated loop in batches of
         check_interval gated launches --, the listed finalize pass and the read-backs: the same launches in the same order
         as the general path makes one by one, hence the same results, in two foreign calls that run without the interpreter
-        lock."""
+        lock.  sobolev: the SobolevFusion iteration on whole 3-D volumes of whole boxes (lsf_sobolev_run_finish: gradient + x
+        pass over the list of all band voxels, then y pass, z pass, update and re-warp box by box)."""
         live_out, lower_threshold, statistics = finalize
         # the number of records; with min < max the stop test can fire (the reference's default: slavcheva_optimizer2d.py:
         # 360-362) and the library enqueues check_interval gated iterations at a time, reading the records in between
@@ -55,8 +66,9 @@ class RunMixin:
         run.grid = whole
         run.sparse_reach = self.sparse_reach if sparse else 0
         run.second_state_late = int(not sparse and n <= dev.StatePrepare.SPLIT_MAX_VOXELS)
-        count_boxes = dev.boxes_ok(whole) and (self.box_walk is True or
-                                               (self.box_walk is None and n >= self.box_walk_min_voxels))
+        count_boxes = sobolev or (dev.boxes_ok(whole) and (self.box_walk is True or
+                                                           (self.box_walk is None and n >= self.box_walk_min_voxels)))
+        run.box_all = int(sobolev)
         box_scratch = None
         if count_boxes:
             box_scratch = torch.empty(int(_lib.lib.lsf_band_boxes_scratch_elements(ctypes.byref(whole))),
@@ -68,10 +80,17 @@ class RunMixin:
         n_interior, n_boundary, opposite, first_opposite, n_boxes = totals_host.tolist()
         lists = torch.empty(max(n_interior + n_boundary, 1), dtype=torch.int32, device=device)
         boxes = box_canonical = None
-        if n_boxes and (self.box_walk is True or 32 * n_interior > self.box_walk_min_band_bytes):
+        if sobolev:
+            boxes = torch.empty((max(n_boxes, 1), 2), dtype=torch.int64, device=device)
+            list_all = torch.empty(max(n_interior + n_boundary, 1), dtype=torch.int32, device=device) \
+                if n_interior and n_boundary else None
+            g4 = [torch.zeros(tuple(live.shape) + (4,), dtype=torch.float32, device=device) for _ in range(2)]
+            taps = np.ascontiguousarray(np.asarray(self.sobolev_kernel, dtype=np.float64))
+            self.last_call.sobolev_boxes = True
+        elif n_boxes and (self.box_walk is True or 32 * n_interior > self.box_walk_min_band_bytes):
             boxes = torch.empty((n_boxes, 2), dtype=torch.int64, device=device)
             box_canonical = torch.empty(n_boxes * dev.BOX_EDGE ** 3, dtype=torch.float32, device=device)
-        self.last_call.box_walk = boxes is not None
+        self.last_call.box_walk = boxes is not None and not sobolev
         records = dev.new_records(iterations, device)
         n_words = iterations * _lib.RECORD_SLOTS * dev.USED_SLOT_WORDS
         words = torch.empty(n_words + 16, dtype=torch.int64, device=device)  # the records' used words, then the statistics
@@ -97,6 +116,27 @@ class RunMixin:
         f.bands, f.records, f.boxes = bands, records, (boxes, box_canonical)
         outcome = _RunOutcome(grid, canonical, None, target, bands, None)
         weights = tuple(self.weights)
+        if sobolev:
+            f.keep = (g4, list_all, taps)
+            self._sobolev_band = f  # what bench.py prices this path over
+            _lib.check(_lib.lib.lsf_sobolev_run_finish(
+                ctypes.byref(run), ctypes.byref(self.params), taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                int(taps.size), ctypes.c_void_p(p_lists), ctypes.c_void_p(p_lists + 4 * n_interior),
+                ctypes.c_void_p(list_all.data_ptr() if list_all is not None else 0), ctypes.c_void_p(boxes.data_ptr()),
+                ctypes.c_void_p(g4[0].data_ptr()), ctypes.c_void_p(g4[1].data_ptr()), ctypes.c_void_p(records.data_ptr()),
+                iterations, ctypes.byref(loop) if loop is not None else None, dev._ptr(target, n, "live_out"),
+                float(lower_threshold), ctypes.c_void_p(stats.data_ptr()) if statistics else none,
+                ctypes.c_void_p(stats_scratch.data_ptr()) if statistics else none, ctypes.c_void_p(words.data_ptr()),
+                ctypes.c_void_p(words_host.data_ptr()), ctypes.byref(result), stream), "lsf_sobolev_run_finish")
+        else:
+            self._run_finish(run, p_lists, n_interior, boxes, box_canonical, records, iterations, loop, target, n,
+                             lower_threshold, stats, stats_scratch, statistics, words, words_host, result, stream)
+        return self._after_run(result, executed, iterations, f, max_value, argmax, energies, weights, states, canonical, grid,
+                               bands, outcome, statistics, words_host, n_words, g4[1] if sobolev else None)
+
+    def _run_finish(self, run, p_lists, n_interior, boxes, box_canonical, records, iterations, loop, target, n,
+                    lower_threshold, stats, stats_scratch, statistics, words, words_host, result, stream):
+        none = ctypes.c_void_p(0)
         _lib.check(_lib.lib.lsf_state_run_finish(
             ctypes.byref(run), ctypes.byref(self.params), ctypes.c_void_p(p_lists),
             ctypes.c_void_p(p_lists + 4 * n_interior), ctypes.c_void_p(boxes.data_ptr() if boxes is not None else 0),
@@ -106,14 +146,21 @@ class RunMixin:
             ctypes.c_void_p(stats.data_ptr()) if statistics else none,
             ctypes.c_void_p(stats_scratch.data_ptr()) if statistics else none, ctypes.c_void_p(words.data_ptr()),
             ctypes.c_void_p(words_host.data_ptr()), ctypes.byref(result), stream), "lsf_state_run_finish")
+
+    def _after_run(self, result, executed, iterations, f, max_value, argmax, energies, weights, states, canonical, grid, bands,
+                   outcome, statistics, words_host, n_words, sobolev_gradient):
         if result.reach_exceeded:
             raise _SparseStateExceeded()  # the pass has left the caller's array alone (its guard); optimize() repeats
         n_exec = iterations if executed.all() else int(executed.sum())
         self._fast = f
         self.iteration_count = n_exec
         self.log = _RunLog(max_value[:n_exec], argmax[:n_exec], energies[:n_exec], weights)
-        # gradient_field() recomputes the last iteration's gradient on demand from its INPUT state, at the listed voxels
-        self._gradient_state = ("recompute_listed", states[(n_exec - 1) % 2], canonical, grid, bands)
+        if sobolev_gradient is not None:
+            # the filtered gradient of the last executed iteration (float4, made planar when read)
+            self._gradient_state = ("float4", _RunGradient(sobolev_gradient), grid.dims)
+        else:
+            # gradient_field() recomputes the last iteration's gradient on demand from its INPUT state, at the listed voxels
+            self._gradient_state = ("recompute_listed", states[(n_exec - 1) % 2], canonical, grid, bands)
         outcome.state = states[n_exec % 2]
         if statistics:
             outcome._raw = words_host[n_words:].numpy().view(np.float64).copy()

@@ -156,6 +156,12 @@ class SlavchevaEngine(RunMixin, SlabMixin, PlanarSobolevMixin):
         slab = self._slab()
         run_ok = (self.library_run and finalize is not None and not self.sobolev and self.use_band_list
                   and self.iteration_hook is None and self.min_iterations > 0 and dev.buffer_addressing_ok(grid))
+        if (self.library_run and finalize is not None and self.sobolev and self.sobolev_boxes and self.use_band_list
+                and self.iteration_hook is None and self.min_iterations > 0 and not slab and grid.dims == 3
+                and dev.boxes_ok(grid) and dev.n_voxels(grid) < (1 << 27) and dev.buffer_addressing_ok(grid)
+                and len(self.sobolev_kernel) in dev.LISTED_TAP_COUNTS):
+            # SobolevFusion on a whole 3-D volume of whole boxes: the call enqueued by the library as well
+            return self._optimize_run(live, canonical, grid, finalize, sobolev=True)
         if run_ok and not slab:
             # a whole volume, no Sobolev filter, nobody watching the iterations: the whole call is enqueued by the library
             # (two host calls; slavcheva_optimizer2d.py:354-388's loop without a Python iteration) -- a fixed iteration count

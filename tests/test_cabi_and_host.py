@@ -117,9 +117,10 @@ def test_ctypes_structs_match_header_layout(pkg):
     # lsf_run_loop, lsf_slab_run (round 6): the out members' offsets are what the binding reads back
     assert ctypes.sizeof(L.RunLoop) == 24 and L.RunLoop.check_interval.offset == 16
     assert ctypes.sizeof(L.StateRunResult) == 48 and L.StateRunResult.compact_faces.offset == 44
-    assert L.SlabRun.layout.offset == ctypes.sizeof(L.StateRun) == 128 and L.SlabRun.cut_slices.offset == 168
-    assert L.SlabRun.cut_entries.offset == 456 and L.SlabRun.out_face_entries.offset == 456 + 2 * 8 * L.SLAB_MAX_CUTS + 8
-    assert ctypes.sizeof(L.SlabRun) == 1624
+    assert L.SlabRun.layout.offset == ctypes.sizeof(L.StateRun) == 136 and L.SlabRun.cut_slices.offset == 176
+    assert L.StateRun.box_all.offset == 128
+    assert L.SlabRun.cut_entries.offset == 464 and L.SlabRun.out_face_entries.offset == 464 + 2 * 8 * L.SLAB_MAX_CUTS + 8
+    assert ctypes.sizeof(L.SlabRun) == 1632
     for macro, value in (("LSF_ABI_VERSION", 4), ("LSF_SLAB_MAX_CUTS", L.SLAB_MAX_CUTS),
                          ("LSF_MAX_KERNEL_TAPS", L.MAX_KERNEL_TAPS),
                          ("LSF_SMOOTHING_KILLING", L.SMOOTHING_KILLING),

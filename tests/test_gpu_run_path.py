@@ -126,6 +126,31 @@ def test_threshold_terminated_sobolev_call_equals_the_oracle(lsf):
     assert float(np.abs(live - live_ref).max()) <= 1e-6 and float(np.abs(opt.warp_field - ref.warp_field).max()) <= 1e-6
 
 
+@pytest.mark.parametrize("fixed", [True, False])
+def test_sobolev_library_run_equals_launch_by_launch(lsf, fixed):
+    """lsf_sobolev_run_finish (the SobolevFusion call of a whole 3-D volume enqueued by the library: gradient + x pass, then
+    the box kernel, per iteration) against the same call made launch by launch from Python: fields, records, report, the
+    filtered gradient of the last iteration -- a fixed count, and a threshold-terminated call (check_interval 3)"""
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live0 = sphere_pair(64, 3, "cuda")
+    loop = dict(max_iterations=7, min_iterations=7) if fixed else \
+        dict(max_iterations=30, min_iterations=2, maximum_warp_length_lower_threshold=0.0435, check_interval=3)  # stops after 5
+    runs = []
+    for library_run in (True, False):
+        opt = lsf.SlavchevaOptimizer3d(field_size=64, compute_method=lsf.ComputeMethod.DIRECT, sobolev_smoothing_enabled=True,
+                                       sobolev_kernel=lsf.generate_1d_sobolev_kernel(7, 0.1), level_set_term_enabled=True,
+                                       smoothing_term_method=lsf.SmoothingTermMethod.KILLING,
+                                       engine_options=dict(library_run=library_run, sparse_min_voxels=0),
+                                       **dict(dict(maximum_warp_length_lower_threshold=0.0), **loop))
+        live = live0.clone()
+        opt.optimize(live, canonical)
+        assert opt.engine.last_call.library_run == library_run and opt.engine.last_call.sobolev_boxes
+        runs.append((opt, live))
+    _same(runs[0], runs[1])
+    n = len(runs[0][0].log.max_warps)
+    assert n == 7 if fixed else 2 <= n < 30
+
+
 def test_upper_threshold_ends_the_library_run(lsf, ref_slavcheva):
     """the reference's orthographic pair moves 6-10 voxels per iteration: with an upper threshold of 5 the first iteration is
     the last (slavcheva_optimizer2d.py:360-362), through the gate of the library-enqueued call too"""
