@@ -544,6 +544,11 @@ int lsf_sobolev_state_gradient_x(const float *state, const float *canonical, flo
                                  const lsf_slavcheva_params *params, const double *taps_host, int32_t n_taps,
                                  const lsf_gate *gate, lsf_iteration_record *record, const int32_t *band_list,
                                  int64_t band_count, int32_t out_bricks, void *stream);
+/* zeros at the voxels of a band list in a float4 buffer (bricks != 0: in the brick layout of lsf_sobolev_state_gradient_x): a
+ * gradient buffer whose non-zero entries all lie at the voxels of a PREVIOUS call's lists is made all-zero again without a
+ * fill of the whole buffer (new design: the reference allocates its gradient per call, slavcheva_optimizer2d.py:343-346) */
+int lsf_zero_listed4(float *field4, const lsf_grid *grid, const int32_t *band_list, int64_t band_count, int32_t bricks,
+                     void *stream);
 int lsf_convolve_axis_listed4(const float *in4, float *out4, const float *zero_mask_source4, const lsf_grid *grid,
                               int32_t axis, const double *taps_host, int32_t n_taps, const lsf_gate *gate,
                               const int32_t *band_list, int64_t band_count, void *stream);

@@ -22,7 +22,7 @@ ABI_VERSION = 4
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "99460b4445395491"
+HEADER_ABI_HASH = "3f3d3b284a3073fd"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -232,6 +232,7 @@ PROTOTYPES = {
     "lsf_band_list_strip_major": (ctypes.c_int, [_vp, _i64, _P(Grid), _i32, _vp, _vp, _vp]),
     "lsf_sobolev_state_gradient_x": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(ctypes.c_double), _i32,
                                                     _P(Gate), _vp, _vp, _i64, _i32, _vp]),
+    "lsf_zero_listed4": (ctypes.c_int, [_vp, _P(Grid), _vp, _i64, _i32, _vp]),
     "lsf_convolve_axis_listed4": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _i32, _P(ctypes.c_double), _i32, _P(Gate), _vp,
                                                  _i64, _vp]),
     "lsf_sobolev_state_update": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _i32,

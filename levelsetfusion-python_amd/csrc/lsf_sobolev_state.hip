@@ -556,6 +556,36 @@ extern "C" int lsf_sobolev_state_gradient_x(const float* state, const float* can
     return launch_status();
 }
 
+// zeros at the voxels of a band list (natural layout or the bricks of lsf_sobolev_state_gradient_x): what makes a gradient
+// buffer of the PREVIOUS call usable again -- every other voxel of it is zero already (268 MB of zero fill per buffer and call
+// at 256^3 against 26 MB of listed voxels)
+__global__ __launch_bounds__(kBlock) void zero_listed4_kernel(vf4* __restrict__ field, const int* __restrict__ list,
+                                                              unsigned count, Grid g, int bricks) {
+    const unsigned k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= count) return;
+    const int i = list[k];
+    long long at = i;
+    if (bricks) {
+        int x, y, z;
+        decode_listed(g, (unsigned)i, x, y, z);
+        at = ((((long long)(z >> 2) * (g.ny >> 2) + (y >> 2)) * (g.nx >> 2) + (x >> 2)) << 6) + (((z & 3) << 4) | ((y & 3) << 2) | (x & 3));
+    }
+    const vf4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    field[at] = zero;
+}
+
+extern "C" int lsf_zero_listed4(float* field4, const lsf_grid* grid, const int32_t* band_list, int64_t band_count,
+                                int32_t bricks, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!field4 || band_count < 0 || band_count > 0x7fffffffll || (band_count && !band_list)) return LSF_ERR_BAD_ARGUMENT;
+    if (bricks && (grid->dims != 3 || grid->nx % 4 || grid->ny % 4 || grid->nz % 4)) return LSF_ERR_BAD_DIMS;
+    if (band_count == 0) return 0;
+    hipLaunchKernelGGL(zero_listed4_kernel, dim3((unsigned)((band_count + kBlock - 1) / kBlock)), dim3(kBlock), 0,
+                       as_stream(stream), reinterpret_cast<vf4*>(field4), band_list, (unsigned)band_count, state_grid(grid),
+                       bricks);
+    return launch_status();
+}
+
 extern "C" int lsf_convolve_axis_listed4(const float* in4, float* out4, const float* zero_mask_source4,
                                          const lsf_grid* grid, int32_t axis, const double* taps_host, int32_t n_taps,
                                          const lsf_gate* gate, const int32_t* band_list, int64_t band_count,

@@ -84,7 +84,7 @@ class RunMixin:
             boxes = torch.empty((max(n_boxes, 1), 2), dtype=torch.int64, device=device)
             list_all = torch.empty(max(n_interior + n_boundary, 1), dtype=torch.int32, device=device) \
                 if n_interior and n_boundary else None
-            g4 = [torch.zeros(tuple(live.shape) + (4,), dtype=torch.float32, device=device) for _ in range(2)]
+            g4 = self._sobolev_gradient_buffers(live, whole, lists, n_interior + n_boundary)
             taps = np.ascontiguousarray(np.asarray(self.sobolev_kernel, dtype=np.float64))
             self.last_call.sobolev_boxes = True
         elif n_boxes and (self.box_walk is True or 32 * n_interior > self.box_walk_min_band_bytes):
@@ -133,6 +133,26 @@ class RunMixin:
                              lower_threshold, stats, stats_scratch, statistics, words, words_host, result, stream)
         return self._after_run(result, executed, iterations, f, max_value, argmax, energies, weights, states, canonical, grid,
                                bands, outcome, statistics, words_host, n_words, g4[1] if sobolev else None)
+
+    def _sobolev_gradient_buffers(self, live, whole, lists, n_listed):
+        """the two float4 gradient buffers of a library-enqueued SobolevFusion call, all zero: the previous call's buffers with
+        zeros written back at ITS listed voxels (every other voxel was never written: lsf_zero_listed4, 2 x 26 MB at 256^3) or,
+        for another shape, fresh zero fills (2 x 268 MB).  The optimizer keeps them between calls (the reference allocates its
+        gradient per call, slavcheva_optimizer2d.py:343-346)."""
+        key = (tuple(live.shape), live.device)
+        cache = getattr(self, "_g4_cache", None)
+        if cache is not None and cache[0] == key:
+            _, g4, old_lists, old_n = cache
+            for t, bricks in ((g4[0], 1), (g4[1], 0)):
+                _lib.check(_lib.lib.lsf_zero_listed4(ctypes.c_void_p(t.data_ptr()), ctypes.byref(whole),
+                                                     ctypes.c_void_p(old_lists.data_ptr()), old_n, bricks, dev.stream_ptr()),
+                           "lsf_zero_listed4")
+        else:
+            self._g4_cache = None  # (let go of another shape's buffers first)
+            g4 = [torch.zeros(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device) for _ in range(2)]
+        # recorded BEFORE the call runs: whatever happens in it, these are the voxels it may have written
+        self._g4_cache = (key, g4, lists, int(n_listed))
+        return g4
 
     def _run_finish(self, run, p_lists, n_interior, boxes, box_canonical, records, iterations, loop, target, n,
                     lower_threshold, stats, stats_scratch, statistics, words, words_host, result, stream):

@@ -151,6 +151,30 @@ def test_sobolev_library_run_equals_launch_by_launch(lsf, fixed):
     assert n == 7 if fixed else 2 <= n < 30
 
 
+def test_sobolev_gradient_buffers_are_reused_across_calls(lsf):
+    """an optimizer keeps its two float4 gradient buffers between SobolevFusion calls and writes zeros back at the PREVIOUS
+    call's listed voxels only (lsf_zero_listed4) instead of two whole-buffer fills: calls on pair A, on another pair B (another
+    band), and on A again give what fresh optimizers give -- fields, records, the gradient field"""
+    from levelsetfusion_python_amd.synthetic import sphere_frame, sphere_pair
+    pairs = [sphere_pair(64, 3, "cuda"), (sphere_frame(64, 3), sphere_frame(64, 6)), sphere_pair(64, 3, "cuda")]
+
+    def make():
+        return lsf.SlavchevaOptimizer3d(field_size=64, compute_method=lsf.ComputeMethod.DIRECT, sobolev_smoothing_enabled=True,
+                                        sobolev_kernel=lsf.generate_1d_sobolev_kernel(7, 0.1),
+                                        maximum_warp_length_lower_threshold=0.0, max_iterations=4, min_iterations=4)
+    kept = make()
+    for canonical, live0 in pairs:
+        fresh = make()
+        runs = []
+        for opt in (kept, fresh):
+            live = live0.clone()
+            opt.optimize(live, canonical)
+            assert opt.engine.last_call.library_run and opt.engine.last_call.sobolev_boxes
+            runs.append((opt, live))
+        _same(runs[0], runs[1])
+        assert float(np.abs(runs[0][0].gradient_field).max()) > 0.0
+
+
 def test_upper_threshold_ends_the_library_run(lsf, ref_slavcheva):
     """the reference's orthographic pair moves 6-10 voxels per iteration: with an upper threshold of 5 the first iteration is
     the last (slavcheva_optimizer2d.py:360-362), through the gate of the library-enqueued call too"""
