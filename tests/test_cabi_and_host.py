@@ -167,6 +167,74 @@ def test_argument_errors_are_reported_not_launched(pkg):
         pkg._lib.check(-2, "x")
 
 
+def test_round6_entry_points_validate_on_the_host(pkg):
+    """the entry points added in round 6 -- whole calls enqueued by the library (lsf_run_loop, lsf_slab_run_*,
+    lsf_sobolev_run_finish), the blocked 2-D level, lsf_zero_listed4, lsf_slab_comm_info -- refuse bad arguments before
+    anything touches a device (no GPU here)"""
+    L = pkg._lib
+    lib = L.lib
+    g2, g3 = L.Grid(2, 1, 64, 64, 0, 1, 0, 0), L.Grid(3, 8, 32, 32, 0, 8, 0, 0)
+    one, two, three, four, five = (ctypes.c_void_p(k * 4096) for k in (1, 2, 3, 4, 5))
+    # lsf_hier_level_run_2d: 2-D, Tikhonov, update applied, no energies, 1..8 iterations per launch, distinct buffers
+    ok = L.HierParams(1.0, 0.05, 0.1, 1, 1, 0)
+    call = lib.lsf_hier_level_run_2d
+    assert call(one, one, two, three, four, five, ctypes.byref(g3), ctypes.byref(ok), one, 4, 8, None) == -2
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(L.HierParams(1.0, 0.05, 0.1, 0, 1, 0)), one, 4, 8,
+                None) == -2
+    assert call(one, one, two, two, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 8, None) == -1
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 0, None) == -1
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 9, None) == -1
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 0, 8, None) == 0  # nothing to do
+    # lsf_zero_listed4
+    assert lib.lsf_zero_listed4(None, ctypes.byref(g3), one, 4, 0, None) == -1
+    assert lib.lsf_zero_listed4(one, ctypes.byref(g3), None, 4, 0, None) == -1
+    assert lib.lsf_zero_listed4(one, ctypes.byref(g2), one, 4, 1, None) == -2                    # bricks are 3-D
+    assert lib.lsf_zero_listed4(one, ctypes.byref(L.Grid(3, 8, 30, 32, 0, 8, 0, 0)), one, 4, 1, None) == -2
+    assert lib.lsf_zero_listed4(one, ctypes.byref(g3), one, 0, 1, None) == 0                     # an empty list
+    # the loop condition of lsf_state_run_finish / lsf_sobolev_run_finish
+    run = L.StateRun()
+    host = (ctypes.c_int64 * 8)()
+    run.live, run.canonical, run.state[0], run.state[1] = 4096, 8192, 12288, 16384
+    run.prepare_scratch, run.totals_device, run.totals_host, run.grid = 20480, 24576, ctypes.addressof(host), g3
+    buf = (ctypes.c_int64 * 64)()
+    res = L.StateRunResult(ctypes.addressof(buf), ctypes.addressof(buf), ctypes.addressof(buf), ctypes.addressof(buf))
+    params = L.SlavchevaParams()
+    finish = lib.lsf_state_run_finish
+
+    def state_finish(iterations, loop):
+        return finish(ctypes.byref(run), ctypes.byref(params), one, one, None, None, one, iterations,
+                      ctypes.byref(loop) if loop is not None else None, one, 0.0, None, None, one, one, ctypes.byref(res), None)
+    assert state_finish(10, L.RunLoop(0, 10, 0.1, 10.0, 4, 0)) == -1    # min_iterations 0: the caller's business
+    assert state_finish(10, L.RunLoop(1, 10, 0.1, 10.0, 0, 0)) == -1    # check_interval
+    assert state_finish(12, L.RunLoop(1, 10, 0.1, 10.0, 4, 0)) == -1    # records != max(min, max)
+    taps = (ctypes.c_double * 7)(*([1.0 / 7] * 7))
+    sob = lib.lsf_sobolev_run_finish
+
+    def sobolev_finish(r, g_a=three, g_b=four):
+        return sob(ctypes.byref(r), ctypes.byref(params), taps, 7, one, one, one, two, g_a, g_b, one, 5, None, one, 0.0, None,
+                   None, one, one, ctypes.byref(res), None)
+    assert sobolev_finish(run) == -1                                     # begun without box_scratch / box_all
+    run.box_scratch, run.box_all = 28672, 1
+    assert sobolev_finish(run, g_a=three, g_b=three) == -1               # one gradient buffer twice
+    # lsf_slab_run_begin / _finish, lsf_slab_comm_info
+    assert lib.lsf_slab_run_begin(None, None) == -1
+    srun = L.SlabRun()
+    assert lib.lsf_slab_run_begin(ctypes.byref(srun), None) == -1        # nothing filled in
+    srun.base = run
+    srun.base.box_scratch, srun.base.box_all = None, 0
+    srun.base.grid = L.Grid(3, 12, 32, 32, 0, 12, 0, 0)
+    srun.layout = L.SlabLayoutC(12, 32, 32, 2, 10, 2, 0, 0)
+    srun.exchange_interval = 3                                           # neither 1 nor the halo
+    assert lib.lsf_slab_run_begin(ctypes.byref(srun), None) == -1
+    srun.exchange_interval = 2
+    srun.layout = L.SlabLayoutC(12, 32, 30, 2, 10, 2, 0, 0)              # does not match the grid
+    assert lib.lsf_slab_run_begin(ctypes.byref(srun), None) == -1
+    assert lib.lsf_slab_run_finish(ctypes.byref(srun), None, ctypes.byref(params), one, one, one, None, one, 5, one, one, one,
+                                   ctypes.byref(res), None) == -1        # no communicator
+    rank, count = ctypes.c_int32(), ctypes.c_int32()
+    assert lib.lsf_slab_comm_info(None, ctypes.byref(rank), ctypes.byref(count)) == -1
+
+
 def test_slab_runtime_argument_errors(pkg):
     """the z-slab runtime (lsf_slab.hip) validates on the host before touching a device or RCCL"""
     L = pkg._lib
