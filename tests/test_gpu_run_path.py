@@ -91,6 +91,29 @@ def test_threshold_terminated_library_run_equals_launch_by_launch(lsf, check_int
     assert a[0].get_convergence_report().iteration_count == n
 
 
+@pytest.mark.parametrize("loop", [dict(min_iterations=3, max_iterations=20, maximum_warp_length_lower_threshold=0.18),  # gate from 3 on: 12
+                                  dict(min_iterations=6, max_iterations=4, maximum_warp_length_lower_threshold=0.18),   # min > max: six
+                                  dict(min_iterations=1, max_iterations=5, maximum_warp_length_lower_threshold=0.0),    # runs into max
+                                  dict(min_iterations=2, max_iterations=9, maximum_warp_length_lower_threshold=0.18,
+                                       maximum_warp_length_upper_threshold=0.24)])                                       # upper bound
+def test_loop_condition_corner_cases_2d_with_boundary_list(lsf, ref_slavcheva, loop):
+    """slavcheva_optimizer2d.py:360-362 at its corners -- the gate opening only from min_iterations on, min > max, the
+    iteration limit, the upper threshold -- on the reference's 64 x 64 pair shrunk to small updates (rate 0.004), whose band
+    runs into the array's faces (two launches per iteration): library-enqueued call == launch by launch == oracle count"""
+    canonical = torch.from_numpy(ref_slavcheva["ortho64.canonical"]).cuda()
+    live0 = torch.from_numpy(ref_slavcheva["ortho64.live"]).cuda()
+    extra = dict(loop, gradient_descent_rate=0.004, check_interval=4)
+    limit = max(loop["min_iterations"], loop["max_iterations"])
+    a = _call(lsf, canonical, live0, limit, True, **extra)
+    b = _call(lsf, canonical, live0, limit, False, **extra)
+    _same(a, b)
+    ref = O.SlavchevaOracle(compute_method=O.DIRECT, smoothing_term_method=O.KILLING, **dict(KILLING, **dict(loop, gradient_descent_rate=0.004)))
+    live_ref = ref_slavcheva["ortho64.live"].copy()
+    ref.optimize(live_ref, ref_slavcheva["ortho64.canonical"])
+    assert len(a[0].log.max_warps) == ref.iteration_count
+    assert np.array_equal(a[1].cpu().numpy(), live_ref)
+
+
 def test_default_loop_condition_equals_the_oracle(lsf):
     """the default-constructed loop through the library-enqueued call against the oracle: the same iteration count, maxima
     and fields (the sphere pair at 48^3; Killing + level set)"""
