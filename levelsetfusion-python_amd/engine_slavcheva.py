@@ -11,13 +11,14 @@ import torch
 
 from . import _lib, device as dev, engine_options
 from .engine_common import _Counted
+from .engine_focus import FocusMixin
 from .engine_outcome import SlavchevaOutcome
 from .engine_run import RunMixin, _SparseStateExceeded
 from .engine_slab import SlabMixin, _HaloTooNarrow
 from .engine_sobolev import PlanarSobolevMixin, _SobolevStatePlan
 
 
-class SlavchevaEngine(RunMixin, SlabMixin, PlanarSobolevMixin):
+class SlavchevaEngine(RunMixin, SlabMixin, PlanarSobolevMixin, FocusMixin):
     """per-iteration-update optimizer with in-place re-warping of the live field
     (nonrigid_opt/slavcheva/slavcheva_optimizer2d.py:332-408), D = 2 or 3, optionally on a z-slab."""
 
@@ -154,10 +155,14 @@ class SlavchevaEngine(RunMixin, SlabMixin, PlanarSobolevMixin):
         dims = grid.dims
         n_rec = max(self.max_iterations, self.min_iterations, 1)
         slab = self._slab()
+        # somebody looks at every iteration (the hook, the focus-neighbourhood trace): launched and synchronised one by one
+        watched = self.iteration_hook is not None or self.focus_voxels is not None
+        if self.focus_voxels is not None:
+            self._focus_begin(live, canonical)
         run_ok = (self.library_run and finalize is not None and not self.sobolev and self.use_band_list
-                  and self.iteration_hook is None and self.min_iterations > 0 and dev.buffer_addressing_ok(grid))
+                  and not watched and self.min_iterations > 0 and dev.buffer_addressing_ok(grid))
         if (self.library_run and finalize is not None and self.sobolev and self.sobolev_boxes and self.use_band_list
-                and self.iteration_hook is None and self.min_iterations > 0 and not slab and grid.dims == 3
+                and not watched and self.min_iterations > 0 and not slab and grid.dims == 3
                 and dev.boxes_ok(grid) and dev.n_voxels(grid) < (1 << 27) and dev.buffer_addressing_ok(grid)
                 and len(self.sobolev_kernel) in dev.LISTED_TAP_COUNTS):
             # SobolevFusion on a whole 3-D volume of whole boxes: the call enqueued by the library as well
@@ -210,7 +215,7 @@ class SlavchevaEngine(RunMixin, SlabMixin, PlanarSobolevMixin):
                            and not getattr(self, "_exchange_every_iteration", False)
                            and self.comm.layout.halo >= max(self.sparse_reach, 2))
             sparse = ((not slab or slab_groups) and self.sparse_reach > 0 and dev.n_voxels(grid) >= self.sparse_min_voxels
-                      and self.iteration_hook is None and not self.sparse_disabled)
+                      and not watched and not self.sparse_disabled)
             # the listed finalize pass wants a zero-filled warp output (192 MB at 256^3, 26 us): filled in the call's
             # prologue, where the card waits for the host, instead of behind the last iteration.  Up to 256^3 IN FRONT of
             # the counting pass: the states written behind it are then the last thing to pass through the 256 MB Infinity
@@ -302,7 +307,7 @@ class SlavchevaEngine(RunMixin, SlabMixin, PlanarSobolevMixin):
         it, n_exec = 0, 0
         dec = None
         early = None
-        hooked = self.iteration_hook is not None
+        hooked = watched
         while it < limit:
             # a run whose stop test cannot fire (min_iterations == max_iterations) has nothing to look at in between: all of
             # it is enqueued at once, whatever check_interval says
@@ -349,7 +354,9 @@ class SlavchevaEngine(RunMixin, SlabMixin, PlanarSobolevMixin):
             if n_exec < it:
                 break
             m = dec["max_value"][n_exec - 1]
-            if hooked:
+            if self.focus_voxels is not None:
+                self._probe_focus(it - 1, lives, warps, states, canonical, grid)
+            if self.iteration_hook is not None:
                 self._call_hook(it - 1, float(m), lives, warps, states, canonical, grid, sob)
             if n_exec >= self.min_iterations and not (np.float32(self.lo) < m < np.float32(self.hi)):
                 break

@@ -84,6 +84,18 @@ class OptimizationLog:
         self._max_warp_locations = value
 
 
+class VoxelLog:
+    """slavcheva_optimizer2d.py:48-55: what one voxel of the focus neighbourhood went through, iteration by iteration"""
+
+    def __init__(self):
+        self.warp_magnitudes = []
+        self.sdf_values = []
+        self.canonical_sdf = 0.0
+
+    def __repr__(self):
+        return str(self.warp_magnitudes) + "; " + str(self.sdf_values)
+
+
 class _SlavchevaOptimizerBase:
     DIMS = 2
 
@@ -95,7 +107,7 @@ class _SlavchevaOptimizerBase:
                  level_set_term_weight=0.2, maximum_warp_length_lower_threshold=0.1,
                  maximum_warp_length_upper_threshold=10000, max_iterations=100, min_iterations=1,
                  sobolev_kernel=None, visualization_settings=None, enable_convergence_status_logging=True,
-                 verbose=False, check_interval=32, comm=None, engine_options=None):
+                 verbose=False, check_interval=32, comm=None, engine_options=None, focus_coordinates=None):
         self.visualization_settings = visualization_settings  # accepted, unused
         self.field_size = field_size
         self.out_path = out_path
@@ -125,6 +137,8 @@ class _SlavchevaOptimizerBase:
         self.verbose = verbose
         self.log = None
         self._warp_field = None
+        self.focus_coordinates = focus_coordinates
+        self.focus_neighborhood_log = None
         self._engine = SlavchevaEngine(
             direct=compute_method == ComputeMethod.DIRECT, level_set_term_enabled=level_set_term_enabled,
             sobolev_smoothing_enabled=sobolev_smoothing_enabled,
@@ -153,6 +167,18 @@ class _SlavchevaOptimizerBase:
         """the SlavchevaEngine behind this optimizer: its knobs (engine_options.SLAVCHEVA_DEFAULTS, also settable through
         the constructor's `engine_options=dict(...)`) and `last_call`, the report of what the last call took"""
         return self._engine
+
+    def _focus_neighbourhood(self, shape):
+        """slavcheva_optimizer2d.py:422-430: the voxels within one step of the focus coordinate (x, y[, z]) that lie
+        inside the field, as (x, y[, z]) keys in the reference's order (x fastest)"""
+        focus = tuple(int(c) for c in self.focus_coordinates)
+        if len(focus) != self.DIMS:
+            raise ValueError("focus_coordinates must be (x, y%s)" % (", z" if self.DIMS == 3 else ""))
+        keys = [()]
+        for axis in range(self.DIMS):  # x first: every later axis becomes the slower one
+            extent = shape[self.DIMS - 1 - axis]
+            keys = [k + (c,) for c in range(focus[axis] - 1, focus[axis] + 2) if 0 <= c < extent for k in keys]
+        return keys
 
     @property
     def iteration_hook(self):
@@ -198,7 +224,21 @@ class _SlavchevaOptimizerBase:
         want_report = self.enable_convergence_status_logging and \
             (self._engine.comm is None or not self._engine.comm.active)
         finalize_args = (live_field if on_device else None, self.maximum_warp_length_lower_threshold, want_report)
+        # the reference traces the 3 x 3 voxels around its module-global focus coordinate on every call (:336-337,
+        # utils/sampling.py:27); here the trace is asked for per optimizer (`focus_coordinates=(x, y[, z])`): a traced call
+        # is synchronised every iteration
+        keys = None if self.focus_coordinates is None else self._focus_neighbourhood(tuple(live.shape))
+        self._engine.focus_voxels = None if keys is None else [k[::-1] for k in keys]
+        self.focus_neighborhood_log = None
         outcome = self._engine.optimize(live, canonical, finalize=finalize_args)
+        if keys is not None:
+            trace = self._engine.focus_trace
+            self.focus_neighborhood_log = {}
+            for v, key in enumerate(keys):
+                entry = self.focus_neighborhood_log[key] = VoxelLog()
+                entry.canonical_sdf = trace["canonical"][v]  # :353-354
+                entry.warp_magnitudes = [w[v] for w in trace["warp"]]  # :319-322
+                entry.sdf_values = [s[v] for s in trace["sdf"]]
         eng_log = self._engine.log
         self.log = OptimizationLog(eng_log)
         if self._engine.comm is None or not self._engine.comm.active:

@@ -628,6 +628,8 @@ class SlavchevaOracle:
         self.iteration_hook = None  # f(it, live, warp, gradient, energies(dict), max_warp, location)
         self.max_region = None      # optional slice along axis 0: restrict the max-warp search (slab tests)
         self.axis0_offset = 0       # slab tests: global index of the array's slice 0 (see _grid_positions)
+        self.focus_voxels = None    # index tuples (axis order): the "focus neighbourhood" trace, :319-322,:422-430
+        self.focus_log = None       # {index tuple: dict(warp_magnitudes=[], sdf_values=[], canonical_sdf=)}
 
     def iteration(self, live, canonical, warp):
         """slavcheva_optimizer2d.py:163-236 (VECTORIZED) / :238-330 (DIRECT).  live, warp updated in place.
@@ -669,6 +671,10 @@ class SlavchevaOracle:
         else:
             _, at = first_argmax(lengths)
         max_warp = float(lengths[at])
+        if self.focus_log is not None:  # :319-322: the update's length before the snap, the live value before the re-warp
+            for index, entry in self.focus_log.items():
+                entry["warp_magnitudes"].append(lengths[index])
+                entry["sdf_values"].append(live[index])
         # DIRECT passes gradient_field to warp_field_advanced (zeroed where snapped, :324-327);
         # VECTORIZED hands only u,v to the C++ twin (:224-234), so its gradient_field is left alone.
         new_live = warp_field_advanced(canonical, live, warp, g if direct else None, axis0_offset=self.axis0_offset)
@@ -684,6 +690,10 @@ class SlavchevaOracle:
                         max_warp_locations=[])
         max_warp = np.inf
         it = 0
+        self.focus_log = None
+        if self.focus_voxels is not None:  # :336-337,:353-354
+            self.focus_log = {tuple(v): dict(warp_magnitudes=[], sdf_values=[], canonical_sdf=canonical_field[tuple(v)])
+                              for v in self.focus_voxels}
         while it < self.min_iterations or (it < self.max_iterations and self.lo < max_warp < self.hi):
             max_warp, at, en = self.iteration(live_field, canonical_field, warp)
             self.log["max_warps"].append(max_warp)

@@ -10,6 +10,7 @@ Outputs
   ref_hierarchical.npz    HierarchicalOptimizer2d runs (per-iteration warp fields)
   ref_slavcheva.npz       SlavchevaOptimizer2d runs (per-iteration live / warp / gradient / energies)
   ref_config1.npz         BASELINE config 1 at full length: the 64 x 64 orthographic pair, 100 fixed iterations
+  ref_focus.npz           the "focus neighbourhood" per-voxel traces of DIRECT SlavchevaOptimizer2d runs
   ref_orthographic.npz    the hand-made orthographic 2-D pairs themselves (tsdf/generation.py:238-353) and the errors
                           the generator raises for fields that cannot hold them
 """
@@ -426,6 +427,47 @@ def slavcheva():
     print("ref_slavcheva.npz:", len(out), "arrays")
 
 
+def focus():
+    """the "focus neighbourhood" trace of DIRECT runs (slavcheva_optimizer2d.py:319-322,:422-430): the 3 x 3 voxels around
+    the module-global focus coordinate -- one inside the band, one in a corner of the field (4 voxels remain)"""
+    out = {}
+    live_full, canon_full = tsdf_gen.generate_initial_orthographic_2d_tsdf_fields(field_size=128)
+    live32 = live_full[46:78, 40:72].copy()
+    canon32 = canon_full[46:78, 40:72].copy()
+    out["ortho32.live"], out["ortho32.canonical"] = live32, canon32
+    k3 = generate_1d_sobolev_kernel(size=3, strength=0.1)
+    out["kernel3"] = k3
+    configs = {
+        "sobolev_direct": dict(compute_method=so.ComputeMethod.DIRECT, sobolev_smoothing_enabled=True, sobolev_kernel=k3),
+        "killing": dict(compute_method=so.ComputeMethod.DIRECT, level_set_term_enabled=True,
+                        smoothing_term_method=st.SmoothingTermMethod.KILLING),
+        "tikhonov_direct": dict(compute_method=so.ComputeMethod.DIRECT),
+    }
+    sviz.SlavchevaVisualizer.write_all_iteration_visualizations = lambda *a, **k: None
+    tmp = tempfile.mkdtemp()
+    for fx, fy in ((16, 14), (0, 31)):
+        sampling.set_focus_coordinates(fx, fy)
+        for name, kw in configs.items():
+            opt = so.SlavchevaOptimizer2d(out_path=tmp, field_size=32, maximum_warp_length_lower_threshold=0.0,
+                                          max_iterations=6, min_iterations=6, **kw)
+            live = live32.copy()
+            with contextlib.redirect_stdout(io.StringIO()):
+                opt.optimize(live, canon32)
+            tag = "ortho32.%s.focus_%d_%d" % (name, fx, fy)
+            keys = list(opt.focus_neighborhood_log.keys())
+            out[tag + ".keys"] = np.array(keys, dtype=np.int64)
+            out[tag + ".warp_magnitudes"] = np.array([opt.focus_neighborhood_log[k].warp_magnitudes for k in keys],
+                                                     dtype=np.float32)
+            out[tag + ".sdf_values"] = np.array([opt.focus_neighborhood_log[k].sdf_values for k in keys],
+                                                dtype=np.float32)
+            out[tag + ".canonical_sdf"] = np.array([opt.focus_neighborhood_log[k].canonical_sdf for k in keys],
+                                                   dtype=np.float32)
+            print(tag, "largest traced update %.5f" % out[tag + ".warp_magnitudes"].max())
+    sampling.set_focus_coordinates(0, 0)
+    np.savez_compressed(os.path.join(HERE, "ref_focus.npz"), **out)
+    print("ref_focus.npz:", len(out), "arrays")
+
+
 def tsdf():
     """nearest-pixel TSDF generation (tsdf/generation.py:130-207, 356-437) on the closed-form synthetic depth image
     (oracle.synthetic_depth_image; only its checksum is stored, the tests regenerate it)"""
@@ -567,12 +609,16 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "orthographic":
         orthographic()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "focus":
+        focus()
+        sys.exit(0)
     literals()
     leaf()
     hierarchical()
     slavcheva()
     config1()
     orthographic()
+    focus()
     tsdf()
     ewa()
     for f in sorted(os.listdir(HERE)):
