@@ -332,6 +332,25 @@ def extra_workload(args, device, world, rank, dist):
         out["roofline"]["dense_equivalent_gbs"] = value * b_alg / 1e9 / world
     if args.workload == "hier2d":
         out["us_per_iteration"] = elapsed / args.steps / (3 * iters) * 1e6
+        # the same pyramid with the reference's DEFAULT threshold (hierarchical_optimizer2d.py:69: 0.001; on this pair no
+        # level gets there within its 100 iterations, so the work is the same): the stop test is looked at launch by launch
+        # on the card, one record read-back per level (round 6) -- next to the path that threshold took before (a HIP graph
+        # per check_interval iterations)
+        for key, blocked in (("us_per_iteration_default_threshold", True),
+                             ("us_per_iteration_default_threshold_graph_path", False)):
+            armed = lsf.HierarchicalOptimizer2d(tikhonov_term_enabled=True, gradient_kernel_enabled=False,
+                                                maximum_chunk_size=4, rate=0.1, maximum_iteration_count=iters,
+                                                maximum_warp_update_threshold=0.001, tikhonov_strength=0.05,
+                                                engine_options=dict(blocked_levels=blocked))
+            for k in range(args.warmup + args.steps):
+                if k == args.warmup:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                armed.optimize(canonical, live0)
+            torch.cuda.synchronize()
+            counts = armed.get_per_level_iteration_counts()
+            out[key] = (time.perf_counter() - t0) / args.steps / sum(counts) * 1e6
+            out["iterations_default_threshold"] = counts
     if args.workload in ("hier-tik", "hier-full", "multiframe") and comm is None:
         # the dominant kernels of this workload: the finest level's launches alone (87.5 % of a step's voxel-updates),
         # HIP events on their stream; kernel_ms = one finest-level iteration, frac = B_alg x n^3 / kernel_ms
@@ -462,6 +481,9 @@ def secondary_measurements(args, device):
             if "us_per_iteration" in d:
                 row["us_per_iteration"] = d["us_per_iteration"]
                 row["note"] = r.get("note")
+                for key in ("us_per_iteration_default_threshold", "us_per_iteration_default_threshold_graph_path",
+                            "iterations_default_threshold"):
+                    row[key] = d.get(key)
             row["wall_s"] = time.perf_counter() - t0
         except Exception as exc:  # noqa: BLE001 -- recorded on the line
             row["error"] = "%s: %s" % (type(exc).__name__, exc)

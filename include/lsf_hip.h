@@ -240,18 +240,24 @@ int lsf_hier_iteration(const float *packed_live4, const float *canonical, float 
 
 /* warp -= rate*g ; the record's max_packed = max |g|   (hierarchical_optimizer2d.py:220-225).  warp_planar may be
  * NULL: only the maximum (the warp was moved by lsf_convolve_xyz already). */
-/* A whole 2-D level with a FIXED iteration count, K = iterations_per_launch (1..8) iterations per launch: temporal blocking
- * through LDS (round 6; BASELINE config 2 is launch-bound -- a 512^2 level is 1024 voxels per CU).  Replaces `iterations`
- * calls of lsf_hier_iteration (Tikhonov term, apply_update = 1, no energies; hierarchical_optimizer2d.py:184-225 with a
- * threshold that cannot fire) with ceil(iterations / K) launches whose workgroups each advance a 32 x 32 tile K iterations
- * inside LDS, recomputing the K - 1 - j rings of voxels around it that iteration j needs (identical arithmetic on identical
- * inputs: identical results).  Launch b reads (warp_a, g_a) when b is even, (warp_b, g_b) when odd, and writes the other
- * pair; after the call the warp and the last iteration's gradient are in the _a buffers when ceil(iterations / K) is even,
- * in the _b buffers otherwise.  records[0..iterations): one record per iteration (the caller has zeroed them), maxima only.
+/* A whole 2-D level, K = iterations_per_launch (1..8) iterations per launch: temporal blocking through LDS (round 6;
+ * BASELINE config 2 is launch-bound -- a 512^2 level is 1024 voxels per CU).  Replaces `iterations` calls of
+ * lsf_hier_iteration (Tikhonov term, apply_update = 1, no energies; hierarchical_optimizer2d.py:184-225) with
+ * ceil(iterations / K) launches whose workgroups each advance a 32 x 32 tile K iterations inside LDS, recomputing the
+ * K - 1 - j rings of voxels around it that iteration j needs (identical arithmetic on identical inputs: identical results).
+ * Launch b reads (warp_a, g_a) when b is even, (warp_b, g_b) when odd, and writes the other pair.  records[0..iterations):
+ * one record per iteration (the caller has zeroed them), maxima only.
+ * threshold <= 0 (the stop test cannot fire): after the call the warp and the last iteration's gradient are in the _a
+ * buffers when ceil(iterations / K) is even, in the _b buffers otherwise.
+ * threshold > 0 (hierarchical_optimizer2d.py:169-171: an iteration whose maximum is below it is the level's last): launch
+ * b > 0 first looks at the K records of launch b - 1 and does nothing when one of them is below the threshold or empty.  The
+ * launch in which the level converged is then the last to have written anything and its input pair is intact: the caller
+ * reads the records, finds the first iteration j below the threshold and, unless j is its launch's last iteration, calls
+ * again with that launch's input pair as (_a), its output pair as (_b), iterations = j + 1 - b K and threshold = 0.
  * LSF_ERR_BAD_DIMS for anything but dims = 2, tikhonov_enabled, apply_update, compute_energy = 0. */
 int lsf_hier_level_run_2d(const float *packed_live4, const float *canonical, float *warp_a, float *warp_b, float *g_a,
                           float *g_b, const lsf_grid *grid, const lsf_hier_params *params, lsf_iteration_record *records,
-                          int32_t iterations, int32_t iterations_per_launch, void *stream);
+                          int32_t iterations, int32_t iterations_per_launch, float threshold, void *stream);
 int lsf_hier_update(const float *g_planar, float *warp_planar, const lsf_grid *grid, float rate,
                     const lsf_gate *gate, lsf_iteration_record *record, void *stream);
 

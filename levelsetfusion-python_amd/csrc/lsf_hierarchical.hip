@@ -205,8 +205,11 @@ __global__ __launch_bounds__(kBlock) void hier_update_kernel(const float* __rest
 // workgroups compute for those voxels: the same arithmetic on the same inputs --, and stores its own tile's warp and last
 // gradient: no grid-wide barrier (4-5 us on this chip, more than a launch boundary), no hand-off.  Array edges clip the
 // regions; the Laplacian's edge rule (a missing neighbour is the centre) then applies exactly where the level ends.  Every
-// iteration's maximum is taken over the tile's OWN voxels.  Only for runs whose stop test cannot fire (threshold <= 0: the
-// warp after K iterations is wanted whatever the K maxima are) and without the energy printouts.
+// iteration's maximum is taken over the tile's OWN voxels.  Without the energy printouts.  The stop test
+// (hierarchical_optimizer2d.py:169-171: a maximum below the threshold ends the level) is looked at launch by launch: a launch
+// whose predecessor holds an iteration that met it -- or that did not run itself -- is a no-op, so the launch in which the
+// level converged is the last one to write, its INPUT buffers stay as they were, and the caller repeats it with the number
+// of iterations the reference would have run (lsf_hier_level_run_2d).
 constexpr int kBlkMaxK = 8, kBlkThreads = 1024;  // (tiles of 32 x 32 or 16 x 16 voxels, see lsf_hier_level_run_2d)
 
 template <int T>
@@ -217,7 +220,23 @@ __global__ __launch_bounds__(kBlkThreads) void hier2d_blocked_kernel(const float
                                                                      const float* __restrict__ g_in,
                                                                      float* __restrict__ g_out, Grid g, float amp,
                                                                      float strength, float rate,
-                                                                     lsf_iteration_record* records, int k) {
+                                                                     lsf_iteration_record* records, int k,
+                                                                     const lsf_iteration_record* previous,
+                                                                     int previous_count, float threshold) {
+    if (previous_count > 0) {
+        // the predecessor's records, one (record, slot) word per lane -- one round trip instead of a chain of them; every wave
+        // of every workgroup reads the same words and takes the same way
+        static_assert(LSF_RECORD_SLOTS * kBlkMaxK == kWave, "one lane per slot of a launch's records");
+        const int l = threadIdx.x & (kWave - 1), r = l / LSF_RECORD_SLOTS;
+        unsigned long long p = r < previous_count ? previous[r].slot[l % LSF_RECORD_SLOTS].max_packed : ~0ull;
+#pragma unroll
+        for (int step = 1; step < LSF_RECORD_SLOTS; step <<= 1) {
+            const unsigned long long q = __shfl_xor(p, step);
+            p = q > p ? q : p;
+        }
+        const bool met = r < previous_count && (p == 0ull || unpack_max_value(p) < threshold);
+        if (__any(met)) return;
+    }
     // (row pitch W + 1: a ring's left / right columns are cells a row apart -- at a pitch of 48 or 32 words they would
     // fall into two LDS banks, or one)
     constexpr int H = kBlkMaxK, N = T + 2 * H, W = N + 1;
@@ -464,7 +483,7 @@ extern "C" int lsf_hier_update(const float* g_planar, float* warp_planar, const 
 extern "C" int lsf_hier_level_run_2d(const float* packed_live4, const float* canonical, float* warp_a, float* warp_b,
                                      float* g_a, float* g_b, const lsf_grid* grid, const lsf_hier_params* params,
                                      lsf_iteration_record* records, int32_t iterations, int32_t iterations_per_launch,
-                                     void* stream) {
+                                     float threshold, void* stream) {
     if (int e = check_grid(grid)) return e;
     if (!packed_live4 || !canonical || !warp_a || !warp_b || warp_a == warp_b || !g_a || !g_b || g_a == g_b || !params ||
         !records || iterations < 0 || iterations_per_launch < 1 || iterations_per_launch > kBlkMaxK)
@@ -485,14 +504,19 @@ extern "C" int lsf_hier_level_run_2d(const float* packed_live4, const float* can
     for (int32_t i = 0; i < iterations; i += iterations_per_launch, ++launch) {
         const int k = iterations - i < iterations_per_launch ? iterations - i : iterations_per_launch;
         const bool even = (launch & 1) == 0;  // launch b reads (warp_a, g_a) when b is even and writes the other pair
+        // a stop test that can fire: the launch looks at its predecessor's records first
+        const lsf_iteration_record* previous = threshold > 0.0f && launch > 0 ? records + i - iterations_per_launch : nullptr;
+        const int previous_count = previous ? iterations_per_launch : 0;
         if (small)
             hipLaunchKernelGGL(hier2d_blocked_kernel<16>, dim3(tiles), dim3(kBlkThreads), 0, s, packed, canonical,
                                even ? warp_a : warp_b, even ? warp_b : warp_a, even ? g_a : g_b, even ? g_b : g_a, g,
-                               params->data_term_amplifier, params->tikhonov_strength, params->rate, records + i, k);
+                               params->data_term_amplifier, params->tikhonov_strength, params->rate, records + i, k,
+                               previous, previous_count, threshold);
         else
             hipLaunchKernelGGL(hier2d_blocked_kernel<32>, dim3(tiles), dim3(kBlkThreads), 0, s, packed, canonical,
                                even ? warp_a : warp_b, even ? warp_b : warp_a, even ? g_a : g_b, even ? g_b : g_a, g,
-                               params->data_term_amplifier, params->tikhonov_strength, params->rate, records + i, k);
+                               params->data_term_amplifier, params->tikhonov_strength, params->rate, records + i, k,
+                               previous, previous_count, threshold);
         if (int e = launch_status()) return e;
     }
     return 0;

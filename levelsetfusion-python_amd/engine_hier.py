@@ -362,7 +362,7 @@ class HierarchicalEngine:
         hooked = self.iteration_hook is not None
         if (self.blocked_levels and canonical.dim() == 2 and not slab and not hooked and not self.collect_iteration_data
                 and self.tikhonov_term_enabled and not self.gradient_kernel_enabled and not self.compute_energy
-                and max_it >= 1 and not float(self.maximum_warp_update_threshold) > 0.0):
+                and max_it >= 1):
             return self._optimize_level_blocked(canonical, packed, warp)
         if (self.use_graphs and not slab and not self.collect_iteration_data and not hooked and max_it >= 4
                 and self.check_interval >= 2 and n_vox <= self.graph_max_voxels
@@ -457,25 +457,45 @@ class HierarchicalEngine:
     BLOCKED_ITERATIONS_PER_LAUNCH = 8
 
     def _optimize_level_blocked(self, canonical, packed, warp):
-        """2-D levels whose stop test cannot fire (threshold <= 0), Tikhonov term, no filter, no energy printouts: the whole
-        level in ONE foreign call, K = 8 iterations per launch advanced inside LDS tile by tile (lsf_hier_level_run_2d:
-        temporal blocking -- a 512^2 level is launch-bound, 7.5 us per iteration from a HIP graph against ~1 us of work).
-        Same arithmetic on the same inputs: warp, gradient and every iteration's maximum equal the per-iteration path's
-        (tests/test_gpu_blocked_levels.py)."""
+        """2-D levels, Tikhonov term, no filter, no energy printouts: the whole level in ONE foreign call, K = 8 iterations
+        per launch advanced inside LDS tile by tile (lsf_hier_level_run_2d: temporal blocking -- a 512^2 level is
+        launch-bound, 7.5 us per iteration from a HIP graph against ~1 us of work).  Same arithmetic on the same inputs:
+        warp, gradient and every iteration's maximum equal the per-iteration path's (tests/test_gpu_blocked_levels.py).
+        A stop test that can fire (threshold > 0, hierarchical_optimizer2d.py:169-171) is looked at launch by launch on
+        the card; the launch in which the level converged is then repeated from its untouched inputs with the reference's
+        number of iterations, so the level ends exactly where the reference's ends."""
         max_it = self.maximum_iteration_count
         grid = dev.make_grid(canonical.shape)
         n = dev.n_voxels(grid)
         K = self.BLOCKED_ITERATIONS_PER_LAUNCH
+        thr = np.float32(self.maximum_warp_update_threshold)
+        gated = bool(thr > 0.0)
         warps = [warp, torch.empty_like(warp)]
         F = [torch.zeros_like(warp), torch.empty_like(warp)]
         records = dev.new_records(max_it, canonical.device)
         params = _lib.HierParams(float(self.data_term_amplifier), float(self.tikhonov_strength), float(self.rate), 1, 1, 0)
-        _lib.check(_lib.lib.lsf_hier_level_run_2d(
-            dev._ptr(packed, 4 * n, "packed live"), dev._ptr(canonical, n, "canonical"),
-            dev._ptr(warps[0], 2 * n, "warp"), dev._ptr(warps[1], 2 * n, "warp"), dev._ptr(F[0], 2 * n, "gradient"),
-            dev._ptr(F[1], 2 * n, "gradient"), ctypes.byref(grid), ctypes.byref(params),
-            ctypes.c_void_p(records.data_ptr()), max_it, K, dev.stream_ptr()), "lsf_hier_level_run_2d")
+        p_packed, p_canonical = dev._ptr(packed, 4 * n, "packed live"), dev._ptr(canonical, n, "canonical")
+        p_warp = [dev._ptr(w, 2 * n, "warp") for w in warps]
+        p_g = [dev._ptr(g, 2 * n, "gradient") for g in F]
+
+        def run(first, record_ptr, iterations, threshold):  # launches reading pair `first` first
+            _lib.check(_lib.lib.lsf_hier_level_run_2d(
+                p_packed, p_canonical, p_warp[first], p_warp[1 - first], p_g[first], p_g[1 - first], ctypes.byref(grid),
+                ctypes.byref(params), record_ptr, iterations, K, threshold, dev.stream_ptr()), "lsf_hier_level_run_2d")
+
+        run(0, ctypes.c_void_p(records.data_ptr()), max_it, float(thr) if gated else 0.0)
         launches = (max_it + K - 1) // K
+        dec = None
+        if gated:
+            dec = dev.decode_records(dev.records_to_host(records[:max_it]))
+            ran = int(dec["executed"].sum())  # whole launches: a multiple of K, or every iteration
+            below = np.nonzero(dec["max_value"][:ran] < thr)[0]
+            n_exec = int(below[0]) + 1 if below.size else ran
+            last = (n_exec - 1) // K  # the launch the level ended in; the ones behind it were no-ops
+            if n_exec < min((last + 1) * K, max_it):
+                # ... in the middle of it: once more from its inputs, as many iterations as the reference runs
+                run(last % 2, ctypes.c_void_p(dev.new_records(K, canonical.device).data_ptr()), n_exec - last * K, 0.0)
+            launches = last + 1
         if launches % 2:
             warp.copy_(warps[1])
         lv = HierarchicalEngine._Level()
@@ -484,6 +504,11 @@ class HierarchicalEngine:
         lv.F = [final, final]  # _final_gradient reads F[n_exec % 2]
         lv.report_g = None
         self.last_call.blocked_levels += 1
+        if gated:
+            # (the level's results are made of `dec` at the end of optimize(): the card has nothing queued right now)
+            self._pending_levels.append((lv, dec, n_exec))
+            self.level_results.append(None)
+            return warp
         # nothing on the host depends on this level's records (a fixed count): they are read with the other levels' at the
         # end of optimize() -- ONE synchronisation per call instead of one per level, with the next level's launches
         # already queued behind this one's
@@ -495,6 +520,12 @@ class HierarchicalEngine:
         """the records of the levels _optimize_level_blocked left unread: one transfer, then every level's results"""
         pending, self._pending_levels = self._pending_levels, []
         if not pending:
+            return
+        if isinstance(pending[0][1], dict):  # levels with a stop test: their records were read level by level
+            first = self.level_results.index(None)
+            self.level_results = self.level_results[:first]
+            for lv, dec, n_exec in pending:
+                self._finish_level(lv, n_exec, dec)
             return
         used = torch.cat([dev.slot_view(records)[:n, :, :dev.USED_SLOT_WORDS].reshape(-1) for _, records, n in pending])
         host = dev.pinned_scratch("level records", used.numel(), torch.int64)[:used.numel()]

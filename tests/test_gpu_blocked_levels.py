@@ -1,7 +1,8 @@
-"""2-D pyramid levels with a fixed iteration count advanced EIGHT iterations per launch inside LDS tiles
+"""2-D pyramid levels advanced EIGHT iterations per launch inside LDS tiles
 (lsf_hier_level_run_2d, engine option blocked_levels; round 6: BASELINE config 2 is launch-bound) against the
 one-launch-per-iteration path and against the oracle: warp, every iteration's maximum and its location, the last gradient
--- bit for bit (a tile recomputes the rings of voxels around it with the same arithmetic on the same inputs).
+-- bit for bit (a tile recomputes the rings of voxels around it with the same arithmetic on the same inputs) --, with a
+fixed iteration count and with a stop test that fires anywhere inside a launch.
 Reference loop: nonrigid_opt/hierarchical/hierarchical_optimizer2d.py:184-225."""
 import numpy as np
 import pytest
@@ -73,18 +74,61 @@ def test_blocked_levels_equal_the_oracle_in_the_divergent_regime(lsf):
     assert float(np.abs(want).max()) > 1e-3
 
 
-def test_threshold_terminated_and_filtered_runs_keep_the_per_iteration_path(lsf):
+def test_filtered_runs_keep_the_per_iteration_path(lsf):
     from levelsetfusion_python_amd.synthetic import sphere_pair
     canonical, live = sphere_pair(64, 2, "cuda")
     base = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=8, rate=0.1,
                 maximum_iteration_count=10, tikhonov_strength=0.05)
-    opt = lsf.HierarchicalOptimizer2d(maximum_warp_update_threshold=0.001, **base)
-    opt.optimize(canonical, live)
-    assert opt.engine.last_call.blocked_levels == 0
     opt = lsf.HierarchicalOptimizer2d(maximum_warp_update_threshold=0.0, **dict(base, gradient_kernel_enabled=True,
                                                                                kernel=lsf.generate_1d_sobolev_kernel(3, 0.1)))
     opt.optimize(canonical, live)
     assert opt.engine.last_call.blocked_levels == 0
+
+
+# where in its launch of eight the level converges: its first iteration (a repeated launch of one), the last of the first
+# launch, the first / the middle / the last of the second, the middle of the short third launch (20 - 16 = 4 iterations),
+# the last iteration allowed, never
+@pytest.mark.parametrize("stop_at", [0, 7, 8, 10, 12, 15, 17, 19, None])
+def test_stop_test_inside_a_launch(lsf, stop_at):
+    """four levels (16^2 ... 128^2), 20 iterations at most; the threshold is put just above the maximum of iteration
+    `stop_at` of the coarsest level of an unterminated run, so the reference leaves that level behind that iteration (the
+    finer levels end where their own maxima say): counts, maxima, warp and last gradient are the per-iteration path's and
+    the oracle's"""
+    n = 128
+    canonical, live = O.sphere_pair(n, d=2)
+    base = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=8, rate=0.1,
+                maximum_iteration_count=20, tikhonov_strength=0.05)
+    free = O.HierarchicalOracle(maximum_warp_update_threshold=0.0, **base)
+    free.optimize(canonical, live)
+    maxima = np.float32(free.per_level_max_updates[0])
+    assert len(maxima) == 20
+    threshold = 1e-12 if stop_at is None else float(np.nextafter(maxima[stop_at], np.float32(np.inf)))
+    assert stop_at is None or np.all(maxima[:stop_at] >= np.float32(threshold))  # ... and no earlier iteration is below it
+    kw = dict(base, maximum_warp_update_threshold=threshold)
+    a = _run(lsf, canonical, live, True, **kw)
+    b = _run(lsf, canonical, live, False, **kw)
+    _same(a, b)
+    assert a[0].get_per_level_iteration_counts()[0] == (20 if stop_at is None else stop_at + 1)
+    o = O.HierarchicalOracle(**kw)
+    want = o.optimize(canonical, live)
+    assert np.array_equal(a[1], want)
+    assert a[0].get_per_level_iteration_counts() == o.per_level_iteration_counts
+    for mine, theirs in zip(a[0].get_per_level_maximum_updates(), o.per_level_max_updates):
+        assert np.array_equal(np.float32(mine), np.float32(theirs))
+
+
+@pytest.mark.parametrize("n,chunk,threshold", [(128, 8, 0.033), (256, 8, 0.044), (512, 4, 0.0875)])
+def test_threshold_terminated_pyramids(lsf, n, chunk, threshold):
+    """several levels, each ending where its own maxima say (the coarse ones early, the finest may run out)"""
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live = sphere_pair(n, 2, "cuda")
+    kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=chunk, rate=0.1,
+              maximum_iteration_count=60, maximum_warp_update_threshold=threshold, tikhonov_strength=0.05)
+    a = _run(lsf, canonical, live, True, **kw)
+    b = _run(lsf, canonical, live, False, **kw)
+    _same(a, b)
+    counts = a[0].get_per_level_iteration_counts()
+    assert min(counts) < 60 and len(set(counts)) >= 3, counts
 
 
 def test_entry_point_refuses_what_it_does_not_implement(lsf):
@@ -94,10 +138,10 @@ def test_entry_point_refuses_what_it_does_not_implement(lsf):
     ok = _lib.HierParams(1.0, 0.05, 0.1, 1, 1, 0)
     call = _lib.lib.lsf_hier_level_run_2d
     one, two, three, four, five = (ctypes.c_void_p(k * 4096) for k in (1, 2, 3, 4, 5))
-    assert call(one, one, two, three, four, five, ctypes.byref(g3), ctypes.byref(ok), one, 4, 8, None) == -2  # 3-D
+    assert call(one, one, two, three, four, five, ctypes.byref(g3), ctypes.byref(ok), one, 4, 8, 0.0, None) == -2  # 3-D
     assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(_lib.HierParams(1.0, 0.05, 0.1, 0, 1, 0)),
-                one, 4, 8, None) == -2  # no Tikhonov term
+                one, 4, 8, 0.0, None) == -2  # no Tikhonov term
     assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(_lib.HierParams(1.0, 0.05, 0.1, 1, 1, 1)),
-                one, 4, 8, None) == -2  # energies
-    assert call(one, one, two, two, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 8, None) == -1    # same buffer twice
-    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 9, None) == -1  # K > 8
+                one, 4, 8, 0.0, None) == -2  # energies
+    assert call(one, one, two, two, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 8, 0.0, None) == -1    # same buffer twice
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 9, 0.0, None) == -1  # K > 8
