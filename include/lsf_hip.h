@@ -187,6 +187,15 @@ int lsf_downsample2x_linear(const float *fine, float *coarse, const lsf_grid *fi
 int lsf_convolve_axis(const float *in_planar, float *out_planar, const float *zero_mask_source,
                       const lsf_grid *grid, int32_t planes, int32_t axis, const double *taps_host,
                       int32_t n_taps, const lsf_gate *gate, void *stream);
+/* the LAST pass of a hierarchical iteration's 3-D filter (axis 2; axis 1 is accepted too -- the reference's 2-D filter ends
+ * with its x pass, convolution.py:77-83, which this does not cover; 3 / 5 / 7 / 9 taps, no zero mask): the
+ * same pass, which also moves the warp by the filtered gradient it writes, component by component -- warp -= rate * out
+ * (hierarchical_optimizer2d.py:220-222; what lsf_convolve_xyz does on large levels): lsf_hier_update is then called with
+ * a NULL warp (the maximum only), or not at all when the next iteration takes the maximum (lsf_hier_params::previous_max).
+ * LSF_ERR_BAD_DIMS for other tap counts. */
+int lsf_convolve_axis_update(const float *in_planar, float *out_planar, float *warp_planar, float rate,
+                             const lsf_grid *grid, int32_t planes, int32_t axis, const double *taps_host,
+                             int32_t n_taps, const lsf_gate *gate, void *stream);
 
 /* the three passes of a 3-D filter (x, then y, then z: convolution.py:94-105) in one launch, without a zero mask: the
  * result equals three lsf_convolve_axis calls bit for bit (x and y passes on every slice the z pass reads, z pass on the

@@ -521,10 +521,10 @@ __global__ __launch_bounds__(kBlock) void convolve_x_kernel(const float* __restr
 // Same arithmetic as the tiled kernels: float64 products and sums in tap order, one rounding per pass.
 constexpr int kMarch = 32;
 
-template <int AXIS, int NT, bool MASK, bool FMA>
+template <int AXIS, int NT, bool MASK, bool FMA, bool UPDATE = false>
 __device__ inline void convolve_march(const float* __restrict__ in, float* __restrict__ out,
                                       const float* __restrict__ mask_src, const Grid& g, const TapsN<NT>& taps,
-                                      const lsf_gate& gate) {
+                                      const lsf_gate& gate, float* __restrict__ warp = nullptr, float rate = 0.0f) {
     if (gate_closed(gate)) return;
     const int lx = threadIdx.x & (kTileX - 1), w = threadIdx.x / kTileX;
     const int x = blockIdx.x * kTileX + lx;
@@ -541,6 +541,7 @@ __device__ inline void convolve_march(const float* __restrict__ in, float* __res
     const float* __restrict__ src = in + (long long)blockIdx.z * g.plane + fixed + x;
     float* __restrict__ dst = out + (long long)blockIdx.z * g.plane + fixed + x;
     const float* __restrict__ msk = MASK ? mask_src + (long long)blockIdx.z * g.plane + fixed + x : nullptr;
+    float* __restrict__ moved = UPDATE ? warp + (long long)blockIdx.z * g.plane + fixed + x : nullptr;
     constexpr int c = NT / 2, lo = NT - 1 - c;
     float v[kMarch + NT - 1];  // v[q] = in[a0 - lo + q], zero outside the array (np.convolve's zero padding)
 #pragma unroll
@@ -548,6 +549,11 @@ __device__ inline void convolve_march(const float* __restrict__ in, float* __res
         const int a = a0 - lo + q;
         const float t = src[min(max(a, 0), len - 1) * stride];  // < plane < 2^31 (check_grid)
         v[q] = (a >= 0 && a < len && q < count + NT - 1) ? t : 0.0f;
+    }
+    float wv[UPDATE ? kMarch : 1];  // the run's warp values, fetched with the inputs (a load inside the loop below would
+    if (UPDATE) {                    // put a memory round trip in front of every store)
+#pragma unroll
+        for (int m = 0; m < kMarch; ++m) wv[m] = moved[(a0 + min(m, count - 1)) * stride];
     }
     double win[NT];
 #pragma unroll
@@ -563,6 +569,7 @@ __device__ inline void convolve_march(const float* __restrict__ in, float* __res
             const int o = (a0 + m) * stride;
             if (MASK && fabsf(msk[o]) < 1e-6f) r = 0.0f;
             dst[o] = r;
+            if (UPDATE) moved[o] = wv[m] - rate * r;  // lsf_hier_update's component-wise half (a11), as lsf_convolve_xyz
         }
     }
 }
@@ -683,6 +690,38 @@ __global__ __launch_bounds__(kBlock) void march_z_kernel(const float* __restrict
                                                          const float* __restrict__ mask_src, Grid g, TapsN<NT> taps,
                                                          lsf_gate gate) {
     convolve_march<2, NT, MASK, FMA>(in, out, mask_src, g, taps, gate);
+}
+
+// the LAST pass of a hierarchical iteration's filter (y in 2-D, z in 3-D): as it writes the filtered gradient it also
+// moves the warp by it, component by component (hierarchical_optimizer2d.py:220-222) -- what lsf_convolve_xyz does on
+// large levels; the maximum, which needs all components of a voxel, stays lsf_hier_update's (or the next iteration's)
+template <int AXIS, int NT, bool FMA>
+__global__ __launch_bounds__(kBlock) void march_update_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              float* __restrict__ warp, float rate, Grid g,
+                                                              TapsN<NT> taps, lsf_gate gate) {
+    convolve_march<AXIS, NT, false, FMA, true>(in, out, nullptr, g, taps, gate, warp, rate);
+}
+
+template <int NT>
+static bool launch_update_pass(const float* in, float* out, float* warp, float rate, const Grid& g, int planes, int axis,
+                               const double* taps_host, const lsf_gate& gt, hipStream_t s) {
+    TapsN<NT> taps;
+    for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
+    const int slices = g.z_end - g.z_begin;
+    const unsigned tiles_x = (unsigned)(g.nx + kTileX - 1) / kTileX, waves = kBlock / kTileX;
+    const bool fma = taps_are_float32(taps_host, NT);
+    const unsigned runs = (unsigned)((axis == 1 ? g.ny : slices) + kMarch - 1) / kMarch;
+    const unsigned others = (unsigned)(axis == 1 ? slices : g.ny);
+    const dim3 grid(tiles_x, runs * ((others + waves - 1) / waves), (unsigned)planes);
+    if (grid.y > 65535u) return false;
+    if (axis == 1) {
+        if (fma) hipLaunchKernelGGL((march_update_kernel<1, NT, true>), grid, dim3(kBlock), 0, s, in, out, warp, rate, g, taps, gt);
+        else hipLaunchKernelGGL((march_update_kernel<1, NT, false>), grid, dim3(kBlock), 0, s, in, out, warp, rate, g, taps, gt);
+    } else {
+        if (fma) hipLaunchKernelGGL((march_update_kernel<2, NT, true>), grid, dim3(kBlock), 0, s, in, out, warp, rate, g, taps, gt);
+        else hipLaunchKernelGGL((march_update_kernel<2, NT, false>), grid, dim3(kBlock), 0, s, in, out, warp, rate, g, taps, gt);
+    }
+    return true;
 }
 
 template <int NT>
@@ -953,6 +992,30 @@ extern "C" int lsf_convolve_axis(const float* in_planar, float* out_planar, cons
                            in_planar, out_planar, zero_mask_source, g, taps, gt);
     }
     return launch_status();
+}
+
+extern "C" int lsf_convolve_axis_update(const float* in_planar, float* out_planar, float* warp_planar, float rate,
+                                        const lsf_grid* grid, int32_t planes, int32_t axis, const double* taps_host,
+                                        int32_t n_taps, const lsf_gate* gate, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!in_planar || !out_planar || in_planar == out_planar || !warp_planar || warp_planar == out_planar ||
+        warp_planar == in_planar || !taps_host)
+        return LSF_ERR_BAD_ARGUMENT;
+    if (n_taps < 1 || n_taps > LSF_MAX_KERNEL_TAPS) return LSF_ERR_KERNEL_TOO_LONG;
+    if (axis < 1 || axis >= grid->dims || planes < 1 || planes > 4) return LSF_ERR_BAD_ARGUMENT;
+    if (n_taps != 3 && n_taps != 5 && n_taps != 7 && n_taps != 9) return LSF_ERR_BAD_DIMS;
+    Grid g = make_grid(grid);
+    if (g.z_end - g.z_begin == 0) return 0;
+    lsf_gate gt = gate ? *gate : lsf_gate{nullptr, 0, 0.0f, 0.0f};
+    hipStream_t s = as_stream(stream);
+    bool done = false;
+    switch (n_taps) {
+        case 3: done = launch_update_pass<3>(in_planar, out_planar, warp_planar, rate, g, planes, axis, taps_host, gt, s); break;
+        case 5: done = launch_update_pass<5>(in_planar, out_planar, warp_planar, rate, g, planes, axis, taps_host, gt, s); break;
+        case 7: done = launch_update_pass<7>(in_planar, out_planar, warp_planar, rate, g, planes, axis, taps_host, gt, s); break;
+        default: done = launch_update_pass<9>(in_planar, out_planar, warp_planar, rate, g, planes, axis, taps_host, gt, s); break;
+    }
+    return done ? launch_status() : LSF_ERR_BAD_DIMS;
 }
 
 // =====================================================================================================

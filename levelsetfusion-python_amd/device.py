@@ -346,6 +346,29 @@ def convolve_axis(src, dst, zero_mask_source, grid, axis, taps, gate=None, band=
 XYZ_TAP_COUNTS = (3, 5, 7, 9)
 
 
+def convolve_axis_update_ok(grid, taps):
+    """can the filter's last pass also move the warp (lsf_convolve_axis_update: the register-window pass along z, whose
+    launch grid must fit)?  3-D only: the reference's 2-D filter ends with its x pass (math_utils/convolution.py:77-83)"""
+    if len(taps) not in XYZ_TAP_COUNTS or grid.dims != 3:
+        return False
+    slices = grid.z_end - grid.z_begin
+    return ((slices + 31) // 32) * ((grid.ny + 3) // 4) <= 65535
+
+
+def convolve_axis_update(src, dst, warp, rate, grid, axis, taps, gate=None):
+    """the last pass of a hierarchical iteration's filter, which also moves the warp: warp -= rate * dst"""
+    taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float64))
+    length = (grid.nx, grid.ny, grid.nz)[axis]
+    if length < taps.size:  # (as convolve_axis)
+        raise ValueError("cannot convolve a field of extent %d with a %d-tap kernel" % (length, taps.size))
+    planes = src.shape[0]
+    n = n_voxels(grid) * planes
+    check(lib.lsf_convolve_axis_update(_ptr(src, n, "conv src"), _ptr(dst, n, "conv dst"), _ptr(warp, n, "warp"),
+                                       float(rate), ctypes.byref(grid), planes, axis,
+                                       taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), taps.size, _gate_ref(gate),
+                                       stream_ptr()), "lsf_convolve_axis_update")
+
+
 def convolve_xyz_ok(grid, taps):
     """can lsf_convolve_xyz run this 3-D filter (nx % 4 == 0, 3 / 5 / 7 / 9 taps that fit every axis)?"""
     n = len(taps)

@@ -228,9 +228,11 @@ class HierarchicalEngine:
         # gradient it belongs to anyway (as g_prev, for the Laplacian): that kernel writes it into the previous record
         # (lsf_hier_params::previous_max, an LSF_GATE_OPEN gate naming the record), and only the last iteration of a
         # batch keeps the separate maximum pass (44 us of 520 per 256^3 iteration).
+        # (smaller levels, whose filter runs pass by pass: the last pass moves the warp, lsf_convolve_axis_update)
         lv.defer_max = (dims == 3 and tik and ker and float(self.maximum_warp_update_threshold) <= 0.0
-                        and self.fused_filter and n >= self.fused_filter_min_voxels
-                        and dev.convolve_xyz_ok(grid, self.gradient_kernel)
+                        and ((self.fused_filter and n >= self.fused_filter_min_voxels
+                              and dev.convolve_xyz_ok(grid, self.gradient_kernel))
+                             or dev.convolve_axis_update_ok(grid, self.gradient_kernel))
                         and self.defer_maximum)
         if lv.defer_max:
             lv.params_prevmax = _lib.HierParams.from_buffer_copy(lv.params)
@@ -285,8 +287,15 @@ class HierarchicalEngine:
                 axes, moved = (), True
             for k, axis in enumerate(axes):
                 dst = out if k == len(axes) - 1 else lv.S[(k + 1) % 2]
-                dev.convolve_axis(src, dst, None, lv.grid if axis == 2 else lv.full_grid, axis, self.gradient_kernel,
-                                  gate)
+                if k == len(axes) - 1 and dev.convolve_axis_update_ok(lv.grid, self.gradient_kernel):
+                    # the last pass moves the warp by the gradient it writes (one launch reads and writes the warp
+                    # instead of lsf_hier_update reading the gradient again)
+                    dev.convolve_axis_update(src, dst, lv.warp, self.rate, lv.grid if axis == 2 else lv.full_grid, axis,
+                                             self.gradient_kernel, gate)
+                    moved = True
+                else:
+                    dev.convolve_axis(src, dst, None, lv.grid if axis == 2 else lv.full_grid, axis,
+                                      self.gradient_kernel, gate)
                 src = dst
             if not (moved and defer_max):
                 dev.hier_update(out, None if moved else lv.warp, lv.grid, self.rate, gate, lv.records, rec_idx)
@@ -573,7 +582,10 @@ class HierarchicalEngine:
                     lv.records[K].copy_(lv.records[K - 1])
                     lv.records[:K].zero_()
                     for j in range(K):
-                        self._enqueue(lv, j, K if j == 0 else j - 1, j % 2)
+                        # (a stop test that cannot fire: an iteration's maximum is left to the next one's first kernel,
+                        # the batch's last keeps its own pass -- see _make_level)
+                        self._enqueue(lv, j, K if j == 0 else j - 1, j % 2, defer_max=lv.defer_max and j + 1 < K,
+                                      prev_deferred=lv.defer_max and j > 0)
             entry = self._graphs[key] = (lv, graph)
         lv, graph = entry
         lv.canonical.copy_(canonical)

@@ -185,6 +185,15 @@ def test_round6_entry_points_validate_on_the_host(pkg):
     assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 0, 0.0, None) == -1
     assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 9, 0.0, None) == -1
     assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 0, 8, 0.0, None) == 0  # nothing to do
+    # lsf_convolve_axis_update: the last axis only, 3 / 5 / 7 / 9 taps, distinct buffers
+    taps = (ctypes.c_double * 9)(*([0.1] * 9))
+    upd = lib.lsf_convolve_axis_update
+    assert upd(one, one, three, 0.1, ctypes.byref(g3), 3, 2, taps, 7, None, None) == -1           # in == out
+    assert upd(one, two, two, 0.1, ctypes.byref(g3), 3, 2, taps, 7, None, None) == -1             # warp == out
+    assert upd(one, two, None, 0.1, ctypes.byref(g3), 3, 2, taps, 7, None, None) == -1            # no warp
+    assert upd(one, two, three, 0.1, ctypes.byref(g3), 3, 0, taps, 7, None, None) == -1           # the x pass
+    assert upd(one, two, three, 0.1, ctypes.byref(g2), 2, 2, taps, 7, None, None) == -1           # axis 2 of a 2-D field
+    assert upd(one, two, three, 0.1, ctypes.byref(g3), 3, 2, taps, 4, None, None) == -2           # four taps
     # lsf_zero_listed4
     assert lib.lsf_zero_listed4(None, ctypes.byref(g3), one, 4, 0, None) == -1
     assert lib.lsf_zero_listed4(one, ctypes.byref(g3), None, 4, 0, None) == -1
@@ -468,7 +477,7 @@ def test_bench_scaling_modes_parse():
         sys.argv = ["bench.py", "--gpus", "8", "--scaling", "strong", "--workload", "hier2d"]
         a = bench.parse()
         assert (a.scaling, a.gpus, a.size) == ("strong", 8, 512)
-        assert [s[0] for s in bench.SECONDARY] == ["killing", "killing-pairs", "killing-default", "hier-tik", "hier-full", "multiframe",
-                                                  "sobolev", "hier2d"]
+        assert [s[0] for s in bench.SECONDARY] == ["killing", "killing-pairs", "killing-default", "hier-tik", "hier-full", "config3",
+                                                  "multiframe", "sobolev", "hier2d"]
     finally:
         sys.argv = old

@@ -47,8 +47,8 @@ def test_default_workload_line():
     assert r["traffic"] is None and r["traffic_source"]["loaded_build_id"]
     # the other configurations of BASELINE.json ride on the same line (here at 1/4 of their edge lengths)
     sec = {row["workload"]: row for row in d["secondary"]}
-    assert sorted(sec) == ["hier-full", "hier-tik", "hier2d", "killing", "killing-default", "killing-pairs", "multiframe",
-                           "sobolev"]
+    assert sorted(sec) == ["config3", "hier-full", "hier-tik", "hier2d", "killing", "killing-default", "killing-pairs",
+                           "multiframe", "sobolev"]
     default = sec.pop("killing-default")  # the reference's default loop condition: ms per call, iterations executed
     assert "error" not in default, default
     assert 1 <= default["iterations_executed"] <= 100 and default["ms_per_call"] > 0
@@ -61,6 +61,7 @@ def test_default_workload_line():
         assert "error" not in row, row
         assert row["ms_per_step"] > 0 and row["visited_voxel_updates_per_s"] > 0 and row["frac"] > 0 and row["config"]
     # the hierarchical rows name their dominant kernels and time them alone (HIP events): one finest-level iteration
+    assert sec["config3"]["size"] == 64 and "7-tap" in sec["config3"]["config"]  # BASELINE config 3 (here 64^3)
     for name in ("hier-tik", "hier-full", "multiframe"):
         row = sec[name]
         assert row["kernel"] and "hier_iteration_kernel" in row["kernel"] and row["kernel_ms"] > 0

@@ -605,6 +605,46 @@ def test_state_pack_unpack_finalize(lsf):
             assert np.allclose(got[3:5], want[3:5], rtol=1e-12, atol=0.0)     # float64 sums in a different order
 
 
+def test_last_filter_pass_that_moves_the_warp(lsf):
+    """lsf_convolve_axis_update (the last pass of a hierarchical iteration's filter, which also moves the warp) == the plain
+    pass + lsf_hier_update's warp half, bit for bit: along z in 3-D (what the engine uses) and along y in 2-D, ragged extents, every tap count, a
+    z-range, float32-valued and arbitrary taps; a closed gate leaves gradient and warp alone"""
+    from levelsetfusion_python_amd import _lib, device as dev
+    gen = torch.Generator("cuda").manual_seed(11)
+    for shape in ((37, 35, 72), (64, 64, 64), (9, 10, 12), (70, 130), (33, 47)):
+        dims = len(shape)
+        grids = [dev.make_grid(shape)] + ([dev.make_grid(shape, 5, shape[0] - 3, 11)] if dims == 3 and shape[0] > 12 else [])
+        for grid in grids:
+            for n_taps in (3, 5, 7, 9):
+                taps = lsf.generate_1d_sobolev_kernel(n_taps, 0.1) if n_taps in (3, 7) else \
+                    np.linspace(-0.2, 1.0, n_taps).astype(np.float64) / 3.0  # (not float32 values: the other arithmetic)
+                assert dev.convolve_axis_update_ok(grid, taps) == (dims == 3)
+                src = torch.randn((dims,) + shape, device="cuda", generator=gen)
+                warp0 = torch.randn((dims,) + shape, device="cuda", generator=gen)
+                want_g, want_w = torch.full_like(src, 7.0), warp0.clone()
+                dev.convolve_axis(src, want_g, None, grid, dims - 1, taps)
+                rec = dev.new_records(1, src.device)
+                dev.hier_update(want_g, want_w, grid, 0.3, None, rec, 0)
+                got_g, got_w = torch.full_like(src, 7.0), warp0.clone()
+                dev.convolve_axis_update(src, got_g, got_w, 0.3, grid, dims - 1, taps)
+                assert torch.equal(got_g, want_g) and torch.equal(got_w, want_w), (shape, n_taps)
+                assert not torch.equal(got_w, warp0)
+    # a closed gate (the previous iteration converged): nothing is written
+    shape = (16, 16, 64)
+    grid = dev.make_grid(shape)
+    rec = dev.new_records(2, "cuda")
+    dev.set_record_max(rec, 0, int(np.float32(0.001).view(np.uint32)) << 32 | 5)
+    gate = _lib.Gate(rec.data_ptr(), _lib.GATE_HIERARCHICAL, 0.01, 0.0)
+    src, warp = torch.randn((3,) + shape, device="cuda", generator=gen), torch.randn((3,) + shape, device="cuda", generator=gen)
+    g_out, w0 = torch.full_like(src, 7.0), warp.clone()
+    dev.convolve_axis_update(src, g_out, warp, 0.3, grid, 2, lsf.generate_1d_sobolev_kernel(7, 0.1), gate)
+    assert torch.equal(warp, w0) and bool((g_out == 7.0).all())
+    # what the entry point does not implement
+    with pytest.raises(Exception):
+        dev.convolve_axis_update(src, g_out, warp, 0.3, grid, 2, np.ones(4))  # four taps
+    assert not dev.convolve_axis_update_ok(grid, np.ones(4))
+
+
 def test_fused_xyz_filter_equals_three_passes(lsf):
     """lsf_convolve_xyz (x, y and z pass in one launch) == three lsf_convolve_axis passes, bit for bit: ragged
     extents (tiles, rows and z chunks that end early), every supported tap count, a closed gate leaves dst alone"""
