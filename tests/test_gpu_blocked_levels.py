@@ -131,6 +131,18 @@ def test_threshold_terminated_pyramids(lsf, n, chunk, threshold):
     assert min(counts) < 60 and len(set(counts)) >= 3, counts
 
 
+def test_threshold_terminated_levels_on_fields_that_are_not_square(lsf):
+    """128 x 512 with a stop test: tiles clipped on one axis, levels that end inside a launch"""
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live = (t[192:320].contiguous() for t in sphere_pair(512, 2, "cuda"))
+    kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=4, rate=0.1,
+              maximum_iteration_count=45, maximum_warp_update_threshold=0.0875, tikhonov_strength=0.05)
+    a = _run(lsf, canonical, live, True, **kw)
+    _same(a, _run(lsf, canonical, live, False, **kw))
+    counts = a[0].get_per_level_iteration_counts()
+    assert any(c % 8 not in (0, 45 % 8) for c in counts) or min(counts) < 45, counts
+
+
 def test_entry_point_refuses_what_it_does_not_implement(lsf):
     import ctypes
     from levelsetfusion_python_amd import _lib
