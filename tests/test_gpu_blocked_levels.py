@@ -143,6 +143,23 @@ def test_threshold_terminated_levels_on_fields_that_are_not_square(lsf):
     assert any(c % 8 not in (0, 45 % 8) for c in counts) or min(counts) < 45, counts
 
 
+@pytest.mark.parametrize("threshold", [0.0, 0.033])
+def test_per_level_convergence_reports_of_blocked_levels(lsf, threshold):
+    """the reports are made at the end of the call, from what every level left behind: equal to the per-iteration path's"""
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live = sphere_pair(128, 2, "cuda")
+    kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=8, rate=0.1,
+              maximum_iteration_count=30, maximum_warp_update_threshold=threshold, tikhonov_strength=0.05,
+              logging_parameters=lsf.HierarchicalOptimizer2d.LoggingParameters(collect_per_level_convergence_reports=True))
+    a, b = _run(lsf, canonical, live, True, **kw), _run(lsf, canonical, live, False, **kw)
+    _same(a, b)
+    ra, rb = a[0].get_per_level_convergence_reports(), b[0].get_per_level_convergence_reports()
+    assert len(ra) == len(rb) == 4 and all(x == y for x, y in zip(ra, rb)), (ra, rb)
+    assert [r.iteration_count for r in ra] == a[0].get_per_level_iteration_counts()
+    if threshold > 0:
+        assert not ra[0].iteration_limit_reached and ra[-1].iteration_limit_reached
+
+
 def test_entry_point_refuses_what_it_does_not_implement(lsf):
     import ctypes
     from levelsetfusion_python_amd import _lib
