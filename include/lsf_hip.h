@@ -263,10 +263,16 @@ int lsf_hier_iteration(const float *packed_live4, const float *canonical, float 
  * launch in which the level converged is then the last to have written anything and its input pair is intact: the caller
  * reads the records, finds the first iteration j below the threshold and, unless j is its launch's last iteration, calls
  * again with that launch's input pair as (_a), its output pair as (_b), iterations = j + 1 - b K and threshold = 0.
- * LSF_ERR_BAD_DIMS for anything but dims = 2, tikhonov_enabled, apply_update, compute_energy = 0. */
+ * With a gradient kernel (taps_host / n_taps = 3, 5, 7 or 9; NULL / 0: none; hierarchical_optimizer2d.py:213-216): the
+ * launch also runs the filter's y and x passes (convolution.py:77-83) and the update behind them -- what lsf_hier_iteration
+ * with apply_update = 0, two lsf_convolve_axis passes and lsf_hier_update do in four launches; params->apply_update must
+ * then be 0 as it is for those.  An iteration consumes n_taps / 2 + 1 rings of the tile's surroundings instead of one:
+ * iterations_per_launch * (n_taps / 2 + 1) <= 8 (two iterations per launch for seven taps), LSF_ERR_BAD_ARGUMENT otherwise.
+ * LSF_ERR_BAD_DIMS for anything but dims = 2, tikhonov_enabled, compute_energy = 0, apply_update = (n_taps == 0). */
 int lsf_hier_level_run_2d(const float *packed_live4, const float *canonical, float *warp_a, float *warp_b, float *g_a,
-                          float *g_b, const lsf_grid *grid, const lsf_hier_params *params, lsf_iteration_record *records,
-                          int32_t iterations, int32_t iterations_per_launch, float threshold, void *stream);
+                          float *g_b, const lsf_grid *grid, const lsf_hier_params *params, const double *taps_host,
+                          int32_t n_taps, lsf_iteration_record *records, int32_t iterations,
+                          int32_t iterations_per_launch, float threshold, void *stream);
 int lsf_hier_update(const float *g_planar, float *warp_planar, const lsf_grid *grid, float rate,
                     const lsf_gate *gate, lsf_iteration_record *record, void *stream);
 

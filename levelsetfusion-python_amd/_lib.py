@@ -22,7 +22,7 @@ ABI_VERSION = 4
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "cd442b72c36a5425"
+HEADER_ABI_HASH = "4b9a0d2c0f2405b2"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -180,8 +180,8 @@ PROTOTYPES = {
                                         _vp]),
     "lsf_hier_iteration": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _P(Grid), _P(HierParams), _P(Gate), _vp, _vp]),
     "lsf_hier_update": (ctypes.c_int, [_vp, _vp, _P(Grid), _f32, _P(Gate), _vp, _vp]),
-    "lsf_hier_level_run_2d": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _P(Grid), _P(HierParams), _vp, _i32, _i32,
-                                            ctypes.c_float, _vp]),
+    "lsf_hier_level_run_2d": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _P(Grid), _P(HierParams), _P(ctypes.c_double),
+                                            _i32, _vp, _i32, _i32, ctypes.c_float, _vp]),
     "lsf_slavcheva_gradient": (ctypes.c_int, [_vp, _vp, _vp, _vp, _P(Grid), _P(SlavchevaParams), _P(Gate), _vp,
                                               _vp, _i64, _vp]),
     "lsf_convolve_axis_listed": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _i32, _i32, _P(ctypes.c_double), _i32,

@@ -382,6 +382,207 @@ __global__ __launch_bounds__(kBlkThreads) void hier2d_blocked_kernel(const float
     }
 }
 
+// ---- ... and with the gradient kernel (the reference's default constructor, hierarchical_optimizer2d.py:63-73,213-216) -------
+// Per iteration and voxel the filter (y pass, then x pass: math_utils/convolution.py:77-83; zero padding, float64 sums in tap
+// order, one float32 rounding per pass) widens what an iteration depends on to R + 1 = taps / 2 + 1 voxels: the raw gradient
+// needs the previous FILTERED gradient one voxel around (the Laplacian), the y pass the raw gradient R rows up and down, the x
+// pass the y pass's results R columns left and right.  So K iterations of a tile need the previous gradient K (R + 1) and the
+// warp (K - 1)(R + 1) + R voxels around it: K = 2 for seven taps inside the same 48 x 48 image (8 rings).  Iteration j, with
+// r = (K - 1 - j)(R + 1) rings still to be produced for later iterations:
+//   G  raw gradient             on the cells at most r + R rings out                      (LDS: s_raw)
+//   Y  y pass                   where |dx| <= r + R and |dy| <= r                         (LDS: s_t)
+//   X  x pass, update, maximum  on the cells at most r rings out: the filtered gradient replaces the previous one, the warp
+//      moves by it; the maximum is taken over the tile's own voxels
+// One launch instead of four per iteration (lsf_hier_iteration, two filter passes, lsf_hier_update): the per-iteration path
+// runs at 20 us per iteration from a HIP graph.  Cells outside the ARRAY are never written and hold zeros: the filter's zero
+// padding.  Same arithmetic on the same inputs as the four kernels: the same bits.
+template <int T, int NT, bool FMA>
+__global__ __launch_bounds__(kBlkThreads) void hier2d_blocked_filter_kernel(const float4* __restrict__ packed,
+                                                                            const float* __restrict__ canonical,
+                                                                            const float* __restrict__ warp_in,
+                                                                            float* __restrict__ warp_out,
+                                                                            const float* __restrict__ g_in,
+                                                                            float* __restrict__ g_out, Grid g, float amp,
+                                                                            float strength, float rate, TapsN<NT> taps,
+                                                                            lsf_iteration_record* records, int k,
+                                                                            const lsf_iteration_record* previous,
+                                                                            int previous_count, float threshold) {
+    if (previous_count > 0) {  // (as hier2d_blocked_kernel: the predecessor's records, one word per lane)
+        const int l = threadIdx.x & (kWave - 1), r = l / LSF_RECORD_SLOTS;
+        unsigned long long p = r < previous_count ? previous[r].slot[l % LSF_RECORD_SLOTS].max_packed : ~0ull;
+#pragma unroll
+        for (int step = 1; step < LSF_RECORD_SLOTS; step <<= 1) {
+            const unsigned long long q = __shfl_xor(p, step);
+            p = q > p ? q : p;
+        }
+        const bool met = r < previous_count && (p == 0ull || unpack_max_value(p) < threshold);
+        if (__any(met)) return;
+    }
+    constexpr int R = NT / 2, S = R + 1;  // the filter's reach; rings an iteration consumes
+    constexpr int H = kBlkMaxK, N = T + 2 * H, W = N + 1;
+    constexpr int C = (N * N + kBlkThreads - 1) / kBlkThreads;
+    __shared__ float s_w[2][N * W];    // the warp's two components
+    __shared__ float s_gp[2][N * W];   // the previous (filtered) gradient; the x pass writes the next one over it
+    __shared__ float s_raw[2][N * W];  // the raw gradient
+    __shared__ float s_t[2][N * W];    // the y pass's results
+    __shared__ unsigned long long s_best[kBlkMaxK][kBlkThreads / kWave];
+    const int tiles_x = (g.nx + T - 1) / T;
+    const int tx0 = (int)(blockIdx.x % tiles_x) * T, ty0 = (int)(blockIdx.x / tiles_x) * T;
+    const int tx1 = min(tx0 + T, g.nx), ty1 = min(ty0 + T, g.ny);
+    const long long plane = g.plane;
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    for (int i = threadIdx.x; i < N * W; i += kBlkThreads) {  // zeros wherever nothing is ever computed: the zero padding
+        s_raw[0][i] = 0.0f; s_raw[1][i] = 0.0f;
+        s_t[0][i] = 0.0f; s_t[1][i] = 0.0f;
+    }
+    // the cells of a thread, numbered ring by ring (hier2d_blocked_kernel), with their distance from the tile along each axis
+    int cell[C], rx[C], ry[C], vox[C], nb[C];
+    float fx[C], fy[C], cn[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const int q = (int)threadIdx.x + c * kBlkThreads;
+        int u, v, r = 0;
+        if (q < T * T) {
+            u = q % T;
+            v = q / T;
+        } else {
+            const int h = q - T * T;
+            r = 1;
+            while (r < H && h >= 4 * r * (T + r)) ++r;
+            const int p = h - 4 * (r - 1) * (T + r - 1), side = T + 2 * r;
+            if (p < side) { u = p - r; v = -r; }
+            else if (p < 2 * side) { u = p - side - r; v = T - 1 + r; }
+            else if (p < 3 * side - 2) { u = -r; v = p - 2 * side + 1 - r; }
+            else { u = T - 1 + r; v = p - (3 * side - 2) + 1 - r; }
+        }
+        const int x = tx0 + u, y = ty0 + v;
+        const bool in_array = q < N * N && x >= 0 && x < g.nx && y >= 0 && y < g.ny;
+        cell[c] = (v + H) * W + (u + H);
+        rx[c] = in_array ? max(max(tx0 - x, x - (tx1 - 1)), 0) : 0x7fff;
+        ry[c] = in_array ? max(max(ty0 - y, y - (ty1 - 1)), 0) : 0x7fff;
+        vox[c] = in_array ? y * g.nx + x : 0;
+        fx[c] = (float)x;
+        fy[c] = (float)y;
+        nb[c] = (y > 0 ? 1 : 0) | (y < g.ny - 1 ? 2 : 0) | (x > 0 ? 4 : 0) | (x < g.nx - 1 ? 8 : 0);
+        cn[c] = 0.0f;
+    }
+    {
+        float v[C][4];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (max(rx[c], ry[c]) <= k * S) {
+                v[c][0] = g_in[vox[c]];
+                v[c][1] = g_in[plane + vox[c]];
+                v[c][2] = warp_in[vox[c]];
+                v[c][3] = warp_in[plane + vox[c]];
+                cn[c] = canonical[vox[c]];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (max(rx[c], ry[c]) <= k * S) {
+                s_gp[0][cell[c]] = v[c][0];
+                s_gp[1][cell[c]] = v[c][1];
+                s_w[0][cell[c]] = v[c][2];
+                s_w[1][cell[c]] = v[c][3];
+            }
+        }
+    }
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {
+        const int r = (k - 1 - j) * S;
+        // G: the raw gradient
+        {
+            float w0[C], w1[C];
+            Packed smp[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if (max(rx[c], ry[c]) <= r + R) {
+                    w0[c] = s_w[0][cell[c]];
+                    w1[c] = s_w[1][cell[c]];
+                    smp[c] = gather_packed<2>(packed, g, fx[c] + w0[c], fy[c] + w1[c], 0.0f);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if (max(rx[c], ry[c]) <= r + R) {
+                    const int l = cell[c];
+                    const float diff = smp[c].l - cn[c];
+                    const float live_grad[2] = {smp[c].gx, smp[c].gy};
+                    const int up = (nb[c] & 1) ? W : 0, down = (nb[c] & 2) ? W : 0, left = (nb[c] & 4) ? 1 : 0,
+                              right = (nb[c] & 8) ? 1 : 0;
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        const float* a = s_gp[d];
+                        const float a0 = a[l];
+                        const float d2y = second_difference_f64(a[l - up], a0, a[l + down]);
+                        const float d2x = second_difference_f64(a[l - left], a0, a[l + right]);
+                        const float lap = d2y + d2x;
+                        const float gd = diff * live_grad[d];
+                        s_raw[d][l] = amp * gd - strength * lap;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // Y: out[y] = sum_j k[j] * in[y + R - j]
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (rx[c] <= r + R && ry[c] <= r) {
+                const int l = cell[c];
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc = mac<FMA>(acc, taps.k[t], (double)s_raw[d][l + (R - t) * W]);
+                    s_t[d][l] = (float)acc;
+                }
+            }
+        }
+        __syncthreads();
+        // X, the update, the maximum
+        unsigned long long best = 0ull;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (max(rx[c], ry[c]) <= r) {
+                const int l = cell[c];
+                float gv[3] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc = mac<FMA>(acc, taps.k[t], (double)s_t[d][l + (R - t)]);
+                    gv[d] = (float)acc;
+                    s_gp[d][l] = gv[d];
+                    s_w[d][l] = s_w[d][l] - rate * gv[d];
+                }
+                if (max(rx[c], ry[c]) == 0) {
+                    const unsigned long long p = pack_max(vec_length<2>(gv), (unsigned)vox[c] + g.index_offset);
+                    best = p > best ? p : best;
+                }
+            }
+        }
+        const unsigned long long m = wave_max_u64(best);
+        if (lane == 0) s_best[j][wave] = m;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if (max(rx[c], ry[c]) == 0) {
+            g_out[vox[c]] = s_gp[0][cell[c]];
+            g_out[plane + vox[c]] = s_gp[1][cell[c]];
+            warp_out[vox[c]] = s_w[0][cell[c]];
+            warp_out[plane + vox[c]] = s_w[1][cell[c]];
+        }
+    }
+    if (wave == 0) {
+        for (int j = 0; j < k; ++j) {
+            const unsigned long long mm = wave_max_u64(lane < kBlkThreads / kWave ? s_best[j][lane] : 0ull);
+            if (lane == 0 && mm != 0ull) atomicMax(record_max(records + j), mm);
+        }
+    }
+}
+
 template <int D, bool TIK, bool UPDATE>
 void launch_hier(bool energy, unsigned blocks, hipStream_t s, const float4* packed, const float* canonical,
                  float* warp, const float* g_prev, float* g_out, const Grid& g, const lsf_hier_params* p,
@@ -480,18 +681,45 @@ extern "C" int lsf_hier_update(const float* g_planar, float* warp_planar, const 
     return launch_status();
 }
 
+template <int NT>
+static int launch_blocked_filter(bool small, bool fma, unsigned tiles, hipStream_t s, const float4* packed,
+                                 const float* canonical, const float* w_in, float* w_out, const float* g_in, float* g_out,
+                                 const Grid& g, const lsf_hier_params* params, const double* taps_host,
+                                 lsf_iteration_record* records, int k, const lsf_iteration_record* previous,
+                                 int previous_count, float threshold) {
+    TapsN<NT> taps;
+    for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
+#define LSF_LAUNCH_BLOCKED(TILE, FMA)                                                                                   \
+    hipLaunchKernelGGL((hier2d_blocked_filter_kernel<TILE, NT, FMA>), dim3(tiles), dim3(kBlkThreads), 0, s, packed,       \
+                       canonical, w_in, w_out, g_in, g_out, g, params->data_term_amplifier, params->tikhonov_strength,   \
+                       params->rate, taps, records, k, previous, previous_count, threshold)
+    if (small && fma) LSF_LAUNCH_BLOCKED(16, true);
+    else if (small) LSF_LAUNCH_BLOCKED(16, false);
+    else if (fma) LSF_LAUNCH_BLOCKED(32, true);
+    else LSF_LAUNCH_BLOCKED(32, false);
+#undef LSF_LAUNCH_BLOCKED
+    return launch_status();
+}
+
 extern "C" int lsf_hier_level_run_2d(const float* packed_live4, const float* canonical, float* warp_a, float* warp_b,
                                      float* g_a, float* g_b, const lsf_grid* grid, const lsf_hier_params* params,
-                                     lsf_iteration_record* records, int32_t iterations, int32_t iterations_per_launch,
-                                     float threshold, void* stream) {
+                                     const double* taps_host, int32_t n_taps, lsf_iteration_record* records,
+                                     int32_t iterations, int32_t iterations_per_launch, float threshold, void* stream) {
     if (int e = check_grid(grid)) return e;
     if (!packed_live4 || !canonical || !warp_a || !warp_b || warp_a == warp_b || !g_a || !g_b || g_a == g_b || !params ||
-        !records || iterations < 0 || iterations_per_launch < 1 || iterations_per_launch > kBlkMaxK)
+        !records || iterations < 0 || iterations_per_launch < 1 || iterations_per_launch > kBlkMaxK || n_taps < 0 ||
+        (n_taps > 0 && !taps_host))
         return LSF_ERR_BAD_ARGUMENT;
-    // 2-D, Tikhonov term, the update applied in the launch, no energy sums, the level's own packed field
-    if (grid->dims != 2 || !params->tikhonov_enabled || !params->apply_update || params->compute_energy ||
+    // 2-D, Tikhonov term, no energy sums, the level's own packed field; the update applied in the launch -- by the iteration
+    // itself without a gradient kernel (apply_update), behind the filter with one (apply_update off, as lsf_hier_iteration
+    // is called then)
+    const bool filtered = n_taps > 0;
+    if (grid->dims != 2 || !params->tikhonov_enabled || (params->apply_update != 0) == filtered || params->compute_energy ||
         params->previous_max || params->packed_nz != 0)
         return LSF_ERR_BAD_DIMS;
+    if (filtered && n_taps != 3 && n_taps != 5 && n_taps != 7 && n_taps != 9) return LSF_ERR_BAD_DIMS;
+    // the rings an iteration consumes (1, or taps / 2 + 1 with a filter) times the iterations of a launch: inside the image
+    if (iterations_per_launch * (filtered ? n_taps / 2 + 1 : 1) > kBlkMaxK) return LSF_ERR_BAD_ARGUMENT;
     const Grid g = make_grid(grid);
     // 32 x 32 tiles keep the recomputed rings cheapest (1.5 x the level's voxels over a launch of eight); levels too small
     // to give every CU such a tile take 16 x 16 tiles: more workgroups, each with a third of the cells
@@ -499,6 +727,7 @@ extern "C" int lsf_hier_level_run_2d(const float* packed_live4, const float* can
     const bool small = tiles_of(32) < 192u;
     const unsigned tiles = tiles_of(small ? 16 : 32);
     const float4* packed = reinterpret_cast<const float4*>(packed_live4);
+    const bool fma = filtered && taps_are_float32(taps_host, n_taps);
     hipStream_t s = as_stream(stream);
     int launch = 0;
     for (int32_t i = 0; i < iterations; i += iterations_per_launch, ++launch) {
@@ -507,16 +736,29 @@ extern "C" int lsf_hier_level_run_2d(const float* packed_live4, const float* can
         // a stop test that can fire: the launch looks at its predecessor's records first
         const lsf_iteration_record* previous = threshold > 0.0f && launch > 0 ? records + i - iterations_per_launch : nullptr;
         const int previous_count = previous ? iterations_per_launch : 0;
+        const float* w_in = even ? warp_a : warp_b;
+        float* w_out = even ? warp_b : warp_a;
+        const float* g_in = even ? g_a : g_b;
+        float* g_out = even ? g_b : g_a;
+        if (filtered) {
+            int e = 0;
+            switch (n_taps) {
+                case 3: e = launch_blocked_filter<3>(small, fma, tiles, s, packed, canonical, w_in, w_out, g_in, g_out, g, params, taps_host, records + i, k, previous, previous_count, threshold); break;
+                case 5: e = launch_blocked_filter<5>(small, fma, tiles, s, packed, canonical, w_in, w_out, g_in, g_out, g, params, taps_host, records + i, k, previous, previous_count, threshold); break;
+                case 7: e = launch_blocked_filter<7>(small, fma, tiles, s, packed, canonical, w_in, w_out, g_in, g_out, g, params, taps_host, records + i, k, previous, previous_count, threshold); break;
+                default: e = launch_blocked_filter<9>(small, fma, tiles, s, packed, canonical, w_in, w_out, g_in, g_out, g, params, taps_host, records + i, k, previous, previous_count, threshold); break;
+            }
+            if (e) return e;
+            continue;
+        }
         if (small)
-            hipLaunchKernelGGL(hier2d_blocked_kernel<16>, dim3(tiles), dim3(kBlkThreads), 0, s, packed, canonical,
-                               even ? warp_a : warp_b, even ? warp_b : warp_a, even ? g_a : g_b, even ? g_b : g_a, g,
-                               params->data_term_amplifier, params->tikhonov_strength, params->rate, records + i, k,
-                               previous, previous_count, threshold);
+            hipLaunchKernelGGL(hier2d_blocked_kernel<16>, dim3(tiles), dim3(kBlkThreads), 0, s, packed, canonical, w_in, w_out,
+                               g_in, g_out, g, params->data_term_amplifier, params->tikhonov_strength, params->rate,
+                               records + i, k, previous, previous_count, threshold);
         else
-            hipLaunchKernelGGL(hier2d_blocked_kernel<32>, dim3(tiles), dim3(kBlkThreads), 0, s, packed, canonical,
-                               even ? warp_a : warp_b, even ? warp_b : warp_a, even ? g_a : g_b, even ? g_b : g_a, g,
-                               params->data_term_amplifier, params->tikhonov_strength, params->rate, records + i, k,
-                               previous, previous_count, threshold);
+            hipLaunchKernelGGL(hier2d_blocked_kernel<32>, dim3(tiles), dim3(kBlkThreads), 0, s, packed, canonical, w_in, w_out,
+                               g_in, g_out, g, params->data_term_amplifier, params->tikhonov_strength, params->rate,
+                               records + i, k, previous, previous_count, threshold);
         if (int e = launch_status()) return e;
     }
     return 0;

@@ -370,8 +370,8 @@ class HierarchicalEngine:
         n_vox = canonical.numel()
         hooked = self.iteration_hook is not None
         if (self.blocked_levels and canonical.dim() == 2 and not slab and not hooked and not self.collect_iteration_data
-                and self.tikhonov_term_enabled and not self.gradient_kernel_enabled and not self.compute_energy
-                and max_it >= 1):
+                and self.tikhonov_term_enabled and not self.compute_energy and max_it >= 1
+                and (not self.gradient_kernel_enabled or len(self.gradient_kernel) in dev.XYZ_TAP_COUNTS)):
             return self._optimize_level_blocked(canonical, packed, warp)
         if (self.use_graphs and not slab and not self.collect_iteration_data and not hooked and max_it >= 4
                 and self.check_interval >= 2 and n_vox <= self.graph_max_voxels
@@ -466,9 +466,12 @@ class HierarchicalEngine:
     BLOCKED_ITERATIONS_PER_LAUNCH = 8
 
     def _optimize_level_blocked(self, canonical, packed, warp):
-        """2-D levels, Tikhonov term, no filter, no energy printouts: the whole level in ONE foreign call, K = 8 iterations
+        """2-D levels, Tikhonov term, no energy printouts: the whole level in ONE foreign call, K = 8 iterations
         per launch advanced inside LDS tile by tile (lsf_hier_level_run_2d: temporal blocking -- a 512^2 level is
-        launch-bound, 7.5 us per iteration from a HIP graph against ~1 us of work).  Same arithmetic on the same inputs:
+        launch-bound, 7.5 us per iteration from a HIP graph against ~1 us of work).  With the gradient kernel (the
+        reference's default constructor) the launch also runs the filter's two passes and the update behind them -- one
+        launch instead of four per iteration -- and an iteration consumes taps / 2 + 1 rings of a tile's surroundings: K = 2
+        for seven taps.  Same arithmetic on the same inputs:
         warp, gradient and every iteration's maximum equal the per-iteration path's (tests/test_gpu_blocked_levels.py).
         A stop test that can fire (threshold > 0, hierarchical_optimizer2d.py:169-171) is looked at launch by launch on
         the card; the launch in which the level converged is then repeated from its untouched inputs with the reference's
@@ -477,12 +480,21 @@ class HierarchicalEngine:
         grid = dev.make_grid(canonical.shape)
         n = dev.n_voxels(grid)
         K = self.BLOCKED_ITERATIONS_PER_LAUNCH
+        taps, n_taps = None, 0
+        if self.gradient_kernel_enabled:
+            kernel = np.ascontiguousarray(np.asarray(self.gradient_kernel, dtype=np.float64))
+            n_taps = int(kernel.size)
+            if min(canonical.shape) < n_taps:  # (the reference cannot do this either: np.convolve's 'same' mode)
+                raise ValueError("cannot convolve a field of extent %d with a %d-tap kernel" % (min(canonical.shape), n_taps))
+            taps = kernel.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+            K = max(1, K // (n_taps // 2 + 1))
         thr = np.float32(self.maximum_warp_update_threshold)
         gated = bool(thr > 0.0)
         warps = [warp, torch.empty_like(warp)]
         F = [torch.zeros_like(warp), torch.empty_like(warp)]
         records = dev.new_records(max_it, canonical.device)
-        params = _lib.HierParams(float(self.data_term_amplifier), float(self.tikhonov_strength), float(self.rate), 1, 1, 0)
+        params = _lib.HierParams(float(self.data_term_amplifier), float(self.tikhonov_strength), float(self.rate), 1,
+                                 int(n_taps == 0), 0)
         p_packed, p_canonical = dev._ptr(packed, 4 * n, "packed live"), dev._ptr(canonical, n, "canonical")
         p_warp = [dev._ptr(w, 2 * n, "warp") for w in warps]
         p_g = [dev._ptr(g, 2 * n, "gradient") for g in F]
@@ -490,7 +502,8 @@ class HierarchicalEngine:
         def run(first, record_ptr, iterations, threshold):  # launches reading pair `first` first
             _lib.check(_lib.lib.lsf_hier_level_run_2d(
                 p_packed, p_canonical, p_warp[first], p_warp[1 - first], p_g[first], p_g[1 - first], ctypes.byref(grid),
-                ctypes.byref(params), record_ptr, iterations, K, threshold, dev.stream_ptr()), "lsf_hier_level_run_2d")
+                ctypes.byref(params), taps, n_taps, record_ptr, iterations, K, threshold, dev.stream_ptr()),
+                "lsf_hier_level_run_2d")
 
         run(0, ctypes.c_void_p(records.data_ptr()), max_it, float(thr) if gated else 0.0)
         launches = (max_it + K - 1) // K

@@ -39,7 +39,7 @@ HIERARCHICAL_DEFAULTS = dict(
     fused_filter=True,             # (False: three convolve_axis passes -- measurements, tests)
     fused_filter_min_voxels=1 << 23,
     defer_maximum=True,            # (False: every iteration keeps its own maximum pass)
-    blocked_levels=True,           # 2-D levels (Tikhonov, no filter): 8 iterations per launch inside LDS tiles, a stop test
+    blocked_levels=True,           # 2-D levels (Tikhonov term, +/- gradient kernel): K iterations per launch inside LDS tiles, a stop test
                                    # looked at launch by launch (lsf_hier_level_run_2d); False: one launch per iteration
 )
 

@@ -178,13 +178,13 @@ def test_round6_entry_points_validate_on_the_host(pkg):
     # lsf_hier_level_run_2d: 2-D, Tikhonov, update applied, no energies, 1..8 iterations per launch, distinct buffers
     ok = L.HierParams(1.0, 0.05, 0.1, 1, 1, 0)
     call = lib.lsf_hier_level_run_2d
-    assert call(one, one, two, three, four, five, ctypes.byref(g3), ctypes.byref(ok), one, 4, 8, 0.0, None) == -2
-    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(L.HierParams(1.0, 0.05, 0.1, 0, 1, 0)), one, 4, 8, 0.0,
+    assert call(one, one, two, three, four, five, ctypes.byref(g3), ctypes.byref(ok), None, 0, one, 4, 8, 0.0, None) == -2
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(L.HierParams(1.0, 0.05, 0.1, 0, 1, 0)), None, 0, one, 4, 8, 0.0,
                 None) == -2
-    assert call(one, one, two, two, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 8, 0.0, None) == -1
-    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 0, 0.0, None) == -1
-    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 9, 0.0, None) == -1
-    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 0, 8, 0.0, None) == 0  # nothing to do
+    assert call(one, one, two, two, four, five, ctypes.byref(g2), ctypes.byref(ok), None, 0, one, 4, 8, 0.0, None) == -1
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), None, 0, one, 4, 0, 0.0, None) == -1
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), None, 0, one, 4, 9, 0.0, None) == -1
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), None, 0, one, 0, 8, 0.0, None) == 0  # nothing to do
     # lsf_convolve_axis_update: the last axis only, 3 / 5 / 7 / 9 taps, distinct buffers
     taps = (ctypes.c_double * 9)(*([0.1] * 9))
     upd = lib.lsf_convolve_axis_update

@@ -74,13 +74,60 @@ def test_blocked_levels_equal_the_oracle_in_the_divergent_regime(lsf):
     assert float(np.abs(want).max()) > 1e-3
 
 
-def test_filtered_runs_keep_the_per_iteration_path(lsf):
+# with the gradient kernel (the reference's default constructor): the filter's passes and the update run in the launch too;
+# an iteration consumes taps / 2 + 1 rings, so a launch holds 4 / 2 / 2 / 1 iterations for 3 / 5 / 7 / 9 taps
+@pytest.mark.parametrize("n_taps", [3, 5, 7, 9])
+@pytest.mark.parametrize("n,chunk,iterations", [(512, 4, 21), (128, 8, 12), (64, 4, 5)])
+def test_filtered_blocked_levels_equal_one_launch_per_iteration(lsf, n_taps, n, chunk, iterations):
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live = sphere_pair(n, 2, "cuda")
+    kernel = lsf.generate_1d_sobolev_kernel(n_taps, 0.1) if n_taps in (3, 7) else \
+        np.linspace(-0.1, 0.5, n_taps).astype(np.float64) / 1.7  # (not float32 values: the two-instruction arithmetic)
+    kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=True, kernel=kernel, maximum_chunk_size=chunk, rate=0.1,
+              maximum_iteration_count=iterations, maximum_warp_update_threshold=0.0, tikhonov_strength=0.05)
+    a = _run(lsf, canonical, live, True, **kw)
+    b = _run(lsf, canonical, live, False, **kw)
+    _same(a, b)
+    assert float(torch.as_tensor(a[1]).abs().max()) > 1e-3
+
+
+def test_filtered_blocked_levels_on_fields_that_are_not_square(lsf):
+    from levelsetfusion_python_amd.synthetic import sphere_pair
+    canonical, live = (t[192:320].contiguous() for t in sphere_pair(512, 2, "cuda"))
+    kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=True, kernel=lsf.generate_1d_sobolev_kernel(7, 0.1),
+              maximum_chunk_size=4, rate=0.1, maximum_iteration_count=15, maximum_warp_update_threshold=0.0,
+              tikhonov_strength=0.05)
+    _same(_run(lsf, canonical, live, True, **kw), _run(lsf, canonical, live, False, **kw))
+
+
+@pytest.mark.parametrize("n_taps", [3, 7])
+def test_filtered_blocked_levels_equal_the_oracle(lsf, n_taps):
+    """the reference's default configuration (Tikhonov term + gradient kernel, hierarchical_optimizer2d.py:63-73) at 128^2,
+    fixed count and with a stop test that fires: warp, counts and maxima == oracle"""
+    canonical, live = O.sphere_pair(128, d=2)
+    kernel = O.generate_1d_sobolev_kernel(n_taps, 0.1)
+    for threshold, iterations in ((0.0, 11), (0.037, 40)):
+        kw = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=True, maximum_chunk_size=8, rate=0.1,
+                  maximum_iteration_count=iterations, maximum_warp_update_threshold=threshold, tikhonov_strength=0.05)
+        opt, warp = _run(lsf, canonical, live, True, kernel=kernel, **kw)
+        o = O.HierarchicalOracle(kernel=kernel, **kw)
+        want = o.optimize(canonical, live)
+        assert np.array_equal(warp, want)
+        assert opt.get_per_level_iteration_counts() == o.per_level_iteration_counts
+        for mine, theirs in zip(opt.get_per_level_maximum_updates(), o.per_level_max_updates):
+            assert np.array_equal(np.float32(mine), np.float32(theirs))
+        if threshold > 0:
+            assert min(o.per_level_iteration_counts) < iterations, o.per_level_iteration_counts
+
+
+def test_energy_printouts_keep_the_per_iteration_path(lsf):
     from levelsetfusion_python_amd.synthetic import sphere_pair
     canonical, live = sphere_pair(64, 2, "cuda")
-    base = dict(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=8, rate=0.1,
-                maximum_iteration_count=10, tikhonov_strength=0.05)
-    opt = lsf.HierarchicalOptimizer2d(maximum_warp_update_threshold=0.0, **dict(base, gradient_kernel_enabled=True,
-                                                                               kernel=lsf.generate_1d_sobolev_kernel(3, 0.1)))
+    opt = lsf.HierarchicalOptimizer2d(tikhonov_term_enabled=True, gradient_kernel_enabled=False, maximum_chunk_size=8,
+                                      rate=0.1, maximum_iteration_count=10, tikhonov_strength=0.05,
+                                      maximum_warp_update_threshold=0.0,
+                                      verbosity_parameters=lsf.HierarchicalOptimizer2d.VerbosityParameters(
+                                          print_iteration_data_energy=True))
     opt.optimize(canonical, live)
     assert opt.engine.last_call.blocked_levels == 0
 
@@ -167,10 +214,10 @@ def test_entry_point_refuses_what_it_does_not_implement(lsf):
     ok = _lib.HierParams(1.0, 0.05, 0.1, 1, 1, 0)
     call = _lib.lib.lsf_hier_level_run_2d
     one, two, three, four, five = (ctypes.c_void_p(k * 4096) for k in (1, 2, 3, 4, 5))
-    assert call(one, one, two, three, four, five, ctypes.byref(g3), ctypes.byref(ok), one, 4, 8, 0.0, None) == -2  # 3-D
-    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(_lib.HierParams(1.0, 0.05, 0.1, 0, 1, 0)),
+    assert call(one, one, two, three, four, five, ctypes.byref(g3), ctypes.byref(ok), None, 0, one, 4, 8, 0.0, None) == -2  # 3-D
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(_lib.HierParams(1.0, 0.05, 0.1, 0, 1, 0)), None, 0,
                 one, 4, 8, 0.0, None) == -2  # no Tikhonov term
-    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(_lib.HierParams(1.0, 0.05, 0.1, 1, 1, 1)),
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(_lib.HierParams(1.0, 0.05, 0.1, 1, 1, 1)), None, 0,
                 one, 4, 8, 0.0, None) == -2  # energies
-    assert call(one, one, two, two, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 8, 0.0, None) == -1    # same buffer twice
-    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), one, 4, 9, 0.0, None) == -1  # K > 8
+    assert call(one, one, two, two, four, five, ctypes.byref(g2), ctypes.byref(ok), None, 0, one, 4, 8, 0.0, None) == -1    # same buffer twice
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), None, 0, one, 4, 9, 0.0, None) == -1  # K > 8
