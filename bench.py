@@ -351,6 +351,22 @@ def extra_workload(args, device, world, rank, dist):
             counts = armed.get_per_level_iteration_counts()
             out[key] = (time.perf_counter() - t0) / args.steps / sum(counts) * 1e6
             out["iterations_default_threshold"] = counts
+        # ... and with the gradient kernel as well: the reference's default constructor (hierarchical_optimizer2d.py:63-73:
+        # Tikhonov term + kernel, threshold 0.001).  Blocked levels run the filter's two passes and the update inside the
+        # launch (two iterations per launch for seven taps); the graph path takes four launches per iteration
+        for key, blocked in (("us_per_iteration_default_constructor", True),
+                             ("us_per_iteration_default_constructor_graph_path", False)):
+            full = lsf.HierarchicalOptimizer2d(tikhonov_term_enabled=True, gradient_kernel_enabled=True, kernel=k7,
+                                               maximum_chunk_size=4, rate=0.1, maximum_iteration_count=iters,
+                                               maximum_warp_update_threshold=0.001, tikhonov_strength=0.05,
+                                               engine_options=dict(blocked_levels=blocked))
+            for k in range(args.warmup + args.steps):
+                if k == args.warmup:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                full.optimize(canonical, live0)
+            torch.cuda.synchronize()
+            out[key] = (time.perf_counter() - t0) / args.steps / sum(full.get_per_level_iteration_counts()) * 1e6
     if args.workload in ("hier-tik", "hier-full", "multiframe") and comm is None:
         # the dominant kernels of this workload: the finest level's launches alone (87.5 % of a step's voxel-updates),
         # HIP events on their stream; kernel_ms = one finest-level iteration, frac = B_alg x n^3 / kernel_ms
@@ -486,7 +502,8 @@ def secondary_measurements(args, device):
                 row["us_per_iteration"] = d["us_per_iteration"]
                 row["note"] = r.get("note")
                 for key in ("us_per_iteration_default_threshold", "us_per_iteration_default_threshold_graph_path",
-                            "iterations_default_threshold"):
+                            "iterations_default_threshold", "us_per_iteration_default_constructor",
+                            "us_per_iteration_default_constructor_graph_path"):
                     row[key] = d.get(key)
             row["wall_s"] = time.perf_counter() - t0
         except Exception as exc:  # noqa: BLE001 -- recorded on the line

@@ -70,6 +70,9 @@ def test_default_workload_line():
     assert sec["killing"]["size"] == 128 and sec["killing"]["kernel_ms"] > 0
     assert sec["hier2d"]["size"] == 128 and sec["hier2d"]["us_per_iteration"] > 0 and "LAUNCH-BOUND" in sec["hier2d"]["note"]
     assert abs(sec["hier2d"]["us_per_iteration"] - sec["hier2d"]["ms_per_step"] * 1e3 / 300) < 1e-6
+    for key in ("us_per_iteration_default_threshold", "us_per_iteration_default_constructor",
+                "us_per_iteration_default_constructor_graph_path"):  # the stop test armed; + the gradient kernel
+        assert sec["hier2d"][key] > 0, key
 
 
 def test_hier2d_workload_line():
