@@ -3,6 +3,8 @@
 torch is plumbing here: it owns device memory and the HIP stream.  Every wrapper validates dtype, device,
 contiguity and element counts on the host BEFORE the launch (a hand-written kernel that reads past a buffer can
 take the whole GPU down), then passes raw device pointers + the current HIP stream to the library.
+The common helpers live in device_core.py, the field operations (warps, pyramids, filters) in device_fields.py; this module
+re-exports both and holds the optimizers' kernels.
 """
 import ctypes
 
@@ -11,384 +13,9 @@ import torch
 
 from . import _lib
 from ._lib import Gate, Grid, HierParams, SlavchevaParams, check, lib
-
-RECORD_WORDS = _lib.RECORD_BYTES // 8  # an iteration record is 8 slots x 512 int64 words (see lsf_iteration_record)
-
-
-def require_gpu():
-    if not torch.cuda.is_available():
-        raise RuntimeError("levelsetfusion-python_amd needs an AMD GPU (ROCm): torch.cuda.is_available() is False. "
-                           "There is no CPU execution path in this package.")
-
-
-# torch.cuda.current_stream() / current_device() walk half a dozen Python frames each (device-type look-up, availability
-# check, an environment read): ~4 us per call, a dozen calls per optimize() -- cProfile of one call, tools/host_profile.py.
-# The two raw queries behind them are single C calls.
-_raw_device = getattr(torch._C, "_cuda_getDevice", None)
-_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
-_raw_checked = False
-
-
-def _check_raw_queries():
-    """the two queries are private to torch: the first time a GPU is used they are held against the public calls, and
-    dropped for good if they are missing, raise, or answer differently (another torch release)"""
-    global _raw_device, _raw_stream, _raw_checked
-    _raw_checked = True
-    try:
-        ok = (_raw_device is not None and _raw_stream is not None
-              and _raw_device() == torch.cuda.current_device()
-              and _raw_stream(_raw_device()) == torch.cuda.current_stream().cuda_stream)
-    except Exception:  # noqa: BLE001 -- any failure means: use the public calls
-        ok = False
-    if not ok:
-        _raw_device = _raw_stream = None
-
-
-def current_device_index():
-    if not _raw_checked:
-        _check_raw_queries()
-    return _raw_device() if _raw_device is not None else torch.cuda.current_device()
-
-
-def current_stream_handle():
-    """the current HIP stream of the current device as an integer (hipStream_t)"""
-    if not _raw_checked:
-        _check_raw_queries()
-    if _raw_stream is not None and _raw_device is not None:
-        return _raw_stream(_raw_device())
-    return torch.cuda.current_stream().cuda_stream
-
-
-def stream_ptr():
-    return ctypes.c_void_p(current_stream_handle())
-
-
-_PINNED = {}
-
-
-def pinned_scratch(name, numel, dtype):
-    """a small page-locked host buffer that lives as long as the process (one per device, STREAM and purpose): the
-    landing place of the few numbers a call reads back, without a host allocation per call.  The optimizers are
-    single-caller objects (as the reference's are): a buffer is consumed before the next call on the same stream fills it
-    again -- and optimizers that run side by side (experiment/multipair.py: pairs in flight, one thread and one stream
-    each) never share one."""
-    # one buffer per purpose, grown to the largest length asked for
-    key = (current_device_index(), current_stream_handle(), name, dtype)
-    buf = _PINNED.get(key)
-    if buf is None or buf.numel() < int(numel):
-        buf = _PINNED[key] = torch.empty(max(int(numel), 2 * buf.numel() if buf is not None else 0), dtype=dtype,
-                                         pin_memory=True)
-    return buf[:int(numel)]
-
-
-def make_grid(shape, z_begin=0, z_end=None, z_global_offset=0):
-    """shape: spatial extents (ny, nx) or (nz, ny, nx)"""
-    shape = tuple(int(s) for s in shape)
-    if len(shape) == 2:
-        nz, (ny, nx), dims = 1, shape, 2
-    elif len(shape) == 3:
-        (nz, ny, nx), dims = shape, 3
-    else:
-        raise ValueError("fields must be 2-D or 3-D, got shape %r" % (shape,))
-    z_end = nz if z_end is None else z_end
-    if not (0 <= z_begin <= z_end <= nz):
-        raise ValueError("bad z range [%d, %d) for nz = %d" % (z_begin, z_end, nz))
-    return Grid(dims, nz, ny, nx, z_begin, z_end, z_global_offset, 0)
-
-
-def n_voxels(grid):
-    return grid.nz * grid.ny * grid.nx
-
-
-def _ptr(t, numel, name, dtype=torch.float32, allow_none=False):
-    if t is None:
-        if allow_none:
-            return ctypes.c_void_p(0)
-        raise ValueError("%s: tensor required" % name)
-    if not isinstance(t, torch.Tensor) or not t.is_cuda:
-        raise ValueError("%s: expected a CUDA/ROCm tensor" % name)
-    if t.device.index != current_device_index():
-        # kernels are launched on the CURRENT device's current stream (stream_ptr): a tensor that lives elsewhere
-        # would be reached through a peer mapping at best
-        raise ValueError("%s is on %s but the current device is cuda:%d (torch.cuda.set_device / torch.cuda.device)"
-                         % (name, t.device, torch.cuda.current_device()))
-    if t.dtype != dtype:
-        raise ValueError("%s: expected dtype %s, got %s" % (name, dtype, t.dtype))
-    if not t.is_contiguous():
-        raise ValueError("%s: tensor must be contiguous" % name)
-    if t.numel() != numel:
-        raise ValueError("%s: expected %d elements, got %d" % (name, numel, t.numel()))
-    return ctypes.c_void_p(t.data_ptr())
-
-
-def _record_ptr(records, index, name="records"):
-    """records: int64 tensor [n, 4] (raw 32-byte records); returns pointer to record `index`"""
-    if records.dtype != torch.int64 or not records.is_cuda or not records.is_contiguous() or records.dim() != 2 \
-            or records.shape[1] != RECORD_WORDS:
-        raise ValueError("%s: expected a contiguous CUDA int64 tensor of shape [n, %d]" % (name, RECORD_WORDS))
-    if not (0 <= index < records.shape[0]):
-        raise IndexError("%s: record index %d out of range [0, %d)" % (name, index, records.shape[0]))
-    return ctypes.c_void_p(records.data_ptr() + index * _lib.RECORD_BYTES)
-
-
-def new_records(n, device):
-    return torch.zeros((n, RECORD_WORDS), dtype=torch.int64, device=device)
-
-
-def make_gate(records, prev_index, mode, a, b=0.0):
-    """gate on record `prev_index` (None / negative: always run)"""
-    if records is None or prev_index is None or prev_index < 0:
-        return None
-    return Gate(_record_ptr(records, prev_index).value, int(mode), float(a), float(b))
-
-
-def _gate_ref(gate):
-    return ctypes.byref(gate) if gate is not None else None
-
-
-def slot_view(records):
-    """[n, RECORD_WORDS] (tensor or array) -> [n, slots, SLOT_WORDS]: word 0 = packed max, words 1..3 = energies"""
-    return records.reshape(records.shape[0], _lib.RECORD_SLOTS, _lib.SLOT_WORDS)
-
-
-def set_record_max(records, index, packed):
-    """make record `index` read as `packed` to a gate (slot 0 holds it, the other slots are cleared)"""
-    records[index].zero_()
-    records[index, 0] = packed
-
-
-USED_SLOT_WORDS = 4  # packed max + three energies; the rest of a slot is padding (slots sit 4 KiB apart)
-
-
-def records_to_host(records):
-    """device records [n, RECORD_WORDS] -> numpy int64 [n, slots, 4]: only the used words cross PCIe, into a page-locked
-    buffer (no staging copy); the call returns when they have arrived"""
-    used = slot_view(records)[:, :, :USED_SLOT_WORDS].contiguous()
-    if not used.is_cuda:
-        return used.numpy()
-    host = pinned_scratch("records", used.numel(), used.dtype)
-    host.copy_(used.view(-1), non_blocking=True)
-    torch.cuda.current_stream().synchronize()
-    return host.numpy().reshape(tuple(used.shape)).copy()
-
-
-def decode_records(records_host):
-    """records_host: numpy int64 [n, slots, >= 4] (records_to_host) or [n, RECORD_WORDS] -> dict of arrays (max value,
-    linear arg-max index, energies, executed); combines the slots of every record: max of the packed maxima, sum of the
-    energies"""
-    raw = records_host
-    if raw.ndim == 2:
-        raw = slot_view(np.ascontiguousarray(raw))
-    if raw.dtype == np.int64 and raw.ndim == 3 and raw.shape[2] >= USED_SLOT_WORDS and raw.flags.c_contiguous:
-        # one host call into the library (lsf_records_decode) instead of a dozen numpy calls: ~30 -> ~8 us per optimize()
-        n = raw.shape[0]
-        max_value, index = np.empty(n, np.float32), np.empty(n, np.int64)
-        energies, executed = np.empty((n, 3), np.float64), np.empty(n, np.bool_)
-        check(lib.lsf_records_decode(raw.ctypes.data, n, raw.shape[1], raw.shape[2], max_value.ctypes.data,
-                                     index.ctypes.data, energies.ctypes.data, executed.ctypes.data), "lsf_records_decode")
-        return dict(executed=executed, max_value=max_value, argmax=index, data_energy=energies[:, 0],
-                    smoothing_energy=energies[:, 1], level_set_energy=energies[:, 2])
-    words = raw.view(np.uint64)  # same item size: no copy, strides kept
-    packed = words[:, :, 0].max(axis=1)
-    energies = np.ascontiguousarray(raw[:, :, 1:4]).view(np.float64).sum(axis=1)
-    executed = packed != 0
-    max_value = (packed >> np.uint64(32)).astype(np.uint32).view(np.float32)
-    index = (~packed.astype(np.uint32)).astype(np.int64)
-    return dict(executed=executed, max_value=max_value, argmax=index, data_energy=energies[:, 0],
-                smoothing_energy=energies[:, 1], level_set_energy=energies[:, 2])
-
-
-# ---------------------------------------------------------------------------------------------- layout
-def deinterleave(interleaved, channels):
-    n = interleaved.numel() // channels
-    out = torch.empty((channels,) + tuple(interleaved.shape[:-1]), dtype=torch.float32, device=interleaved.device)
-    check(lib.lsf_deinterleave(_ptr(interleaved, n * channels, "interleaved"), _ptr(out, n * channels, "planar"),
-                               n, channels, stream_ptr()), "lsf_deinterleave")
-    return out
-
-
-def interleave(planar):
-    channels = planar.shape[0]
-    n = planar.numel() // channels
-    out = torch.empty(tuple(planar.shape[1:]) + (channels,), dtype=torch.float32, device=planar.device)
-    check(lib.lsf_interleave(_ptr(planar, n * channels, "planar"), _ptr(out, n * channels, "interleaved"), n,
-                             channels, stream_ptr()), "lsf_interleave")
-    return out
-
-
-def halo_copy(scalar, planar, msg_lo, msg_hi, halo, z_lo, z_hi, unpack):
-    """pack (unpack=False) / unpack the halo messages of a scalar field [z,y,x] and a planar vector field [c,z,y,x]"""
-    ref = scalar if scalar is not None else planar[0]
-    grid = make_grid(ref.shape)
-    planes = 0 if planar is None else planar.shape[0]
-    n = n_voxels(grid)
-    per_msg = (1 + planes) * halo * grid.ny * grid.nx
-    check(lib.lsf_halo_copy(_ptr(scalar, n, "scalar", allow_none=True),
-                            _ptr(planar, n * planes, "planar", allow_none=True) if planar is not None
-                            else ctypes.c_void_p(0),
-                            _ptr(msg_lo, per_msg, "msg_lo", allow_none=True),
-                            _ptr(msg_hi, per_msg, "msg_hi", allow_none=True), ctypes.byref(grid), planes, int(halo),
-                            int(z_lo), int(z_hi), int(bool(unpack)), stream_ptr()), "lsf_halo_copy")
-
-
-# ---------------------------------------------------------------------------------------------- a1-a3
-def warp_field(field, warp_planar, oob_value, grid=None, out=None):
-    grid = grid or make_grid(field.shape)
-    n = n_voxels(grid)
-    out = torch.empty_like(field) if out is None else out
-    check(lib.lsf_warp_field(_ptr(field, n, "field"), _ptr(warp_planar, n * grid.dims, "warp"),
-                             _ptr(out, n, "out"), ctypes.byref(grid), float(oob_value), stream_ptr()),
-          "lsf_warp_field")
-    return out
-
-
-def warp_field_advanced(canonical, live, warp_planar, gradient_planar, flags, grid=None, out=None):
-    grid = grid or make_grid(live.shape)
-    n = n_voxels(grid)
-    out = torch.empty_like(live) if out is None else out
-    check(lib.lsf_warp_field_advanced(_ptr(canonical, n, "canonical"), _ptr(live, n, "live"),
-                                      _ptr(warp_planar, n * grid.dims, "warp"),
-                                      _ptr(gradient_planar, n * grid.dims, "gradient", allow_none=True),
-                                      _ptr(out, n, "new_live"), ctypes.byref(grid), int(flags), stream_ptr()),
-          "lsf_warp_field_advanced")
-    return out
-
-
-# ---------------------------------------------------------------------------------------------- a4-a6
-def pack_live_gradient(live, grid=None):
-    grid = grid or make_grid(live.shape)
-    n = n_voxels(grid)
-    out = torch.empty(tuple(live.shape) + (4,), dtype=torch.float32, device=live.device)
-    check(lib.lsf_pack_live_gradient(_ptr(live, n, "live"), _ptr(out, 4 * n, "packed"), ctypes.byref(grid),
-                                     stream_ptr()), "lsf_pack_live_gradient")
-    return out
-
-
-def restrict_mean(fine, channels):
-    """fine: [z,]y,x (channels == 1) or [z,]y,x,4"""
-    spatial = tuple(fine.shape) if channels == 1 else tuple(fine.shape[:-1])
-    grid = make_grid(spatial)
-    coarse_spatial = tuple(s // 2 for s in spatial)
-    out = torch.empty(coarse_spatial + (() if channels == 1 else (channels,)), dtype=torch.float32,
-                      device=fine.device)
-    check(lib.lsf_restrict_mean(_ptr(fine, n_voxels(grid) * channels, "fine"),
-                                _ptr(out, out.numel(), "coarse"), ctypes.byref(grid), channels, stream_ptr()),
-          "lsf_restrict_mean")
-    return out
-
-
-def prolong_repeat(coarse_planar):
-    dims = coarse_planar.shape[0]
-    fine_spatial = tuple(2 * s for s in coarse_planar.shape[1:])
-    grid = make_grid(fine_spatial)
-    out = torch.empty((dims,) + fine_spatial, dtype=torch.float32, device=coarse_planar.device)
-    check(lib.lsf_prolong_repeat(_ptr(coarse_planar, coarse_planar.numel(), "coarse"),
-                                 _ptr(out, n_voxels(grid) * dims, "fine"), ctypes.byref(grid), stream_ptr()),
-          "lsf_prolong_repeat")
-    return out
-
-
-def downsample2x_linear(fine, channels):
-    """3-D, fine: z,y,x (channels == 1) or z,y,x,4"""
-    spatial = tuple(fine.shape) if channels == 1 else tuple(fine.shape[:-1])
-    if len(spatial) != 3:
-        raise NotImplementedError("Cases other than 3D not yet implemented")
-    if any(s % 2 for s in spatial):
-        raise ValueError("Each field dimension must be evenly divisible by 2.")
-    grid = make_grid(spatial)
-    out = torch.empty(tuple(s // 2 for s in spatial) + (() if channels == 1 else (channels,)), dtype=torch.float32,
-                      device=fine.device)
-    check(lib.lsf_downsample2x_linear(_ptr(fine, n_voxels(grid) * channels, "fine"), _ptr(out, out.numel(), "coarse"),
-                                      ctypes.byref(grid), channels, stream_ptr()), "lsf_downsample2x_linear")
-    return out
-
-
-def upsample2x_linear(coarse, channels=1):
-    spatial = tuple(coarse.shape) if channels == 1 else tuple(coarse.shape[:-1])
-    if len(spatial) != 3:
-        raise NotImplementedError("Cases other than 3D not yet implemented")
-    fine_spatial = tuple(2 * s for s in spatial)
-    grid = make_grid(fine_spatial)
-    out = torch.empty(fine_spatial + (() if channels == 1 else (channels,)), dtype=torch.float32, device=coarse.device)
-    check(lib.lsf_upsample2x_linear(_ptr(coarse, coarse.numel(), "coarse"), _ptr(out, out.numel(), "fine"),
-                                    ctypes.byref(grid), channels, stream_ptr()), "lsf_upsample2x_linear")
-    return out
-
-
-# ---------------------------------------------------------------------------------------------- a9/a10
-LISTED_TAP_COUNTS = (3, 5, 7, 9)  # lsf_convolve_axis_listed
-
-
-def convolve_axis(src, dst, zero_mask_source, grid, axis, taps, gate=None, band=None):
-    """one pass of the separable filter; band: an LSF_BAND_ALL list -- the zero-preserving pass at its voxels only"""
-    taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float64))
-    if taps.ndim != 1 or not (1 <= taps.size <= _lib.MAX_KERNEL_TAPS):
-        raise ValueError("kernel must be 1-D with 1..%d taps" % _lib.MAX_KERNEL_TAPS)
-    length = (grid.nx, grid.ny, grid.nz)[axis]
-    if length < taps.size:
-        # the reference cannot do this either: np.convolve(..., 'same') returns max(M, N) samples
-        raise ValueError("cannot convolve a field of extent %d with a %d-tap kernel" % (length, taps.size))
-    planes = src.shape[0]
-    n = n_voxels(grid) * planes
-    if band is not None:
-        check(lib.lsf_convolve_axis_listed(_ptr(src, n, "conv src"), _ptr(dst, n, "conv dst"),
-                                           _ptr(zero_mask_source, n, "zero mask"), ctypes.byref(grid), planes, axis,
-                                           taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), taps.size,
-                                           _gate_ref(gate), band.pointer, band.count, stream_ptr()),
-              "lsf_convolve_axis_listed")
-        return
-    check(lib.lsf_convolve_axis(_ptr(src, n, "conv src"), _ptr(dst, n, "conv dst"),
-                                _ptr(zero_mask_source, n, "zero mask", allow_none=True), ctypes.byref(grid),
-                                planes, axis, taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), taps.size,
-                                _gate_ref(gate), stream_ptr()), "lsf_convolve_axis")
-
-
-XYZ_TAP_COUNTS = (3, 5, 7, 9)
-
-
-def convolve_axis_update_ok(grid, taps):
-    """can the filter's last pass also move the warp (lsf_convolve_axis_update: the register-window pass along z, whose
-    launch grid must fit)?  3-D only: the reference's 2-D filter ends with its x pass (math_utils/convolution.py:77-83)"""
-    if len(taps) not in XYZ_TAP_COUNTS or grid.dims != 3:
-        return False
-    slices = grid.z_end - grid.z_begin
-    return ((slices + 31) // 32) * ((grid.ny + 3) // 4) <= 65535
-
-
-def convolve_axis_update(src, dst, warp, rate, grid, axis, taps, gate=None):
-    """the last pass of a hierarchical iteration's filter, which also moves the warp: warp -= rate * dst"""
-    taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float64))
-    length = (grid.nx, grid.ny, grid.nz)[axis]
-    if length < taps.size:  # (as convolve_axis)
-        raise ValueError("cannot convolve a field of extent %d with a %d-tap kernel" % (length, taps.size))
-    planes = src.shape[0]
-    n = n_voxels(grid) * planes
-    check(lib.lsf_convolve_axis_update(_ptr(src, n, "conv src"), _ptr(dst, n, "conv dst"), _ptr(warp, n, "warp"),
-                                       float(rate), ctypes.byref(grid), planes, axis,
-                                       taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), taps.size, _gate_ref(gate),
-                                       stream_ptr()), "lsf_convolve_axis_update")
-
-
-def convolve_xyz_ok(grid, taps):
-    """can lsf_convolve_xyz run this 3-D filter (nx % 4 == 0, 3 / 5 / 7 / 9 taps that fit every axis)?"""
-    n = len(taps)
-    return (grid.dims == 3 and n in XYZ_TAP_COUNTS and grid.nx % 4 == 0 and min(grid.nx, grid.ny, grid.nz) >= n
-            and ((grid.ny + 15) // 16) * ((grid.z_end - grid.z_begin + 31) // 32) <= 65535)
-
-
-def convolve_xyz(src, dst, grid, taps, gate=None, warp=None, rate=0.0):
-    """the x, y and z passes of convolve_axis (no zero mask) in one launch (lsf_convolve_xyz): same result, one read
-    and one write of the field instead of three; warp: also warp -= rate * dst (the hierarchical update)"""
-    taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float64))
-    if not convolve_xyz_ok(grid, taps):
-        raise ValueError("lsf_convolve_xyz cannot run this grid / kernel; use three convolve_axis passes")
-    planes = src.shape[0]
-    n = n_voxels(grid) * planes
-    check(lib.lsf_convolve_xyz(_ptr(src, n, "conv src"), _ptr(dst, n, "conv dst"),
-                               _ptr(warp, n, "warp", allow_none=True), float(rate), ctypes.byref(grid), planes,
-                               taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), taps.size, _gate_ref(gate),
-                               stream_ptr()), "lsf_convolve_xyz")
-
+from .device_core import *  # noqa: F401,F403
+from .device_core import _PINNED, _gate_ref, _ptr, _record_ptr  # noqa: F401
+from .device_fields import *  # noqa: F401,F403
 
 # ------------------------------------------------------------------------------------- optimizer kernels
 def hier_iteration(packed, canonical, warp, g_prev, g_out, grid, params, gate, records, index):
