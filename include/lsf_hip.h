@@ -268,7 +268,9 @@ int lsf_hier_iteration(const float *packed_live4, const float *canonical, float 
  * with apply_update = 0, two lsf_convolve_axis passes and lsf_hier_update do in four launches; params->apply_update must
  * then be 0 as it is for those.  An iteration consumes n_taps / 2 + 1 rings of the tile's surroundings instead of one:
  * iterations_per_launch * (n_taps / 2 + 1) <= 8 (two iterations per launch for seven taps), LSF_ERR_BAD_ARGUMENT otherwise.
- * LSF_ERR_BAD_DIMS for anything but dims = 2, tikhonov_enabled, compute_energy = 0, apply_update = (n_taps == 0). */
+ * Without the Tikhonov term (tikhonov_enabled = 0) a voxel's update depends on nothing around it but through the filter:
+ * iterations_per_launch * (tikhonov_enabled + n_taps / 2) <= 8 in general.
+ * LSF_ERR_BAD_DIMS for anything but dims = 2, compute_energy = 0, apply_update = (n_taps == 0). */
 int lsf_hier_level_run_2d(const float *packed_live4, const float *canonical, float *warp_a, float *warp_b, float *g_a,
                           float *g_b, const lsf_grid *grid, const lsf_hier_params *params, const double *taps_host,
                           int32_t n_taps, lsf_iteration_record *records, int32_t iterations,

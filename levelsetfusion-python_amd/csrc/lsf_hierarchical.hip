@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kBlkThreads) void hier2d_blocked_kernel(const float
                                                                      float strength, float rate,
                                                                      lsf_iteration_record* records, int k,
                                                                      const lsf_iteration_record* previous,
-                                                                     int previous_count, float threshold) {
+                                                                     int previous_count, float threshold, int tik) {
     if (previous_count > 0) {
         // the predecessor's records, one (record, slot) word per lane -- one round trip instead of a chain of them; every wave
         // of every workgroup reads the same words and takes the same way
@@ -294,9 +294,9 @@ __global__ __launch_bounds__(kBlkThreads) void hier2d_blocked_kernel(const float
         float v[C][4];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            if (ring[c] <= k) {
-                v[c][0] = g_in[vox[c]];
-                v[c][1] = g_in[plane + vox[c]];
+            if (ring[c] <= (tik ? k : 0)) {  // (without the Tikhonov term a voxel depends on nothing around it)
+                v[c][0] = tik ? g_in[vox[c]] : 0.0f;
+                v[c][1] = tik ? g_in[plane + vox[c]] : 0.0f;
                 v[c][2] = warp_in[vox[c]];
                 v[c][3] = warp_in[plane + vox[c]];
                 cn[c] = canonical[vox[c]];
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlkThreads) void hier2d_blocked_kernel(const float
         }
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            if (ring[c] <= k) {
+            if (ring[c] <= (tik ? k : 0)) {
                 s_g[0][0][cell[c]] = v[c][0];
                 s_g[0][1][cell[c]] = v[c][1];
                 s_w[0][cell[c]] = v[c][2];
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(kBlkThreads) void hier2d_blocked_kernel(const float
     }
     __syncthreads();
     for (int j = 0; j < k; ++j) {  // (k is uniform over the grid)
-        const int cur = j & 1, nxt = cur ^ 1, reach = k - 1 - j;
+        const int cur = j & 1, nxt = cur ^ 1, reach = tik ? k - 1 - j : 0;
         float w0[C], w1[C];
         Packed smp[C];
 #pragma unroll
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(kBlkThreads) void hier2d_blocked_kernel(const float
                     const float d2x = second_difference_f64(a[l - left], a0, a[l + right]);
                     const float lap = d2y + d2x;
                     const float gd = diff * live_grad[d];
-                    gv[d] = amp * gd - strength * lap;
+                    gv[d] = tik ? amp * gd - strength * lap : amp * gd;
                 }
                 s_g[nxt][0][l] = gv[0];
                 s_g[nxt][1][l] = gv[1];
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(kBlkThreads) void hier2d_blocked_filter_kernel(cons
                                                                             float strength, float rate, TapsN<NT> taps,
                                                                             lsf_iteration_record* records, int k,
                                                                             const lsf_iteration_record* previous,
-                                                                            int previous_count, float threshold) {
+                                                                            int previous_count, float threshold, int tik) {
     if (previous_count > 0) {  // (as hier2d_blocked_kernel: the predecessor's records, one word per lane)
         const int l = threadIdx.x & (kWave - 1), r = l / LSF_RECORD_SLOTS;
         unsigned long long p = r < previous_count ? previous[r].slot[l % LSF_RECORD_SLOTS].max_packed : ~0ull;
@@ -418,7 +418,8 @@ __global__ __launch_bounds__(kBlkThreads) void hier2d_blocked_filter_kernel(cons
         const bool met = r < previous_count && (p == 0ull || unpack_max_value(p) < threshold);
         if (__any(met)) return;
     }
-    constexpr int R = NT / 2, S = R + 1;  // the filter's reach; rings an iteration consumes
+    constexpr int R = NT / 2;      // the filter's reach
+    const int S = tik ? R + 1 : R;  // rings an iteration consumes (the Laplacian of the previous gradient: one more)
     constexpr int H = kBlkMaxK, N = T + 2 * H, W = N + 1;
     constexpr int C = (N * N + kBlkThreads - 1) / kBlkThreads;
     __shared__ float s_w[2][N * W];    // the warp's two components
@@ -471,8 +472,8 @@ __global__ __launch_bounds__(kBlkThreads) void hier2d_blocked_filter_kernel(cons
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             if (max(rx[c], ry[c]) <= k * S) {
-                v[c][0] = g_in[vox[c]];
-                v[c][1] = g_in[plane + vox[c]];
+                v[c][0] = tik ? g_in[vox[c]] : 0.0f;
+                v[c][1] = tik ? g_in[plane + vox[c]] : 0.0f;
                 v[c][2] = warp_in[vox[c]];
                 v[c][3] = warp_in[plane + vox[c]];
                 cn[c] = canonical[vox[c]];
@@ -519,7 +520,7 @@ __global__ __launch_bounds__(kBlkThreads) void hier2d_blocked_filter_kernel(cons
                         const float d2x = second_difference_f64(a[l - left], a0, a[l + right]);
                         const float lap = d2y + d2x;
                         const float gd = diff * live_grad[d];
-                        s_raw[d][l] = amp * gd - strength * lap;
+                        s_raw[d][l] = tik ? amp * gd - strength * lap : amp * gd;
                     }
                 }
             }
@@ -692,7 +693,7 @@ static int launch_blocked_filter(bool small, bool fma, unsigned tiles, hipStream
 #define LSF_LAUNCH_BLOCKED(TILE, FMA)                                                                                   \
     hipLaunchKernelGGL((hier2d_blocked_filter_kernel<TILE, NT, FMA>), dim3(tiles), dim3(kBlkThreads), 0, s, packed,       \
                        canonical, w_in, w_out, g_in, g_out, g, params->data_term_amplifier, params->tikhonov_strength,   \
-                       params->rate, taps, records, k, previous, previous_count, threshold)
+                       params->rate, taps, records, k, previous, previous_count, threshold, params->tikhonov_enabled)
     if (small && fma) LSF_LAUNCH_BLOCKED(16, true);
     else if (small) LSF_LAUNCH_BLOCKED(16, false);
     else if (fma) LSF_LAUNCH_BLOCKED(32, true);
@@ -714,12 +715,14 @@ extern "C" int lsf_hier_level_run_2d(const float* packed_live4, const float* can
     // itself without a gradient kernel (apply_update), behind the filter with one (apply_update off, as lsf_hier_iteration
     // is called then)
     const bool filtered = n_taps > 0;
-    if (grid->dims != 2 || !params->tikhonov_enabled || (params->apply_update != 0) == filtered || params->compute_energy ||
-        params->previous_max || params->packed_nz != 0)
+    if (grid->dims != 2 || (params->apply_update != 0) == filtered || params->compute_energy || params->previous_max ||
+        params->packed_nz != 0)
         return LSF_ERR_BAD_DIMS;
     if (filtered && n_taps != 3 && n_taps != 5 && n_taps != 7 && n_taps != 9) return LSF_ERR_BAD_DIMS;
-    // the rings an iteration consumes (1, or taps / 2 + 1 with a filter) times the iterations of a launch: inside the image
-    if (iterations_per_launch * (filtered ? n_taps / 2 + 1 : 1) > kBlkMaxK) return LSF_ERR_BAD_ARGUMENT;
+    // the rings an iteration consumes (the Tikhonov term's Laplacian: 1; a filter: taps / 2) times the iterations of a launch:
+    // inside the image
+    const int tik = params->tikhonov_enabled ? 1 : 0;
+    if (iterations_per_launch * ((filtered ? n_taps / 2 : 0) + tik) > kBlkMaxK) return LSF_ERR_BAD_ARGUMENT;
     const Grid g = make_grid(grid);
     // 32 x 32 tiles keep the recomputed rings cheapest (1.5 x the level's voxels over a launch of eight); levels too small
     // to give every CU such a tile take 16 x 16 tiles: more workgroups, each with a third of the cells
@@ -754,11 +757,11 @@ extern "C" int lsf_hier_level_run_2d(const float* packed_live4, const float* can
         if (small)
             hipLaunchKernelGGL(hier2d_blocked_kernel<16>, dim3(tiles), dim3(kBlkThreads), 0, s, packed, canonical, w_in, w_out,
                                g_in, g_out, g, params->data_term_amplifier, params->tikhonov_strength, params->rate,
-                               records + i, k, previous, previous_count, threshold);
+                               records + i, k, previous, previous_count, threshold, params->tikhonov_enabled);
         else
             hipLaunchKernelGGL(hier2d_blocked_kernel<32>, dim3(tiles), dim3(kBlkThreads), 0, s, packed, canonical, w_in, w_out,
                                g_in, g_out, g, params->data_term_amplifier, params->tikhonov_strength, params->rate,
-                               records + i, k, previous, previous_count, threshold);
+                               records + i, k, previous, previous_count, threshold, params->tikhonov_enabled);
         if (int e = launch_status()) return e;
     }
     return 0;

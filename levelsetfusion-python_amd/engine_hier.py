@@ -370,7 +370,7 @@ class HierarchicalEngine:
         n_vox = canonical.numel()
         hooked = self.iteration_hook is not None
         if (self.blocked_levels and canonical.dim() == 2 and not slab and not hooked and not self.collect_iteration_data
-                and self.tikhonov_term_enabled and not self.compute_energy and max_it >= 1
+                and not self.compute_energy and max_it >= 1
                 and (not self.gradient_kernel_enabled or len(self.gradient_kernel) in dev.XYZ_TAP_COUNTS)):
             return self._optimize_level_blocked(canonical, packed, warp)
         if (self.use_graphs and not slab and not self.collect_iteration_data and not hooked and max_it >= 4
@@ -466,7 +466,7 @@ class HierarchicalEngine:
     BLOCKED_ITERATIONS_PER_LAUNCH = 8
 
     def _optimize_level_blocked(self, canonical, packed, warp):
-        """2-D levels, Tikhonov term, no energy printouts: the whole level in ONE foreign call, K = 8 iterations
+        """2-D levels, no energy printouts: the whole level in ONE foreign call, K = 8 iterations
         per launch advanced inside LDS tile by tile (lsf_hier_level_run_2d: temporal blocking -- a 512^2 level is
         launch-bound, 7.5 us per iteration from a HIP graph against ~1 us of work).  With the gradient kernel (the
         reference's default constructor) the launch also runs the filter's two passes and the update behind them -- one
@@ -487,14 +487,17 @@ class HierarchicalEngine:
             if min(canonical.shape) < n_taps:  # (the reference cannot do this either: np.convolve's 'same' mode)
                 raise ValueError("cannot convolve a field of extent %d with a %d-tap kernel" % (min(canonical.shape), n_taps))
             taps = kernel.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
-            K = max(1, K // (n_taps // 2 + 1))
+        # rings of a tile's surroundings an iteration consumes: one for the Tikhonov term's Laplacian, taps / 2 for the filter
+        rings = int(bool(self.tikhonov_term_enabled)) + n_taps // 2
+        if rings:
+            K = max(1, K // rings)
         thr = np.float32(self.maximum_warp_update_threshold)
         gated = bool(thr > 0.0)
         warps = [warp, torch.empty_like(warp)]
         F = [torch.zeros_like(warp), torch.empty_like(warp)]
         records = dev.new_records(max_it, canonical.device)
-        params = _lib.HierParams(float(self.data_term_amplifier), float(self.tikhonov_strength), float(self.rate), 1,
-                                 int(n_taps == 0), 0)
+        params = _lib.HierParams(float(self.data_term_amplifier), float(self.tikhonov_strength), float(self.rate),
+                                 int(bool(self.tikhonov_term_enabled)), int(n_taps == 0), 0)
         p_packed, p_canonical = dev._ptr(packed, 4 * n, "packed live"), dev._ptr(canonical, n, "canonical")
         p_warp = [dev._ptr(w, 2 * n, "warp") for w in warps]
         p_g = [dev._ptr(g, 2 * n, "gradient") for g in F]

@@ -179,8 +179,14 @@ def test_round6_entry_points_validate_on_the_host(pkg):
     ok = L.HierParams(1.0, 0.05, 0.1, 1, 1, 0)
     call = lib.lsf_hier_level_run_2d
     assert call(one, one, two, three, four, five, ctypes.byref(g3), ctypes.byref(ok), None, 0, one, 4, 8, 0.0, None) == -2
-    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(L.HierParams(1.0, 0.05, 0.1, 0, 1, 0)), None, 0, one, 4, 8, 0.0,
-                None) == -2
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(L.HierParams(1.0, 0.05, 0.1, 1, 0, 0)), None, 0, one, 4, 8, 0.0,
+                None) == -2  # no gradient kernel: the iteration applies the update itself
+    taps7 = (ctypes.c_double * 7)(*([0.1] * 7))
+    filtered = L.HierParams(1.0, 0.05, 0.1, 1, 0, 0)
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), taps7, 7, one, 4, 2, 0.0, None) == -2  # ... behind the filter with one
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(filtered), taps7, 7, one, 4, 3, 0.0, None) == -1  # 3 x 4 rings
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(filtered), taps7, 4, one, 4, 1, 0.0, None) == -2  # four taps
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(filtered), None, 7, one, 4, 2, 0.0, None) == -1  # taps missing
     assert call(one, one, two, two, four, five, ctypes.byref(g2), ctypes.byref(ok), None, 0, one, 4, 8, 0.0, None) == -1
     assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), None, 0, one, 4, 0, 0.0, None) == -1
     assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), None, 0, one, 4, 9, 0.0, None) == -1

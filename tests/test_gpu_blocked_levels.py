@@ -120,6 +120,27 @@ def test_filtered_blocked_levels_equal_the_oracle(lsf, n_taps):
             assert min(o.per_level_iteration_counts) < iterations, o.per_level_iteration_counts
 
 
+@pytest.mark.parametrize("n_taps", [0, 3, 7])
+@pytest.mark.parametrize("threshold", [0.0, 0.03])
+def test_blocked_levels_without_the_tikhonov_term(lsf, n_taps, threshold):
+    """the data term alone (a voxel's update then depends on nothing around it: eight iterations per launch, no recomputed
+    rings), and the data term behind the gradient kernel: == the per-iteration path and the oracle"""
+    canonical, live = O.sphere_pair(128, d=2)
+    kernel = O.generate_1d_sobolev_kernel(n_taps, 0.1) if n_taps else None
+    kw = dict(tikhonov_term_enabled=False, gradient_kernel_enabled=bool(n_taps), maximum_chunk_size=8, rate=0.2,
+              maximum_iteration_count=19, maximum_warp_update_threshold=threshold)
+    opt, warp = _run(lsf, canonical, live, True, kernel=kernel, **kw)
+    other, warp_b = _run(lsf, canonical, live, False, kernel=kernel, **kw)
+    assert np.array_equal(warp, warp_b)
+    assert opt.get_per_level_iteration_counts() == other.get_per_level_iteration_counts()
+    o = O.HierarchicalOracle(kernel=kernel, **kw)
+    want = o.optimize(canonical, live)
+    assert np.array_equal(warp, want) and float(np.abs(want).max()) > 1e-3
+    assert opt.get_per_level_iteration_counts() == o.per_level_iteration_counts
+    for mine, theirs in zip(opt.get_per_level_maximum_updates(), o.per_level_max_updates):
+        assert np.array_equal(np.float32(mine), np.float32(theirs))
+
+
 def test_energy_printouts_keep_the_per_iteration_path(lsf):
     from levelsetfusion_python_amd.synthetic import sphere_pair
     canonical, live = sphere_pair(64, 2, "cuda")
@@ -215,8 +236,8 @@ def test_entry_point_refuses_what_it_does_not_implement(lsf):
     call = _lib.lib.lsf_hier_level_run_2d
     one, two, three, four, five = (ctypes.c_void_p(k * 4096) for k in (1, 2, 3, 4, 5))
     assert call(one, one, two, three, four, five, ctypes.byref(g3), ctypes.byref(ok), None, 0, one, 4, 8, 0.0, None) == -2  # 3-D
-    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(_lib.HierParams(1.0, 0.05, 0.1, 0, 1, 0)), None, 0,
-                one, 4, 8, 0.0, None) == -2  # no Tikhonov term
+    assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(_lib.HierParams(1.0, 0.05, 0.1, 1, 0, 0)), None, 0,
+                one, 4, 8, 0.0, None) == -2  # the update left to a filter that is not there
     assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(_lib.HierParams(1.0, 0.05, 0.1, 1, 1, 1)), None, 0,
                 one, 4, 8, 0.0, None) == -2  # energies
     assert call(one, one, two, two, four, five, ctypes.byref(g2), ctypes.byref(ok), None, 0, one, 4, 8, 0.0, None) == -1    # same buffer twice
