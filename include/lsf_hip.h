@@ -187,6 +187,11 @@ int lsf_downsample2x_linear(const float *fine, float *coarse, const lsf_grid *fi
 int lsf_convolve_axis(const float *in_planar, float *out_planar, const float *zero_mask_source,
                       const lsf_grid *grid, int32_t planes, int32_t axis, const double *taps_host,
                       int32_t n_taps, const lsf_gate *gate, void *stream);
+/* the x and the y pass of a 3-D filter in one launch, without a zero mask (levels below lsf_convolve_xyz's size, where the
+ * passes are launch-bound): the result equals lsf_convolve_axis along x, then along y, bit for bit, on the grid's z-range.
+ * nx % 4 == 0, 3 / 5 / 7 / 9 taps (LSF_ERR_BAD_DIMS / LSF_ERR_KERNEL_TOO_LONG otherwise). */
+int lsf_convolve_xy(const float *in_planar, float *out_planar, const lsf_grid *grid, int32_t planes,
+                    const double *taps_host, int32_t n_taps, const lsf_gate *gate, void *stream);
 /* the LAST pass of a hierarchical iteration's 3-D filter (axis 2; axis 1 is accepted too -- the reference's 2-D filter ends
  * with its x pass, convolution.py:77-83, which this does not cover; 3 / 5 / 7 / 9 taps, no zero mask): the
  * same pass, which also moves the warp by the filtered gradient it writes, component by component -- warp -= rate * out

@@ -22,7 +22,7 @@ ABI_VERSION = 4
 # time, and tests/test_cabi_and_host.py checks this constant against the header in the tree -- so editing a struct or
 # a prototype in the header without revisiting the binding fails on the CPU, and a stale or variant .so cannot be
 # called through structures of another shape.
-HEADER_ABI_HASH = "4b9a0d2c0f2405b2"
+HEADER_ABI_HASH = "2b52a5b7ac923a65"
 
 ERRORS = {-1: "LSF_ERR_BAD_ARGUMENT", -2: "LSF_ERR_BAD_DIMS", -3: "LSF_ERR_KERNEL_TOO_LONG",
           -4: "LSF_ERR_RCCL_UNAVAILABLE", -5: "LSF_ERR_RCCL_FAILED", -6: "LSF_ERR_NOT_RESIDENT"}
@@ -174,6 +174,7 @@ PROTOTYPES = {
     "lsf_downsample2x_linear": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _vp]),
     "lsf_convolve_axis": (ctypes.c_int, [_vp, _vp, _vp, _P(Grid), _i32, _i32, _P(ctypes.c_double), _i32,
                                          _P(Gate), _vp]),
+    "lsf_convolve_xy": (ctypes.c_int, [_vp, _vp, _P(Grid), _i32, _P(ctypes.c_double), _i32, _P(Gate), _vp]),
     "lsf_convolve_axis_update": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_float, _P(Grid), _i32, _i32, _P(ctypes.c_double),
                                                 _i32, _P(Gate), _vp]),
     "lsf_convolve_xyz": (ctypes.c_int, [_vp, _vp, _vp, _f32, _P(Grid), _i32, _P(ctypes.c_double), _i32, _P(Gate),

@@ -885,6 +885,82 @@ __global__ __launch_bounds__(kBlock, 5) void convolve_xyz_kernel(const float* __
     }
 }
 
+// ---- the x and the y pass of a 3-D filter in ONE launch (levels below the fused kernel's size: its 64 x 16-column blocks
+// march through 32 slices, which leaves most of the chip idle at 128^3 and below; there the passes are launch-bound and one
+// launch less per iteration is what counts).  A block owns a 64 x 16 tile of ONE slice: the raw tile with its x / y reach goes
+// through LDS, the x pass writes its float32-rounded results back to LDS, the y pass reads them.  convolve_xyz_kernel's first
+// two stages, slice by slice: the same arithmetic as the single passes.
+template <int NT, bool FMA>
+__global__ __launch_bounds__(kBlock) void convolve_xy_kernel(const float* __restrict__ in, float* __restrict__ out, Grid g,
+                                                             TapsN<NT> taps, unsigned tiles_y, lsf_gate gate) {
+    if (gate_closed(gate)) return;
+    constexpr int R = NT / 2;
+    constexpr int kStaged = kXyzRows + 2 * R;
+    constexpr int kQuads = kStaged * (kXyzCols / 4);
+    constexpr int kLoads = (kQuads + kBlock - 1) / kBlock;
+    __shared__ __attribute__((aligned(16))) float raw[kStaged][kXyzCols];
+    __shared__ float xs[kStaged][kTileX];
+    const int t = threadIdx.x, lx = t & (kTileX - 1), wy = t / kTileX;
+    const int x0 = blockIdx.x * kTileX;
+    const int y0 = (int)(blockIdx.y % tiles_y) * kXyzRows;
+    const int p = g.z_begin + (int)(blockIdx.y / tiles_y);  // the slice
+    const float* __restrict__ src = in + (long long)blockIdx.z * g.plane + (long long)p * g.nx * g.ny;
+    float* __restrict__ dst = out + (long long)blockIdx.z * g.plane + (long long)p * g.nx * g.ny;
+    const cvf4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int m = 0; m < kLoads; ++m) {
+        const int q = t + m * kBlock;
+        const int row = q / (kXyzCols / 4), col = (q % (kXyzCols / 4)) * 4;
+        const int gx = x0 - 4 + col, gy = y0 - R + row;
+        const bool ok = q < kQuads && gx >= 0 && gx < g.nx && gy >= 0 && gy < g.ny;  // nx % 4 == 0: quads are in or out whole
+        const cvf4 v = ok ? *reinterpret_cast<const cvf4*>(src + gy * g.nx + gx) : zero4;
+        if (q < kQuads) *reinterpret_cast<cvf4*>(&raw[row][col]) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < (kStaged + 3) / 4; ++m) {  // x pass: rows wy, wy + 4, ...
+        const int r = wy + 4 * m;
+        if (r < kStaged) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc = mac<FMA>(acc, taps.k[j], (double)raw[r][lx + 4 + R - j]);
+            xs[r][lx] = (float)acc;
+        }
+    }
+    __syncthreads();
+    double d[4 + 2 * R];  // y pass: four consecutive rows share their taps
+#pragma unroll
+    for (int i = 0; i < 4 + 2 * R; ++i) d[i] = (double)xs[4 * wy + i][lx];
+    if (x0 + lx < g.nx) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int y = y0 + 4 * wy + k;
+            if (y < g.ny) {
+                double acc = 0.0;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) acc = mac<FMA>(acc, taps.k[j], d[k + 2 * R - j]);
+                dst[y * g.nx + x0 + lx] = (float)acc;
+            }
+        }
+    }
+}
+
+template <int NT>
+static bool launch_xy(const float* in, float* out, const Grid& g, int planes, const double* taps_host, const lsf_gate& gt,
+                      hipStream_t s) {
+    TapsN<NT> taps;
+    for (int j = 0; j < NT; ++j) taps.k[j] = taps_host[j];
+    const unsigned tiles_x = (unsigned)(g.nx + kTileX - 1) / kTileX, tiles_y = (unsigned)(g.ny + kXyzRows - 1) / kXyzRows;
+    const unsigned long long blocks_y = (unsigned long long)tiles_y * (unsigned)(g.z_end - g.z_begin);
+    if (blocks_y > 65535ull) return false;
+    const dim3 grid(tiles_x, (unsigned)blocks_y, (unsigned)planes);
+    if (taps_are_float32(taps_host, NT))
+        hipLaunchKernelGGL((convolve_xy_kernel<NT, true>), grid, dim3(kBlock), 0, s, in, out, g, taps, tiles_y, gt);
+    else
+        hipLaunchKernelGGL((convolve_xy_kernel<NT, false>), grid, dim3(kBlock), 0, s, in, out, g, taps, tiles_y, gt);
+    return true;
+}
+
 template <int NT>
 static void launch_xyz(const float* in, float* out, float* warp, float rate, const Grid& g, int planes,
                        const double* taps_host, const lsf_gate& gt, hipStream_t s) {
@@ -992,6 +1068,27 @@ extern "C" int lsf_convolve_axis(const float* in_planar, float* out_planar, cons
                            in_planar, out_planar, zero_mask_source, g, taps, gt);
     }
     return launch_status();
+}
+
+extern "C" int lsf_convolve_xy(const float* in_planar, float* out_planar, const lsf_grid* grid, int32_t planes,
+                               const double* taps_host, int32_t n_taps, const lsf_gate* gate, void* stream) {
+    if (int e = check_grid(grid)) return e;
+    if (!in_planar || !out_planar || in_planar == out_planar || !taps_host || planes < 1 || planes > 4)
+        return LSF_ERR_BAD_ARGUMENT;
+    if (grid->dims != 3 || grid->nx % 4 != 0) return LSF_ERR_BAD_DIMS;
+    if (grid->z_end == grid->z_begin) return 0;
+    if (n_taps != 3 && n_taps != 5 && n_taps != 7 && n_taps != 9) return LSF_ERR_KERNEL_TOO_LONG;
+    const Grid g = make_grid(grid);
+    const lsf_gate gt = gate ? *gate : lsf_gate{nullptr, 0, 0.0f, 0.0f};
+    hipStream_t s = as_stream(stream);
+    bool done = false;
+    switch (n_taps) {
+        case 3: done = launch_xy<3>(in_planar, out_planar, g, planes, taps_host, gt, s); break;
+        case 5: done = launch_xy<5>(in_planar, out_planar, g, planes, taps_host, gt, s); break;
+        case 7: done = launch_xy<7>(in_planar, out_planar, g, planes, taps_host, gt, s); break;
+        default: done = launch_xy<9>(in_planar, out_planar, g, planes, taps_host, gt, s); break;
+    }
+    return done ? launch_status() : LSF_ERR_BAD_DIMS;
 }
 
 extern "C" int lsf_convolve_axis_update(const float* in_planar, float* out_planar, float* warp_planar, float rate,

@@ -157,6 +157,22 @@ def convolve_axis(src, dst, zero_mask_source, grid, axis, taps, gate=None, band=
 XYZ_TAP_COUNTS = (3, 5, 7, 9)
 
 
+def convolve_xy_ok(grid, taps):
+    """x and y pass of a 3-D filter in one launch (lsf_convolve_xy)?"""
+    return (grid.dims == 3 and len(taps) in XYZ_TAP_COUNTS and grid.nx % 4 == 0 and min(grid.nx, grid.ny) >= len(taps)
+            and ((grid.ny + 15) // 16) * (grid.z_end - grid.z_begin) <= 65535)
+
+
+def convolve_xy(src, dst, grid, taps, gate=None):
+    """dst = the y pass of the x pass of src (3-D, no zero mask), on the grid's z-range"""
+    taps = np.ascontiguousarray(np.asarray(taps, dtype=np.float64))
+    planes = src.shape[0]
+    n = n_voxels(grid) * planes
+    check(lib.lsf_convolve_xy(_ptr(src, n, "conv src"), _ptr(dst, n, "conv dst"), ctypes.byref(grid), planes,
+                              taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), taps.size, _gate_ref(gate),
+                              stream_ptr()), "lsf_convolve_xy")
+
+
 def convolve_axis_update_ok(grid, taps):
     """can the filter's last pass also move the warp (lsf_convolve_axis_update: the register-window pass along z, whose
     launch grid must fit)?  3-D only: the reference's 2-D filter ends with its x pass (math_utils/convolution.py:77-83)"""

@@ -285,7 +285,13 @@ class HierarchicalEngine:
                 # x, y, z in one launch, which also moves the warp by its filtered gradient, component by component
                 dev.convolve_xyz(src, out, lv.grid, self.gradient_kernel, gate, lv.warp, self.rate)
                 axes, moved = (), True
+            if len(axes) == 3 and self.fused_filter and dev.convolve_xy_ok(lv.full_grid, self.gradient_kernel):
+                # smaller 3-D levels: the x and the y pass in one launch (these levels are launch-bound)
+                dev.convolve_xy(src, lv.S[1], lv.full_grid, self.gradient_kernel, gate)
+                src, axes = lv.S[1], [None, None, 2]
             for k, axis in enumerate(axes):
+                if axis is None:
+                    continue
                 dst = out if k == len(axes) - 1 else lv.S[(k + 1) % 2]
                 if k == len(axes) - 1 and dev.convolve_axis_update_ok(lv.grid, self.gradient_kernel):
                     # the last pass moves the warp by the gradient it writes (one launch reads and writes the warp

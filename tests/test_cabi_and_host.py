@@ -191,6 +191,12 @@ def test_round6_entry_points_validate_on_the_host(pkg):
     assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), None, 0, one, 4, 0, 0.0, None) == -1
     assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), None, 0, one, 4, 9, 0.0, None) == -1
     assert call(one, one, two, three, four, five, ctypes.byref(g2), ctypes.byref(ok), None, 0, one, 0, 8, 0.0, None) == 0  # nothing to do
+    # lsf_convolve_xy: 3-D, nx % 4 == 0, 3 / 5 / 7 / 9 taps
+    xy = lib.lsf_convolve_xy
+    assert xy(one, one, ctypes.byref(g3), 3, (ctypes.c_double * 9)(), 7, None, None) == -1      # in == out
+    assert xy(one, two, ctypes.byref(g2), 2, (ctypes.c_double * 9)(), 7, None, None) == -2      # 2-D
+    assert xy(one, two, ctypes.byref(L.Grid(3, 8, 32, 30, 0, 8, 0, 0)), 3, (ctypes.c_double * 9)(), 7, None, None) == -2  # nx % 4
+    assert xy(one, two, ctypes.byref(g3), 3, (ctypes.c_double * 9)(), 4, None, None) == -3      # four taps
     # lsf_convolve_axis_update: the last axis only, 3 / 5 / 7 / 9 taps, distinct buffers
     taps = (ctypes.c_double * 9)(*([0.1] * 9))
     upd = lib.lsf_convolve_axis_update

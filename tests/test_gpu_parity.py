@@ -605,6 +605,38 @@ def test_state_pack_unpack_finalize(lsf):
             assert np.allclose(got[3:5], want[3:5], rtol=1e-12, atol=0.0)     # float64 sums in a different order
 
 
+def test_fused_xy_filter_equals_two_passes(lsf):
+    """lsf_convolve_xy (x and y pass of a 3-D filter in one launch, slice by slice) == lsf_convolve_axis along x, then along
+    y, bit for bit: ragged extents, every tap count, float32-valued and arbitrary taps, a z-range (slices outside it are not
+    written), a closed gate"""
+    from levelsetfusion_python_amd import _lib, device as dev
+    gen = torch.Generator("cuda").manual_seed(5)
+    for shape in ((37, 35, 72), (64, 64, 64), (9, 10, 12), (5, 130, 132), (16, 16, 16)):
+        grids = [dev.make_grid(shape)] + ([dev.make_grid(shape, 4, shape[0] - 2, 9)] if shape[0] > 8 else [])
+        for grid in grids:
+            for n_taps in (3, 5, 7, 9):
+                taps = lsf.generate_1d_sobolev_kernel(n_taps, 0.1) if n_taps in (3, 7) else \
+                    np.linspace(-0.2, 1.0, n_taps).astype(np.float64) / 3.0
+                assert dev.convolve_xy_ok(grid, taps)
+                for planes in (1, 3):
+                    src = torch.randn((planes,) + shape, device="cuda", generator=gen)
+                    a, want, got = torch.full_like(src, 5.0), torch.full_like(src, 7.0), torch.full_like(src, 7.0)
+                    dev.convolve_axis(src, a, None, grid, 0, taps)
+                    dev.convolve_axis(a, want, None, grid, 1, taps)
+                    dev.convolve_xy(src, got, grid, taps)
+                    assert torch.equal(got, want), (shape, n_taps, planes, float((got - want).abs().max()))
+    shape = (16, 16, 64)
+    grid = dev.make_grid(shape)
+    rec = dev.new_records(2, "cuda")
+    dev.set_record_max(rec, 0, int(np.float32(0.001).view(np.uint32)) << 32 | 5)
+    gate = _lib.Gate(rec.data_ptr(), _lib.GATE_HIERARCHICAL, 0.01, 0.0)
+    src, out = torch.randn((3,) + shape, device="cuda", generator=gen), torch.full((3,) + shape, 7.0, device="cuda")
+    dev.convolve_xy(src, out, grid, lsf.generate_1d_sobolev_kernel(7, 0.1), gate)
+    assert bool((out == 7.0).all())
+    assert not dev.convolve_xy_ok(dev.make_grid((16, 16, 18)), np.ones(7))  # nx % 4
+    assert not dev.convolve_xy_ok(dev.make_grid((16, 16)), np.ones(7))      # 2-D: the reference's order is y, then x
+
+
 def test_last_filter_pass_that_moves_the_warp(lsf):
     """lsf_convolve_axis_update (the last pass of a hierarchical iteration's filter, which also moves the warp) == the plain
     pass + lsf_hier_update's warp half, bit for bit: along z in 3-D (what the engine uses) and along y in 2-D, ragged extents, every tap count, a
