@@ -16,10 +16,17 @@ from ._lib import Gate, Grid, HierParams, SlavchevaParams, check, lib
 RECORD_WORDS = _lib.RECORD_BYTES // 8  # an iteration record is 8 slots x 512 int64 words (see lsf_iteration_record)
 
 
+_gpu_seen = False
+
+
 def require_gpu():
+    global _gpu_seen
+    if _gpu_seen:  # (a card does not go away: the check's environment reads are then paid once, not twice per call)
+        return
     if not torch.cuda.is_available():
         raise RuntimeError("levelsetfusion-python_amd needs an AMD GPU (ROCm): torch.cuda.is_available() is False. "
                            "There is no CPU execution path in this package.")
+    _gpu_seen = True
 
 
 # torch.cuda.current_stream() / current_device() walk half a dozen Python frames each (device-type look-up, availability
